@@ -1,0 +1,27 @@
+"""deepgemm_amd -- MI355X (gfx950) native FP8 blockwise-scaled GEMM with DeepGEMM's operator surface.
+
+Drop-in for the reference's FP8 GEMM path (``deep_gemm/__init__.py:17-78``): same function names, argument order,
+keyword names and defaults.  ``import deep_gemm`` (the alias package at the repository root) resolves to this package.
+"""
+from . import _lib                                    # loads the HIP extension; ImportError if it is not built
+from .runtime import (                                # noqa: F401
+    set_num_sms, get_num_sms, set_tc_util, get_tc_util, set_pdl, get_pdl,
+    set_ignore_compile_dims, set_block_size_multiple_of,
+    set_forced_config, list_configs, last_config,
+)
+from .gemm import (                                   # noqa: F401
+    fp8_gemm_nt, fp8_gemm_nn, fp8_gemm_tn, fp8_gemm_tt,
+    m_grouped_fp8_gemm_nt_contiguous, m_grouped_fp8_gemm_nn_contiguous, m_grouped_fp8_gemm_nt_masked,
+)
+from .layout import transform_sf_into_required_layout                 # noqa: F401
+from . import testing, utils                                          # noqa: F401
+from .utils import *                                                  # noqa: F401,F403
+
+# Names the reference exports for the same entry points (csrc/apis/gemm.hpp:711-717, deep_gemm/__init__.py:77)
+fp8_fp4_gemm_nt, fp8_fp4_gemm_nn, fp8_fp4_gemm_tn, fp8_fp4_gemm_tt = fp8_gemm_nt, fp8_gemm_nn, fp8_gemm_tn, fp8_gemm_tt
+m_grouped_fp8_fp4_gemm_nt_contiguous = m_grouped_fp8_gemm_nt_contiguous
+m_grouped_fp8_fp4_gemm_nn_contiguous = m_grouped_fp8_gemm_nn_contiguous
+m_grouped_fp8_fp4_gemm_nt_masked = m_grouped_fp8_gemm_nt_masked
+fp8_m_grouped_gemm_nt_masked = m_grouped_fp8_gemm_nt_masked
+
+__version__ = '0.1.0'

@@ -1,0 +1,57 @@
+"""ctypes binding of the C ABI in ``include/deepgemm_amd.h`` (the analogue of the reference's pybind ``_C`` module,
+csrc/python_api.cpp:17-28).  Importing this module requires the compiled HIP extension; there is NO fallback path:
+a missing library is an ImportError, a failing call is a RuntimeError carrying ``dg_last_error()``."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so the extension shares the same HIP runtime)
+
+from .build import LIB_PATH
+
+_i32, _i64, _vp, _cp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/deepgemm_amd.h
+SIGNATURES = {
+    'dg_fp8_gemm_nt': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i32, _i64, _i32, _i32, _vp]),
+    'dg_m_grouped_fp8_gemm_nt_contiguous': (_i32, [_vp] * 6 + [_i32] * 4 + [_i64] * 11 + [_i32, _i32, _vp]),
+    'dg_m_grouped_fp8_gemm_nt_masked': (_i32, [_vp] * 6 + [_i32] * 5 + [_i64] * 14 + [_vp]),
+    'dg_transpose_sf_fp32': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    'dg_set_num_cus': (_i32, [_i32]),
+    'dg_get_num_cus': (_i32, []),
+    'dg_set_forced_config': (_i32, [_cp]),
+    'dg_list_configs': (_cp, []),
+    'dg_last_config': (_cp, []),
+    'dg_last_error': (_cp, []),
+    'dg_version': (_cp, []),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'deepgemm_amd: the HIP extension {LIB_PATH} has not been built. '
+            'Run `python -m deepgemm_amd.build` (needs hipcc, cross-compiles gfx950 without a GPU).')
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(handle, name)     # AttributeError here means the header and the library disagree
+        fn.restype, fn.argtypes = restype, argtypes
+    return handle
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(lib.dg_last_error().decode() or f'deepgemm_amd call failed with code {rc}')
+
+
+def current_stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('deepgemm_amd: operands must live on the GPU (there is no CPU path); '
+                               f'got a tensor on {t.device}')

@@ -1,0 +1,37 @@
+"""Ahead-of-time build of the HIP extension (`libdeepgemm_amd.so`) for gfx950.
+
+There is no JIT: the reference's NVCC/NVRTC runtime (csrc/jit/) is replaced by one `hipcc` invocation whose output is
+kept in-tree next to the sources, so that it travels with the repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libdeepgemm_amd.so')
+SOURCES = ['dg_api.hip']
+HEADERS = ['fp8_gemm_kernels.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > built for f in SOURCES + HEADERS)
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    if force or is_stale():
+        tmp = LIB_PATH + f'.{os.getpid()}.tmp'
+        cmd = [HIPCC, *FLAGS, *SOURCES, '-o', tmp]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build_extension(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,310 @@
+// Host side of the C ABI declared in include/deepgemm_amd.h: argument checks, tile-configuration heuristics
+// (the analogue of get_best_config, reference csrc/jit_kernels/heuristics/common.hpp:14-52, re-derived for 256 CUs /
+// 160 KiB LDS / wave64) and kernel launches.  Kernels are compiled ahead of time for gfx950; there is no JIT.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/deepgemm_amd.h"
+#include "fp8_gemm_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local std::string g_forced_config = "auto";
+thread_local std::string g_last_config = "";
+int g_num_cus_override = 0;
+
+int fail(const char* file, int line, const char* what) {
+    g_last_error = std::string("Assertion error (") + file + ":" + std::to_string(line) + "): " + what;
+    return 1;
+}
+
+#define DG_CHECK(cond)                                 \
+    do {                                               \
+        if (!(cond))                                   \
+            return fail(__FILE__, __LINE__, #cond);    \
+    } while (0)
+
+#define DG_HIP_CHECK(expr)                                                                  \
+    do {                                                                                    \
+        const hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                             \
+            g_last_error = std::string("HIP error (" __FILE__ ":") + std::to_string(__LINE__) + \
+                           "): " + hipGetErrorString(e_);                                   \
+            return 2;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+int device_cu_count() {
+    static int cached = -1;
+    if (cached < 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = cus;
+        else
+            cached = 256;   // MI355X; only reached when no device is visible (host-only unit tests)
+    }
+    return cached;
+}
+
+int num_cus() { return g_num_cus_override > 0 ? g_num_cus_override : device_cu_count(); }
+
+using KernelFn = void (*)(const dg::GemmParams);
+
+struct Config {
+    const char* name;
+    int bm, bn, threads;
+    int blocks_per_cu;      // residency by LDS (2 stages x (bm + bn) x 128 B of 160 KiB) and registers
+    float efficiency;       // relative MFMA efficiency of the tile shape (heuristic weight, refined by measurement)
+    bool fast;
+    KernelFn fn;
+};
+
+const Config kConfigs[] = {
+    {"fast_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4>},
+    {"fast_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_fast_kernel<128, 256, 2, 4>},
+    {"fast_128x128", 128, 128, 256, 2, 0.70f, true, dg::dg_fp8_gemm_fast_kernel<128, 128, 2, 2>},
+    {"fast_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_fast_kernel<64, 256, 1, 4>},
+    {"fast_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_fast_kernel<32, 256, 1, 4>},
+    {"fast_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_fast_kernel<16, 256, 1, 4>},
+    {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
+
+bool fast_eligible(const dg::GemmParams& p) {
+    if (p.sfb_gran_n != 128 || p.a_sk != 1 || p.b_sk != 1 || p.k % 128 != 0)
+        return false;
+    if (!aligned16(p.a) || !aligned16(p.b) || p.a_sm % 16 || p.b_sn % 16 || p.a_sg % 16 || p.b_sg % 16)
+        return false;
+    // The LDS-DMA source offsets are 32-bit: one tile's rows must stay within 2 GiB of its base.
+    if (p.a_sm > (1 << 22) || p.b_sn > (1 << 22))
+        return false;
+    return true;
+}
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
+const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expected_m, int bm_must_divide) {
+    if (g_forced_config != "auto") {
+        for (int i = 0; i < kNumConfigs; ++i)
+            if (g_forced_config == kConfigs[i].name)
+                return &kConfigs[i];
+        return nullptr;
+    }
+    const bool fast_ok = fast_eligible(p);
+    const Config* best = nullptr;
+    double best_cost = 0;
+    for (int i = 0; i < kNumConfigs; ++i) {
+        const Config& c = kConfigs[i];
+        if (c.fast && !fast_ok)
+            continue;
+        if (bm_must_divide > 0 && bm_must_divide % c.bm != 0)
+            continue;
+        const int m_eff = expected_m > 0 ? expected_m : m_for_tiling;
+        const int groups = (p.gemm_type == dg::kMasked) ? p.num_groups : 1;
+        const long tiles = static_cast<long>(groups) * ceil_div(m_eff, c.bm) * ceil_div(p.n, c.bn);
+        const long slots = static_cast<long>(num_cus()) * c.blocks_per_cu;
+        const long rounds = (tiles + slots - 1) / slots;
+        // A round costs the work of blocks_per_cu co-resident tiles per CU; tiny tiles are HBM/latency dominated.
+        const double tile_work = static_cast<double>(c.bm) * c.bn / c.efficiency + 4096.0;
+        const double cost = static_cast<double>(rounds) * c.blocks_per_cu * tile_work;
+        if (best == nullptr || cost < best_cost) {
+            best = &c;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
+    const int bm_must_divide =
+        (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) ? p.m_alignment : 0;
+    const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide);
+    if (cfg == nullptr) {
+        g_last_error = "no kernel configuration available (forced config '" + g_forced_config + "')";
+        return 3;
+    }
+    if (cfg->fast && !fast_eligible(p)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs K-major 16-byte aligned operands and k % 128 == 0";
+        return 3;
+    }
+    if (bm_must_divide > 0 && bm_must_divide % cfg->bm != 0) {
+        g_last_error = std::string("config '") + cfg->name + "' does not divide the contiguous-layout M alignment";
+        return 3;
+    }
+    g_last_config = cfg->name;
+    p.num_m_tiles = ceil_div(p.m, cfg->bm);
+    p.num_n_tiles = ceil_div(p.n, cfg->bn);
+    // L2 grouping: with 8 XCDs each chunk of tiles should be a compact rectangle (see swizzled_tile).
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
+    p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
+
+    long grid;
+    const long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
+    if (p.gemm_type == dg::kMasked) {
+        const long slots = static_cast<long>(num_cus()) * cfg->blocks_per_cu;
+        const long max_tiles = total * p.num_groups;
+        grid = max_tiles < slots ? max_tiles : slots;
+    } else {
+        grid = total;
+    }
+    if (grid <= 0)
+        return 0;
+    if (grid > 0x7fffffffL)
+        return fail(__FILE__, __LINE__, "grid too large");
+    hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0,
+                       static_cast<hipStream_t>(stream), p);
+    DG_HIP_CHECK(hipGetLastError());
+    if (getenv("DG_PRINT_CONFIGS") != nullptr)
+        fprintf(stderr, "[deepgemm_amd] type=%d m=%d n=%d k=%d groups=%d -> %s grid=%ld\n", p.gemm_type, p.m, p.n, p.k,
+                p.num_groups, cfg->name, grid);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                   int m, int n, int k,
+                   int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                   int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                   int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
+    DG_CHECK(m >= 0 && n >= 0 && k >= 0);
+    if (m == 0 || n == 0)
+        return 0;
+    DG_CHECK(k > 0);   // k == 0 is resolved by the caller (D = C or 0) without a kernel, as in the reference
+    DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr);
+    DG_CHECK(a_stride_m == 1 || a_stride_k == 1);
+    DG_CHECK(b_stride_n == 1 || b_stride_k == 1);
+    DG_CHECK(sfb_gran_n == 1 || sfb_gran_n == 128);
+    DG_CHECK(d_dtype == DG_BF16 || d_dtype == DG_FP32);
+    DG_CHECK(d_stride_m >= n);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.sfa = sfa; p.b = static_cast<const uint8_t*>(b); p.sfb = sfb; p.d = d;
+    p.layout = nullptr;
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = a_stride_m; p.a_sk = a_stride_k; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+    p.d_sm = d_stride_m;
+    p.sfb_gran_n = sfb_gran_n; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
+    p.gemm_type = dg::kNormal; p.m_alignment = 0;
+    return launch_gemm(p, 0, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                        const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                        int64_t a_stride_m, int64_t a_stride_k,
+                                        int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                        int64_t sfa_stride_m, int64_t sfa_stride_k,
+                                        int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                        int64_t d_stride_m, int use_psum, int m_alignment, void* stream) {
+    DG_CHECK(m >= 0 && n > 0 && k > 0 && num_groups > 0);
+    if (m == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr && grouped_layout != nullptr);
+    DG_CHECK(a_stride_k == 1);                          // reference gemm.hpp:181: A must be K-major
+    DG_CHECK(b_stride_n == 1 || b_stride_k == 1);
+    DG_CHECK(m_alignment > 0 && m_alignment % 16 == 0);
+    DG_CHECK(d_stride_m >= n);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.sfa = sfa; p.b = static_cast<const uint8_t*>(b); p.sfb = sfb; p.d = d;
+    p.layout = grouped_layout;
+    p.m = m; p.n = n; p.k = k; p.num_groups = num_groups;
+    p.a_sm = a_stride_m; p.a_sk = a_stride_k;
+    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k;
+    p.sfb_sg = sfb_stride_g; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+    p.d_sm = d_stride_m;
+    p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
+    p.gemm_type = use_psum ? dg::kContiguousPsum : dg::kContiguous;
+    p.m_alignment = m_alignment;
+    return launch_gemm(p, 0, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                    const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
+                                    int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                    int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                    int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_k,
+                                    int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                    int64_t d_stride_g, int64_t d_stride_m, void* stream) {
+    DG_CHECK(expected_m > 0 && m_max > 0 && n > 0 && k > 0 && num_groups > 0);   // reference gemm.hpp:274
+    DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr && masked_m != nullptr);
+    DG_CHECK(a_stride_k == 1 && b_stride_k == 1);       // reference gemm.hpp:263
+    DG_CHECK(d_stride_m >= n);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.sfa = sfa; p.b = static_cast<const uint8_t*>(b); p.sfb = sfb; p.d = d;
+    p.layout = masked_m;
+    p.m = m_max; p.n = n; p.k = k; p.num_groups = num_groups;
+    p.a_sg = a_stride_g; p.a_sm = a_stride_m; p.a_sk = a_stride_k;
+    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sg = sfa_stride_g; p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k;
+    p.sfb_sg = sfb_stride_g; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+    p.d_sg = d_stride_g; p.d_sm = d_stride_m;
+    p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
+    p.gemm_type = dg::kMasked; p.m_alignment = 0;
+    return launch_gemm(p, expected_m < m_max ? expected_m : m_max, stream);
+}
+
+int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream) {
+    DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
+    if (batches == 0 || mn == 0 || sf_k == 0)
+        return 0;
+    DG_CHECK(sf != nullptr && out != nullptr);
+    DG_CHECK(batches <= 65535);
+    const int aligned_mn = (mn + 3) / 4 * 4;
+    const dim3 grid((mn + 63) / 64, (sf_k + 63) / 64, batches);
+    hipLaunchKernelGGL(dg::dg_transpose_sf_fp32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       sf, out, mn, sf_k, aligned_mn);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int dg_set_num_cus(int n) {
+    if (n < 0)
+        return fail(__FILE__, __LINE__, "num_cus >= 0");
+    g_num_cus_override = n;
+    return 0;
+}
+
+int dg_get_num_cus(void) { return num_cus(); }
+
+int dg_set_forced_config(const char* name) {
+    if (name == nullptr)
+        return fail(__FILE__, __LINE__, "name != nullptr");
+    if (std::strcmp(name, "auto") != 0) {
+        bool known = false;
+        for (int i = 0; i < kNumConfigs; ++i)
+            known = known || std::strcmp(name, kConfigs[i].name) == 0;
+        if (!known) {
+            g_last_error = std::string("unknown kernel configuration '") + name + "'";
+            return 1;
+        }
+    }
+    g_forced_config = name;
+    return 0;
+}
+
+const char* dg_list_configs(void) {
+    static std::string joined;
+    if (joined.empty())
+        for (int i = 0; i < kNumConfigs; ++i)
+            joined += std::string(i ? "," : "") + kConfigs[i].name;
+    return joined.c_str();
+}
+
+const char* dg_last_config(void) { return g_last_config.c_str(); }
+const char* dg_last_error(void) { return g_last_error.c_str(); }
+const char* dg_version(void) { return "deepgemm_amd 0.1.0 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,595 @@
+// CDNA4 (gfx950) device code of the FP8 blockwise-scaled GEMM path.
+//
+// What it computes (reference semantics: deep_gemm/include/deep_gemm/impls/sm90_fp8_gemm_1d2d.cuh:283-347,416-418):
+//   D[m,n] = cast( sum_kb (sfa[m,kb] * sfb[n/128,kb]) * (sum_{k in 128-block kb} A[m,k] * B[n,k]) )
+// How it is built for MI355X (nothing here mirrors the reference's TMA/WGMMA structure):
+//   * one v_mfma_f32_16x16x128_f8f6f4 consumes exactly one 128-K scale block of a 16x16 output tile, so the FP32
+//     promotion is `acc += (sfa*sfb) * mfma(...)` with a zero C operand -- 4 VALU FMAs per 32-cycle MFMA;
+//   * operand roles are swapped (B rows feed the MFMA's A slot, A rows its B slot) so that in the C/D register map
+//     (col = lane & 15, row = 4 * (lane >> 4) + reg) every lane owns ONE m: one SFA value per lane per 16-row subtile,
+//     SFB is wave-uniform;
+//   * LDS tiles are [row][128 B] with the 16-byte chunk index XOR-ed by (row & 7); lane (r, g) of a fragment reads
+//     chunks g and g+4 of row r (a K permutation shared by both operands, so the contraction is unchanged), which
+//     makes both ds_read_b128 of a fragment bank-conflict free;
+//   * the fast path fills LDS with global_load_lds_dwordx4 (LDS-DMA): 8 lanes cover one full 128-byte line of a row,
+//     the swizzle is applied on the per-lane SOURCE address (the LDS image of a wave instruction is lane-linear);
+//   * B-tile rows are stored permuted so that after the last K block every lane holds 4*NS consecutive n of one m
+//     (16-byte BF16 stores).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dg {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+enum GemmType : int { kNormal = 0, kContiguous = 1, kContiguousPsum = 2, kMasked = 3 };
+
+struct GemmParams {
+    const uint8_t* a;
+    const float* sfa;
+    const uint8_t* b;
+    const float* sfb;
+    void* d;
+    const int32_t* layout;          // grouped_layout (contiguous) or masked_m (masked)
+    int m, n, k, num_groups;        // masked: m = m_max (rows per group)
+    int64_t a_sg, a_sm, a_sk;       // strides in elements (= bytes for FP8)
+    int64_t b_sg, b_sn, b_sk;
+    int64_t sfa_sg, sfa_sm, sfa_sk;
+    int64_t sfb_sg, sfb_sn, sfb_sk;
+    int64_t d_sg, d_sm;
+    int sfb_gran_n;                 // 128 or 1
+    int d_dtype;                    // 0 bf16, 1 fp32
+    int accumulate;
+    int gemm_type;
+    int m_alignment;                // contiguous layouts
+    int num_m_tiles, num_n_tiles;   // per group
+    int group_m;                    // tile-order swizzle: m-tiles per L2 group
+    int d_vec_ok;                   // 16-byte aligned D rows => vector stores
+};
+
+struct Tile {
+    int m0, n0;       // first row (within the group's A/D for masked, global otherwise) / first column
+    int group;        // B / SFB group (masked: also A / SFA / D group)
+    int m_end;        // rows >= m_end are not computed from A (clamped loads)
+    int zero_from;    // rows in [zero_from, m0 + BM) are stored as zeros; rows in [m_end, zero_from) are skipped
+    bool valid;
+};
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// Block b runs on XCD b % 8 (observed, speed only): give each XCD a contiguous chunk of the tile order, then walk
+// the tiles in groups of `group_m` m-tiles so that a chunk is a compact rectangle sharing A and B panels in its L2.
+__device__ __forceinline__ void swizzled_tile(int bid, int nwg, int num_m_tiles, int num_n_tiles, int group_m,
+                                              int& mt, int& nt) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = group_m * num_n_tiles;
+    const int grp = lin / per_group, in_grp = lin - grp * per_group;
+    const int first_m = grp * group_m;
+    const int h = imin(num_m_tiles - first_m, group_m);
+    mt = first_m + in_grp % h;
+    nt = in_grp / h;
+}
+
+// Maps a linear tile id to a tile for every GEMM type (reference scheduler semantics:
+// deep_gemm/include/deep_gemm/scheduler/gemm.cuh:156-237, :311-319).  `state` carries the masked-layout walk.
+struct MaskedWalk { int group = 0; int cum_m_tiles = 0; };
+
+template <int BM, int BN>
+__device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, MaskedWalk& walk) {
+    Tile t;
+    t.valid = true;
+    if (p.gemm_type == kMasked) {
+        // Persistent walk over groups; masked_m lives on the device (README: the CPU never learns the counts).
+        int nmt;
+        while (true) {
+            if (walk.group >= p.num_groups) { t.valid = false; return t; }
+            nmt = (imin(p.layout[walk.group], p.m) + BM - 1) / BM;
+            if (tile_id < (walk.cum_m_tiles + nmt) * p.num_n_tiles)
+                break;
+            walk.cum_m_tiles += nmt;
+            ++walk.group;
+        }
+        const int local = tile_id - walk.cum_m_tiles * p.num_n_tiles;
+        const int nt = local / nmt, mt = local - nt * nmt;     // m fastest: the tiles sharing a B panel run together
+        t.group = walk.group;
+        t.m0 = mt * BM;
+        t.n0 = nt * BN;
+        t.m_end = imin(p.layout[walk.group], p.m);
+        t.zero_from = t.m0 + BM;
+        return t;
+    }
+    const int num_tiles = p.num_m_tiles * p.num_n_tiles;
+    if (tile_id >= num_tiles) { t.valid = false; return t; }
+    int mt, nt;
+    swizzled_tile(tile_id, num_tiles, p.num_m_tiles, p.num_n_tiles, p.group_m, mt, nt);
+    t.m0 = mt * BM;
+    t.n0 = nt * BN;
+    t.group = 0;
+    t.m_end = p.m;
+    t.zero_from = t.m0 + BM;
+    if (p.gemm_type == kContiguous) {
+        const int g = p.layout[t.m0];
+        if (g < 0) { t.m_end = t.m0; t.zero_from = t.m0; }
+        t.group = imax(g, 0);
+    } else if (p.gemm_type == kContiguousPsum) {
+        // Group g owns rows [align(end[g-1], alignment), end[g]); the gap up to the next aligned start is zero-filled.
+        int start = 0;
+        t.m_end = t.m0;                                    // rows past the last group: left untouched
+        for (int g = 0; g < p.num_groups; ++g) {
+            const int end = p.layout[g];
+            const int next = (end + p.m_alignment - 1) / p.m_alignment * p.m_alignment;
+            if (t.m0 >= start && t.m0 < next) {
+                t.group = g;
+                t.m_end = imax(imin(end, p.m), t.m0);
+                t.zero_from = t.m_end;
+                break;
+            }
+            start = next;
+        }
+    }
+    return t;
+}
+
+__device__ __forceinline__ v4f mfma_fp8_k128(const v8i& rows_operand, const v8i& cols_operand) {
+    // Zero scale operands select the unscaled encoding (v_mfma_f32_16x16x128_f8f6f4, cbsz = blgp = 0 => e4m3 x e4m3).
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(rows_operand, cols_operand, zero, 0, 0, 0, 0, 0, 0);
+}
+
+// LDS tile geometry shared by every kernel: row r of a tile occupies bytes [r*128, r*128+128); logical 16-byte chunk c
+// of that row is stored at chunk position c ^ (r & 7).
+__device__ __forceinline__ int lds_chunk_offset(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// Fragment of 16 rows starting at `tile_rows` (row index multiple of 16): lane (r = lane & 15, g = lane >> 4) gets the
+// 32 bytes {chunk g, chunk g + 4} of row r.
+__device__ __forceinline__ v8i load_fragment(const uint8_t* tile_rows, int frag_off) {
+    const v4i lo = *reinterpret_cast<const v4i*>(tile_rows + frag_off);
+    const v4i hi = *reinterpret_cast<const v4i*>(tile_rows + (frag_off ^ 64));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// B-tile row permutation: LDS row position p (within the BN-row tile) holds global column n0 + perm(p), chosen so that
+// the MFMA row slot i = 4 * lg + r of N-subtile ns lands on column wave_n0 + lg * 4 * NS + ns * 4 + r.
+template <int WN>
+__device__ __forceinline__ int b_row_perm(int p) {
+    constexpr int NS = WN / 16;
+    const int w = p / WN, q = p % WN, ns = q >> 4, i = q & 15;
+    return w * WN + (i >> 2) * (4 * NS) + ns * 4 + (i & 3);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 v;
+    v[0] = static_cast<__bf16>(lo);
+    v[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ __forceinline__ float round_bf16(float x) { return bf16_lo(pack_bf16(x, 0.f)); }
+
+// Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
+// accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
+template <int MS, int NS>
+__device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
+                                           int m_base, int n_base) {
+    const int lane = threadIdx.x & 63, lg = lane >> 4;
+    const int n_lane = n_base + lg * (4 * NS);
+    const bool full_n = (n_lane + 4 * NS <= p.n);
+    #pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        const int row = m_base + ms * 16 + (lane & 15);
+        const bool compute_row = row < t.m_end;
+        const bool zero_row = row >= t.zero_from;
+        if (!compute_row && !zero_row)
+            continue;
+        if (p.d_dtype == 0) {
+            uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+            if (full_n && p.d_vec_ok) {
+                #pragma unroll
+                for (int h = 0; h < NS / 2; ++h) {
+                    uint32_t w[4];
+                    #pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const v4f v = acc[ms][2 * h + j];
+                        w[2 * j] = zero_row ? 0u : pack_bf16(v[0], v[1]);
+                        w[2 * j + 1] = zero_row ? 0u : pack_bf16(v[2], v[3]);
+                    }
+                    uint4* dst = reinterpret_cast<uint4*>(drow + n_lane + h * 8);
+                    if (p.accumulate && !zero_row) {
+                        const uint4 old = *dst;
+                        const uint32_t o[4] = {old.x, old.y, old.z, old.w};
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            w[j] = pack_bf16(bf16_lo(o[j]) + bf16_lo(w[j]), bf16_hi(o[j]) + bf16_hi(w[j]));
+                    }
+                    *dst = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            } else {
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = n_lane + ns * 4 + r;
+                        if (col < p.n) {
+                            float v = zero_row ? 0.f : round_bf16(acc[ms][ns][r]);
+                            if (p.accumulate && !zero_row)
+                                v = v + bf16_lo(static_cast<uint32_t>(drow[col]));
+                            drow[col] = static_cast<uint16_t>(pack_bf16(v, 0.f) & 0xffffu);
+                        }
+                    }
+            }
+        } else {
+            float* drow = reinterpret_cast<float*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                v4f v = acc[ms][ns];
+                if (zero_row) v = v4f{0.f, 0.f, 0.f, 0.f};
+                const int col = n_lane + ns * 4;
+                if (full_n && p.d_vec_ok) {
+                    v4f* dst = reinterpret_cast<v4f*>(drow + col);
+                    if (p.accumulate && !zero_row) v += *dst;
+                    *dst = v;
+                } else {
+                    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < p.n)
+                            drow[col + r] = (p.accumulate && !zero_row) ? drow[col + r] + v[r] : v[r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path: K-major A and B, K % 128 == 0, 16-byte aligned rows.  LDS-DMA double buffer, one barrier per K block.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_fast_kernel(const GemmParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_UNITS = BM / 8, B_UNITS = BN / 8;                  // 1 KiB LDS-DMA pieces (8 rows x 128 B)
+    constexpr int A_ITERS = (A_UNITS + NW - 1) / NW, B_ITERS = (B_UNITS + NW - 1) / NW;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && NS % 2 == 0, "wave tile must be a multiple of 16 x 32");
+    static_assert(128 % WN == 0 || WN % 128 == 0, "a wave must not straddle an SFB block unevenly");
+    static_assert(WN <= 128, "one SFB value per wave");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+
+    // Per-lane constants of the LDS-DMA source pattern: lane -> (row lane >> 3 of the piece, stored chunk lane & 7).
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    // Fragment read offsets.
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int m_clamp = t.m_end - 1 - t.m0;               // last loadable local row
+            const int n_clamp = p.n - 1 - t.n0;
+
+            int a_off[A_ITERS], b_off[B_ITERS];
+            #pragma unroll
+            for (int j = 0; j < A_ITERS; ++j) {
+                const int row = imin((wave + NW * j) * 8 + piece_row, m_clamp);
+                a_off[j] = row * static_cast<int>(p.a_sm) + src_chunk * 16;
+            }
+            #pragma unroll
+            for (int j = 0; j < B_ITERS; ++j) {
+                const int row = imin(b_row_perm<WN>((wave + NW * j) * 8 + piece_row), n_clamp);
+                b_off[j] = row * static_cast<int>(p.b_sn) + src_chunk * 16;
+            }
+
+            auto issue_stage = [&](int stage, int kb) {
+                uint8_t* stage_base = lds + stage * STAGE_BYTES;
+                const uint8_t* a_k = a_base + kb * 128;
+                const uint8_t* b_k = b_base + kb * 128;
+                #pragma unroll
+                for (int j = 0; j < A_ITERS; ++j) {
+                    const int unit = wave + NW * j;
+                    if (A_UNITS % NW == 0 || unit < A_UNITS)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(a_k + a_off[j]),
+                            (__attribute__((address_space(3))) void*)(stage_base + unit * 1024), 16, 0, 0);
+                }
+                #pragma unroll
+                for (int j = 0; j < B_ITERS; ++j) {
+                    const int unit = wave + NW * j;
+                    if (B_UNITS % NW == 0 || unit < B_UNITS)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(b_k + b_off[j]),
+                            (__attribute__((address_space(3))) void*)(stage_base + A_BYTES + unit * 1024), 16, 0, 0);
+                }
+            };
+
+            // Scale pointers: one SFA value per lane per M-subtile, one SFB value per wave.
+            const float* sfa_lane[MS];
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+                const int row = t.m0 + imin(wm * WM + ms * 16 + (lane & 15), m_clamp);
+                sfa_lane[ms] = p.sfa + ad_group * p.sfa_sg + static_cast<int64_t>(row) * p.sfa_sm;
+            }
+            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
+                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
+
+            float sa_cur[MS], sa_nxt[MS];
+            float sb_cur, sb_nxt = 0.f;
+            issue_stage(0, 0);
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                sa_cur[ms] = sfa_lane[ms][0];
+            sb_cur = sfb_wave[0];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const int cur = kb & 1;
+                if (kb + 1 < num_kb) {
+                    issue_stage(cur ^ 1, kb + 1);
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        sa_nxt[ms] = sfa_lane[ms][static_cast<int64_t>(kb + 1) * p.sfa_sk];
+                    sb_nxt = sfb_wave[static_cast<int64_t>(kb + 1) * p.sfb_sk];
+                }
+
+                const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
+                const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
+                v8i bf[NS];
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                    const float scale = sa_cur[ms] * sb_cur;
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        const v4f part = mfma_fp8_k128(bf[ns], af);
+                        acc[ms][ns] += scale * part;
+                    }
+                }
+
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    sa_cur[ms] = sa_nxt[ms];
+                sb_cur = sb_nxt;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+
+        store_tile<MS, NS>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic path: any operand majorness / alignment / K tail, both SFB granularities.  128 x 128 tile, 4 waves,
+// register-staged loads written into the same swizzled LDS image.  Correctness first.
+// ---------------------------------------------------------------------------------------------------------------
+// 16 consecutive elements along the unit-stride dimension starting at `src`; elements >= nvalid read as zero.
+__device__ __forceinline__ uint4 fetch16(const uint8_t* src, int nvalid) {
+    if (nvalid >= 16 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+        return *reinterpret_cast<const uint4*>(src);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int e = 0; e < 16; ++e)
+        if (e < nvalid)
+            w[e >> 2] |= static_cast<uint32_t>(src[e]) << ((e & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Loads one 128-row x 128-K operand tile into registers (4 x 16 bytes per thread of a 256-thread block).
+//   K-major  (stride_k == 1): item i -> row (tid + 256 i) / 8, chunk (tid + 256 i) % 8 (16 bytes along K)
+//   MN-major (stride_mn == 1): item i -> k (tid + 256 i) / 8, row-chunk (tid + 256 i) % 8 (16 rows at one k)
+struct StagedTile { uint4 v[4]; };
+
+__device__ __forceinline__ StagedTile stage_load(const uint8_t* base, int64_t stride_mn, int64_t stride_k,
+                                                 int rows_valid, int k_valid, bool permute_rows) {
+    StagedTile s;
+    const int tid = threadIdx.x;
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int item = tid + 256 * i;
+        if (stride_k == 1) {
+            const int p = item >> 3, chunk = item & 7;
+            const int row = permute_rows ? b_row_perm<64>(p) : p;
+            const int nvalid = row < rows_valid ? imin(imax(k_valid - chunk * 16, 0), 16) : 0;
+            s.v[i] = nvalid > 0 ? fetch16(base + static_cast<int64_t>(row) * stride_mn + chunk * 16, nvalid)
+                                : make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            const int kk = item >> 3, row0 = (item & 7) * 16;
+            const int nvalid = kk < k_valid ? imin(imax(rows_valid - row0, 0), 16) : 0;
+            s.v[i] = nvalid > 0 ? fetch16(base + static_cast<int64_t>(kk) * stride_k + row0, nvalid)
+                                : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    return s;
+}
+
+// inverse of b_row_perm<64> restricted to one 64-row wave range is not needed: MN-major loads write each byte to
+// the LDS row position whose permuted row equals the loaded row, found through a small search-free formula below.
+template <int WN>
+__device__ __forceinline__ int b_row_perm_inv(int n_local) {
+    constexpr int NS = WN / 16;
+    const int w = n_local / WN, q = n_local % WN;
+    const int hi = q / (4 * NS), rem = q % (4 * NS), ns = rem >> 2, lo = rem & 3;
+    return w * WN + ns * 16 + hi * 4 + lo;
+}
+
+__device__ __forceinline__ void stage_store(uint8_t* tile, const StagedTile& s, int64_t stride_k, bool permute_rows) {
+    const int tid = threadIdx.x;
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int item = tid + 256 * i;
+        if (stride_k == 1) {
+            const int p = item >> 3, chunk = item & 7;
+            *reinterpret_cast<uint4*>(tile + lds_chunk_offset(p, chunk)) = s.v[i];
+        } else {
+            const int kk = item >> 3, row0 = (item & 7) * 16;
+            const uint32_t w[4] = {s.v[i].x, s.v[i].y, s.v[i].z, s.v[i].w};
+            #pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + e;
+                const int p = permute_rows ? b_row_perm_inv<64>(row) : row;
+                tile[lds_chunk_offset(p, kk >> 4) + (kk & 15)] = static_cast<uint8_t>(w[e >> 2] >> ((e & 3) * 8));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void dg_fp8_gemm_generic_kernel(const GemmParams p) {
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MS = 4, NS = 4;
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 128 * 128];
+    uint8_t* a_lds = lds;
+    uint8_t* b_lds = lds + BM * 128;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lg = lane >> 4;
+    const int num_kb = (p.k + 127) / 128;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int rows_a = t.m_end - t.m0, rows_b = p.n - t.n0;
+
+            int sfa_row[MS];
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                sfa_row[ms] = t.m0 + imin(wm * WM + ms * 16 + (lane & 15), rows_a - 1);
+            const float* sfa_g = p.sfa + ad_group * p.sfa_sg;
+            const float* sfb_g = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg;
+
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const int k_valid = imin(p.k - kb * 128, 128);
+                const StagedTile sa = stage_load(a_base + static_cast<int64_t>(kb) * 128 * p.a_sk, p.a_sm, p.a_sk,
+                                                 rows_a, k_valid, false);
+                const StagedTile sb = stage_load(b_base + static_cast<int64_t>(kb) * 128 * p.b_sk, p.b_sn, p.b_sk,
+                                                 rows_b, k_valid, p.b_sk == 1);
+                __syncthreads();                     // previous K block's fragments are consumed
+                stage_store(a_lds, sa, p.a_sk, false);
+                stage_store(b_lds, sb, p.b_sk, true);
+                __syncthreads();
+
+                float sa_v[MS];
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    sa_v[ms] = sfa_g[static_cast<int64_t>(sfa_row[ms]) * p.sfa_sm + static_cast<int64_t>(kb) * p.sfa_sk];
+
+                const uint8_t* a_tile = a_lds + (wm * WM) * 128;
+                const uint8_t* b_tile = b_lds + (wn * WN) * 128;
+                v8i bf[NS];
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+
+                if (p.sfb_gran_n == 128) {
+                    const float sb_v = sfb_g[static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn +
+                                             static_cast<int64_t>(kb) * p.sfb_sk];
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                        const float scale = sa_v[ms] * sb_v;
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            acc[ms][ns] += scale * mfma_fp8_k128(bf[ns], af);
+                    }
+                } else {
+                    // Per-column SFB (recipe (1,1,128)): reference sm90_fp8_gemm_1d1d.cuh:303-311.
+                    float sb_n[NS][4];
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = imin(t.n0 + wn * WN + lg * (4 * NS) + ns * 4 + r, p.n - 1);
+                            sb_n[ns][r] = sfb_g[static_cast<int64_t>(col) * p.sfb_sn + static_cast<int64_t>(kb) * p.sfb_sk];
+                        }
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns) {
+                            const v4f part = mfma_fp8_k128(bf[ns], af);
+                            #pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[ms][ns][r] += (sa_v[ms] * sb_n[ns][r]) * part[r];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        store_tile<MS, NS>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+    }
+}
+
+// SF layout kernel: [batches, mn, sf_k] row-major FP32 -> MN-major with mn padded to a multiple of 4 floats
+// (semantics of transpose_fp32, deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:12-50).  One block moves a
+// 64 (mn) x 64 (sf_k) patch through LDS so that both the read (along sf_k) and the write (along mn) are coalesced.
+__global__ __launch_bounds__(256)
+void dg_transpose_sf_fp32_kernel(const float* __restrict__ sf, float* __restrict__ out, int mn, int sf_k, int aligned_mn) {
+    __shared__ float patch[64][65];
+    const int batch = blockIdx.z;
+    const int mn0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const float* src = sf + static_cast<int64_t>(batch) * mn * sf_k;
+    float* dst = out + static_cast<int64_t>(batch) * aligned_mn * sf_k;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int row = mn0 + i, col = k0 + tx;
+        if (row < mn && col < sf_k)
+            patch[i][tx] = src[static_cast<int64_t>(row) * sf_k + col];
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int col = k0 + j, row = mn0 + tx;
+        if (row < mn && col < sf_k)
+            dst[static_cast<int64_t>(col) * aligned_mn + row] = patch[tx][j];
+    }
+}
+
+}  // namespace dg

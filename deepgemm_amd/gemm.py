@@ -1,0 +1,165 @@
+"""The FP8 GEMM operator surface (host side): validation, trivial cases, SF layout step, C-ABI call.
+
+Signatures, keyword names/defaults, assertion order and in-place semantics follow the reference's API layer
+(``csrc/apis/gemm.hpp:19-297`` and the ``m.def`` table at ``:645-717``).  Differences, all supersets:
+  * MN-major FP8 operands, ``c`` accumulation and FP32 outputs are accepted for every dense layout (the reference only
+    accepts them on SM100);
+  * ``compiled_dims`` and ``disable_ue8m0_cast`` are accepted and do not affect results (there is no JIT and scales are
+    consumed as FP32).
+Every call is asynchronous on the current torch stream and never synchronises.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import lib, check, current_stream_ptr, require_device
+from .errors import host_assert
+from .layout import check_major_type_cd, is_k_major, major_check, transform_sf_pair_into_required_layout
+from . import runtime
+
+_BF16, _FP32 = 0, 1
+TensorPair = Tuple[torch.Tensor, torch.Tensor]
+
+
+def _check_ab_fp8(t: torch.Tensor, dims: int):
+    host_assert(t.dim() == dims, f't.dim() == {dims}')
+    host_assert(t.dtype == torch.float8_e4m3fn, 'ab.scalar_type() == torch::kFloat8_e4m3fn')
+    return tuple(int(s) for s in t.shape)
+
+
+def _dtype_code(d: torch.Tensor) -> int:
+    return _BF16 if d.dtype == torch.bfloat16 else _FP32
+
+
+def _early_return(m: int, n: int, k: int, d: torch.Tensor, c: Optional[torch.Tensor]) -> bool:
+    """csrc/apis/gemm.hpp:19-46."""
+    if m == 0 or n == 0:
+        return True
+    is_cd_same = c is not None and c.data_ptr() == d.data_ptr()
+    if is_cd_same:
+        host_assert(c.shape == d.shape and c.stride() == d.stride(), 'c->sizes() == d.sizes() and c->strides() == d.strides()')
+    host_assert(d.dtype in (torch.bfloat16, torch.float), 'd.scalar_type() == torch::kBFloat16 or d.scalar_type() == torch::kFloat')
+    if c is not None:
+        check_major_type_cd(c)
+        host_assert(d.dtype == c.dtype, 'd.scalar_type() == c.value().scalar_type()')
+    if k == 0:
+        if not is_cd_same:
+            d.copy_(c) if c is not None else d.zero_()
+        return True
+    if c is not None and not is_cd_same:
+        d.copy_(c)
+    return False
+
+
+def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch.Tensor] = None,
+                recipe: Optional[Tuple[int, int, int]] = None, recipe_a: Optional[Tuple[int, int]] = None,
+                recipe_b: Optional[Tuple[int, int]] = None, compiled_dims: str = 'nk',
+                disable_ue8m0_cast: bool = False) -> None:
+    """D = C + A @ B^T with per-128-block FP32 scales; ``a = (A_fp8 [M,K], SFA)``, ``b = (B_fp8 [N,K], SFB)``."""
+    (a_data, a_sf), (b_data, b_sf) = a, b
+    major_check(a_data), major_check(b_data)
+    check_major_type_cd(d)
+    m, k = _check_ab_fp8(a_data, 2)
+    n, k_ = _check_ab_fp8(b_data, 2)
+    host_assert(d.dim() == 2, 'd.dim() == 2')
+    host_assert((m, n) == tuple(d.shape) and k == k_, 'm == m_ and n == n_ and k == k_')
+    host_assert(d.dtype in (torch.bfloat16, torch.float), 'd.scalar_type() == torch::kBFloat16 or d.scalar_type() == torch::kFloat')
+    if _early_return(m, n, k, d, c):
+        return
+    sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
+                                                              None, None, disable_ue8m0_cast)
+    require_device(a_data, b_data, sfa, sfb, d)
+    check(lib.dg_fp8_gemm_nt(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
+        a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
+        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), gran_n,
+        d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
+
+
+def fp8_gemm_nn(a, b, d, c=None, recipe=None, recipe_a=None, recipe_b=None, compiled_dims='nk', disable_ue8m0_cast=False) -> None:
+    """``b = (B [K,N], SFB [K/128, N/128])``: a transposed view of NT (csrc/apis/gemm.hpp:126-137)."""
+    fp8_gemm_nt(a, (b[0].transpose(0, 1), b[1].transpose(0, 1)), d, c, recipe, recipe_a, recipe_b, compiled_dims, disable_ue8m0_cast)
+
+
+def fp8_gemm_tn(a, b, d, c=None, recipe=None, recipe_a=None, recipe_b=None, compiled_dims='mn', disable_ue8m0_cast=False) -> None:
+    fp8_gemm_nt((a[0].transpose(0, 1), a[1].transpose(0, 1)), (b[0].transpose(0, 1), b[1].transpose(0, 1)),
+                d, c, recipe, recipe_a, recipe_b, compiled_dims, disable_ue8m0_cast)
+
+
+def fp8_gemm_tt(a, b, d, c=None, recipe=None, recipe_a=None, recipe_b=None, compiled_dims='mn', disable_ue8m0_cast=False) -> None:
+    fp8_gemm_nt((a[0].transpose(0, 1), a[1].transpose(0, 1)), b, d, c, recipe, recipe_a, recipe_b, compiled_dims, disable_ue8m0_cast)
+
+
+def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, grouped_layout: torch.Tensor,
+                                     recipe=None, recipe_a=None, recipe_b=None, compiled_dims: str = 'nk',
+                                     disable_ue8m0_cast: bool = False, use_psum_layout: bool = False,
+                                     ensure_zero_padding: bool = True,
+                                     expected_m_for_psum_layout: Optional[int] = None) -> None:
+    """Rows of ``a [M,K]`` are grouped contiguously (each group padded to the M alignment); ``b [G,N,K]``."""
+    (a_data, a_sf), (b_data, b_sf) = a, b
+    host_assert(is_k_major(a_data), 'major_a == cute::UMMA::Major::K')
+    major_check(b_data)
+    host_assert(grouped_layout.is_contiguous(), 'grouped_layout.is_contiguous()')
+    m, k = _check_ab_fp8(a_data, 2)
+    num_groups, n, k_ = _check_ab_fp8(b_data, 3)
+    host_assert(d.dim() == 2, 'd.dim() == 2')
+    host_assert((m, n) == tuple(d.shape) and k == k_, 'm == m_ and n == n_ and k == k_')
+    host_assert(n > 0 and k > 0 and num_groups > 0, 'n > 0 and k > 0 and num_groups > 0')
+    host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
+    host_assert(grouped_layout.dtype == torch.int, 'grouped_layout.scalar_type() == torch::kInt')
+    host_assert(grouped_layout.dim() == 1, 'grouped_layout.dim() == 1')
+    if use_psum_layout:
+        host_assert(grouped_layout.numel() == num_groups, 'num_groups == num_groups_')
+    else:
+        host_assert(grouped_layout.numel() == m, 'm == m__')
+        host_assert(expected_m_for_psum_layout is None, 'not expected_m_for_psum_layout.has_value()')
+    check_major_type_cd(d)
+    if m == 0:
+        return
+    sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
+                                                         None, num_groups, disable_ue8m0_cast)
+    require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
+    check(lib.dg_m_grouped_fp8_gemm_nt_contiguous(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
+        num_groups, m, n, k, a_data.stride(0), a_data.stride(1),
+        b_data.stride(0), b_data.stride(1), b_data.stride(2), sfa.stride(0), sfa.stride(1),
+        sfb.stride(0), sfb.stride(1), sfb.stride(2), d.stride(0), int(use_psum_layout),
+        runtime.get_mk_alignment_for_contiguous_layout(), current_stream_ptr()))
+
+
+def m_grouped_fp8_gemm_nn_contiguous(a, b, d, grouped_layout, recipe=None, recipe_a=None, recipe_b=None,
+                                     compiled_dims='nk', disable_ue8m0_cast=False, use_psum_layout=False,
+                                     ensure_zero_padding=True) -> None:
+    """``b = (B [G,K,N], SFB [G,K/128,N/128])`` (csrc/apis/gemm.hpp:234-248)."""
+    m_grouped_fp8_gemm_nt_contiguous(a, (b[0].transpose(1, 2), b[1].transpose(1, 2)), d, grouped_layout, recipe, recipe_a,
+                                     recipe_b, compiled_dims, disable_ue8m0_cast, use_psum_layout, ensure_zero_padding, None)
+
+
+def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, masked_m: torch.Tensor, expected_m: int,
+                                 recipe=None, recipe_a=None, recipe_b=None, compiled_dims: str = 'nk',
+                                 disable_ue8m0_cast: bool = False) -> None:
+    """``a [G,M,K]``, ``b [G,N,K]``, ``d [G,M,N]``; only ``d[g, :masked_m[g]]`` is written; ``masked_m`` stays on
+    the device, ``expected_m`` is a tuning hint."""
+    (a_data, a_sf), (b_data, b_sf) = a, b
+    host_assert(is_k_major(a_data) and is_k_major(b_data), 'major_a == cute::UMMA::Major::K and major_b == cute::UMMA::Major::K')
+    host_assert(masked_m.is_contiguous(), 'masked_m.is_contiguous()')
+    num_groups, m, k = _check_ab_fp8(a_data, 3)
+    num_groups_, n, k_ = _check_ab_fp8(b_data, 3)
+    host_assert(d.dim() == 3, 'd.dim() == 3')
+    host_assert(num_groups == num_groups_ == d.size(0) == masked_m.numel(),
+                'num_groups == num_groups_ and num_groups == num_groups__ and num_groups == num_groups___')
+    host_assert((m, n) == tuple(d.shape[1:]) and k == k_, 'm == m_ and n == n_ and k == k_')
+    host_assert(expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0,
+                'expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0')
+    host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
+    host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
+    check_major_type_cd(d)
+    sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
+                                                         num_groups, num_groups, disable_ue8m0_cast)
+    require_device(a_data, b_data, sfa, sfb, d, masked_m)
+    check(lib.dg_m_grouped_fp8_gemm_nt_masked(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), masked_m.data_ptr(),
+        num_groups, m, n, k, int(expected_m),
+        a_data.stride(0), a_data.stride(1), a_data.stride(2), b_data.stride(0), b_data.stride(1), b_data.stride(2),
+        sfa.stride(0), sfa.stride(1), sfa.stride(2), sfb.stride(0), sfb.stride(1), sfb.stride(2),
+        d.stride(0), d.stride(1), current_stream_ptr()))

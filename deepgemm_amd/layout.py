@@ -1,0 +1,147 @@
+"""Scaling-factor layout handling of the FP8 path (host side).
+
+Mirrors ``csrc/utils/layout.hpp:13-117``, ``csrc/apis/layout.hpp:14-90`` and ``csrc/jit_kernels/impls/smxx_layout.hpp:
+120-153`` of the reference: SFA (1 x 128 granularity) is handed to the kernel MN-major with the MN extent padded to a
+multiple of 4 floats ("TMA aligned" in the reference; on CDNA4 it makes the per-lane SFA reads of a wave contiguous),
+SFB (128 x 128) is only checked.  FP32 scales only: packed-UE8M0 (int) scales are an SM100 input format that is listed
+as "next" in SURVEY.md section 8(f) and rejected here with the reference's own assertion text.
+"""
+from typing import Optional, Tuple, Union
+
+import torch
+
+from ._lib import lib, check, current_stream_ptr, require_device
+from .errors import host_assert
+from ._intmath import ceil_div, align
+
+_TMA_ALIGNMENT_BYTES = 16
+
+
+def get_tma_aligned_size(x: int, element_size: int) -> int:
+    host_assert(_TMA_ALIGNMENT_BYTES % element_size == 0, 'kNumTMAAlignmentBytes % element_size == 0')
+    return align(x, _TMA_ALIGNMENT_BYTES // element_size)
+
+
+def major_check(t: torch.Tensor) -> None:
+    host_assert(t.dim() in (2, 3), 'dim == 2 or dim == 3')
+    if t.dim() == 3:
+        host_assert(t.stride(0) == t.size(-2) * t.size(-1), 't.stride(0) == t.size(-2) * t.size(-1)')
+    host_assert(t.stride(-2) == 1 or t.stride(-1) == 1, 't.stride(-2) == 1 or t.stride(-1) == 1')
+
+
+def is_k_major(t: torch.Tensor) -> bool:
+    """K-major (unit stride on the last dim) vs MN-major, decided from strides like ``get_major_type_ab``."""
+    major_check(t)
+    return t.stride(-1) == 1
+
+
+def check_major_type_cd(t: torch.Tensor) -> None:
+    major_check(t)
+    host_assert(t.stride(-1) == 1, 't.stride(-1) == 1')
+
+
+def get_default_recipe(sfa_dtype: torch.dtype, sfb_dtype: torch.dtype) -> Tuple[int, int, int]:
+    # gfx950 plays the role of the reference's FP32-scale architecture (csrc/utils/layout.hpp:64-77, arch_major == 9).
+    host_assert(sfa_dtype == torch.float and sfb_dtype == torch.float,
+                'sfa_dtype == torch::kFloat and sfb_dtype == torch::kFloat')
+    return 1, 128, 128
+
+
+def check_sf_layout(sf: torch.Tensor, mn: int, k: int, gran_mn: int, gran_k: int, num_groups: Optional[int],
+                    tma_stride_check: bool = False, sfb_check: bool = False,
+                    type_check: Optional[torch.dtype] = None) -> torch.Tensor:
+    if type_check is not None:
+        host_assert(sf.dtype == type_check, 'sf.scalar_type() == type_check.value()')
+    host_assert(sf.dtype in (torch.float, torch.int), 'sf_dtype == torch::kFloat or sf_dtype == torch::kInt')
+    host_assert(sf.dim() == int(num_groups is not None) + 2, 'sf.dim() == static_cast<int>(num_groups.has_value()) + 2')
+    if num_groups is not None:
+        host_assert(sf.size(-3) == num_groups, 'sf.size(-3) == num_groups.value()')
+    host_assert(sf.size(-2) == ceil_div(mn, gran_mn), 'sf.size(-2) == ceil_div(mn, gran_mn)')
+    host_assert(sf.size(-1) == ceil_div(k, gran_k * (1 if sf.dtype == torch.float else 4)),
+                'sf.size(-1) == ceil_div(k, gran_k * (sf_dtype == torch::kFloat ? 1 : 4))')
+    if tma_stride_check:
+        if num_groups is not None:
+            host_assert(sf.stride(-3) == sf.stride(-1) * sf.size(-1), 'sf.stride(-3) == sf.stride(-1) * sf.size(-1)')
+        host_assert(sf.stride(-2) == 1 or mn == 1, 'sf.stride(-2) == 1 or mn == 1')
+        host_assert(sf.stride(-1) == get_tma_aligned_size(mn, sf.element_size()),
+                    'sf.stride(-1) == get_tma_aligned_size(mn, sf.element_size())')
+    if sfb_check:
+        if num_groups is not None:
+            host_assert(sf.stride(-3) == sf.size(-2) * sf.size(-1), 'sf.stride(-3) == sf.size(-2) * sf.size(-1)')
+        host_assert((sf.stride(-1) == 1 and sf.stride(-2) == sf.size(-1)) or
+                    (sf.stride(-1) == sf.size(-2) and sf.stride(-2) == 1),
+                    'SFB must be contiguous, or contiguous after transposing the last two dimensions')
+    return sf
+
+
+def get_mn_major_tma_aligned_tensor(sf: torch.Tensor) -> torch.Tensor:
+    """[..., mn, sf_k] FP32 -> same logical tensor with strides (aligned_mn * sf_k, 1, aligned_mn).
+
+    Zero-copy when the input already has that layout (smxx_layout.hpp:124-125); otherwise one launch of the HIP
+    transpose kernel (contiguous input) or a strided torch copy (anything else), as in the reference."""
+    host_assert(sf.dim() in (2, 3), 'dim == 2 or dim == 3')
+    host_assert(sf.dtype == torch.float, 'sf.scalar_type() == torch::kFloat')
+    batched = sf.unsqueeze(0) if sf.dim() == 2 else sf
+    nb, mn, sf_k = batched.shape
+    aligned_mn = get_tma_aligned_size(mn, sf.element_size())
+    if (batched.stride(0) == aligned_mn * sf_k or sf.dim() == 2) and batched.stride(1) == 1 and batched.stride(2) == aligned_mn:
+        return sf
+    out = torch.empty_strided((nb, mn, sf_k), (aligned_mn * sf_k, 1, aligned_mn), dtype=sf.dtype, device=sf.device)
+    if batched.is_contiguous() and batched.is_cuda and nb <= 65535:
+        check(lib.dg_transpose_sf_fp32(batched.data_ptr(), out.data_ptr(), nb, mn, sf_k, current_stream_ptr()))
+    else:
+        out.copy_(batched)
+    return out.squeeze(0) if sf.dim() == 2 else out
+
+
+Recipe = Union[Tuple[int, int, int], Tuple[int, int]]
+
+
+def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe: Recipe,
+                                      num_groups: Optional[int] = None, is_sfa: Optional[bool] = None,
+                                      disable_ue8m0_cast: bool = False,
+                                      psum_layout: Optional[torch.Tensor] = None) -> torch.Tensor:
+    recipe = tuple(recipe)
+    if len(recipe) == 3:
+        host_assert(is_sfa is not None, 'is_sfa.has_value()')
+        gran_mn, gran_k = (recipe[0] if is_sfa else recipe[1]), recipe[2]
+    elif len(recipe) == 2:
+        host_assert(is_sfa is None, 'not is_sfa.has_value()')
+        gran_mn, gran_k = recipe
+    else:
+        raise RuntimeError('Assertion error (layout.py): Invalid recipe')
+    check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups)
+
+    # (FP32, 1, 128): MN-major, padded -- csrc/apis/layout.hpp:40-42
+    if sf.dtype == torch.float and gran_mn == 1 and gran_k == 128:
+        return get_mn_major_tma_aligned_tensor(sf)
+    # (FP32, 128, 128): only checked -- csrc/apis/layout.hpp:44-46
+    if sf.dtype == torch.float and gran_mn == 128 and gran_k == 128:
+        return check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups, False, True, torch.float)
+    raise RuntimeError('Assertion error (layout.py): Unknown SF transformation '
+                       '(packed UE8M0 / gran_k = 32 scales are not supported on gfx950 yet)')
+
+
+def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, recipe_b,
+                                           num_groups_a, num_groups_b, disable_ue8m0_cast=False, psum_layout=None):
+    """Returns (sfa', sfb', gran_n_of_sfb).  Recipe selection: csrc/apis/layout.hpp:74-80."""
+    if recipe_a is None and recipe is None:
+        recipe = get_default_recipe(sfa.dtype, sfb.dtype)
+    host_assert((recipe_a is not None) == (recipe_b is not None), 'recipe_a.has_value() == recipe_b.has_value()')
+    host_assert((recipe_a is not None) != (recipe is not None), 'recipe_a.has_value() != recipe.has_value()')
+    if recipe is not None:
+        recipe = tuple(recipe)
+        host_assert(len(recipe) == 3, 'recipe must be (gran_m, gran_n, gran_k)')
+        host_assert(recipe[0] == 1 and recipe[2] == 128 and recipe[1] in (1, 128),
+                    'supported recipes: (1, 128, 128) and (1, 1, 128)')
+        t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe, num_groups_a, True, disable_ue8m0_cast, psum_layout)
+        t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe, num_groups_b, False, disable_ue8m0_cast)
+        gran_n = recipe[1]
+    else:
+        recipe_a, recipe_b = tuple(recipe_a), tuple(recipe_b)
+        host_assert(recipe_a == (1, 128) and recipe_b[1] == 128 and recipe_b[0] in (1, 128),
+                    'supported recipes: recipe_a = (1, 128), recipe_b in ((1, 128), (128, 128))')
+        t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe_a, num_groups_a, None, disable_ue8m0_cast, psum_layout)
+        t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe_b, num_groups_b, None, disable_ue8m0_cast)
+        gran_n = recipe_b[0]
+    return t_sfa, t_sfb, gran_n

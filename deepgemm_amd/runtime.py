@@ -1,0 +1,71 @@
+"""Process-global knobs with the reference's names (csrc/apis/runtime.hpp:12-49, csrc/apis/layout.hpp:142-150).
+
+``num_sms`` maps to the CU budget of a persistent launch (0 / unset = all 256 CUs).  ``tc_util``, ``pdl``,
+``ignore_compile_dims`` and ``block_size_multiple_of`` only influence NVIDIA codegen/launch in the reference; they are
+accepted and stored so that callers keep working, and never change results."""
+from typing import Optional, Tuple, Union
+
+from ._lib import lib, check
+
+_LEGACY_MK_ALIGNMENT = 128      # reference csrc/jit_kernels/heuristics/runtime.hpp:10
+_state = {'tc_util': 100, 'pdl': False, 'ignore_compile_dims': False, 'block_size_multiple_of': (1, 1),
+          'mk_alignment': _LEGACY_MK_ALIGNMENT}
+
+
+def set_num_sms(new_num_sms: int) -> None:
+    check(lib.dg_set_num_cus(int(new_num_sms)))
+
+
+def get_num_sms() -> int:
+    return int(lib.dg_get_num_cus())
+
+
+def set_tc_util(new_tc_util: int) -> None:
+    _state['tc_util'] = int(new_tc_util)
+
+
+def get_tc_util() -> int:
+    return _state['tc_util']
+
+
+def set_pdl(new_enable_pdl: bool) -> None:
+    _state['pdl'] = bool(new_enable_pdl)
+
+
+def get_pdl() -> bool:
+    return _state['pdl']
+
+
+def set_ignore_compile_dims(new_value: bool) -> None:
+    _state['ignore_compile_dims'] = bool(new_value)
+
+
+def set_block_size_multiple_of(new_value: Union[int, Tuple[int, int]]) -> None:
+    _state['block_size_multiple_of'] = (new_value, new_value) if isinstance(new_value, int) else tuple(new_value)
+
+
+def set_mk_alignment_for_contiguous_layout(new_value: int) -> None:
+    _state['mk_alignment'] = int(new_value)
+
+
+def get_mk_alignment_for_contiguous_layout() -> int:
+    return _state['mk_alignment']
+
+
+def get_theoretical_mk_alignment_for_contiguous_layout(expected_m: Optional[int] = None) -> int:
+    """The reference returns 128 off SM100 (heuristics/runtime.hpp:47-49); the CDNA4 kernels tile M in 128-row
+    blocks for the contiguous layout as well."""
+    return _LEGACY_MK_ALIGNMENT
+
+
+def set_forced_config(name: str) -> None:
+    """Tuning hook: force a kernel configuration ('auto' restores the heuristic)."""
+    check(lib.dg_set_forced_config(name.encode()))
+
+
+def list_configs():
+    return lib.dg_list_configs().decode().split(',')
+
+
+def last_config() -> str:
+    return lib.dg_last_config().decode()

@@ -1,0 +1,172 @@
+"""Synthetic input construction for the FP8 GEMM path, restating the reference's test generators
+(``tests/generators.py:115-187`` shape sweeps, ``:301-408`` tensors) with an explicit ``device`` so that the same
+inputs can be produced on the host (oracle / golden fixtures) and on the GPU.
+
+Inputs are BF16 ``randn`` tensors; the kernel gets their FP8 quantisation (A: 1 x 128 per-token scales, B: 128 x 128
+block scales, FP32, no UE8M0 rounding -- the reference's SM90 "1D2D" convention), the reference result is the FP32
+matmul of the UNQUANTISED inputs cast to the output dtype.
+"""
+import random
+from dataclasses import dataclass
+from typing import Iterator, List, Optional, Tuple
+
+import torch
+
+from ..utils.math import align, ceil_div, per_block_cast_to_fp8, per_token_cast_to_fp8
+from .. import runtime
+
+FP8_MAX_DIFF = 1e-3         # reference gate: calc_diff vs the unquantised result (tests/generators.py:65-70)
+
+# DeepSeek-V3 shape lists of the reference sweep (tests/generators.py:119-121, :159-160, :177-178)
+DENSE_NK = [(2112, 7168), (576, 7168), (24576, 1536), (32768, 512), (7168, 16384), (4096, 7168), (7168, 2048)]
+DENSE_M_FWD = [1, 128, 4096]
+GROUPED_NK = [(6144, 7168), (7168, 3072), (4096, 4096), (4096, 2048)]
+CONTIGUOUS_GROUPS = [(4, 8192), (8, 4096)]
+MASKED_GROUPS = [(32, 192), (6, 1024), (32, 20), (6, 20)]
+MASKED_MAX_M = 4096
+
+
+def reset_seed(seed: int = 0) -> None:
+    random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def _with_major(data: torch.Tensor, sf: torch.Tensor, k_major: bool):
+    """K-major keeps the row-major tensor; MN-major re-materialises it column-major behind the same logical shape."""
+    return (data, sf) if k_major else (data.mT.contiguous().mT, sf)
+
+
+def cast_a(x: torch.Tensor, k_major: bool = True):
+    return _with_major(*per_token_cast_to_fp8(x, use_ue8m0=False), k_major)
+
+
+def cast_b(x: torch.Tensor, k_major: bool = True, per_token: bool = False):
+    quant = per_token_cast_to_fp8(x, use_ue8m0=False) if per_token else per_block_cast_to_fp8(x, use_ue8m0=False)
+    return _with_major(*quant, k_major)
+
+
+def grouped_cast(x: torch.Tensor, per_block: bool, k_major: bool = True):
+    groups, mn, k = x.shape
+    data = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    sf = torch.empty((groups, ceil_div(mn, 128) if per_block else mn, ceil_div(k, 128)), device=x.device, dtype=torch.float)
+    for i in range(groups):
+        data[i], sf[i] = per_block_cast_to_fp8(x[i], use_ue8m0=False) if per_block else per_token_cast_to_fp8(x[i], use_ue8m0=False)
+    return (data, sf) if k_major else (data.mT.contiguous().mT, sf)
+
+
+@dataclass
+class DenseCase:
+    a: tuple
+    b: tuple
+    c: Optional[torch.Tensor]
+    d: torch.Tensor
+    ref_d: torch.Tensor
+    a_bf16: torch.Tensor
+    b_bf16: torch.Tensor
+
+
+def generate_normal(m: int, n: int, k: int, a_k_major: bool = True, b_k_major: bool = True, accumulate: bool = False,
+                    out_dtype: torch.dtype = torch.bfloat16, per_token_b: bool = False, device: str = 'cuda') -> DenseCase:
+    """tests/generators.py:301-324.  ``per_token_b`` selects the (1, 1, 128) recipe's per-column SFB."""
+    a = torch.randn((m, k), device=device, dtype=torch.bfloat16)
+    b = torch.randn((n, k), device=device, dtype=torch.bfloat16)
+    d = torch.randn((m, n), device=device, dtype=out_dtype) * 32 if accumulate else \
+        torch.empty((m, n), device=device, dtype=out_dtype)
+    c = d if accumulate else None
+    ref = (a.float() @ b.float().t() + (c if accumulate else 0)).to(out_dtype)
+    return DenseCase(cast_a(a, a_k_major), cast_b(b, b_k_major, per_token_b), c, d, ref, a, b)
+
+
+@dataclass
+class ContiguousCase:
+    m: int
+    a: tuple
+    b: tuple
+    grouped_layout: torch.Tensor
+    d: torch.Tensor
+    ref_d: torch.Tensor
+    actual_ms: List[int]
+    aligned_ms: List[int]
+
+
+def generate_m_grouped_contiguous(num_groups: int, expected_m_per_group: int, n: int, k: int, b_k_major: bool = True,
+                                  use_psum_layout: bool = False, device: str = 'cuda',
+                                  actual_ms: Optional[List[int]] = None) -> ContiguousCase:
+    """tests/generators.py:327-366: per-group M = int(expected * U(0.7, 1.3)) aligned up, padding rows zeroed / -1."""
+    alignment = runtime.get_mk_alignment_for_contiguous_layout()
+    if actual_ms is None:
+        actual_ms = [int(expected_m_per_group * random.uniform(0.7, 1.3)) for _ in range(num_groups)]
+    aligned_ms = [align(x, alignment) for x in actual_ms]
+    m = sum(aligned_ms)
+    a = torch.randn((m, k), device=device, dtype=torch.bfloat16)
+    b = torch.randn((num_groups, n, k), device=device, dtype=torch.bfloat16)
+    layout = torch.empty(num_groups if use_psum_layout else m, device=device, dtype=torch.int32)
+    d = torch.empty((m, n), device=device, dtype=torch.bfloat16)
+    ref = torch.randn((m, n), device=device, dtype=torch.bfloat16)
+    start = 0
+    for i, (actual, aligned) in enumerate(zip(actual_ms, aligned_ms)):
+        if use_psum_layout:
+            layout[i] = start + actual
+        else:
+            layout[start:start + actual] = i
+            layout[start + actual:start + aligned] = -1
+        a[start + actual:start + aligned] = 0
+        ref[start:start + aligned] = (a[start:start + aligned].float() @ b[i].float().t()).to(torch.bfloat16)
+        start += aligned
+    return ContiguousCase(m, cast_a(a), grouped_cast(b, per_block=True, k_major=b_k_major), layout, d, ref, actual_ms, aligned_ms)
+
+
+@dataclass
+class MaskedCase:
+    a: tuple
+    b: tuple
+    masked_m: torch.Tensor
+    d: torch.Tensor
+    ref_d: torch.Tensor
+
+
+def generate_m_grouped_masked(num_groups: int, max_m: int, expected_m_per_group: int, n: int, k: int,
+                              device: str = 'cuda', masked_ms: Optional[List[int]] = None) -> MaskedCase:
+    """tests/generators.py:380-408."""
+    a = torch.randn((num_groups, max_m, k), device=device, dtype=torch.bfloat16)
+    b = torch.randn((num_groups, n, k), device=device, dtype=torch.bfloat16)
+    d = torch.empty((num_groups, max_m, n), device=device, dtype=torch.bfloat16)
+    ref = torch.einsum('gmk,gnk->gmn', a.float(), b.float()).to(torch.bfloat16)
+    if masked_ms is None:
+        masked_ms = [int(expected_m_per_group * random.uniform(0.7, 1.3)) for _ in range(num_groups)]
+    assert max(masked_ms) <= max_m
+    masked = torch.tensor(masked_ms, device=device, dtype=torch.int32)
+    a_q = grouped_cast(a, per_block=False)
+    for j, rows in enumerate(masked_ms):
+        a_q[1][j, rows:] = 0
+    return MaskedCase(a_q, grouped_cast(b, per_block=True), masked, d, ref)
+
+
+def enumerate_normal() -> Iterator[Tuple[int, int, int, bool, bool, bool, torch.dtype, bool]]:
+    """(m, n, k, a_k_major, b_k_major, accumulate, out_dtype, per_token_b): forward shapes plus the backward dgrad /
+    wgrad forms of tests/generators.py:115-154 (MN-major operands, FP32 accumulation with the (1,1,128) recipe)."""
+    for m in DENSE_M_FWD:
+        for n, k in DENSE_NK:
+            yield m, n, k, True, True, False, torch.bfloat16, False
+            yield m, n, k, True, True, True, torch.bfloat16, False
+    for n, k in DENSE_NK:
+        m = 4096
+        yield m, k, n, True, False, False, torch.bfloat16, False         # dgrad
+        yield n, m, k, False, False, True, torch.float, True             # wgrad, FP32 accumulate
+        yield n, m, k, False, False, False, torch.bfloat16, False        # wgrad, BF16
+
+
+def enumerate_m_grouped_contiguous() -> Iterator[Tuple[int, int, int, int, bool, bool]]:
+    for use_psum in (True, False):
+        for groups, expected in CONTIGUOUS_GROUPS:
+            for n, k in GROUPED_NK:
+                for b_k_major in (True, False):
+                    yield groups, expected, n, k, b_k_major, use_psum
+
+
+def enumerate_m_grouped_masked() -> Iterator[Tuple[int, int, int, int, int]]:
+    for groups, expected in MASKED_GROUPS:
+        for n, k in GROUPED_NK:
+            yield groups, MASKED_MAX_M, expected, n, k

@@ -1,0 +1,10 @@
+"""Layout helpers re-exported under the reference's ``deep_gemm.utils.layout`` names (deep_gemm/utils/layout.py:1-21)."""
+from ..layout import get_tma_aligned_size, get_mn_major_tma_aligned_tensor        # noqa: F401
+from ..runtime import (                                                            # noqa: F401
+    set_mk_alignment_for_contiguous_layout,
+    get_mk_alignment_for_contiguous_layout,
+    get_theoretical_mk_alignment_for_contiguous_layout,
+)
+
+get_m_alignment_for_contiguous_layout = get_mk_alignment_for_contiguous_layout
+get_k_alignment_for_contiguous_layout = get_mk_alignment_for_contiguous_layout

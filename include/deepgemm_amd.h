@@ -1,0 +1,99 @@
+/*
+ * deepgemm_amd C ABI -- the drop-in boundary of the MI355X FP8 blockwise-scaled GEMM path.
+ *
+ * Every entry point replaces one host driver of the reference (deepseek-ai/DeepGEMM v2.6.1, paths relative to
+ * /root/reference).  A caller (the Python host layer in deepgemm_amd/, or any FFI) passes raw DEVICE pointers,
+ * element strides and a hipStream_t; nothing here allocates, synchronises or touches torch.
+ *
+ * Conventions
+ *   - a / b        : FP8 e4m3fn (OCP) bytes.  Element (row, k) lives at ptr[row * stride_mn + k * stride_k]; exactly one of the
+ *                    two strides is 1 (K-major or MN-major operand, reference csrc/utils/layout.hpp:13-24).
+ *   - sfa          : FP32 per-(row, 128-K-block) scales, element (m, kb) at sfa[m * sfa_stride_m + kb * sfa_stride_k]
+ *                    (the reference hands the kernel an MN-major, 16-byte aligned tensor: stride_m = 1,
+ *                    stride_k = align(M, 4); any strides are accepted here).
+ *   - sfb          : FP32 scales, element (n / sfb_gran_n, kb) at sfb[(n / sfb_gran_n) * sfb_stride_n + kb * sfb_stride_k];
+ *                    sfb_gran_n is 128 (recipe (1,128,128)) or 1 (recipe (1,1,128)).
+ *   - d            : row-major output, d_dtype DG_BF16 or DG_FP32, row stride d_stride_m (may exceed n).
+ *   - accumulate   : 0 => D = A B^T;  1 => D_mem = D_mem + cast(A B^T) in D's dtype (the reference's reduce-add epilogue).
+ *   - stream       : hipStream_t (0 = default stream).  Calls are asynchronous and never synchronise.
+ *   - return value : 0 on success; non-zero => dg_last_error() describes the violated condition (thread-local text).
+ *
+ * Arithmetic (reference deep_gemm/include/deep_gemm/impls/sm90_fp8_gemm_1d2d.cuh:283-347, :416-418):
+ *   D[m,n] = cast( sum_kb (sfa[m,kb] * sfb[n/gran,kb]) * ( sum_{k in block kb} A[m,k] * B[n,k] ) ), FP32 throughout,
+ *   one round-to-nearest-even cast at the end.
+ */
+#ifndef DEEPGEMM_AMD_H
+#define DEEPGEMM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_BF16 0
+#define DG_FP32 1
+
+/* Dense GEMM, NT form.  Replaces sm90_fp8_gemm_1d2d (csrc/jit_kernels/impls/sm90_fp8_gemm_1d2d.hpp:81),
+ * sm90_fp8_gemm_1d1d (impls/sm90_fp8_gemm_1d1d.hpp:78) and sm100_fp8_fp4_gemm_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:93)
+ * as called from fp8_fp4_gemm_nt (csrc/apis/gemm.hpp:73-124); nn/tn/tt are stride changes on the same entry point. */
+int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                   int m, int n, int k,
+                   int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                   int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                   int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
+
+/* M-grouped contiguous GEMM.  Replaces sm90_m_grouped_fp8_gemm_contiguous_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:147) /
+ * sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:161) as called from
+ * m_grouped_fp8_fp4_gemm_nt_contiguous (csrc/apis/gemm.hpp:166-232).
+ *   a [m, k] K-major; b [num_groups, n, k] (b_stride_g between groups); sfb [num_groups, ceil(n/128), ceil(k/128)];
+ *   d [m, n] BF16.  grouped_layout: int32 [m] group id per row, negative = padding row (use_psum = 0; the group of an
+ *   m_alignment-row block is taken from its first row and a negative id makes the block all zeros), or int32 [num_groups]
+ *   cumulative row ends (use_psum = 1; group g owns rows [align(end[g-1], m_alignment), end[g]); the alignment-gap rows
+ *   of D are written as zeros). */
+int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                        const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                        int64_t a_stride_m, int64_t a_stride_k,
+                                        int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                        int64_t sfa_stride_m, int64_t sfa_stride_k,
+                                        int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                        int64_t d_stride_m, int use_psum, int m_alignment, void* stream);
+
+/* M-grouped masked GEMM.  Replaces sm90_m_grouped_fp8_gemm_masked_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:224) /
+ * sm100_m_grouped_fp8_fp4_gemm_masked_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:244) as called from
+ * m_grouped_fp8_fp4_gemm_nt_masked (csrc/apis/gemm.hpp:250-297).
+ *   a [num_groups, m_max, k]; b [num_groups, n, k]; d [num_groups, m_max, n] BF16; masked_m int32 [num_groups] ON THE
+ *   DEVICE (read inside the kernel); rows >= masked_m[g] are not written.  expected_m is a tuning hint only. */
+int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                    const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
+                                    int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                    int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                    int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_k,
+                                    int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                    int64_t d_stride_g, int64_t d_stride_m, void* stream);
+
+/* SF layout kernel.  Replaces transpose_fp32 (deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:12-50) as driven by
+ * get_mn_major_tma_aligned_tensor (csrc/jit_kernels/impls/smxx_layout.hpp:120-153):
+ * sf [batches, mn, sf_k] row-major FP32 -> out element (b, i, j) at out[b * aligned_mn * sf_k + j * aligned_mn + i],
+ * aligned_mn = align(mn, 4).  Padding slots are not written. */
+int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream);
+
+/* Runtime knobs (reference csrc/apis/runtime.hpp:12-41: set/get_num_sms; the analogue here is the CU budget a
+ * persistent launch may occupy, 0 = all CUs of the device). */
+int dg_set_num_cus(int num_cus);
+int dg_get_num_cus(void);
+
+/* Tuning / test hook: force a kernel configuration by name for subsequent calls on this thread
+ * ("auto" restores the heuristic).  Unknown names are an error.  dg_list_configs() returns a comma-separated list. */
+int dg_set_forced_config(const char* name);
+const char* dg_list_configs(void);
+/* Name of the configuration the last GEMM call on this thread selected (for DG_PRINT_CONFIGS-style logging). */
+const char* dg_last_config(void);
+
+const char* dg_last_error(void);
+const char* dg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPGEMM_AMD_H */
