@@ -66,13 +66,21 @@ struct Config {
 };
 
 const Config kConfigs[] = {
-    {"fast_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4>},
-    {"fast_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_fast_kernel<128, 256, 2, 4>},
-    {"fast_128x128", 128, 128, 256, 2, 0.70f, true, dg::dg_fp8_gemm_fast_kernel<128, 128, 2, 2>},
-    {"fast_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_fast_kernel<64, 256, 1, 4>},
-    {"fast_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_fast_kernel<32, 256, 1, 4>},
-    {"fast_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_fast_kernel<16, 256, 1, 4>},
+    {"fast_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
+    {"fast_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_fast_kernel<128, 256, 2, 4, 0>},
+    {"fast_128x128", 128, 128, 256, 2, 0.70f, true, dg::dg_fp8_gemm_fast_kernel<128, 128, 2, 2, 0>},
+    {"fast_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_fast_kernel<64, 256, 1, 4, 0>},
+    {"fast_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_fast_kernel<32, 256, 1, 4, 0>},
+    {"fast_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_fast_kernel<16, 256, 1, 4, 0>},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
+    // experimental variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of the heuristic)
+    {"x_p1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 1>},
+    {"x_p2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 2>},
+    {"pipe_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
+    {"pipe_s2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
+    {"pipe_s4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 4>},
+    {"pipe_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 0>},
+    {"pipe_128x128", 128, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -104,7 +112,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     double best_cost = 0;
     for (int i = 0; i < kNumConfigs; ++i) {
         const Config& c = kConfigs[i];
-        if (c.fast && !fast_ok)
+        if ((c.fast && !fast_ok) || c.efficiency <= 0.f)
             continue;
         if (bm_must_divide > 0 && bm_must_divide % c.bm != 0)
             continue;

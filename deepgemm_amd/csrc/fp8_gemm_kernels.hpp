@@ -247,10 +247,51 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
     }
 }
 
+
+// One 128-K block of a wave tile, software-pipelined by hand: MFMA i+DEPTH is issued before the FP32 promotion of
+// MFMA i, so the matrix pipe never waits for a VALU read of its own result (hipcc serialises the naive form into
+// mfma / s_nop 11 / fma).  sched_group_barrier pins the interleave: 1 MFMA, then 4 VALU FMAs (+ the LDS reads of the
+// next A fragment at the head of each M-subtile).
+template <int MS, int NS, int DEPTH>
+__device__ __forceinline__ void compute_block_pipelined(const uint8_t* a_tile, const uint8_t* b_tile, int frag_off,
+                                                        const float (&scale)[MS], v4f (&acc)[MS][NS]) {
+    constexpr int TOTAL = MS * NS;
+    v8i bf[NS];
+    #pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+    v8i af[2];
+    af[0] = load_fragment(a_tile, frag_off);
+    v4f part[DEPTH + 1];
+    #pragma unroll
+    for (int i = 0; i < TOTAL + DEPTH; ++i) {
+        if (i < TOTAL) {
+            const int ms = i / NS, ns = i % NS;
+            if (ns == 0 && ms + 1 < MS)
+                af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
+            part[i % (DEPTH + 1)] = mfma_fp8_k128(bf[ns], af[ms & 1]);
+        }
+        if (i >= DEPTH) {
+            const int j = i - DEPTH, ms = j / NS, ns = j % NS;
+            const v4f pr = part[j % (DEPTH + 1)];
+            #pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[ms][ns][r] = __builtin_fmaf(scale[ms], pr[r], acc[ms][ns][r]);
+        }
+        if (i < TOTAL) {
+            if (i % NS == 0 && i / NS + 1 < MS)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the next A fragment's two ds_read_b128
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
+        }
+        if (i >= DEPTH)
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);         // its four promotion FMAs
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Fast path: K-major A and B, K % 128 == 0, 16-byte aligned rows.  LDS-DMA double buffer, one barrier per K block.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_fast_kernel(const GemmParams p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -362,18 +403,26 @@ void dg_fp8_gemm_fast_kernel(const GemmParams p) {
 
                 const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
-                v8i bf[NS];
-                #pragma unroll
-                for (int ns = 0; ns < NS; ++ns)
-                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
-                    const float scale = sa_cur[ms] * sb_cur;
+                if constexpr (PIPE > 0) {
+                    float scale[MS];
                     #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns) {
-                        const v4f part = mfma_fp8_k128(bf[ns], af);
-                        acc[ms][ns] += scale * part;
+                    for (int ms = 0; ms < MS; ++ms)
+                        scale[ms] = sa_cur[ms] * sb_cur;
+                    compute_block_pipelined<MS, NS, PIPE>(a_tile, b_tile, frag_off, scale, acc);
+                } else {
+                    v8i bf[NS];
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                        const float scale = sa_cur[ms] * sb_cur;
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns) {
+                            const v4f part = mfma_fp8_k128(bf[ns], af);
+                            acc[ms][ns] += scale * part;
+                        }
                     }
                 }
 
@@ -388,6 +437,236 @@ void dg_fp8_gemm_fast_kernel(const GemmParams p) {
 
         store_tile<MS, NS>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path, hand-scheduled: same tiles / LDS image / LDS-DMA staging as dg_fp8_gemm_fast_kernel, but the MFMA +
+// FP32-promotion stream is written as one inline-asm statement per 16x16x128 step:
+//     v_mfma  part[i & 3] = Bfrag[ns] x Afrag[ms]            (zero C operand: one 128-K scale block)
+//     4 x v_fmac  acc[step i-3] += scale[step i-3] * part[(i-3) & 3]
+// i.e. the promotion of step i-3 rides in the shadow of MFMA i (three MFMAs = 96 matrix-pipe cycles separate a
+// result from its first VALU read, which also satisfies the 12-wait-state XDL-write -> VALU-read rule without
+// s_nop padding).  The ring runs across K blocks: the last three steps of block kb are promoted during the first
+// three MFMAs of block kb+1 with block kb's scales.  hipcc, left alone, emits mfma / s_nop 11 / fma per step.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mfma_promote_step(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
+                                                  float (&c)[4], float scale, const v4f& part_old) {
+    asm volatile(
+        "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+        "v_fmac_f32 %1, %7, %8\n\t"
+        "v_fmac_f32 %2, %7, %9\n\t"
+        "v_fmac_f32 %3, %7, %10\n\t"
+        "v_fmac_f32 %4, %7, %11"
+        : "=&v"(part_new), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+        : "v"(rows_operand), "v"(cols_operand), "v"(scale), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]),
+          "v"(part_old[3])
+        : "memory");
+}
+
+// Forces `x` to be materialised in a VGPR at this point of the instruction stream (scheduling fence for one value).
+__device__ __forceinline__ void pin_vgpr(float& x) { asm volatile("" : "+v"(x)); }
+
+__device__ __forceinline__ void promote_only(float (&c)[4], float scale, const v4f& part_old) {
+    // Drain step.  s_nop 3 keeps >= 12 wait states between the last MFMA and the first read of its result even if
+    // every intervening instruction issues back to back.
+    asm volatile(
+        "s_nop 3\n\t"
+        "v_fmac_f32 %0, %4, %5\n\t"
+        "v_fmac_f32 %1, %4, %6\n\t"
+        "v_fmac_f32 %2, %4, %7\n\t"
+        "v_fmac_f32 %3, %4, %8"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+        : "v"(scale), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]), "v"(part_old[3])
+        : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+__device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    constexpr int TOTAL = MS * NS, DEPTH = 3;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_UNITS = BM / 8, B_UNITS = BN / 8;
+    constexpr int A_ITERS = (A_UNITS + NW - 1) / NW, B_ITERS = (B_UNITS + NW - 1) / NW;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && NS % 2 == 0, "wave tile must be a multiple of 16 x 32");
+    static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
+    static_assert(TOTAL >= DEPTH + 1, "pipeline ring needs at least 4 steps per K block");
+    static_assert(SPREAD == 0 || SPREAD * (A_ITERS + B_ITERS) <= TOTAL, "not enough steps to spread the LDS-DMA pieces");
+    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
+                  "the row permutation of a B piece must be lane-independent: perm(p0 + slab) = perm(p0) + perm(slab)");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+
+    // Per-lane byte offsets of the LDS-DMA source pattern inside the first 8*NW-row slab of a tile; the slab index and
+    // the K block go into the (wave-uniform) soffset of the buffer instruction.
+    const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        float acc[MS][NS][4];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[ms][ns][r] = 0.f;
+
+        if (t.m_end > t.m0) {
+            // Buffer descriptors bound each tile to its valid rows: out-of-range lanes of an edge tile fetch nothing
+            // (those rows / columns are never stored), so no per-lane clamping is needed.
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            const float* sfa_group = p.sfa + ad_group * p.sfa_sg;
+            const int sfa_rows = (p.gemm_type == kMasked) ? p.m : p.m;
+            const int sfa_extent = (static_cast<int>(p.sfa_sm) * (sfa_rows - 1) + static_cast<int>(p.sfa_sk) * (num_kb - 1) + 1) * 4;
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sfa_group), 0, sfa_extent, 0x00020000);
+            const int sfa_voff = (t.m0 + wm * WM + (lane & 15)) * static_cast<int>(p.sfa_sm) * 4;
+            const int sfa_ms_stride = 16 * static_cast<int>(p.sfa_sm) * 4, sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4;
+            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
+                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
+
+            // One LDS-DMA piece (1 KiB = 8 rows x 128 B) of the stage; pieces 0..A_ITERS-1 belong to A, the rest to B.
+            auto issue_piece = [&](int stage, int kb, int q) {
+                uint8_t* stage_base = lds + stage * STAGE_BYTES;
+                if (q < A_ITERS) {
+                    const int unit = wave + NW * q;
+                    if (A_UNITS % NW == 0 || unit < A_UNITS)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            a_rsrc, (__attribute__((address_space(3))) void*)(stage_base + unit * 1024), 16, a_voff,
+                            q * (NW * 8) * lda + kb * 128, 0, 0);
+                } else {
+                    const int j = q - A_ITERS, unit = wave + NW * j;
+                    if (B_UNITS % NW == 0 || unit < B_UNITS)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            b_rsrc, (__attribute__((address_space(3))) void*)(stage_base + A_BYTES + unit * 1024), 16,
+                            b_voff, b_row_perm<WN>(j * (NW * 8)) * ldb + kb * 128, 0, 0);
+                }
+            };
+            auto issue_stage = [&](int stage, int kb) {
+                #pragma unroll
+                for (int q = 0; q < A_ITERS + B_ITERS; ++q)
+                    issue_piece(stage, kb, q);
+            };
+            auto load_sfa = [&](int ms, int kb) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    sfa_rsrc, sfa_voff, ms * sfa_ms_stride + kb * sfa_kb_stride, 0));
+            };
+
+            // scale[ms]: SFA value of the current K block, multiplied by SFB at the top of the block; reloaded in place
+            // for the next block as soon as the last promotion that needs it has been issued.
+            float scale[MS], scale_tail = 0.f, sa_tail_next = 0.f;
+            float sb_cur, sb_nxt = 0.f;
+            v4f part[DEPTH + 1];
+            #pragma unroll
+            for (int i = 0; i <= DEPTH; ++i)
+                part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+
+            issue_stage(0, 0);
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                scale[ms] = load_sfa(ms, 0);
+            sb_cur = sfb_wave[0];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const int cur = kb & 1;
+                const bool has_next = kb + 1 < num_kb;
+                // Form the block's scales BEFORE any new LDS-DMA is in flight: hipcc waits vmcnt(0) at the first use of an
+                // ordinary load result, which would drain the prefetch if it happened after issue_stage.
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    scale[ms] *= sb_cur;
+                    pin_vgpr(scale[ms]);
+                }
+                if (has_next) {
+                    if constexpr (SPREAD == 0)
+                        issue_stage(cur ^ 1, kb + 1);
+                    sb_nxt = sfb_wave[static_cast<int64_t>(kb + 1) * p.sfb_sk];
+                }
+                // SFA reloads are unconditional: past the last K block the buffer descriptor bounds the access.
+                sa_tail_next = load_sfa(MS - 1, kb + 1);
+
+                const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
+                const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
+                v8i bf[NS], af[2];
+                bf[0] = load_fragment(b_tile, frag_off);
+                af[0] = load_fragment(a_tile, frag_off);
+                #pragma unroll
+                for (int ns = 1; ns < NS; ++ns)
+                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+
+                #pragma unroll
+                for (int i = 0; i < TOTAL; ++i) {
+                    const int ms = i / NS, ns = i % NS;
+                    const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
+                    const int jms = j / NS, jns = j % NS;
+                    const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;     // i < DEPTH: previous block's tail
+                    mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
+                    if (ns == 0 && ms + 1 < MS)
+                        af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
+                    if (i >= DEPTH && jns == NS - 1 && jms < MS - 1)
+                        scale[jms] = load_sfa(jms, kb + 1);          // subtile jms fully promoted: fetch its next scale
+                    if constexpr (SPREAD > 0) {
+                        // spread the next stage's LDS-DMA pieces over the first steps, one per SPREAD MFMAs
+                        if (i % SPREAD == SPREAD - 1 && i / SPREAD < A_ITERS + B_ITERS && has_next)
+                            issue_piece(cur ^ 1, kb + 1, i / SPREAD);
+                    }
+                }
+                static_assert((TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
+                scale_tail = scale[MS - 1];
+                scale[MS - 1] = sa_tail_next;
+                sb_cur = sb_nxt;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // drain the ring: steps TOTAL-3 .. TOTAL-1 of the last K block
+            #pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                const int j = TOTAL - DEPTH + i;
+                promote_only(acc[j / NS][j % NS], scale_tail, part[(TOTAL + i + 1) & DEPTH]);
+            }
+        }
+
+        v4f out[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
+        store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+    }
+}
+
+// The body lives in a __device__ function: it uses gfx950-only types (buffer resources) that the host pass of hipcc
+// cannot name, and a __global__ function whose body the host pass rejects gets no launch stub.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
+    pipe_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

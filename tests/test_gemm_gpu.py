@@ -1,0 +1,277 @@
+"""GPU parity tests of the FP8 GEMM path: the HIP kernels (through the public operators / C ABI) against the CPU
+oracle on the same seeded inputs, the committed golden fixtures, the reference's own gate, and size-independent
+properties at BASELINE.json's full sizes.  Modeled on the reference's tests/test_fp8_fp4.py."""
+import random
+
+import pytest
+import torch
+
+import deepgemm_amd as dg
+import oracle
+from deepgemm_amd.testing import calc_diff, generators as gen
+from gpu_helpers import assert_close_fp32, assert_close_to_oracle, cpu_pair, oracle_dense
+
+pytestmark = pytest.mark.gpu
+FAST = ['fast_256x256', 'fast_128x256', 'fast_128x128', 'fast_64x256', 'fast_32x256', 'fast_16x256',
+        'pipe_256x256', 'pipe_s2_256x256', 'pipe_s4_256x256', 'pipe_128x256', 'pipe_128x128', 'x_p1_256x256', 'x_p2_256x256']
+
+
+@pytest.fixture(autouse=True)
+def _auto_config():
+    dg.set_forced_config('auto')
+    dg.set_mk_alignment_for_contiguous_layout(128)
+    yield
+    dg.set_forced_config('auto')
+
+
+def test_c1_unit_scale_exact(golden_gemm):
+    """BASELINE.json config 1 on the GPU: integer operands, unit scales -> bit-exact BF16 torch.matmul, every config."""
+    a, b = golden_gemm.fp8('c1_a_q').cuda(), golden_gemm.fp8('c1_b_q').cuda()
+    sfa, sfb = torch.ones(128, 4, device='cuda'), torch.ones(1, 4, device='cuda')
+    want = golden_gemm.bf16('c1_ref_d')
+    for cfg in FAST + ['generic_128x128', 'auto']:
+        dg.set_forced_config(cfg)
+        d = torch.full((128, 128), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt((a, sfa), (b, sfb), d)
+        assert torch.equal(d.cpu(), want), cfg
+
+
+def test_golden_fixtures(golden_gemm):
+    g = golden_gemm
+    for name in ['g64x192x384', 'g33x200x256', 'g128x128x1024', 'g96x136x640_f32']:
+        fp32 = name.endswith('_f32')
+        a, sfa, b, sfb = g.fp8(f'{name}_a_q'), g.raw(f'{name}_sfa'), g.fp8(f'{name}_b_q'), g.raw(f'{name}_sfb')
+        stored = g.raw(f'{name}_oracle_d') if fp32 else g.bf16(f'{name}_oracle_d')
+        ref_d = g.raw(f'{name}_ref_d') if fp32 else g.bf16(f'{name}_ref_d')
+        for cfg in ('auto', 'generic_128x128'):
+            dg.set_forced_config(cfg)
+            d = torch.empty(stored.shape, device='cuda', dtype=stored.dtype)
+            dg.fp8_gemm_nt((a.cuda(), sfa.cuda()), (b.cuda(), sfb.cuda()), d)
+            (assert_close_fp32 if fp32 else assert_close_to_oracle)(d, stored, f'{name}/{cfg}')
+            assert calc_diff(d.cpu(), ref_d) < gen.FP8_MAX_DIFF
+
+
+DENSE_SHAPES = [(1, 128, 128), (7, 136, 256), (128, 2112, 512), (129, 576, 384), (256, 256, 1024), (300, 520, 384),
+                (16, 4096, 512), (64, 256, 7168), (384, 768, 256)]
+
+
+@pytest.mark.parametrize('m,n,k', DENSE_SHAPES)
+def test_dense_nt_vs_oracle(m, n, k):
+    gen.reset_seed(m * 7 + n)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    configs = ['auto', 'generic_128x128'] + FAST
+    for cfg in configs:
+        dg.set_forced_config(cfg)
+        case.d.fill_(float('nan'))
+        dg.fp8_gemm_nt(case.a, case.b, case.d)
+        assert_close_to_oracle(case.d, want, f'{(m, n, k)}/{cfg}')
+        assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF, cfg
+
+
+@pytest.mark.parametrize('layout', ['nt', 'nn', 'tn', 'tt'])
+@pytest.mark.parametrize('m,n,k', [(256, 384, 512), (130, 200, 384), (2048, 1024, 256)])
+def test_dense_layouts_vs_oracle(layout, m, n, k):
+    """nn / tn / tt are transposed views (csrc/apis/gemm.hpp:126-164); both the strided-view and the alias entry."""
+    gen.reset_seed(1)
+    a_k_major, b_k_major = layout[0] == 'n', layout[1] == 't'
+    case = gen.generate_normal(m, n, k, a_k_major, b_k_major)
+    want = oracle_dense(case)
+    dg.fp8_gemm_nt(case.a, case.b, case.d)                                   # MN-major operands as strided views
+    assert_close_to_oracle(case.d, want, f'{layout} view')
+    a = case.a if a_k_major else (case.a[0].T, case.a[1].T)
+    b = case.b if b_k_major else (case.b[0].T, case.b[1].T)
+    assert a[0].is_contiguous() and b[0].is_contiguous()
+    case.d.fill_(float('nan'))
+    getattr(dg, f'fp8_gemm_{layout}')(a, b, case.d)
+    assert_close_to_oracle(case.d, want, f'{layout} alias')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+
+
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float])
+@pytest.mark.parametrize('cfg', ['auto', 'generic_128x128', 'fast_128x128'])
+def test_accumulate_and_fp32_out(out_dtype, cfg):
+    gen.reset_seed(2)
+    dg.set_forced_config(cfg)
+    case = gen.generate_normal(200, 384, 512, accumulate=True, out_dtype=out_dtype)
+    c_cpu = case.c.cpu().clone()
+    want = oracle_dense(case, c_cpu=c_cpu)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c)                         # c is d: accumulate in place
+    (assert_close_fp32 if out_dtype == torch.float else assert_close_to_oracle)(case.d, want, 'in place')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    # c in a different buffer: copied into d first (gemm.hpp:43-44), c itself untouched
+    d2 = torch.empty_like(case.d)
+    c2 = c_cpu.cuda()
+    dg.fp8_gemm_nt(case.a, case.b, d2, c=c2)
+    assert torch.equal(d2, case.d) and torch.equal(c2.cpu(), c_cpu)
+    # plain FP32 output without accumulation
+    if out_dtype == torch.float:
+        d3 = torch.empty_like(case.d)
+        dg.fp8_gemm_nt(case.a, case.b, d3)
+        d3_want = torch.empty(d3.shape, dtype=torch.float)
+        oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), d3_want)
+        assert_close_fp32(d3, d3_want, 'fp32 out')
+
+
+def test_wgrad_recipe_per_column_sfb():
+    """Recipe (1, 1, 128): per-row SFA x per-column SFB, FP32 accumulate (reference sm90_fp8_gemm_1d1d)."""
+    gen.reset_seed(3)
+    for a_k, b_k in ((True, True), (False, False)):
+        case = gen.generate_normal(192, 264, 640, a_k, b_k, accumulate=True, out_dtype=torch.float, per_token_b=True)
+        want = oracle_dense(case, gran_n=1, c_cpu=case.c.cpu().clone())
+        dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c, recipe=(1, 1, 128))
+        assert_close_fp32(case.d, want, 'recipe (1,1,128)')
+        assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    case = gen.generate_normal(64, 128, 256, per_token_b=True)
+    want = oracle_dense(case, gran_n=1)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, recipe_a=(1, 128), recipe_b=(1, 128))
+    assert_close_to_oracle(case.d, want, 'recipe_a/recipe_b')
+
+
+def test_k_tail_sub_views_and_wide_d():
+    gen.reset_seed(4)
+    # K not a multiple of 128 (quantisers zero-pad the last block): generic path
+    case = gen.generate_normal(70, 136, 200)
+    dg.fp8_gemm_nt(case.a, case.b, case.d)
+    assert_close_to_oracle(case.d, oracle_dense(case), 'k tail')
+    assert dg.last_config() == 'generic_128x128'
+    # operands that are column sub-views of wider buffers (leading dimension > k) and D wider than N (A5)
+    big = gen.generate_normal(160, 256, 1024)
+    a_view, b_view = big.a[0][:, 128:640], big.b[0][:, 128:640]
+    sfa_view, sfb_view = big.a[1][:, 1:5].contiguous(), big.b[1][:, 1:5].contiguous()
+    d_wide = torch.full((160, 300), -5.0, device='cuda', dtype=torch.bfloat16)
+    d = d_wide[:, :256]
+    for cfg in ('auto', 'generic_128x128'):
+        dg.set_forced_config(cfg)
+        dg.fp8_gemm_nt((a_view, sfa_view), (b_view, sfb_view), d)
+        want = torch.empty((160, 256), dtype=torch.bfloat16)
+        oracle.fp8_gemm_nt(a_view.cpu(), sfa_view.cpu(), b_view.cpu(), sfb_view.cpu(), want)
+        assert_close_to_oracle(d, want, f'sub views/{cfg}')
+        assert bool((d_wide[:, 256:] == -5.0).all())
+    # SFA already MN-major (zero-copy path) and SFB transposed-contiguous
+    dg.set_forced_config('auto')
+    case = gen.generate_normal(130, 256, 512)
+    sfa_t = dg.get_mn_major_tma_aligned_tensor(case.a[1])
+    assert sfa_t.stride() == (1, 132)
+    sfb_t = case.b[1].t().contiguous().t()
+    dg.fp8_gemm_nt((case.a[0], sfa_t), (case.b[0], sfb_t), case.d)
+    assert_close_to_oracle(case.d, oracle_dense(case), 'pre-transposed SF')
+
+
+def test_back_to_back_launches_and_side_stream():
+    """Calls are stream-ordered and non-blocking."""
+    gen.reset_seed(5)
+    case = gen.generate_normal(512, 512, 1024)
+    want = oracle_dense(case)
+    for _ in range(5):
+        dg.fp8_gemm_nt(case.a, case.b, case.d)
+    assert_close_to_oracle(case.d, want, 'back to back')
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    d2 = torch.empty_like(case.d)
+    with torch.cuda.stream(side):
+        dg.fp8_gemm_nt(case.a, case.b, d2)
+    side.synchronize()
+    assert torch.equal(d2, case.d)
+
+
+@pytest.mark.parametrize('use_psum', [False, True])
+@pytest.mark.parametrize('b_k_major', [True, False])
+def test_m_grouped_contiguous_vs_oracle(use_psum, b_k_major):
+    gen.reset_seed(6)
+    for actual_ms, n, k in (([100, 0, 130, 256], 256, 384), ([300, 77], 520, 256), ([128] * 8, 4096, 512)):
+        case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, b_k_major, use_psum, actual_ms=actual_ms)
+        want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
+        oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), use_psum)
+        for cfg in (['auto', 'generic_128x128'] + (['fast_128x256', 'fast_128x128', 'fast_64x256', 'pipe_128x256', 'pipe_128x128'] if b_k_major else [])):
+            dg.set_forced_config(cfg)
+            case.d.fill_(float('nan'))
+            if b_k_major:
+                dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout, use_psum_layout=use_psum)
+            else:
+                b_alias = (case.b[0].mT, case.b[1].mT)
+                assert b_alias[0].is_contiguous()
+                dg.m_grouped_fp8_gemm_nn_contiguous(case.a, b_alias, case.d, case.grouped_layout, use_psum_layout=use_psum)
+            start = 0
+            for actual, aligned in zip(case.actual_ms, case.aligned_ms):
+                rows = slice(start, start + actual)
+                assert_close_to_oracle(case.d[rows], want[rows], f'{cfg} rows {rows}')
+                pad = case.d[start + actual:start + aligned]
+                assert bool((pad == 0).all()), f'{cfg}: padding rows must be zeros'
+                start += aligned
+            assert calc_diff(torch.nan_to_num(case.d), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
+
+
+def test_m_grouped_contiguous_reference_shapes_sampled():
+    """One reference-sized case (8 groups x ~512 rows, N=4096, K=7168 = BASELINE config 4): reference gate on all rows,
+    oracle on a row sample per group."""
+    gen.reset_seed(0)
+    case = gen.generate_m_grouped_contiguous(8, 512, 4096, 7168)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    start = 0
+    for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+        rows = torch.tensor(sorted(random.sample(range(start, start + actual), 8)))
+        want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows.cuda()].cpu(), case.a[1][rows.cuda()].cpu(),
+                                                  case.b[0][g].cpu(), case.b[1][g].cpu())
+        assert_close_to_oracle(case.d[rows.cuda()], want, f'group {g}')
+        assert bool((case.d[start + actual:start + aligned] == 0).all())
+        start += aligned
+
+
+@pytest.mark.parametrize('masked_ms,max_m,n,k', [([5, 0, 64, 33], 64, 256, 384), ([200, 1, 129], 256, 520, 256),
+                                                  ([20] * 6 + [0, 64], 64, 4096, 512)])
+def test_m_grouped_masked_vs_oracle(masked_ms, max_m, n, k):
+    gen.reset_seed(7)
+    case = gen.generate_m_grouped_masked(len(masked_ms), max_m, 0, n, k, masked_ms=masked_ms)
+    want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
+    oracle.m_grouped_fp8_gemm_nt_masked(*cpu_pair(case.a), *cpu_pair(case.b), want, case.masked_m.cpu())
+    expected_m = max(1, int(sum(masked_ms) / len(masked_ms)))
+    for cfg in ['auto', 'generic_128x128'] + FAST:
+        dg.set_forced_config(cfg)
+        case.d.fill_(float('nan'))
+        dg.m_grouped_fp8_gemm_nt_masked(case.a, case.b, case.d, case.masked_m, expected_m)
+        for g, rows in enumerate(masked_ms):
+            if rows:
+                assert_close_to_oracle(case.d[g, :rows], want[g, :rows], f'{cfg} group {g}')
+                assert calc_diff(case.d[g, :rows], case.ref_d[g, :rows]) < gen.FP8_MAX_DIFF
+            assert bool(torch.isnan(case.d[g, rows:]).all()), f'{cfg}: rows >= masked_m must not be written'
+
+
+def test_full_size_c2_properties():
+    """BASELINE.json config 2 (4096 x 4096 x 7168): reference gate on the whole output, oracle on sampled rows, and
+    size-independent properties that must hold bit-exactly: power-of-two scaling of SFA/SFB and row permutation of A."""
+    gen.reset_seed(0)
+    case = gen.generate_normal(4096, 4096, 7168)
+    dg.fp8_gemm_nt(case.a, case.b, case.d)
+    assert dg.last_config().startswith('fast_')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    rows = torch.tensor(sorted(random.sample(range(4096), 48)), device='cuda')
+    want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows].cpu(), case.a[1][rows].cpu(), case.b[0].cpu(), case.b[1].cpu())
+    assert_close_to_oracle(case.d[rows], want, 'sampled rows')
+    # scaling SFA by 2 and SFB by 1/4 scales every product exactly by 1/2
+    d2 = torch.empty_like(case.d)
+    dg.fp8_gemm_nt((case.a[0], case.a[1] * 2), (case.b[0], case.b[1] * 0.25), d2)
+    assert torch.equal(d2.float() * 2, case.d.float())
+    # permuting the rows of A (and SFA) permutes the rows of D, whatever tile / wave / lane each row lands in
+    perm = torch.randperm(4096, device='cuda')
+    d3 = torch.empty_like(case.d)
+    dg.fp8_gemm_nt((case.a[0][perm].contiguous(), case.a[1][perm].contiguous()), case.b, d3)
+    assert torch.equal(d3, case.d[perm])
+    # every dense configuration agrees bit-for-bit on the same problem (same per-element arithmetic order)
+    for cfg in ('fast_128x256', 'fast_128x128', 'pipe_256x256', 'pipe_s2_256x256', 'pipe_128x128'):
+        dg.set_forced_config(cfg)
+        d4 = torch.empty_like(case.d)
+        dg.fp8_gemm_nt(case.a, case.b, d4)
+        assert torch.equal(d4, case.d), cfg
+
+
+def test_reference_sweep_subset_gate():
+    """A slice of the reference's dense sweep (tests/generators.py:119-121) at the reference's own gate."""
+    gen.reset_seed(0)
+    for m in (1, 128, 4096):
+        for n, k in ((2112, 7168), (576, 7168), (7168, 2048), (24576, 1536)):
+            case = gen.generate_normal(m, n, k)
+            dg.fp8_gemm_nt(case.a, case.b, case.d)
+            diff = calc_diff(case.d, case.ref_d)
+            assert diff < gen.FP8_MAX_DIFF, (m, n, k, diff, dg.last_config())

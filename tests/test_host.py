@@ -1,0 +1,174 @@
+"""CPU tests of the host layer: C-ABI surface, argument validation, trivial cases, knobs.  No kernel is launched."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import deepgemm_amd as dg
+from deepgemm_amd import _lib
+from deepgemm_amd.testing import generators as gen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'deepgemm_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 10
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), f'{name} declared in include/deepgemm_amd.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == names
+    assert b'gfx950' in _lib.lib.dg_version()
+
+
+def test_reference_operator_names_exist():
+    import deep_gemm
+    for name in ['fp8_gemm_nt', 'fp8_gemm_nn', 'fp8_gemm_tn', 'fp8_gemm_tt', 'fp8_fp4_gemm_nt', 'fp8_fp4_gemm_nn',
+                 'fp8_fp4_gemm_tn', 'fp8_fp4_gemm_tt', 'm_grouped_fp8_gemm_nt_contiguous', 'm_grouped_fp8_gemm_nn_contiguous',
+                 'm_grouped_fp8_gemm_nt_masked', 'm_grouped_fp8_fp4_gemm_nt_contiguous', 'm_grouped_fp8_fp4_gemm_nn_contiguous',
+                 'm_grouped_fp8_fp4_gemm_nt_masked', 'fp8_m_grouped_gemm_nt_masked', 'transform_sf_into_required_layout',
+                 'get_tma_aligned_size', 'get_mn_major_tma_aligned_tensor', 'set_num_sms', 'get_num_sms', 'set_tc_util',
+                 'get_tc_util', 'set_pdl', 'get_pdl', 'set_ignore_compile_dims', 'set_block_size_multiple_of',
+                 'set_mk_alignment_for_contiguous_layout', 'get_mk_alignment_for_contiguous_layout',
+                 'get_theoretical_mk_alignment_for_contiguous_layout', 'get_m_alignment_for_contiguous_layout',
+                 'per_token_cast_to_fp8', 'per_block_cast_to_fp8', 'per_channel_cast_to_fp8', 'ceil_to_ue8m0', 'align', 'ceil_div']:
+        assert hasattr(deep_gemm, name), name
+    from deep_gemm.testing import bench, bench_kineto, calc_diff, count_bytes, assert_bitwise_equal, get_arch_major  # noqa: F401
+    from deep_gemm.utils import per_custom_dims_cast_to_fp8  # noqa: F401
+
+
+def test_knobs_round_trip():
+    assert dg.get_num_sms() == 256
+    dg.set_num_sms(128)
+    assert dg.get_num_sms() == 128
+    dg.set_num_sms(0)
+    assert dg.get_num_sms() == 256
+    dg.set_tc_util(80), dg.set_pdl(True)
+    assert dg.get_tc_util() == 80 and dg.get_pdl() is True
+    dg.set_tc_util(100), dg.set_pdl(False)
+    assert dg.get_mk_alignment_for_contiguous_layout() == 128 == dg.get_theoretical_mk_alignment_for_contiguous_layout(20)
+    dg.set_mk_alignment_for_contiguous_layout(64)
+    assert dg.get_m_alignment_for_contiguous_layout() == 64
+    dg.set_mk_alignment_for_contiguous_layout(128)
+    dg.set_block_size_multiple_of(2), dg.set_ignore_compile_dims(True), dg.set_ignore_compile_dims(False)
+    with pytest.raises(RuntimeError, match='unknown kernel configuration'):
+        dg.set_forced_config('bogus')
+    dg.set_forced_config('generic_128x128'), dg.set_forced_config('auto')
+    assert 'fast_256x256' in dg.list_configs()
+
+
+def test_c_abi_reports_errors_without_launching():
+    lib = _lib.lib
+    # empty problems return success before any pointer is looked at
+    assert lib.dg_fp8_gemm_nt(None, None, None, None, None, 0, 128, 128, 128, 1, 128, 1, 1, 4, 1, 1, 128, 128, 0, 0, None) == 0
+    rc = lib.dg_fp8_gemm_nt(1, 1, 1, 1, 1, 16, 16, 128, 128, 1, 128, 1, 1, 16, 1, 1, 7, 16, 0, 0, None)
+    assert rc != 0 and b'sfb_gran_n' in lib.dg_last_error()
+    rc = lib.dg_fp8_gemm_nt(1, 1, 1, 1, 1, 16, 16, 128, 128, 2, 128, 1, 1, 16, 1, 1, 128, 16, 0, 0, None)
+    assert rc != 0 and b'a_stride_m == 1 || a_stride_k == 1' in lib.dg_last_error()
+    rc = lib.dg_m_grouped_fp8_gemm_nt_masked(1, 1, 1, 1, 1, 1, 2, 64, 128, 128, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, None)
+    assert rc != 0 and b'expected_m > 0' in lib.dg_last_error()
+    with pytest.raises(RuntimeError, match='Assertion error'):
+        _lib.check(rc)
+
+
+def _case(m=32, n=64, k=256, **kw):
+    torch.manual_seed(0)
+    return gen.generate_normal(m, n, k, device='cpu', **kw)
+
+
+def test_cpu_tensors_fail_loudly():
+    c = _case()
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.fp8_gemm_nt(c.a, c.b, c.d)
+
+
+def test_validation_messages():
+    c = _case()
+    with pytest.raises(RuntimeError, match=r'Assertion error \(gemm.py:\d+\): ab.scalar_type'):
+        dg.fp8_gemm_nt((c.a[0].view(torch.uint8), c.a[1]), c.b, c.d)
+    with pytest.raises(RuntimeError, match='m == m_ and n == n_ and k == k_'):
+        dg.fp8_gemm_nt(c.a, c.b, torch.empty(32, 65, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match='d.scalar_type'):
+        dg.fp8_gemm_nt(c.a, c.b, torch.empty(32, 64, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match=r't.stride\(-1\) == 1'):
+        dg.fp8_gemm_nt(c.a, c.b, torch.empty(64, 32, dtype=torch.bfloat16).t())
+    with pytest.raises(RuntimeError, match='ceil_div'):
+        dg.fp8_gemm_nt((c.a[0], c.a[1][:, :1]), c.b, c.d)                       # SFA with too few K blocks
+    with pytest.raises(RuntimeError, match='recipe_a.has_value'):
+        dg.fp8_gemm_nt(c.a, c.b, c.d, recipe=(1, 128, 128), recipe_a=(1, 128), recipe_b=(128, 128))
+    with pytest.raises(RuntimeError, match='sfa_dtype == torch::kFloat'):
+        dg.fp8_gemm_nt((c.a[0], c.a[1].to(torch.int)), c.b, c.d)
+    with pytest.raises(RuntimeError, match=r'd.scalar_type\(\) == c'):
+        dg.fp8_gemm_nt(c.a, c.b, c.d, c=torch.zeros(32, 64))
+    # grouped: A must be K-major, D must be BF16, layout length must match
+    torch.manual_seed(0)
+    g = gen.generate_m_grouped_contiguous(2, 0, 64, 256, device='cpu', actual_ms=[128, 128])
+    with pytest.raises(RuntimeError, match='major_a'):
+        dg.m_grouped_fp8_gemm_nt_contiguous((g.a[0].t().contiguous().t(), g.a[1]), g.b, g.d, g.grouped_layout)
+    with pytest.raises(RuntimeError, match='m == m__'):
+        dg.m_grouped_fp8_gemm_nt_contiguous(g.a, g.b, g.d, g.grouped_layout[:-1].contiguous())
+    with pytest.raises(RuntimeError, match='kBFloat16'):
+        dg.m_grouped_fp8_gemm_nt_contiguous(g.a, g.b, g.d.float(), g.grouped_layout)
+    mk = gen.generate_m_grouped_masked(2, 64, 0, 64, 256, device='cpu', masked_ms=[3, 64])
+    with pytest.raises(RuntimeError, match='expected_m > 0'):
+        dg.m_grouped_fp8_gemm_nt_masked(mk.a, mk.b, mk.d, mk.masked_m, 0)
+    with pytest.raises(RuntimeError, match='kInt'):
+        dg.m_grouped_fp8_gemm_nt_masked(mk.a, mk.b, mk.d, mk.masked_m.long(), 8)
+
+
+def test_trivial_cases_need_no_kernel():
+    """csrc/apis/gemm.hpp:19-46: m == 0 or n == 0 -> no-op; k == 0 -> D = C or 0."""
+    fp8 = torch.float8_e4m3fn
+    d = torch.full((0, 64), 7.0, dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((torch.empty(0, 256, dtype=fp8), torch.empty(0, 2)), (torch.empty(64, 256, dtype=fp8), torch.empty(1, 2)), d)
+    d = torch.full((4, 8), 7.0, dtype=torch.bfloat16)
+    a0, b0 = (torch.empty(4, 0, dtype=fp8), torch.empty(4, 0)), (torch.empty(8, 0, dtype=fp8), torch.empty(1, 0))
+    dg.fp8_gemm_nt(a0, b0, d)
+    assert bool((d == 0).all())
+    c = torch.arange(32, dtype=torch.float32).view(4, 8).to(torch.bfloat16)
+    dg.fp8_gemm_nt(a0, b0, d, c=c)
+    assert torch.equal(d, c)
+    g = gen.generate_m_grouped_contiguous(2, 0, 64, 256, device='cpu', actual_ms=[0, 0])
+    dg.m_grouped_fp8_gemm_nt_contiguous(g.a, g.b, g.d, g.grouped_layout)       # m == 0: no-op
+
+
+def test_sf_layout_helpers_on_host():
+    assert dg.get_tma_aligned_size(4097, 4) == 4100 and dg.get_tma_aligned_size(5, 2) == 8
+    sf = torch.rand(4097, 7)
+    out = dg.get_mn_major_tma_aligned_tensor(sf)
+    assert torch.equal(out, sf) and out.stride() == (1, 4100)
+    assert dg.get_mn_major_tma_aligned_tensor(out).data_ptr() == out.data_ptr()       # already in layout: zero copy
+    grouped = torch.rand(3, 130, 5)
+    out = dg.get_mn_major_tma_aligned_tensor(grouped)
+    assert torch.equal(out, grouped) and out.stride() == (132 * 5, 1, 132)
+    t = dg.transform_sf_into_required_layout(sf, 4097, 7 * 128, (1, 128, 128), is_sfa=True)
+    assert t.stride() == (1, 4100)
+    sfb = torch.rand(33, 7)
+    assert dg.transform_sf_into_required_layout(sfb, 33 * 128, 7 * 128, (1, 128, 128), is_sfa=False) is sfb
+    with pytest.raises(RuntimeError, match='SFB must be contiguous'):
+        dg.transform_sf_into_required_layout(torch.rand(33, 14)[:, ::2], 33 * 128, 7 * 128, (128, 128))
+    with pytest.raises(RuntimeError, match='Unknown SF transformation'):
+        dg.transform_sf_into_required_layout(torch.zeros(64, 2, dtype=torch.int), 64, 1024, (1, 128))
+
+
+def test_generators_follow_reference_conventions():
+    gen.reset_seed(0)
+    g = gen.generate_m_grouped_contiguous(4, 200, 64, 256, device='cpu')
+    assert g.m == sum(g.aligned_ms) and all(x % 128 == 0 for x in g.aligned_ms)
+    start = 0
+    for i, (actual, aligned) in enumerate(zip(g.actual_ms, g.aligned_ms)):
+        assert bool((g.grouped_layout[start:start + actual] == i).all())
+        assert bool((g.grouped_layout[start + actual:start + aligned] == -1).all())
+        assert bool((g.a[0][start + actual:start + aligned].view(torch.uint8) == 0).all())
+        start += aligned
+    shapes = list(gen.enumerate_normal())
+    assert (4096, 4096, 7168, True, True, False, torch.bfloat16, False) in shapes and len(shapes) == 3 * 7 * 2 + 7 * 3
