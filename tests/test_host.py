@@ -63,7 +63,7 @@ def test_knobs_round_trip():
     with pytest.raises(RuntimeError, match='unknown kernel configuration'):
         dg.set_forced_config('bogus')
     dg.set_forced_config('generic_128x128'), dg.set_forced_config('auto')
-    assert 'fast_256x256' in dg.list_configs()
+    assert 'pipe_256x256' in dg.list_configs()
 
 
 def test_c_abi_reports_errors_without_launching():

@@ -11,7 +11,7 @@ echo "smoke exit $?" >> gpurun_out/session.log
 timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --maxfail=12 --tb=short -p no:cacheprovider > gpurun_out/pytest.log 2>&1
 echo "pytest exit $?" >> gpurun_out/session.log
 tail -5 gpurun_out/pytest.log >> gpurun_out/session.log
-timeout 600 python tools/sweep.py --out gpurun_out/sweep_c2.jsonl > gpurun_out/sweep.log 2>&1
+timeout 600 python tools/sweep.py --out gpurun_out/sweep_c2.jsonl ${SWEEP_ARGS} > gpurun_out/sweep.log 2>&1
 echo "sweep exit $?" >> gpurun_out/session.log
 timeout 600 python bench.py --steps 100 --warmup 20 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench exit $?" >> gpurun_out/session.log

@@ -23,14 +23,20 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--out', default='')
+    ap.add_argument('--sets', type=int, default=4, help='rotating input sets (1 = operands stay in the Infinity Cache)')
     args = ap.parse_args()
     configs = args.configs.split(',') if args.configs else [c for c in dg.list_configs() if not c.startswith('generic')]
     out = open(args.out, 'w') if args.out else None
     flush = torch.empty(int(512e6) // 4, dtype=torch.int, device='cuda')
     for shape in args.shapes.split(','):
         m, n, k = (int(x) for x in shape.split('x'))
-        gen.reset_seed(0)
-        case = gen.generate_normal(m, n, k)
+        cases = []
+        for i in range(args.sets):
+            gen.reset_seed(i)
+            c_ = gen.generate_normal(m, n, k)
+            c_.a = (c_.a[0], dg.get_mn_major_tma_aligned_tensor(c_.a[1]))
+            cases.append(c_)
+        case = cases[0]
         times = {c: [] for c in configs}
         diffs = {}
         for c in configs:
@@ -50,8 +56,9 @@ def main():
                 flush.zero_()
                 start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 start.record()
-                for _ in range(args.iters):
-                    dg.fp8_gemm_nt(case.a, case.b, case.d)
+                for it in range(args.iters):
+                    cc = cases[it % len(cases)]
+                    dg.fp8_gemm_nt(cc.a, cc.b, cc.d)
                 end.record()
                 torch.cuda.synchronize()
                 times[c].append(start.elapsed_time(end) / args.iters * 1e3)
