@@ -9,6 +9,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def _ensure_built():
+    # The package has no fallback path: build the HIP extension (hipcc cross-compiles gfx950 without a GPU) before any
+    # test module imports it.  On the GPU box the prebuilt library travels with the snapshot and this is a no-op.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_dg_build', os.path.join(ROOT, 'deepgemm_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build_extension()
+
+
+_ensure_built()
+
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
