@@ -17,6 +17,7 @@ thread_local std::string g_last_error;
 thread_local std::string g_forced_config = "auto";
 thread_local std::string g_last_config = "";
 int g_num_cus_override = 0;
+thread_local long long* g_debug_buffer = nullptr;
 
 int fail(const char* file, int line, const char* what) {
     g_last_error = std::string("Assertion error (") + file + ":" + std::to_string(line) + "): " + what;
@@ -63,9 +64,11 @@ struct Config {
     float efficiency;       // relative MFMA efficiency of the tile shape (heuristic weight, refined by measurement)
     bool fast;
     KernelFn fn;
+    bool ring = false;      // ring kernels read SFA through a buffer descriptor that assumes the MN-major layout
 };
 
 const Config kConfigs[] = {
+    {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
     {"pipe_128x128", 128, 128, 256, 2, 0.80f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 2>},
@@ -81,6 +84,14 @@ const Config kConfigs[] = {
     {"abl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 1>},
     {"abl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 2>},
     {"abl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 3>},
+    {"abl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 4>},
+    {"abl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 5>},
+    {"rabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 1>, true},
+    {"rabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 2>, true},
+    {"rabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 3>, true},
+    {"ring_p2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 2>, true},
+    {"ring_p4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 4>, true},
+    {"ring_p8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 8>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
@@ -113,7 +124,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     double best_cost = 0;
     for (int i = 0; i < kNumConfigs; ++i) {
         const Config& c = kConfigs[i];
-        if ((c.fast && !fast_ok) || c.efficiency <= 0.f)
+        if ((c.fast && !fast_ok) || c.efficiency <= 0.f || (c.ring && p.sfa_sm != 1))
             continue;
         if (bm_must_divide > 0 && bm_must_divide % c.bm != 0)
             continue;
@@ -145,6 +156,10 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major 16-byte aligned operands and k % 128 == 0";
         return 3;
     }
+    if (cfg->ring && p.sfa_sm != 1) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs MN-major SFA (sfa_stride_m == 1)";
+        return 3;
+    }
     if (bm_must_divide > 0 && bm_must_divide % cfg->bm != 0) {
         g_last_error = std::string("config '") + cfg->name + "' does not divide the contiguous-layout M alignment";
         return 3;
@@ -156,6 +171,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
+    p.dbg = g_debug_buffer;
 
     long grid;
     const long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
@@ -301,6 +317,11 @@ int dg_set_forced_config(const char* name) {
         }
     }
     g_forced_config = name;
+    return 0;
+}
+
+int dg_set_debug_buffer(void* device_buffer) {
+    g_debug_buffer = static_cast<long long*>(device_buffer);
     return 0;
 }
 

@@ -49,7 +49,13 @@ struct GemmParams {
     int num_m_tiles, num_n_tiles;   // per group
     int group_m;                    // tile-order swizzle: m-tiles per L2 group
     int d_vec_ok;                   // 16-byte aligned D rows => vector stores
+    long long* dbg;                 // tuning aid (normally null): per wave {kernel entry, K loop begin, K loop end, after stores} s_memtime ticks
 };
+
+__device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
+    if (p.dbg != nullptr && (threadIdx.x & 63) == 0)
+        p.dbg[(static_cast<long long>(blockIdx.x) * waves_per_block + (threadIdx.x >> 6)) * 4 + slot] = t;
+}
 
 struct Tile {
     int m0, n0;       // first row (within the group's A/D for masked, global otherwise) / first column
@@ -493,7 +499,8 @@ __device__ __forceinline__ void promote_only(float (&c)[4], float scale, const v
 }
 
 // ABLATE (timing experiments only, results are garbage): 1 = no LDS-DMA / vmcnt / barrier inside the K loop,
-// 2 = additionally no FP32 promotion (bare MFMA stream), 3 = loads and barriers kept but no promotion.
+// 2 = additionally no FP32 promotion (bare MFMA stream), 3 = loads and barriers kept but no promotion,
+// 4 = as 2 and no LDS fragment reads in the loop either (pure matrix-pipe rate), 5 = as 4 but with the promotion.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, int ABLATE = 0>
 __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -524,6 +531,8 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
     // the K block go into the (wave-uniform) soffset of the buffer instruction.
     const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
     const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    long long t_loop0 = 0, t_loop1 = 0;
 
     MaskedWalk walk;
     const int num_launched = gridDim.x;
@@ -604,6 +613,8 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 
+            v8i bf[NS], af[2];
+            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
             for (int kb = 0; kb < num_kb; ++kb) {
                 const int cur = kb & 1;
                 const bool has_next = kb + 1 < num_kb;
@@ -619,16 +630,23 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 for (int ms = 0; ms < MS; ++ms)
                     sa_nxt[ms] = load_sfa(ms, kb + 1);
                 if (has_next) {
-                    if constexpr (SPREAD == 0 && ABLATE != 1 && ABLATE != 2)
+                    if constexpr (SPREAD == 0 && (ABLATE == 0 || ABLATE == 3))
                         issue_stage(cur ^ 1, kb + 1);
                     sb_nxt = sfb_wave[static_cast<int64_t>(kb + 1) * p.sfb_sk];
                 }
 
                 const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
-                v8i bf[NS], af[2];
-                bf[0] = load_fragment(b_tile, frag_off);
-                af[0] = load_fragment(a_tile, frag_off);
+                if (ABLATE < 4 || kb == 0) {
+                    bf[0] = load_fragment(b_tile, frag_off);
+                    af[0] = load_fragment(a_tile, frag_off);
+                }
+                if (ABLATE >= 4 && kb == 0) {
+                    #pragma unroll
+                    for (int ns = 1; ns < NS; ++ns)
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    af[1] = load_fragment(a_tile + 2048, frag_off);
+                }
 
                 #pragma unroll
                 for (int i = 0; i < TOTAL; ++i) {
@@ -638,15 +656,15 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                     const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;     // i < DEPTH: previous block's tail
                     // Fragment reads ride one step ahead of their first use: B subtile ns+1 during the first M-subtile,
                     // A subtile ms+1 at the head of subtile ms.
-                    if (ms == 0 && ns + 1 < NS)
+                    if (ABLATE < 4 && ms == 0 && ns + 1 < NS)
                         bf[ns + 1] = load_fragment(b_tile + (ns + 1) * 2048, frag_off);
-                    if (ns == 0 && ms + 1 < MS)
+                    if (ABLATE < 4 && ns == 0 && ms + 1 < MS)
                         af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
-                    if constexpr (ABLATE >= 2)
+                    if constexpr (ABLATE == 2 || ABLATE == 3 || ABLATE == 4)
                         mfma_only_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], part[(i + 1) & DEPTH]);
                     else
                         mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
-                    if constexpr (SPREAD > 0 && ABLATE != 1 && ABLATE != 2) {
+                    if constexpr (SPREAD > 0 && (ABLATE == 0 || ABLATE == 3)) {
                         // spread the next stage's LDS-DMA pieces over the first steps, one per SPREAD MFMAs
                         if (i % SPREAD == SPREAD - 1 && i / SPREAD < A_ITERS + B_ITERS && has_next)
                             issue_piece(cur ^ 1, kb + 1, i / SPREAD);
@@ -655,11 +673,12 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 static_assert((TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
                 scale_tail = scale[MS - 1];
                 sb_cur = sb_nxt;
-                if constexpr (ABLATE != 1 && ABLATE != 2) {
+                if constexpr (ABLATE == 0 || ABLATE == 3) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                 }
             }
+            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             // drain the ring: steps TOTAL-3 .. TOTAL-1 of the last K block
             #pragma unroll
             for (int i = 0; i < DEPTH; ++i) {
@@ -675,6 +694,13 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
         store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_stamp(p, NW, 0, t_entry);
+            dbg_stamp(p, NW, 1, t_loop0);
+            dbg_stamp(p, NW, 2, t_loop1);
+            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
     }
 }
 
@@ -684,6 +710,322 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, int ABLATE = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
     pipe_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, ABLATE>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ring kernel: the fast path's production form.  Same tiles, LDS image, LDS-DMA pieces and MFMA+promotion step as
+// the pipe kernel above, but the global->LDS stream is never drained inside the K loop:
+//   * A lives in a 3-slot ring, B in a 2-slot ring (256x256 tile: 3*32 + 2*32 KiB = all 160 KiB of the CU's LDS);
+//   * ONE barrier P per K block, placed before the last M-subtile round (step TOTAL-NS), certifies "block kb+1 has
+//     landed" (each wave first waits vmcnt(A_ITERS+B_ITERS): everything but its newest two batches of pieces) and
+//     "block kb's A slot is dead"; behind it the wave issues the LDS-DMA of A(kb+3) into that slot and reads the
+//     first fragments of block kb+1 (A subtile 0, and each B subtile right after its last MFMA of block kb), so the
+//     matrix pipe does not see a restart bubble at the block boundary;
+//   * a second, light barrier Q after the first M-subtile round certifies "every wave holds B(kb) in registers",
+//     behind it the LDS-DMA of B(kb+2) goes into that slot.
+//   A and B are therefore prefetched about two K blocks ahead; the per-row scales ride one block ahead in VGPRs,
+//   loaded by inline-asm buffer loads so that hipcc (which would wait vmcnt(0) at their first use and drain the
+//   LDS-DMA queue with them) never sees a VGPR-destination load in the loop.
+// vmcnt bookkeeping (loads retire in order): issue order is ... SF(kb+1) | A(kb+2) x A_ITERS | B(kb+2) x B_ITERS |
+// P_kb: wait vmcnt(A_ITERS+B_ITERS) => SF(kb+1), A(kb+1), B(kb+1) and everything older have landed.
+// K tail: pieces and scale loads of blocks >= num_kb are still issued (the counts stay exact) with bit 31 set in
+// their voffset, which the buffer descriptor's range check turns into a no-op.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MS>
+struct ScaleLanding { float sa[MS]; float sb; };
+
+// SF loads for one K block: MS row scales (SFA is MN-major here: consecutive M-subtiles are 64 bytes apart) and the
+// wave-uniform SFB value, all through buffer descriptors.  The destinations are NOT valid until wait_landing().
+template <int MS>
+__device__ __forceinline__ void issue_scale_loads(ScaleLanding<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
+                                                  const v4i& sfb_rsrc, int sfb_voff) {
+    static_assert(MS == 2 || MS == 4 || MS == 8, "unrolled by hand");
+    // s_nop 4 opening: the descriptor / soffset SGPRs may have been written by the immediately preceding SALU
+    if constexpr (MS == 8) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dword %0, %9, %10, 0 offen\n\t"
+            "buffer_load_dword %1, %9, %10, 0 offen offset:64\n\t"
+            "buffer_load_dword %2, %9, %10, 0 offen offset:128\n\t"
+            "buffer_load_dword %3, %9, %10, 0 offen offset:192\n\t"
+            "buffer_load_dword %4, %9, %10, 0 offen offset:256\n\t"
+            "buffer_load_dword %5, %9, %10, 0 offen offset:320\n\t"
+            "buffer_load_dword %6, %9, %10, 0 offen offset:384\n\t"
+            "buffer_load_dword %7, %9, %10, 0 offen offset:448\n\t"
+            "buffer_load_dword %8, %11, %12, 0 offen"
+            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sa[2]), "=&v"(l.sa[3]), "=&v"(l.sa[4]), "=&v"(l.sa[5]),
+              "=&v"(l.sa[6]), "=&v"(l.sa[7]), "=&v"(l.sb)
+            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+            : "memory");
+    } else if constexpr (MS == 4) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dword %0, %5, %6, 0 offen\n\t"
+            "buffer_load_dword %1, %5, %6, 0 offen offset:64\n\t"
+            "buffer_load_dword %2, %5, %6, 0 offen offset:128\n\t"
+            "buffer_load_dword %3, %5, %6, 0 offen offset:192\n\t"
+            "buffer_load_dword %4, %7, %8, 0 offen"
+            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sa[2]), "=&v"(l.sa[3]), "=&v"(l.sb)
+            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dword %0, %3, %4, 0 offen\n\t"
+            "buffer_load_dword %1, %3, %4, 0 offen offset:64\n\t"
+            "buffer_load_dword %2, %5, %6, 0 offen"
+            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sb)
+            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+            : "memory");
+    }
+}
+
+// Waits until at most ALLOWED vector-memory operations of this wave are outstanding and all its LDS reads have
+// returned; names the landing registers so that no consumer of them can be scheduled above the wait.
+template <int ALLOWED, int MS>
+__device__ __forceinline__ void wait_landing(ScaleLanding<MS>& l) {
+    static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
+    if constexpr (MS == 8)
+        asm volatile("s_waitcnt vmcnt(%c9) lgkmcnt(0)"
+                     : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sa[2]), "+v"(l.sa[3]), "+v"(l.sa[4]), "+v"(l.sa[5]),
+                       "+v"(l.sa[6]), "+v"(l.sa[7]), "+v"(l.sb)
+                     : "i"(ALLOWED) : "memory");
+    else if constexpr (MS == 4)
+        asm volatile("s_waitcnt vmcnt(%c5) lgkmcnt(0)"
+                     : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sa[2]), "+v"(l.sa[3]), "+v"(l.sb)
+                     : "i"(ALLOWED) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%c3) lgkmcnt(0)" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb) : "i"(ALLOWED) : "memory");
+}
+
+__device__ __forceinline__ void raw_barrier() {
+    // A bare s_barrier: __syncthreads() would add a vmcnt(0) fence and drain the LDS-DMA queue.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// RABL (timing experiments only, results are garbage): 1 = no barriers, 2 = no LDS-DMA pieces in the K loop,
+// 3 = every piece re-reads K block 0 (L2-resident source: isolates HBM / L2-miss effects from issue and LDS-write cost).
+// PAD: idle issue cycles appended to every MFMA step (s_nop), a pacing knob.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int RABL = 0, int PAD = 0>
+__device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    constexpr int TOTAL = MS * NS, DEPTH = 3;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
+    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int P_STEP = TOTAL - NS;                 // barrier P sits in front of this step
+    constexpr unsigned OOB = 0x80000000u;        // voffset bit that sends a buffer access out of range
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of LDS-DMA pieces");
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && NS % 2 == 0 && MS % 2 == 0 && MS >= 2, "wave tile shape");
+    static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
+    static_assert(TOTAL >= 2 * NS && TOTAL - DEPTH >= TOTAL - NS, "the ring tail must lie within the last M-subtile");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
+                  "the row permutation of a B piece must be lane-independent");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    // Per-lane byte offsets of a piece's source rows (row part and 16-byte chunk) -- all in the VOFFSET, which is the
+    // part of a buffer address the descriptor range-checks; only the K block offset travels in the soffset.
+    const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    long long t_loop0 = 0, t_loop1 = 0;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        float acc[MS][NS][4];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[ms][ns][r] = 0.f;
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            // Scale descriptors as plain 4 x 32-bit words (inline-asm "s" operands).
+            const float* sfa_group = p.sfa + ad_group * p.sfa_sg;
+            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
+                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
+            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+            const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
+            const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
+            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(sfa_group), sfb_addr = reinterpret_cast<uint64_t>(sfb_wave);
+            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane(sfa_extent), 0x00020000};
+            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane(sfb_extent), 0x00020000};
+            const int sfa_voff = (t.m0 + wm * WM + (lane & 15)) * 4;
+
+            // One LDS-DMA piece of K block j: A piece q -> rows (wave + NW q) * 8 ... + 7 of A slot j % 3.
+            auto issue_a_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                const int voff = static_cast<int>(static_cast<unsigned>(a_voff) +
+                                                  (static_cast<unsigned>(q * (NW * 8) * lda) | (j < num_kb ? 0u : OOB)));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, voff,
+                    RABL == 3 ? 0 : j * 128, 0, 0);
+            };
+            auto issue_b_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
+                                                  (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | (j < num_kb ? 0u : OOB)));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16, voff,
+                    RABL == 3 ? 0 : j * 128, 0, 0);
+            };
+            auto issue_scales = [&](ScaleLanding<MS>& l, int j) {
+                const unsigned oob = j < num_kb ? 0u : OOB;
+                issue_scale_loads<MS>(l, sfa_rsrc, static_cast<int>(static_cast<unsigned>(sfa_voff + j * sfa_kb_stride) | oob),
+                                      sfb_rsrc, static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob));
+            };
+
+            float scale[MS], scale_tail = 0.f;
+            ScaleLanding<MS> land;
+            v4f part[DEPTH + 1];
+            #pragma unroll
+            for (int i = 0; i <= DEPTH; ++i)
+                part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+
+            // ---- prologue: SF(0) A(0) B(0) | wait, consume SF(0) | SF(1) A(1) B(1) A(2) ----
+            issue_scales(land, 0);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
+            wait_landing<A_ITERS + B_ITERS, MS>(land);                // the scales only; the pieces may still fly
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                scale[ms] = land.sa[ms] * land.sb;
+            issue_scales(land, 1);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(2 * A_BYTES, 2, q);
+            asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((MS + 1) + 2 * A_ITERS + B_ITERS) : "memory");   // A(0), B(0) landed
+            raw_barrier();
+
+            // slot offsets (bytes): a_cur is being computed (and re-filled behind barrier P), *_nxt is read behind P
+            int a_cur = 0, a_nxt = A_BYTES, b_nxt = B_BYTES;
+            v8i bf[NS], af[2];
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                bf[ns] = load_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128, frag_off);
+            af[0] = load_fragment(lds + (wm * WM) * 128, frag_off);
+
+            // Issue order per block (vmcnt counts depend on it): SF(kb+1) [end of block kb-1] | A(kb+2) x A_ITERS
+            // [steps 0, 2, ..] | B(kb+2) x B_ITERS [behind Q] | P_kb waits vmcnt(A_ITERS + B_ITERS).
+            constexpr int B_FIRST = (NS > 2 * A_ITERS ? NS : 2 * A_ITERS);
+            static_assert(B_FIRST + 2 * (B_ITERS - 1) < P_STEP, "LDS-DMA pieces must be issued in front of barrier P");
+            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
+                const uint8_t* b_next_tile = lds + B_BASE + b_nxt + (wn * WN) * 128;
+                // A(kb+2) goes into the slot that held A(kb-1): the one after a_nxt in ring order
+                const int a_fill = (a_nxt == (A_SLOTS - 1) * A_BYTES) ? 0 : a_nxt + A_BYTES;
+
+                #pragma unroll
+                for (int i = 0; i < TOTAL; ++i) {
+                    const int ms = i / NS, ns = i % NS;
+                    const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
+                    const int jms = j / NS, jns = j % NS;
+                    const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;
+                    if (i == P_STEP) {
+                        // barrier P: block kb+1 (and its scales) landed everywhere; every read of A(kb) has returned
+                        wait_landing<(RABL == 2 ? 0 : A_ITERS + B_ITERS), MS>(land);
+                        if (RABL != 1) raw_barrier();
+                    }
+                    if (ns == 0) {
+                        if (ms + 1 < MS)
+                            af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
+                        else
+                            af[(ms + 1) & 1] = load_fragment(a_next_tile, frag_off);
+                    }
+                    mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
+                    if constexpr (PAD > 0) asm volatile("s_nop %c0" :: "i"(PAD - 1));
+                    if (ms == MS - 1)
+                        bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
+                    if (RABL != 2 && i % 2 == 0 && i / 2 < A_ITERS && kb > 0)
+                        issue_a_piece(a_fill, kb + 2, i / 2);
+                    if (RABL != 1 && i == NS - 1)
+                        raw_barrier();                                          // barrier Q: B(kb) is in registers
+                    if (RABL != 2 && i >= B_FIRST && (i - B_FIRST) % 2 == 0 && (i - B_FIRST) / 2 < B_ITERS)
+                        issue_b_piece(b_nxt ^ B_BYTES, kb + 2, (i - B_FIRST) / 2);   // B(kb)'s slot
+                }
+                // scales of block kb+1 (landed before P); then their landing registers take SF(kb+2)
+                scale_tail = scale[MS - 1];
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    scale[ms] = land.sa[ms] * land.sb;
+                    pin_vgpr(scale[ms]);
+                }
+                issue_scales(land, kb + 2);
+                a_cur = a_nxt;
+                a_nxt = a_fill;
+                b_nxt ^= B_BYTES;
+            }
+            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            // drain: the LDS-DMA no-ops of the K tail, then the last three promotions
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            #pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                const int j = TOTAL - DEPTH + i;
+                promote_only(acc[j / NS][j % NS], scale_tail, part[(TOTAL + i + 1) & DEPTH]);
+            }
+            __syncthreads();        // the next tile's prologue rewrites slots other waves may still be reading
+        }
+
+        v4f out[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
+        store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_stamp(p, NW, 0, t_entry);
+            dbg_stamp(p, NW, 1, t_loop0);
+            dbg_stamp(p, NW, 2, t_loop1);
+            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int RABL = 0, int PAD = 0>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_ring_kernel(const GemmParams p) {
+    ring_kernel_body<BM, BN, WAVES_M, WAVES_N, RABL, PAD>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -87,6 +87,10 @@ int dg_get_num_cus(void);
  * ("auto" restores the heuristic).  Unknown names are an error.  dg_list_configs() returns a comma-separated list. */
 int dg_set_forced_config(const char* name);
 const char* dg_list_configs(void);
+/* Tuning aid: when non-null, the pipe / ring kernels write 4 int64 s_memtime stamps per wave {kernel entry, K loop
+ * begin, K loop end, after the stores} of each block's first tile to device_buffer[(block * waves + wave) * 4 + i].
+ * The buffer must hold grid * 8 * 4 int64.  Null (the default) disables it. */
+int dg_set_debug_buffer(void* device_buffer);
 /* Name of the configuration the last GEMM call on this thread selected (for DG_PRINT_CONFIGS-style logging). */
 const char* dg_last_config(void);
 

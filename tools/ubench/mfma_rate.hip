@@ -1,0 +1,138 @@
+// Matrix-pipe micro-benchmark for v_mfma_f32_16x16x128_f8f6f4 (FP8 x FP8) on gfx950: cycles per MFMA per SIMD and the
+// shader clock under load, for 1 or 2 waves per SIMD, zero / random operand bits, with / without the promotion FMAs.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip && ./mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// MODE 0: zero-C MFMA into a 4-deep ring, one token VALU per step (the abl4 stream)
+// MODE 1: zero-C MFMA + 4 promotion FMAs per step (the abl5 stream)
+// MODE 2: classic accumulate-in-place MFMA (C = D), 8 independent accumulators, no VALU
+// MODE 3: zero-C MFMA into a ring, no VALU at all
+template <int MODE, int PAD = 0>
+__global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ src, float* __restrict__ out,
+                                                        long long* __restrict__ cycles, int iters) {
+    const int tid = threadIdx.x + blockIdx.x * blockDim.x;
+    v8i a[4], b[2];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) a[i][j] = src[(tid * 67 + i * 8 + j) & 0xffff];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 8; ++j) b[i][j] = src[(tid * 131 + 4096 + i * 8 + j) & 0xffff];
+    v4f part[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    v4f accv[8];
+    for (int i = 0; i < 8; ++i) accv[i] = v4f{0, 0, 0, 0};
+    float scale = 1.0f + tid * 1e-9f;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        #pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if constexpr (MODE == 0) {
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %2, %3, 0\n\tv_add_f32 %1, %1, %4"
+                             : "=&v"(part[i & 3]), "+v"(acc[i & 7])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(part[(i + 1) & 3][0]));
+            } else if constexpr (MODE == 1) {
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+                             "v_fmac_f32 %1, %7, %8\n\tv_fmac_f32 %2, %7, %9\n\tv_fmac_f32 %3, %7, %10\n\tv_fmac_f32 %4, %7, %11"
+                             : "=&v"(part[i & 3]), "+v"(acc[(i * 4) & 31]), "+v"(acc[(i * 4 + 1) & 31]), "+v"(acc[(i * 4 + 2) & 31]),
+                               "+v"(acc[(i * 4 + 3) & 31])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(scale), "v"(part[(i + 1) & 3][0]),
+                               "v"(part[(i + 1) & 3][1]), "v"(part[(i + 1) & 3][2]), "v"(part[(i + 1) & 3][3]));
+            } else if constexpr (MODE == 4) {
+                // the promote step, padded with PAD extra idle issue cycles, and a workgroup barrier every 16 steps
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+                             "v_fmac_f32 %1, %7, %8\n\tv_fmac_f32 %2, %7, %9\n\tv_fmac_f32 %3, %7, %10\n\tv_fmac_f32 %4, %7, %11"
+                             : "=&v"(part[i & 3]), "+v"(acc[(i * 4) & 31]), "+v"(acc[(i * 4 + 1) & 31]), "+v"(acc[(i * 4 + 2) & 31]),
+                               "+v"(acc[(i * 4 + 3) & 31])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(scale), "v"(part[(i + 1) & 3][0]),
+                               "v"(part[(i + 1) & 3][1]), "v"(part[(i + 1) & 3][2]), "v"(part[(i + 1) & 3][3]));
+                if constexpr (PAD > 0 && PAD <= 8) asm volatile("s_nop %c0" :: "i"(PAD - 1));
+                if constexpr (PAD > 8) { asm volatile("s_nop 7"); asm volatile("s_nop %c0" :: "i"(PAD - 9)); }
+                if (i % 16 == 15) __builtin_amdgcn_s_barrier();
+            } else if constexpr (MODE == 2) {
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"
+                             : "+v"(accv[i & 7]) : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]));
+            } else {
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0"
+                             : "=&v"(part[i & 3]) : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]));
+            }
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+    for (int i = 0; i < 32; ++i) r += acc[i];
+    for (int i = 0; i < 4; ++i) r += part[i][0] + part[i][1] + part[i][2] + part[i][3];
+    for (int i = 0; i < 8; ++i) r += accv[i][0] + accv[i][3];
+    out[tid] = r;
+    if ((threadIdx.x & 63) == 0)
+        cycles[tid >> 6] = t1 - t0;
+}
+
+template <int MODE, int PAD = 0>
+void run(const char* name, int threads, const int* src, float* out, long long* cyc, int iters) {
+    const int blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_rate_kernel<MODE, PAD>), dim3(blocks), dim3(threads), 0, 0, src, out, cyc, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const int waves = blocks * threads / 64;
+    std::vector<long long> h(waves);
+    hipMemcpy(h.data(), cyc, waves * sizeof(long long), hipMemcpyDeviceToHost);
+    double mean = 0, mx = 0, mn = 1e30;
+    for (auto c : h) { mean += c; mx = c > mx ? c : mx; mn = c < mn ? c : mn; }
+    mean /= waves;
+    const double mfma_per_simd = 32.0 * iters * (threads / 256);
+    const double flops = 2.0 * 16 * 16 * 128 * 32.0 * iters * waves;
+    printf("%-34s waves/SIMD=%d  wall=%8.1f us  ticks/wave min %9.0f mean %9.0f max %9.0f  max-ticks per MFMA per SIMD=%6.2f  clock~%6.1f MHz  %7.1f TFLOPS\n",
+           name, threads / 256, ms * 1e3, mn, mean, mx, mx / mfma_per_simd, mx / (ms * 1e3), flops / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    const int n = 1 << 16;
+    std::vector<int> rnd(n), zer(n, 0);
+    srand(1);
+    for (auto& x : rnd) {
+        // random FP8 e4m3 bytes without NaN encodings (0x7f / 0xff)
+        unsigned v = 0;
+        for (int b = 0; b < 4; ++b) { unsigned byte = rand() & 0xff; if ((byte & 0x7f) == 0x7f) byte ^= 1; v |= byte << (8 * b); }
+        x = (int)v;
+    }
+    int *d_rnd, *d_zer; float* out; long long* cyc;
+    hipMalloc(&d_rnd, n * 4); hipMalloc(&d_zer, n * 4); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 4096 * 8);
+    hipMemcpy(d_rnd, rnd.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_zer, zer.data(), n * 4, hipMemcpyHostToDevice);
+    const int iters = 2000;
+    run<4, 0>("promote+barrier/16, pad 0", 512, d_rnd, out, cyc, iters);
+    run<4, 2>("promote+barrier/16, pad 2", 512, d_rnd, out, cyc, iters);
+    run<4, 4>("promote+barrier/16, pad 4", 512, d_rnd, out, cyc, iters);
+    run<4, 8>("promote+barrier/16, pad 8", 512, d_rnd, out, cyc, iters);
+    run<4, 12>("promote+barrier/16, pad 12", 512, d_rnd, out, cyc, iters);
+    run<4, 16>("promote+barrier/16, pad 16", 512, d_rnd, out, cyc, iters);
+    run<4, 20>("promote+barrier/16, pad 20", 512, d_rnd, out, cyc, iters);
+    run<4, 24>("promote+barrier/16, pad 24", 512, d_rnd, out, cyc, iters);
+    run<4, 0>("promote+barrier/16 1w, pad 0", 256, d_rnd, out, cyc, iters);
+    run<4, 8>("promote+barrier/16 1w, pad 8", 256, d_rnd, out, cyc, iters);
+    run<4, 16>("promote+barrier/16 1w, pad 16", 256, d_rnd, out, cyc, iters);
+    for (int threads : {256, 512}) {
+        run<3>("bare zero-C ring, zeros", threads, d_zer, out, cyc, iters);
+        run<3>("bare zero-C ring, random", threads, d_rnd, out, cyc, iters);
+        run<2>("accumulate in place, random", threads, d_rnd, out, cyc, iters);
+        run<0>("zero-C + 1 VALU, random", threads, d_rnd, out, cyc, iters);
+        run<1>("zero-C + 4 FMA promote, random", threads, d_rnd, out, cyc, iters);
+        run<1>("zero-C + 4 FMA promote, zeros", threads, d_zer, out, cyc, iters);
+    }
+    return 0;
+}
