@@ -68,6 +68,7 @@ struct Config {
 };
 
 const Config kConfigs[] = {
+    {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true},
     {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
@@ -92,6 +93,17 @@ const Config kConfigs[] = {
     {"ring_p2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 2>, true},
     {"ring_p4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 4>, true},
     {"ring_p8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 8>, true},
+    {"rabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 4>, true},
+    {"rabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 5>, true},
+    {"dabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 1>, true},
+    {"dabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 2>, true},
+    {"dabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 3>, true},
+    {"dabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 4>, true},
+    {"dabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 5>, true},
+    {"dabl6_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 6>, true},
+    {"dabl7_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 7>, true},
+    {"dabl8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 8>, true},
+    {"dabl9_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 9>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);

@@ -182,7 +182,8 @@ __device__ __forceinline__ float round_bf16(float x) { return bf16_lo(pack_bf16(
 
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
-template <int MS, int NS>
+// INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
+template <int MS, int NS, bool INTERLEAVED_ROWS = false>
 __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
                                            int m_base, int n_base) {
     const int lane = threadIdx.x & 63, lg = lane >> 4;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
     const bool full_n = (n_lane + 4 * NS <= p.n);
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
-        const int row = m_base + ms * 16 + (lane & 15);
+        const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
         const bool compute_row = row < t.m_end;
         const bool zero_row = row >= t.zero_from;
         if (!compute_row && !zero_row)
@@ -902,9 +903,16 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                     RABL == 3 ? 0 : j * 128, 0, 0);
             };
             auto issue_scales = [&](ScaleLanding<MS>& l, int j) {
+                if constexpr (RABL == 5) {      // trace build: no scale traffic at all, constant scales
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) l.sa[ms] = 1.f;
+                    l.sb = 1.f;
+                    return;
+                }
                 const unsigned oob = j < num_kb ? 0u : OOB;
-                issue_scale_loads<MS>(l, sfa_rsrc, static_cast<int>(static_cast<unsigned>(sfa_voff + j * sfa_kb_stride) | oob),
-                                      sfb_rsrc, static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob));
+                const int jj = (RABL == 4) ? 0 : j;          // RABL 4: scales always from K block 0 (cache resident)
+                issue_scale_loads<MS>(l, sfa_rsrc, static_cast<int>(static_cast<unsigned>(sfa_voff + jj * sfa_kb_stride) | oob),
+                                      sfb_rsrc, static_cast<int>(static_cast<unsigned>(jj * sfb_kb_stride) | oob));
             };
 
             float scale[MS], scale_tail = 0.f;
@@ -921,6 +929,8 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
             #pragma unroll
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
             wait_landing<A_ITERS + B_ITERS, MS>(land);                // the scales only; the pieces may still fly
+            [[maybe_unused]] int trace_v = 0;                          // RABL 5: lane i = s_memtime at step i of K block 30/31
+            [[maybe_unused]] long long trace_t[4] = {0, 0, 0, 0};
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms)
                 scale[ms] = land.sa[ms] * land.sb;
@@ -931,7 +941,7 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
             #pragma unroll
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(2 * A_BYTES, 2, q);
-            asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((MS + 1) + 2 * A_ITERS + B_ITERS) : "memory");   // A(0), B(0) landed
+            asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((RABL == 5 ? 0 : MS + 1) + 2 * A_ITERS + B_ITERS) : "memory");   // A(0), B(0) landed
             raw_barrier();
 
             // slot offsets (bytes): a_cur is being computed (and re-filled behind barrier P), *_nxt is read behind P
@@ -960,6 +970,14 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                     const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
                     const int jms = j / NS, jns = j % NS;
                     const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;
+                    if constexpr (RABL == 5) {
+                        asm volatile("s_memtime %0" : "=s"(trace_t[i & 3]));
+                        if (i >= 2) {
+                            const int lane_sel = (kb == 30) ? (i - 2) : ((kb == 31) ? (i + 30) : 63);
+                            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v)
+                                         : "s"(static_cast<int>(trace_t[(i - 2) & 3])), "s"(lane_sel));
+                        }
+                    }
                     if (i == P_STEP) {
                         // barrier P: block kb+1 (and its scales) landed everywhere; every read of A(kb) has returned
                         wait_landing<(RABL == 2 ? 0 : A_ITERS + B_ITERS), MS>(land);
@@ -995,6 +1013,9 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                 b_nxt ^= B_BYTES;
             }
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if constexpr (RABL == 5)
+                if (p.dbg != nullptr)
+                    reinterpret_cast<int*>(p.dbg + 8192)[(blockIdx.x * NW + wave) * 64 + lane] = trace_v;
             // drain: the LDS-DMA no-ops of the K tail, then the last three promotions
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             #pragma unroll
@@ -1026,6 +1047,322 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int RABL = 0, int PAD = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_ring_kernel(const GemmParams p) {
     ring_kernel_body<BM, BN, WAVES_M, WAVES_N, RABL, PAD>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Duo kernel: the ring kernel's data movement (3-slot A ring, 2-slot B ring, counted vmcnt, asm scale loads) with the
+// K block cut into four role-split segments per wave:
+//     L_a : scales of the block, LDS-DMA of A(kb+2), fragment reads  B(kb) x NS  and  A(kb) subtiles 0 .. MS/2-1
+//     M_a : MS/2 * NS  MFMA + promotion steps, nothing else in the instruction stream
+//     L_b : LDS-DMA of B(kb+2), fragment reads A(kb) subtiles MS/2 .. MS-1, wait "my pieces of block kb+1 landed"
+//     M_b : the other MS/2 * NS steps
+// with a workgroup barrier in front of every segment and the upper half of the waves (the second wave of every SIMD)
+// running ONE segment behind the lower half.  At any time one wave of a SIMD is in a pure matrix segment -- and
+// alone it sustains the matrix pipe's 32-cycle issue rate, which a wave that also issues LDS / DMA / scalar work
+// between its MFMAs does not (an in-order wave cannot slip an MFMA into a gap shorter than 32 cycles, so two mixed
+// streams on one SIMD leave the pipe idle ~25 % of the time) -- while its partner does all the memory work in the
+// shadow.  Barrier t (counting the lower half's segments) certifies: t = 4kb: block kb landed everywhere and A(kb-1)
+// is dead; t = 4kb+2: B(kb) is in everybody's registers.  Prefetch distance: A 1.5 K blocks, B 1.
+// ---------------------------------------------------------------------------------------------------------------
+// DABL (timing experiments only): 1 = no stagger between the wave halves, 2 = no s_setprio around the matrix segments.
+// Scale landing registers of the duo kernel: with the A rows of a wave interleaved (LDS row position ms * 16 + i holds
+// tile row i * MS + ms) a lane's MS row scales are MS consecutive floats of the MN-major SFA: MS / 4 dwordx4 loads.
+template <int MS>
+struct ScaleLandingV { v4f q[MS / 4]; float sb; };
+
+template <int MS>
+__device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
+                                                    const v4i& sfb_rsrc, int sfb_voff) {
+    static_assert(MS == 8 || MS == 4, "unrolled by hand");
+    if constexpr (MS == 8)
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %3, %4, 0 offen\n\t"
+            "buffer_load_dwordx4 %1, %3, %4, 0 offen offset:16\n\t"
+            "buffer_load_dword %2, %5, %6, 0 offen"
+            : "=&v"(l.q[0]), "=&v"(l.q[1]), "=&v"(l.sb)
+            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+            : "memory");
+    else
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %2, %3, 0 offen\n\t"
+            "buffer_load_dword %1, %4, %5, 0 offen"
+            : "=&v"(l.q[0]), "=&v"(l.sb)
+            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+            : "memory");
+}
+
+template <int ALLOWED, int MS>
+__device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
+    static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
+    if constexpr (MS == 8)
+        asm volatile("s_waitcnt vmcnt(%c3) lgkmcnt(0)" : "+v"(l.q[0]), "+v"(l.q[1]), "+v"(l.sb) : "i"(ALLOWED) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%c2) lgkmcnt(0)" : "+v"(l.q[0]), "+v"(l.sb) : "i"(ALLOWED) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
+__device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
+    constexpr int TOTAL = MS * NS, SEG = HS * NS, DEPTH = 3;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
+    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int A_EARLY = (DABL == 9) ? 0 : A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
+    constexpr unsigned OOB = 0x80000000u;
+    // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
+    constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
+    static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
+    static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
+    static_assert(SEG > DEPTH, "the promotion ring must fit in a segment");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
+                  "the row permutation of a B piece must be lane-independent");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool upper_half = wave >= NW / 2;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    // A rows are interleaved inside a wave's WM rows: LDS row position P holds tile row a_row_of(P).  For the rows of one
+    // piece (P = 8 u + j) that is a_unit_row(u) + j * MS: the lane part goes into a_voff, the unit part is wave-uniform.
+    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
+    const int a_voff = piece_row * MS * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    long long t_loop0 = 0, t_loop1 = 0;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        float acc[MS][NS][4];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[ms][ns][r] = 0.f;
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            const float* sfa_group = p.sfa + ad_group * p.sfa_sg;
+            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
+                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
+            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+            const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
+            const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
+            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(sfa_group), sfb_addr = reinterpret_cast<uint64_t>(sfb_wave);
+            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane(sfa_extent), 0x00020000};
+            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane(sfb_extent), 0x00020000};
+            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
+
+            auto issue_a_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                const int voff = static_cast<int>(static_cast<unsigned>(a_voff) +
+                                                  (static_cast<unsigned>(a_unit_row(unit) * lda) | (j < num_kb ? 0u : OOB)));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, voff, j * 128, 0, 0);
+            };
+            auto issue_b_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
+                                                  (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | (j < num_kb ? 0u : OOB)));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16, voff,
+                    j * 128, 0, 0);
+            };
+            auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
+                const unsigned oob = j < num_kb ? 0u : OOB;
+                issue_scale_loads_v<MS>(l, sfa_rsrc, static_cast<int>(static_cast<unsigned>(sfa_voff + j * sfa_kb_stride) | oob),
+                                      sfb_rsrc, static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob));
+            };
+
+            float scale[MS], scale_tail = 0.f;
+            ScaleLandingV<MS> land;
+            v4f part[DEPTH + 1];
+            #pragma unroll
+            for (int i = 0; i <= DEPTH; ++i)
+                part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                scale[ms] = 0.f;
+
+            // ---- prologue: SF(0) A(0) B(0) A(1) B(1); block 0 and its scales must land before the first segment ----
+            issue_scales(land, 0);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
+            wait_landing_v<A_ITERS + B_ITERS, MS>(land);
+            raw_barrier();
+            if (DABL != 1 && upper_half)
+                raw_barrier();                      // the upper half runs one segment behind from here on
+
+            [[maybe_unused]] int trace_v = 0;
+            auto stamp = [&](int kb, int k) {
+                if constexpr (DABL == 3) {      // trace build: lane 8 * (kb - 28) + k = s_memtime, for K blocks 28 .. 35
+                    long long tt;
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt));
+                    const int lane_sel = (kb >= 28 && kb < 36) ? (kb - 28) * 8 + k : 63;
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v) : "s"(static_cast<int>(tt)), "s"(lane_sel));
+                }
+            };
+            int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;     // slots of A(kb), A(kb+2) [= A(kb-1)'s], B(kb)
+            v8i bf[NS], af[HS];
+            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
+
+                // ---------------- L_a ----------------
+                stamp(kb, 0);
+                raw_barrier();
+                stamp(kb, 1);
+                // fragment reads first: they complete in the shadow of the slow vector-memory issue that follows
+                if (NO_LDS_READS ? kb == 0 : true) {
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h)
+                        af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                }
+                scale_tail = scale[MS - 1];
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                    pin_vgpr(scale[ms]);
+                }
+                if (!NO_SCALES) issue_scales(land, kb + 1);
+                if (!NO_DMA) {
+                    #pragma unroll
+                    for (int q = 0; q < A_EARLY; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+                // ---------------- M_a ----------------
+                stamp(kb, 2);
+                raw_barrier();
+                stamp(kb, 3);
+                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(1);
+                if (DABL == 8) __builtin_amdgcn_s_setprio(0);
+                #pragma unroll
+                for (int i = 0; i < SEG; ++i) {
+                    const int ns = i % NS, h = i / NS;
+                    const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
+                    const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
+                    mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                }
+                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(0);
+                if (DABL == 8) __builtin_amdgcn_s_setprio(1);
+
+                // ---------------- L_b ----------------
+                stamp(kb, 4);
+                raw_barrier();
+                stamp(kb, 5);
+                if (!NO_LDS_READS) {
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h)
+                        af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                }
+                if (!NO_DMA) {
+                    #pragma unroll
+                    for (int q = A_EARLY; q < A_ITERS; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q)
+                        issue_b_piece(b_cur, kb + 2, q);
+                }
+                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);       // block kb+1 and its scales: my pieces have landed
+
+                // ---------------- M_b ----------------
+                stamp(kb, 6);
+                raw_barrier();
+                stamp(kb, 7);
+                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(1);
+                if (DABL == 8) __builtin_amdgcn_s_setprio(0);
+                #pragma unroll
+                for (int i2 = 0; i2 < SEG; ++i2) {
+                    const int i = SEG + i2;
+                    const int ns = i % NS, h = i2 / NS;
+                    const int j = i - DEPTH;
+                    mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
+                }
+                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(0);
+                if (DABL == 8) __builtin_amdgcn_s_setprio(1);
+
+                const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
+                a_fill = a_cur;             // A(kb+3) will take the slot block kb just finished with
+                a_cur = a_next;
+                b_cur ^= B_BYTES;
+            }
+            if (DABL != 1 && !upper_half)
+                raw_barrier();              // pairs with the barrier in front of the upper half's last segment
+            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if constexpr (DABL == 3)
+                if (p.dbg != nullptr)
+                    reinterpret_cast<int*>(p.dbg + 8192)[(blockIdx.x * NW + wave) * 64 + lane] = trace_v;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            #pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                const int j = TOTAL - DEPTH + i;
+                promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
+            }
+            __syncthreads();
+        }
+
+        v4f out[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
+        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_stamp(p, NW, 0, t_entry);
+            dbg_stamp(p, NW, 1, t_loop0);
+            dbg_stamp(p, NW, 2, t_loop1);
+            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_duo_kernel(const GemmParams p) {
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, DABL>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -9,12 +9,13 @@
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 // MODE 0: zero-C MFMA into a 4-deep ring, one token VALU per step (the abl4 stream)
 // MODE 1: zero-C MFMA + 4 promotion FMAs per step (the abl5 stream)
 // MODE 2: classic accumulate-in-place MFMA (C = D), 8 independent accumulators, no VALU
 // MODE 3: zero-C MFMA into a ring, no VALU at all
-template <int MODE, int PAD = 0>
+template <int MODE, int PAD = 0, bool BAR = false>
 __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ src, float* __restrict__ out,
                                                         long long* __restrict__ cycles, int iters) {
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
@@ -29,6 +30,9 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     v4f accv[8];
     for (int i = 0; i < 8; ++i) accv[i] = v4f{0, 0, 0, 0};
     float scale = 1.0f + tid * 1e-9f;
+    v16f big0, big1;
+    for (int i = 0; i < 16; ++i) { big0[i] = 0.f; big1[i] = 0.f; }
+    float dummy = 0.f;
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -56,6 +60,53 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
                 if constexpr (PAD > 0 && PAD <= 8) asm volatile("s_nop %c0" :: "i"(PAD - 1));
                 if constexpr (PAD > 8) { asm volatile("s_nop 7"); asm volatile("s_nop %c0" :: "i"(PAD - 9)); }
                 if (i % 16 == 15) __builtin_amdgcn_s_barrier();
+            } else if constexpr (MODE == 5) {
+                // role-split: 16-step MFMA+promote segments alternate with "load" segments (PAD x 32 idle cycles stand in
+                // for the LDS / DMA work), a workgroup barrier between segments, waves 4-7 one segment behind waves 0-3
+                if (i == 0 && it == 0 && threadIdx.x >= 256) __builtin_amdgcn_s_barrier();
+                if (i % 16 == 0) {
+                    for (int q = 0; q < PAD; ++q) asm volatile("s_nop 7");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_setprio(1);
+                }
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+                             "v_fmac_f32 %1, %7, %8\n\tv_fmac_f32 %2, %7, %9\n\tv_fmac_f32 %3, %7, %10\n\tv_fmac_f32 %4, %7, %11"
+                             : "=&v"(part[i & 3]), "+v"(acc[(i * 4) & 31]), "+v"(acc[(i * 4 + 1) & 31]), "+v"(acc[(i * 4 + 2) & 31]),
+                               "+v"(acc[(i * 4 + 3) & 31])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(scale), "v"(part[(i + 1) & 3][0]),
+                               "v"(part[(i + 1) & 3][1]), "v"(part[(i + 1) & 3][2]), "v"(part[(i + 1) & 3][3]));
+                if (i % 16 == 15) {
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else if constexpr (MODE == 6) {
+                // one 32x32x128 tile step: MFMA (C = 0), MFMA (C = D), 16 promotion FMAs of the previous tile; PAD extra
+                // single-slot instructions (v_mov) per tile step stand in for LDS / DMA / scalar work
+                if (i % 4 == 0) {
+                    v16f& pn = (i & 4) ? big1 : big0;
+                    v16f& po = (i & 4) ? big0 : big1;
+                    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, 0" : "=&v"(pn) : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]));
+                    #pragma unroll
+                    for (int r = 0; r < 8; ++r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[r]) : "v"(scale), "v"(po[r]));
+                    #pragma unroll
+                    for (int r = 0; r < PAD / 2; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(dummy) : "v"(scale));
+                    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0" : "+v"(pn) : "v"(a[(i + 1) & 3]), "v"(b[(i >> 2) & 1]));
+                    #pragma unroll
+                    for (int r = 8; r < 16; ++r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[r]) : "v"(scale), "v"(po[r]));
+                    #pragma unroll
+                    for (int r = 0; r < PAD - PAD / 2; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(dummy) : "v"(scale));
+                    if (BAR && i % 16 == 12) __builtin_amdgcn_s_barrier();
+                }
+            } else if constexpr (MODE == 7) {
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+                             "v_fmac_f32 %1, %7, %8\n\tv_fmac_f32 %2, %7, %9\n\tv_fmac_f32 %3, %7, %10\n\tv_fmac_f32 %4, %7, %11"
+                             : "=&v"(part[i & 3]), "+v"(acc[(i * 4) & 31]), "+v"(acc[(i * 4 + 1) & 31]), "+v"(acc[(i * 4 + 2) & 31]),
+                               "+v"(acc[(i * 4 + 3) & 31])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(scale), "v"(part[(i + 1) & 3][0]),
+                               "v"(part[(i + 1) & 3][1]), "v"(part[(i + 1) & 3][2]), "v"(part[(i + 1) & 3][3]));
+                #pragma unroll
+                for (int r = 0; r < (PAD + (i & 3)) / 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(dummy) : "v"(scale));
+                if (BAR && i % 16 == 15) __builtin_amdgcn_s_barrier();
             } else if constexpr (MODE == 2) {
                 asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"
                              : "+v"(accv[i & 7]) : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]));
@@ -65,24 +116,27 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
             }
         }
     }
+    if constexpr (MODE == 5) { if (threadIdx.x < 256) __builtin_amdgcn_s_barrier(); }   // balance the stagger barrier
     const long long t1 = __builtin_amdgcn_s_memtime();
     float r = 0.f;
     for (int i = 0; i < 32; ++i) r += acc[i];
     for (int i = 0; i < 4; ++i) r += part[i][0] + part[i][1] + part[i][2] + part[i][3];
     for (int i = 0; i < 8; ++i) r += accv[i][0] + accv[i][3];
+    for (int i = 0; i < 16; ++i) r += big0[i] + big1[i];
+    r += dummy;
     out[tid] = r;
     if ((threadIdx.x & 63) == 0)
         cycles[tid >> 6] = t1 - t0;
 }
 
-template <int MODE, int PAD = 0>
+template <int MODE, int PAD = 0, bool BAR = false>
 void run(const char* name, int threads, const int* src, float* out, long long* cyc, int iters) {
     const int blocks = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((mfma_rate_kernel<MODE, PAD>), dim3(blocks), dim3(threads), 0, 0, src, out, cyc, iters);
+        hipLaunchKernelGGL((mfma_rate_kernel<MODE, PAD, BAR>), dim3(blocks), dim3(threads), 0, 0, src, out, cyc, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
     }
@@ -115,6 +169,31 @@ int main() {
     hipMemcpy(d_rnd, rnd.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_zer, zer.data(), n * 4, hipMemcpyHostToDevice);
     const int iters = 2000;
+    run<3>("warm-up", 512, d_rnd, out, cyc, iters);
+    run<6, 0>("32x32x64 pair+16fmac, fill 0", 256, d_rnd, out, cyc, iters);
+    run<6, 8>("32x32x64 pair+16fmac, fill 8", 256, d_rnd, out, cyc, iters);
+    run<6, 12>("32x32x64 pair+16fmac, fill 12", 256, d_rnd, out, cyc, iters);
+    run<6, 16>("32x32x64 pair+16fmac, fill 16", 256, d_rnd, out, cyc, iters);
+    run<7, 0>("16x16x128 +4fmac, fill 0/4", 256, d_rnd, out, cyc, iters);
+    run<7, 8>("16x16x128 +4fmac, fill 8/4", 256, d_rnd, out, cyc, iters);
+    run<7, 12>("16x16x128 +4fmac, fill 12/4", 256, d_rnd, out, cyc, iters);
+    run<7, 16>("16x16x128 +4fmac, fill 16/4", 256, d_rnd, out, cyc, iters);
+    run<6, 0>("32x32x64 pair+16fmac, fill 0", 512, d_rnd, out, cyc, iters);
+    run<6, 8>("32x32x64 pair+16fmac, fill 8", 512, d_rnd, out, cyc, iters);
+    run<6, 16>("32x32x64 pair+16fmac, fill 16", 512, d_rnd, out, cyc, iters);
+    run<6, 24>("32x32x64 pair+16fmac, fill 24", 512, d_rnd, out, cyc, iters);
+    run<6, 8, true>("32x32x64 fill 8 + barrier/4 tiles", 512, d_rnd, out, cyc, iters);
+    run<6, 16, true>("32x32x64 fill 16 + barrier/4 tiles", 512, d_rnd, out, cyc, iters);
+    run<7, 8>("16x16x128 +4fmac, fill 8/4", 512, d_rnd, out, cyc, iters);
+    run<7, 16>("16x16x128 +4fmac, fill 16/4", 512, d_rnd, out, cyc, iters);
+    run<7, 8, true>("16x16x128 fill 8/4 + barrier/16", 512, d_rnd, out, cyc, iters);
+    run<7, 16, true>("16x16x128 fill 16/4 + barrier/16", 512, d_rnd, out, cyc, iters);
+    return 0;
+    run<5, 0>("role-split 16/seg, load 0", 512, d_rnd, out, cyc, iters);
+    run<5, 4>("role-split 16/seg, load 128cyc", 512, d_rnd, out, cyc, iters);
+    run<5, 8>("role-split 16/seg, load 256cyc", 512, d_rnd, out, cyc, iters);
+    run<5, 12>("role-split 16/seg, load 384cyc", 512, d_rnd, out, cyc, iters);
+    run<5, 16>("role-split 16/seg, load 512cyc", 512, d_rnd, out, cyc, iters);
     run<4, 0>("promote+barrier/16, pad 0", 512, d_rnd, out, cyc, iters);
     run<4, 2>("promote+barrier/16, pad 2", 512, d_rnd, out, cyc, iters);
     run<4, 4>("promote+barrier/16, pad 4", 512, d_rnd, out, cyc, iters);
