@@ -29,6 +29,19 @@ PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_M
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/<round>/traffic.json,
+    FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if the
+    newest committed profile is of a different kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')), reverse=True):
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get('kernel') == kernel:
+            return rec['traffic_bytes']
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -41,9 +54,37 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_workload(name: str, sets: int):
+def make_ep_workload(sets: int, world: int, rank: int):
+    """BASELINE configs[4] across ranks: 8 experts per rank (8 * world in total, weights resident on their owner), 48
+    token rows per rank routed to top-8 experts => about 48 rows per expert; one step = all-to-all dispatch + local masked
+    grouped GEMM + all-to-all combine (deepgemm_amd/ep.py)."""
+    from deepgemm_amd import ep
+    from deepgemm_amd.utils.math import per_block_cast_to_fp8, per_token_cast_to_fp8
+    per_rank, max_m, tokens, top_k, n, k = 8, 128, 48, 8, 4096, 7168
+    num_experts = per_rank * world
+    torch.manual_seed(1000 + rank)
+    w = torch.randn((per_rank, n, k), dtype=torch.bfloat16, device='cuda')
+    bq = [per_block_cast_to_fp8(w[g], use_ue8m0=False) for g in range(per_rank)]
+    b_local = (torch.stack([q[0] for q in bq]), torch.stack([q[1] for q in bq]))
+    del w, bq
+    calls = []
+    for i in range(sets):
+        x = per_token_cast_to_fp8(torch.randn((tokens, k), dtype=torch.bfloat16, device='cuda'), use_ue8m0=False)
+        ids = torch.stack([torch.randperm(num_experts, device='cuda')[:top_k] for _ in range(tokens)])
+        calls.append(lambda x=x, ids=ids: ep.ep_m_grouped_fp8_gemm_nt_masked(x, ids, b_local, num_experts, max_m, expected_m=48))
+    flops = 2.0 * tokens * top_k * n * k
+    nbytes = float(b_local[0].numel() + 4 * b_local[1].numel() + tokens * top_k * (k + 4 * k // 128 + 2 * n))
+    desc = {'workload': f'EP m_grouped_fp8_gemm_nt_masked: {num_experts} experts / {world} GPUs ({per_rank} per rank), about 48 rows per expert, '
+                        f'N={n} K={k}; step = RCCL all-to-all dispatch + local masked GEMM + all-to-all combine (BASELINE configs[4])',
+            'n': n, 'k': k, 'experts': num_experts}
+    return calls, flops, nbytes, desc, lambda: float('nan')
+
+
+def make_workload(name: str, sets: int, world: int = 1, rank: int = 0):
     """Returns (list of zero-arg callables, flops per step, algorithmic bytes per step, description, checker)."""
     calls, cases = [], []
+    if name == 'masked' and world > 1:
+        return make_ep_workload(sets, world, rank)
     if name == 'dense':
         m, n, k = 4096, 4096, 7168
         for i in range(sets):
@@ -126,7 +167,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     dg.set_forced_config(args.config)
-    calls, flops, nbytes, desc, check = make_workload(args.workload, args.sets)
+    calls, flops, nbytes, desc, check = make_workload(args.workload, args.sets, world, rank)
 
     for i in range(args.warmup):
         calls[i % len(calls)]()
@@ -156,10 +197,11 @@ def main():
         value = total_flops / elapsed / 1e12
         achieved = flops / kernel_s / 1e12
         mfma_bound = args.workload != 'masked'
+        traffic = measured_traffic(dg.last_config()) if args.workload == 'dense' else None
         roofline = ({'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP8_TFLOPS, 'traffic': None} if mfma_bound else
+                     'frac': achieved / PEAK_FP8_TFLOPS, 'traffic': traffic} if mfma_bound else
                     {'bound': 'hbm', 'achieved': nbytes / kernel_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                     'frac': nbytes / kernel_s / 1e9 / PEAK_HBM_GBS, 'traffic': None})
+                     'frac': nbytes / kernel_s / 1e9 / PEAK_HBM_GBS, 'traffic': traffic})
         roofline.update({'kernel': dg.last_config(), 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
                          'algorithmic_bytes': nbytes, 'tflops': achieved, 'gbs': nbytes / kernel_s / 1e9})
         line = {
@@ -168,7 +210,7 @@ def main():
             'value': value, 'unit': 'TFLOPS', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'fp8_e4m3 (fp32 accumulate, bf16 out)', 'data': 'synthetic',
-            'config': dict(desc, parallelism='replicas only' if world > 1 else 'single GPU', kernel=dg.last_config(),
+            'config': dict(desc, parallelism=('single GPU' if world == 1 else f'ep{world}' if args.workload == 'masked' else 'replicas only'), kernel=dg.last_config(),
                            input_sets=len(calls)),
             'pct_of_mfma_peak': 100.0 * value / world / PEAK_FP8_TFLOPS,
             'calc_diff_vs_reference_expr': diff,

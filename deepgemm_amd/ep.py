@@ -1,0 +1,141 @@
+"""Expert-parallel execution of the M-grouped masked FP8 GEMM: experts sharded across the GPUs of one node, token rows
+exchanged with RCCL all-to-all over xGMI, one local ``m_grouped_fp8_gemm_nt_masked`` per rank.
+
+This is the only place where the FP8 GEMM path has a real exchange step: the groups of a grouped
+GEMM are independent problems that share nothing but the token stream, so rank ``r`` owns experts
+``[r * E / R, (r + 1) * E / R)`` -- their weights ``B[g]`` / ``SFB[g]`` stay resident in its HBM and never move -- and
+one step is
+
+  1. *dispatch*: every (token row, expert) pair travels to the expert's owner: ``K`` FP8 bytes + ``K / 128`` FP32 scales
+     per row, variable split sizes exchanged first with a tiny int64 all-to-all (this replaces the in-kernel count
+     exchange of the reference's fused kernel, deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:357-405);
+  2. *local GEMM*: received rows are packed per local expert into the masked layout ``[G_local, M_max, K]`` with the
+     row counts in a device tensor ``masked_m`` (the kernel reads them on the device) and
+     ``m_grouped_fp8_gemm_nt_masked`` runs once (reference semantics: csrc/apis/gemm.hpp:250-297);
+  3. *combine*: the BF16 result rows (``2 N`` bytes each) return to their source rank in the order they were sent.
+
+xGMI is a point-to-point mesh, so an all-to-all puts only each pair's own traffic on each of the 7 links; at decode
+sizes (<= 64 rows per expert) the messages are a few MB per GPU and latency dominated.
+
+The collective layer is ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU tests, where the
+local GEMM is replaced by the test's checker through the ``local_gemm`` argument).  Nothing here allocates inside a
+captured region or synchronises with the host except for the split sizes, which ``all_to_all_single`` needs as Python
+ints (one small device-to-host copy per step, as in any unfused EP dispatch).
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+TensorPair = Tuple[torch.Tensor, torch.Tensor]
+
+
+def expert_range(num_experts: int, rank: int, world: int) -> Tuple[int, int]:
+    """Experts owned by ``rank``: a contiguous, equally sized block (``num_experts`` must divide by ``world``)."""
+    if num_experts % world != 0:
+        raise RuntimeError(f'num_experts ({num_experts}) must be a multiple of the world size ({world})')
+    per_rank = num_experts // world
+    return rank * per_rank, (rank + 1) * per_rank
+
+
+@dataclass
+class DispatchPlan:
+    """Bookkeeping of one dispatch, needed to route the results back."""
+    send_order: torch.Tensor          # [P] permutation that sorts this rank's (row, expert) pairs by destination expert
+    send_splits: List[int]            # rows sent to each rank
+    recv_splits: List[int]            # rows received from each rank
+    recv_expert: torch.Tensor         # [P_recv] local expert index of every received row
+    recv_slot: torch.Tensor           # [P_recv] row slot inside that expert's masked block
+    masked_m: torch.Tensor            # [G_local] int32 rows per local expert (device tensor)
+
+
+def _all_to_all_rows(rows: torch.Tensor, send_splits: List[int], recv_splits: List[int], group) -> torch.Tensor:
+    out = rows.new_empty((sum(recv_splits),) + tuple(rows.shape[1:]))
+    dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
+    return out
+
+
+def dispatch(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, max_m: int,
+             group=None) -> Tuple[TensorPair, DispatchPlan]:
+    """Sends every (row, expert) pair of this rank to the expert's owner and packs what arrives into the masked layout.
+
+    ``x = (x_fp8 [T, K], sf [T, K / 128])`` are this rank's token rows (already quantised per token, reference
+    ``per_token_cast_to_fp8``); ``expert_ids [T, top_k]`` holds global expert indices.  Returns the local masked
+    operand ``(a [G_local, max_m, K], sfa [G_local, max_m, K / 128])`` and the plan for :func:`combine`.
+    Raises ``RuntimeError`` if a local expert receives more than ``max_m`` rows.
+    """
+    x_fp8, x_sf = x
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    first, last = expert_range(num_experts, rank, world)
+    per_rank = last - first
+    tokens, top_k = expert_ids.shape
+    device = x_fp8.device
+
+    flat_expert = expert_ids.reshape(-1).to(torch.int64)
+    flat_row = torch.arange(tokens, device=device).repeat_interleave(top_k)
+    order = torch.argsort(flat_expert, stable=True)                      # grouped by destination expert (=> by rank)
+    sorted_expert = flat_expert[order]
+    per_expert = torch.bincount(sorted_expert, minlength=num_experts)    # rows this rank sends to each expert
+    send_counts = per_expert.view(world, per_rank)
+
+    # counts first: recv_counts[s, g] = rows rank s sends to my local expert g
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts.contiguous(), group=group)
+    send_splits = send_counts.sum(dim=1).tolist()
+    recv_splits = recv_counts.sum(dim=1).tolist()
+
+    rows = flat_row[order]
+    payload = _all_to_all_rows(x_fp8.view(torch.uint8)[rows], send_splits, recv_splits, group).view(torch.float8_e4m3fn)
+    payload_sf = _all_to_all_rows(x_sf[rows], send_splits, recv_splits, group)
+
+    # received rows arrive rank by rank, inside a rank expert by expert: recover (local expert, slot) of every row
+    recv_expert = torch.repeat_interleave(torch.arange(per_rank, device=device).repeat(world), recv_counts.reshape(-1))
+    masked_m = recv_counts.sum(dim=0)
+    busiest = int(masked_m.max().item()) if masked_m.numel() else 0
+    if busiest > max_m:
+        raise RuntimeError(f'an expert received {busiest} rows, more than max_m = {max_m}')
+    # slot = rank-major running index inside the expert: offset of (source rank, expert) + position inside that run
+    run_offsets = torch.cumsum(recv_counts, dim=0) - recv_counts                       # [world, per_rank]
+    run_start = torch.repeat_interleave(run_offsets.reshape(-1), recv_counts.reshape(-1))
+    flat_run_begin = torch.cumsum(recv_counts.reshape(-1), dim=0) - recv_counts.reshape(-1)
+    pos_in_run = torch.arange(payload.size(0), device=device) - torch.repeat_interleave(flat_run_begin, recv_counts.reshape(-1))
+    recv_slot = run_start + pos_in_run
+
+    k = x_fp8.size(1)
+    a = torch.zeros((per_rank, max_m, k), dtype=torch.float8_e4m3fn, device=device)
+    sfa = torch.zeros((per_rank, max_m, x_sf.size(1)), dtype=torch.float, device=device)
+    a.view(torch.uint8)[recv_expert, recv_slot] = payload.view(torch.uint8)
+    sfa[recv_expert, recv_slot] = payload_sf
+    plan = DispatchPlan(order, send_splits, recv_splits, recv_expert, recv_slot, masked_m.to(torch.int32))
+    return (a, sfa), plan
+
+
+def combine(d: torch.Tensor, plan: DispatchPlan, tokens: int, top_k: int, group=None) -> torch.Tensor:
+    """Returns the result rows to their source ranks: output ``[tokens, top_k, N]`` in the order of ``expert_ids``."""
+    rows_out = d[plan.recv_expert, plan.recv_slot]                       # [P_recv, N] in arrival order
+    back = _all_to_all_rows(rows_out, plan.recv_splits, plan.send_splits, group)
+    out = torch.empty((tokens * top_k, d.size(-1)), dtype=d.dtype, device=d.device)
+    out[plan.send_order] = back
+    return out.view(tokens, top_k, d.size(-1))
+
+
+def _default_local_gemm(a: TensorPair, b: TensorPair, d: torch.Tensor, masked_m: torch.Tensor, expected_m: int) -> None:
+    from .gemm import m_grouped_fp8_gemm_nt_masked          # the HIP path; there is no CPU fallback
+    m_grouped_fp8_gemm_nt_masked(a, b, d, masked_m, expected_m)
+
+
+def ep_m_grouped_fp8_gemm_nt_masked(x: TensorPair, expert_ids: torch.Tensor, b_local: TensorPair, num_experts: int,
+                                    max_m: int, expected_m: Optional[int] = None, group=None,
+                                    local_gemm: Callable = _default_local_gemm) -> torch.Tensor:
+    """One expert-parallel step: dispatch -> local masked grouped GEMM -> combine.
+
+    ``b_local = (B [G_local, N, K] fp8, SFB [G_local, N / 128, K / 128])`` are this rank's resident expert weights.
+    Returns ``[T, top_k, N]`` BF16: row ``(t, j)`` is ``x[t] @ B[expert_ids[t, j]]^T``.
+    """
+    tokens, top_k = expert_ids.shape
+    (a, sfa), plan = dispatch(x, expert_ids, num_experts, max_m, group)
+    groups, n = b_local[0].size(0), b_local[0].size(1)
+    d = torch.empty((groups, max_m, n), dtype=torch.bfloat16, device=a.device)
+    local_gemm((a, sfa), b_local, d, plan.masked_m, expected_m if expected_m is not None else max(1, max_m // 2))
+    return combine(d, plan, tokens, top_k, group)

@@ -1,0 +1,95 @@
+"""Expert-parallel harness on CPU: world_size 2 over gloo, the local grouped GEMM replaced by the oracle (tests may use it
+as the checker; the product path only ever calls the HIP operator).  Covers the N > 1 path of SURVEY.md section 8e:
+expert sharding, count + payload all-to-all, masked-layout packing, combine ordering."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _oracle_local_gemm(a, b, d, masked_m, expected_m):
+    import oracle
+    oracle.m_grouped_fp8_gemm_nt_masked(a[0], a[1], b[0], b[1], d, masked_m)
+
+
+def _worker(rank: int, world: int, port: int, num_experts: int, tokens: int, top_k: int, n: int, k: int, max_m: int, fail_queue):
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import oracle
+        from deepgemm_amd import ep
+        from deepgemm_amd.utils.math import per_block_cast_to_fp8, per_token_cast_to_fp8
+
+        torch.manual_seed(1234)                                   # same expert weights on every rank
+        w = torch.randn((num_experts, n, k), dtype=torch.bfloat16)
+        b_all = [per_block_cast_to_fp8(w[e], use_ue8m0=False) for e in range(num_experts)]
+        first, last = ep.expert_range(num_experts, rank, world)
+        b_local = (torch.stack([b_all[e][0] for e in range(first, last)]), torch.stack([b_all[e][1] for e in range(first, last)]))
+
+        torch.manual_seed(100 + rank)                             # different tokens and routing per rank
+        x = torch.randn((tokens + rank, k), dtype=torch.bfloat16)  # uneven token counts across ranks
+        expert_ids = torch.stack([torch.randperm(num_experts)[:top_k] for _ in range(x.size(0))])
+        xq = per_token_cast_to_fp8(x, use_ue8m0=False)
+
+        out = ep.ep_m_grouped_fp8_gemm_nt_masked(xq, expert_ids, b_local, num_experts, max_m, local_gemm=_oracle_local_gemm)
+        assert out.shape == (x.size(0), top_k, n) and out.dtype == torch.bfloat16
+
+        # unsharded check: every (token, expert) pair computed directly against the full weight set
+        for t in range(x.size(0)):
+            for j in range(top_k):
+                e = int(expert_ids[t, j])
+                want = torch.empty((1, n), dtype=torch.bfloat16)
+                oracle.fp8_gemm_nt(xq[0][t:t + 1], xq[1][t:t + 1], b_all[e][0], b_all[e][1], want)
+                assert torch.equal(out[t, j], want[0]), (rank, t, j, e)
+
+        # capacity overflow is an error, not silent truncation
+        if rank == 0:
+            pass
+        crowded = torch.zeros((max_m + 1, 1), dtype=torch.int64)  # every row to expert 0
+        xs = per_token_cast_to_fp8(torch.randn((max_m + 1, k), dtype=torch.bfloat16), use_ue8m0=False)
+        try:
+            ep.dispatch(xs, crowded, num_experts, max_m)
+            overflowed = False
+        except RuntimeError:
+            overflowed = True
+        flag = torch.tensor([int(overflowed)])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        assert int(flag) == 1                                     # the owner of expert 0 must have refused
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:                                      # noqa: BLE001
+        fail_queue.put(f'rank {rank}: {type(exc).__name__}: {exc}')
+        raise
+
+
+@pytest.mark.parametrize('world,num_experts,top_k', [(2, 4, 2), (2, 8, 3)])
+def test_ep_masked_gemm_world2(world, num_experts, top_k):
+    ctx = mp.get_context('spawn')
+    fail_queue = ctx.SimpleQueue()
+    port = 29650 + num_experts
+    procs = [ctx.Process(target=_worker, args=(r, world, port, num_experts, 11, top_k, 128, 256, 64, fail_queue))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    failures = []
+    while not fail_queue.empty():
+        failures.append(fail_queue.get())
+    assert not failures, failures
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def test_expert_range():
+    from deepgemm_amd import ep
+    assert ep.expert_range(64, 0, 8) == (0, 8) and ep.expert_range(64, 7, 8) == (56, 64)
+    with pytest.raises(RuntimeError):
+        ep.expert_range(10, 0, 4)

@@ -11,8 +11,8 @@ for path in sorted(glob.glob(os.path.join(root, '**', '*kernel_stats.csv'), recu
     print('==', path)
     with open(path) as f:
         for i, row in enumerate(csv.reader(f)):
-            if i < 8:
-                print(','.join(row)[:220])
+            if i == 0 or i < 6 or 'gemm' in row[0]:
+                print(','.join(row)[:240])
 for path in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)):
     print('==', path)
     sums, counts = defaultdict(float), defaultdict(int)
@@ -25,4 +25,13 @@ for path in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv')
             sums[key] += float(row.get('Counter_Value', 0))
             counts[key] += 1
     for (name, counter), total in sorted(sums.items()):
-        print(f'{name:60s} {counter:28s} per-dispatch={total / counts[(name, counter)]:.4g} (n={counts[(name, counter)]})')
+        print(f'{name:60s} {counter:28s} per-dispatch={total / counts[(name, counter)]:.6g} (n={counts[(name, counter)]})')
+    trace = path.replace('counter_collection', 'kernel_trace')
+    if os.path.exists(trace):
+        durs = defaultdict(list)
+        with open(trace) as f:
+            for row in csv.DictReader(f):
+                if 'gemm' in row['Kernel_Name']:
+                    durs[row['Kernel_Name'][:60]].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
+        for name, d in durs.items():
+            print(f'{name:60s} kernel-trace duration us: mean={sum(d) / len(d):.2f} min={min(d):.2f} max={max(d):.2f} (n={len(d)})')
