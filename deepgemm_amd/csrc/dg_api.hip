@@ -76,6 +76,7 @@ const Config kConfigs[] = {
     {"pipe_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_pipe_kernel<64, 256, 1, 4, 1>},
     {"pipe_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_pipe_kernel<32, 256, 1, 4, 0>},
     {"pipe_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_pipe_kernel<16, 256, 1, 4, 0>},
+    {"stream_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6>, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
     // experimental / baseline variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of
     // the heuristic): LDS-DMA piece placement variants and the hipcc-scheduled first version of the fast path.
@@ -132,6 +133,12 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         return nullptr;
     }
     const bool fast_ok = fast_eligible(p);
+    // HBM-bound shapes (decode-sized M: every weight byte is streamed once for <= 64 rows): the deep-ring stream kernel.
+    const int m_hint = expected_m > 0 ? expected_m : m_for_tiling;
+    if (fast_ok && p.sfa_sm == 1 && m_hint <= 64 && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum)
+        for (int i = 0; i < kNumConfigs; ++i)
+            if (std::strcmp(kConfigs[i].name, "stream_64x128") == 0)
+                return &kConfigs[i];
     const Config* best = nullptr;
     double best_cost = 0;
     for (int i = 0; i < kNumConfigs; ++i) {

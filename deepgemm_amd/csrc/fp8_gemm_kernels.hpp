@@ -1366,6 +1366,155 @@ void dg_fp8_gemm_duo_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stream kernel: the HBM-bound end of the path (masked / decode-sized M, small dense M).  A 64 x 128 tile per
+// 4-wave workgroup and a STAGES-deep LDS ring (6 x 24.5 KiB): each stage holds the A and B tiles AND the scales of one
+// K block (SFA rows as one 256-byte LDS-DMA dword piece, SFB as a broadcast dword piece), so the K loop contains no
+// VGPR-destination loads at all -- five K blocks (120 KiB per CU, 30 MB across the chip) stay in flight, one barrier
+// per K block both certifies "block kb has landed" (after a counted vmcnt) and frees the slot of block kb-1.
+// The matrix work (8 MFMAs per wave per K block) is far below the pipe's rate here: weights stream once from HBM.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256;
+    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, STAGE_BYTES = SFB_OFF + SFB_BYTES;
+    constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int PIECES = A_ITERS + B_ITERS + 2;              // per wave per K block, scale pieces included
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(BM == 64 && BN == 128, "one 256-byte SFA piece and one SFB value per tile");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
+    static_assert(MS == 4 && NS % 2 == 0, "a lane reads its MS = 4 row scales with one ds_read_b128");
+    static_assert((STAGES - 1) * PIECES < 64, "vmcnt is a 6-bit counter");
+    static_assert(LDS_BYTES <= 160 * 1024 && STAGES >= 3, "LDS budget");
+    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
+                  "the row permutation of a B piece must be lane-independent");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    // interleaved A rows (LDS row position ms * 16 + i holds tile row i * MS + ms), as in the duo kernel
+    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
+    const int a_voff = piece_row * MS * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            // SFA of the tile's rows: MN-major, rows m0 .. m0+63 are 256 contiguous bytes per K block
+            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+            float* sfa_tile = const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0;
+            const int sfa_rows = imin(p.m - t.m0, BM);
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_kb - 1) * sfa_kb_stride + sfa_rows * 4, 0x00020000);
+            float* sfb_tile = const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg +
+                              static_cast<int64_t>(t.n0 / 128) * p.sfb_sn;
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_kb - 1) * sfb_kb_stride + 4, 0x00020000);
+
+            // All pieces of K block j into ring slot j % STAGES (slot_off in bytes).  Blocks past the end are issued as
+            // out-of-range no-ops so that the vmcnt arithmetic stays exact.
+            auto issue_block = [&](int slot_off, int j) {
+                const unsigned oob = j < num_kb ? 0u : OOB;
+                uint8_t* stage = lds + slot_off;
+                #pragma unroll
+                for (int q = 0; q < A_ITERS; ++q) {
+                    const int unit = wave + NW * q;
+                    const int voff = static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        a_rsrc, (__attribute__((address_space(3))) void*)(stage + unit * 1024), 16, voff, j * 128, 0, 0);
+                }
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q) {
+                    const int unit = wave + NW * q;
+                    const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
+                                                      (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | oob));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, 0);
+                }
+                // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    sfa_rsrc, (__attribute__((address_space(3))) void*)(stage + SFA_OFF), 4,
+                    static_cast<int>(static_cast<unsigned>(lane * 4 + j * sfa_kb_stride) | oob), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF), 4,
+                    static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob), 0, 0, 0);
+            };
+
+            #pragma unroll
+            for (int j = 0; j < STAGES - 1; ++j)
+                issue_block(j * STAGE_BYTES, j);
+
+            int cur = 0, fill = (STAGES - 1) * STAGE_BYTES;
+            for (int kb = 0; kb < num_kb; ++kb) {
+                // block kb: my pieces have landed (the STAGES-2 younger blocks may still fly); then everybody's have,
+                // and everybody is done reading block kb-1, whose slot takes block kb+STAGES-1
+                asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((STAGES - 2) * PIECES) : "memory");
+                raw_barrier();
+                issue_block(fill, kb + STAGES - 1);
+
+                const uint8_t* stage = lds + cur;
+                const v4f sa = *reinterpret_cast<const v4f*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                const float sb = *reinterpret_cast<const float*>(stage + SFB_OFF);
+                const uint8_t* a_tile = stage + (wm * WM) * 128;
+                const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;
+                v8i bf[NS];
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                    const float scale = sa[ms] * sb;
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        const v4f part = mfma_fp8_k128(bf[ns], af);
+                        acc[ms][ns] += scale * part;
+                    }
+                }
+                fill = cur;
+                cur = (cur == (STAGES - 1) * STAGE_BYTES) ? 0 : cur + STAGE_BYTES;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_stream_kernel(const GemmParams p) {
+    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Generic path: any operand majorness / alignment / K tail, both SFB granularities.  128 x 128 tile, 4 waves,
 // register-staged loads written into the same swizzled LDS image.  Correctness first.
 // ---------------------------------------------------------------------------------------------------------------
