@@ -71,7 +71,7 @@ const Config kConfigs[] = {
     {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true},
     {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
-    {"pipe_128x256", 128, 256, 512, 1, 0.85f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
+    {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
     {"pipe_128x128", 128, 128, 256, 2, 0.80f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 2>},
     {"pipe_64x256", 64, 256, 256, 2, 0.60f, true, dg::dg_fp8_gemm_pipe_kernel<64, 256, 1, 4, 1>},
     {"pipe_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_pipe_kernel<32, 256, 1, 4, 0>},
@@ -310,6 +310,22 @@ int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int s
     const dim3 grid((mn + 63) / 64, (sf_k + 63) / 64, batches);
     hipLaunchKernelGGL(dg::dg_transpose_sf_fp32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        sf, out, mn, sf_k, aligned_mn);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols,
+                     int64_t src_ld, int64_t dst_ld, int64_t src_batch_stride, int64_t dst_batch_stride, void* stream) {
+    DG_CHECK(batches >= 0 && rows >= 0 && cols >= 0);
+    if (batches == 0 || rows == 0 || cols == 0)
+        return 0;
+    DG_CHECK(src != nullptr && dst != nullptr && src != dst);
+    DG_CHECK(src_ld >= cols && dst_ld >= rows);
+    DG_CHECK(batches <= 65535 && (rows + 63) / 64 <= 65535);
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64, batches);
+    hipLaunchKernelGGL(dg::dg_transpose_bytes_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), rows, cols, src_ld, dst_ld,
+                       src_batch_stride, dst_batch_stride);
     DG_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1716,4 +1716,53 @@ void dg_transpose_sf_fp32_kernel(const float* __restrict__ sf, float* __restrict
     }
 }
 
+// Operand re-majoring: dst[c][r] = src[r][c] for 1-byte elements (an MN-major FP8 operand -> the K-major form the
+// LDS-DMA kernels consume).  64 x 64 byte patches through LDS; both the global read (16 bytes along c per lane) and the
+// global write (16 bytes along r per lane) are coalesced 16-byte vectors.  HBM-bound: 2 bytes of traffic per element.
+__global__ __launch_bounds__(256)
+void dg_transpose_bytes_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols,
+                               int64_t src_ld, int64_t dst_ld, int64_t src_batch, int64_t dst_batch) {
+    __shared__ uint8_t patch[64][64 + 16];                  // +16: rows stay 16-byte aligned, column walks spread over banks
+    const uint8_t* s = src + static_cast<int64_t>(blockIdx.z) * src_batch;
+    uint8_t* d = dst + static_cast<int64_t>(blockIdx.z) * dst_batch;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;          // 64 rows x 4 vectors of 16 bytes
+    {
+        const int r = r0 + tr, c = c0 + tc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const uint8_t* ptr = s + static_cast<int64_t>(r) * src_ld + c;
+        if (r < rows) {
+            if (c + 16 <= cols && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0) {
+                v = *reinterpret_cast<const uint4*>(ptr);
+            } else {
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (int e = 0; e < 16; ++e)
+                    if (c + e < cols)
+                        w[e >> 2] |= static_cast<uint32_t>(ptr[e]) << ((e & 3) * 8);
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        *reinterpret_cast<uint4*>(&patch[tr][tc]) = v;
+    }
+    __syncthreads();
+    {
+        // output row = source column c0 + tr, 16 consecutive source rows r0 + tc .. + 15
+        const int c = c0 + tr, r = r0 + tc;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        #pragma unroll
+        for (int e = 0; e < 16; ++e)
+            w[e >> 2] |= static_cast<uint32_t>(patch[tc + e][tr]) << ((e & 3) * 8);
+        if (c < cols) {
+            uint8_t* ptr = d + static_cast<int64_t>(c) * dst_ld + r;
+            if (r + 16 <= rows && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0) {
+                *reinterpret_cast<uint4*>(ptr) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                for (int e = 0; e < 16; ++e)
+                    if (r + e < rows)
+                        ptr[e] = static_cast<uint8_t>(w[e >> 2] >> ((e & 3) * 8));
+            }
+        }
+    }
+}
+
 }  // namespace dg

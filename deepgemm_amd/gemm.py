@@ -27,6 +27,24 @@ def _check_ab_fp8(t: torch.Tensor, dims: int):
     return tuple(int(s) for s in t.shape)
 
 
+# MN-major FP8 operands of problems at least this large (in MACs) are re-majored into a K-major scratch buffer by
+# dg_transpose_fp8 (2 bytes of HBM traffic per element) so that the LDS-DMA kernels can stream them; smaller ones go
+# to the generic kernel in place.  0 disables the re-majoring (tests use it to reach the generic kernel's MN-major path).
+REMAJOR_MIN_MACS = 1 << 27
+
+
+def _as_k_major(t: torch.Tensor, macs: int) -> torch.Tensor:
+    if t.stride(-1) == 1 or REMAJOR_MIN_MACS <= 0 or macs < REMAJOR_MIN_MACS:
+        return t
+    require_device(t)
+    mn, k = t.size(-2), t.size(-1)
+    batches = t.size(0) if t.dim() == 3 else 1
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)          # contiguous: K-major
+    check(lib.dg_transpose_fp8(t.data_ptr(), out.data_ptr(), batches, k, mn, t.stride(-1), k,
+                               t.stride(0) if t.dim() == 3 else 0, mn * k, current_stream_ptr()))
+    return out
+
+
 def _dtype_code(d: torch.Tensor) -> int:
     return _BF16 if d.dtype == torch.bfloat16 else _FP32
 
@@ -69,6 +87,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
                                                               None, None, disable_ue8m0_cast)
     require_device(a_data, b_data, sfa, sfb, d)
+    a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
     check(lib.dg_fp8_gemm_nt(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
@@ -119,6 +138,7 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
                                                          None, num_groups, disable_ue8m0_cast)
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
+    b_data = _as_k_major(b_data, m * n * k)
     check(lib.dg_m_grouped_fp8_gemm_nt_contiguous(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
         num_groups, m, n, k, a_data.stride(0), a_data.stride(1),

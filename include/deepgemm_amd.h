@@ -78,6 +78,13 @@ int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void*
  * aligned_mn = align(mn, 4).  Padding slots are not written. */
 int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream);
 
+/* Operand re-majoring for the fast path: dst[b][c][r] = src[b][r][c], 1-byte (FP8) elements, `rows` x `cols` per batch,
+ * leading dimensions / batch strides in elements.  Turns an MN-major operand (the SM100 form of fp8_gemm_nn/tn/tt,
+ * csrc/apis/gemm.hpp:126-164; UMMA descriptors consume it in place there) into the K-major form the LDS-DMA kernels
+ * stream; the host layer owns the scratch buffer. */
+int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols,
+                     int64_t src_ld, int64_t dst_ld, int64_t src_batch_stride, int64_t dst_batch_stride, void* stream);
+
 /* Runtime knobs (reference csrc/apis/runtime.hpp:12-41: set/get_num_sms; the analogue here is the CU budget a
  * persistent launch may occupy, 0 = all CUs of the device). */
 int dg_set_num_cus(int num_cus);

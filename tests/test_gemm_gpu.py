@@ -79,6 +79,16 @@ def test_dense_layouts_vs_oracle(layout, m, n, k):
     want = oracle_dense(case)
     dg.fp8_gemm_nt(case.a, case.b, case.d)                                   # MN-major operands as strided views
     assert_close_to_oracle(case.d, want, f'{layout} view')
+    if m * n * k >= dg.gemm.REMAJOR_MIN_MACS:                                # large: MN-major operands are re-majored
+        assert not dg.last_config().startswith('generic'), (layout, dg.last_config())
+        saved, dg.gemm.REMAJOR_MIN_MACS = dg.gemm.REMAJOR_MIN_MACS, 0       # ... and the in-place generic path agrees
+        try:
+            d_generic = torch.full_like(case.d, float('nan'))
+            dg.fp8_gemm_nt(case.a, case.b, d_generic)
+            assert layout == 'nt' or dg.last_config().startswith('generic')
+            assert_close_to_oracle(d_generic, want, f'{layout} generic')
+        finally:
+            dg.gemm.REMAJOR_MIN_MACS = saved
     a = case.a if a_k_major else (case.a[0].T, case.a[1].T)
     b = case.b if b_k_major else (case.b[0].T, case.b[1].T)
     assert a[0].is_contiguous() and b[0].is_contiguous()
