@@ -105,6 +105,8 @@ const Config kConfigs[] = {
     {"dabl7_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 7>, true},
     {"dabl8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 8>, true},
     {"dabl9_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 9>, true},
+    {"dabl10_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 10>, true},
+    {"dabl11_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 11>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);

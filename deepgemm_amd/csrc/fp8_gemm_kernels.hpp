@@ -1076,7 +1076,6 @@ __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const 
     static_assert(MS == 8 || MS == 4, "unrolled by hand");
     if constexpr (MS == 8)
         asm volatile(
-            "s_nop 4\n\t"
             "buffer_load_dwordx4 %0, %3, %4, 0 offen\n\t"
             "buffer_load_dwordx4 %1, %3, %4, 0 offen offset:16\n\t"
             "buffer_load_dword %2, %5, %6, 0 offen"
@@ -1093,13 +1092,22 @@ __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const 
             : "memory");
 }
 
+// gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; expcnt left at "no wait".
+constexpr int waitcnt_imm(int vmcnt, int lgkmcnt) {
+    return (vmcnt & 0xf) | (0x7 << 4) | ((lgkmcnt & 0xf) << 8) | (((vmcnt >> 4) & 0x3) << 14);
+}
+
+// The wait goes through the builtin so that hipcc's own waitcnt pass sees the LDS counter drained and does not re-wait
+// for the fragment reads inside the following matrix segment; the empty asm ties the landing registers to this point.
 template <int ALLOWED, int MS>
 __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
     static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
     if constexpr (MS == 8)
-        asm volatile("s_waitcnt vmcnt(%c3) lgkmcnt(0)" : "+v"(l.q[0]), "+v"(l.q[1]), "+v"(l.sb) : "i"(ALLOWED) : "memory");
+        asm volatile("" : "+v"(l.q[0]), "+v"(l.q[1]), "+v"(l.sb) :: "memory");
     else
-        asm volatile("s_waitcnt vmcnt(%c2) lgkmcnt(0)" : "+v"(l.q[0]), "+v"(l.sb) : "i"(ALLOWED) : "memory");
+        asm volatile("" : "+v"(l.q[0]), "+v"(l.sb) :: "memory");
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
@@ -1113,6 +1121,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_EARLY = (DABL == 9) ? 0 : A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
+    constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3), LOADPRIO = (DABL == 8 || DABL == 11);
     constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
@@ -1181,25 +1190,31 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                                   __builtin_amdgcn_readfirstlane(sfb_extent), 0x00020000};
             const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
 
+            // Per-piece source offsets (rows + chunk: the bounds-checked part of the address) are loop invariants held in
+            // VGPRs; the K block goes in the soffset.  Blocks past the end re-read the last K block into a dead slot --
+            // no out-of-range arithmetic in the loop, the vmcnt counts stay exact, the bytes come from L2.
+            int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q)
+                a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q)
+                b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
             auto issue_a_piece = [&](int slot_off, int j, int q) {
                 const int unit = wave + NW * q;
-                const int voff = static_cast<int>(static_cast<unsigned>(a_voff) +
-                                                  (static_cast<unsigned>(a_unit_row(unit) * lda) | (j < num_kb ? 0u : OOB)));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, voff, j * 128, 0, 0);
+                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
+                    imin(j, num_kb - 1) * 128, 0, 0);
             };
             auto issue_b_piece = [&](int slot_off, int j, int q) {
                 const int unit = wave + NW * q;
-                const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
-                                                  (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | (j < num_kb ? 0u : OOB)));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16, voff,
-                    j * 128, 0, 0);
+                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
+                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
             };
             auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
-                const unsigned oob = j < num_kb ? 0u : OOB;
-                issue_scale_loads_v<MS>(l, sfa_rsrc, static_cast<int>(static_cast<unsigned>(sfa_voff + j * sfa_kb_stride) | oob),
-                                      sfb_rsrc, static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob));
+                const int jj = imin(j, num_kb - 1);         // past the end: the last block's scales again (never consumed)
+                issue_scale_loads_v<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
             float scale[MS], scale_tail = 0.f;
@@ -1229,10 +1244,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 
             [[maybe_unused]] int trace_v = 0;
             auto stamp = [&](int kb, int k) {
-                if constexpr (DABL == 3) {      // trace build: lane 8 * (kb - 28) + k = s_memtime, for K blocks 28 .. 35
+                if constexpr (TRACE) {      // trace build: lane 8 * (kb - 28) + k = s_memtime, for K blocks 28 .. 35
                     long long tt;
                     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt));
-                    const int lane_sel = (kb >= 28 && kb < 36) ? (kb - 28) * 8 + k : 63;
+                    const int lane_sel = (kb >= 28 && kb < 32) ? (kb - 28) * 8 + k : 63;
                     asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v) : "s"(static_cast<int>(tt)), "s"(lane_sel));
                 }
             };
@@ -1257,26 +1272,37 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     for (int h = 0; h < HS; ++h)
                         af[h] = load_fragment(a_tile + h * 2048, frag_off);
                 }
+                [[maybe_unused]] long long t_in[3];
+                if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[0]) :: "memory");
                 scale_tail = scale[MS - 1];
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
                     scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
                     pin_vgpr(scale[ms]);
                 }
+                if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[1]) :: "memory");
                 if (!NO_SCALES) issue_scales(land, kb + 1);
                 if (!NO_DMA) {
                     #pragma unroll
                     for (int q = 0; q < A_EARLY; ++q)
                         issue_a_piece(a_fill, kb + 2, q);
                 }
+                if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[2]) :: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (TRACE) {
+                    #pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int lane_sel = (kb >= 28 && kb < 32) ? 32 + (kb - 28) * 4 + q : 63;
+                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v) : "s"(static_cast<int>(t_in[q])), "s"(lane_sel));
+                    }
+                }
 
                 // ---------------- M_a ----------------
                 stamp(kb, 2);
                 raw_barrier();
                 stamp(kb, 3);
-                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(1);
-                if (DABL == 8) __builtin_amdgcn_s_setprio(0);
+                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(1);
+                if (LOADPRIO) __builtin_amdgcn_s_setprio(0);
                 #pragma unroll
                 for (int i = 0; i < SEG; ++i) {
                     const int ns = i % NS, h = i / NS;
@@ -1284,8 +1310,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
                 }
-                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(0);
-                if (DABL == 8) __builtin_amdgcn_s_setprio(1);
+                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
+                if (LOADPRIO) __builtin_amdgcn_s_setprio(1);
 
                 // ---------------- L_b ----------------
                 stamp(kb, 4);
@@ -1305,13 +1331,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                         issue_b_piece(b_cur, kb + 2, q);
                 }
                 wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);       // block kb+1 and its scales: my pieces have landed
+                asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]) :: "memory");
 
                 // ---------------- M_b ----------------
                 stamp(kb, 6);
                 raw_barrier();
                 stamp(kb, 7);
-                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(1);
-                if (DABL == 8) __builtin_amdgcn_s_setprio(0);
+                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(1);
+                if (LOADPRIO) __builtin_amdgcn_s_setprio(0);
                 #pragma unroll
                 for (int i2 = 0; i2 < SEG; ++i2) {
                     const int i = SEG + i2;
@@ -1319,8 +1346,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     const int j = i - DEPTH;
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
                 }
-                if (DABL != 2 && DABL != 8) __builtin_amdgcn_s_setprio(0);
-                if (DABL == 8) __builtin_amdgcn_s_setprio(1);
+                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
+                if (LOADPRIO) __builtin_amdgcn_s_setprio(1);
 
                 const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
                 a_fill = a_cur;             // A(kb+3) will take the slot block kb just finished with
@@ -1330,7 +1357,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             if (DABL != 1 && !upper_half)
                 raw_barrier();              // pairs with the barrier in front of the upper half's last segment
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
-            if constexpr (DABL == 3)
+            if constexpr (TRACE)
                 if (p.dbg != nullptr)
                     reinterpret_cast<int*>(p.dbg + 8192)[(blockIdx.x * NW + wave) * 64 + lane] = trace_v;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

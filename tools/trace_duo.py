@@ -29,6 +29,14 @@ for blk in (0, 77):
     base = tr[blk, :, 0].min().item()
     print(f'== workgroup {blk}: per wave, deltas between stamps over K blocks 28..31 ({" ".join(names)} per block; "bar" = wait at the barrier in front of the segment)')
     for w in range(8):
-        row = tr[blk, w, :33]
+        row = tr[blk, w, :32]
         d = (row[1:] - row[:-1]).tolist()
         print(f'wave {w}: t0={row[0].item() - base:6d} | ' + ' | '.join(' '.join(f'{x:4d}' for x in d[8 * b:8 * b + 8]) for b in range(4)))
+        inner = tr[blk, w, 32:48]
+        la = []
+        for b in range(4):
+            s1 = tr[blk, w, 8 * b + 1].item()     # stamp after the L_a barrier
+            e = tr[blk, w, 8 * b + 2].item()      # stamp at the end of L_a
+            q = inner[4 * b:4 * b + 3].tolist()
+            la.append(f'reads-issued {q[0] - s1:4d} mul {q[1] - q[0]:4d} vmem-issued {q[2] - q[1]:4d} lds-wait {e - q[2]:4d}')
+        print('         L_a inner: ' + ' | '.join(la))

@@ -33,6 +33,10 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     v16f big0, big1;
     for (int i = 0; i < 16; ++i) { big0[i] = 0.f; big1[i] = 0.f; }
     float dummy = 0.f;
+    float fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    v2f_ acc2[16];
+    for (int i = 0; i < 16; ++i) acc2[i] = v2f_{0.f, 0.f};
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -107,6 +111,30 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
                 #pragma unroll
                 for (int r = 0; r < (PAD + (i & 3)) / 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(dummy) : "v"(scale));
                 if (BAR && i % 16 == 15) __builtin_amdgcn_s_barrier();
+            } else if constexpr (MODE == 8) {
+                // promotion with packed FMAs: 2 v_pk_fma_f32 per step instead of 4 v_fmac; PAD/4 independent filler VALU
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f sc2 = {scale, scale};
+                const v4f po = part[(i + 1) & 3];
+                const v2f p01 = {po[0], po[1]}, p23 = {po[2], po[3]};
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %3, %4, 0\n\t"
+                             "v_pk_fma_f32 %1, %5, %6, %1\n\tv_pk_fma_f32 %2, %5, %7, %2"
+                             : "=&v"(part[i & 3]), "+v"(acc2[(i * 2) & 15]), "+v"(acc2[(i * 2 + 1) & 15])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(sc2), "v"(p01), "v"(p23));
+                #pragma unroll
+                for (int r = 0; r < (PAD + (i & 3)) / 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(fill[(i + r) & 7]) : "v"(scale));
+                if (BAR && i % 16 == 15) __builtin_amdgcn_s_barrier();
+            } else if constexpr (MODE == 9) {
+                // as MODE 7 but the fillers write 8 different registers (no write-after-write chain)
+                asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+                             "v_fmac_f32 %1, %7, %8\n\tv_fmac_f32 %2, %7, %9\n\tv_fmac_f32 %3, %7, %10\n\tv_fmac_f32 %4, %7, %11"
+                             : "=&v"(part[i & 3]), "+v"(acc[(i * 4) & 31]), "+v"(acc[(i * 4 + 1) & 31]), "+v"(acc[(i * 4 + 2) & 31]),
+                               "+v"(acc[(i * 4 + 3) & 31])
+                             : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]), "v"(scale), "v"(part[(i + 1) & 3][0]),
+                               "v"(part[(i + 1) & 3][1]), "v"(part[(i + 1) & 3][2]), "v"(part[(i + 1) & 3][3]));
+                #pragma unroll
+                for (int r = 0; r < (PAD + (i & 3)) / 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(fill[(i + r) & 7]) : "v"(scale));
+                if (BAR && i % 16 == 15) __builtin_amdgcn_s_barrier();
             } else if constexpr (MODE == 2) {
                 asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"
                              : "+v"(accv[i & 7]) : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]));
@@ -124,6 +152,8 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     for (int i = 0; i < 8; ++i) r += accv[i][0] + accv[i][3];
     for (int i = 0; i < 16; ++i) r += big0[i] + big1[i];
     r += dummy;
+    for (int i = 0; i < 8; ++i) r += fill[i];
+    for (int i = 0; i < 16; ++i) r += acc2[i][0] + acc2[i][1];
     out[tid] = r;
     if ((threadIdx.x & 63) == 0)
         cycles[tid >> 6] = t1 - t0;
@@ -170,6 +200,17 @@ int main() {
     hipMemcpy(d_zer, zer.data(), n * 4, hipMemcpyHostToDevice);
     const int iters = 2000;
     run<3>("warm-up", 512, d_rnd, out, cyc, iters);
+    run<9, 0, true>("fmac x4, fill 0, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<9, 8, true>("fmac x4, fill 2/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<9, 16, true>("fmac x4, fill 4/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<9, 24, true>("fmac x4, fill 6/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<8, 0, true>("pk_fma x2, fill 0, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<8, 8, true>("pk_fma x2, fill 2/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<8, 16, true>("pk_fma x2, fill 4/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<8, 24, true>("pk_fma x2, fill 6/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
+    run<9, 16>("fmac x4, fill 4/step indep, 1 wave", 256, d_rnd, out, cyc, iters);
+    run<8, 16>("pk_fma x2, fill 4/step indep, 1 wave", 256, d_rnd, out, cyc, iters);
+    return 0;
     run<6, 0>("32x32x64 pair+16fmac, fill 0", 256, d_rnd, out, cyc, iters);
     run<6, 8>("32x32x64 pair+16fmac, fill 8", 256, d_rnd, out, cyc, iters);
     run<6, 12>("32x32x64 pair+16fmac, fill 12", 256, d_rnd, out, cyc, iters);
