@@ -13,8 +13,8 @@
 //     makes both ds_read_b128 of a fragment bank-conflict free;
 //   * the fast path fills LDS with global_load_lds_dwordx4 (LDS-DMA): 8 lanes cover one full 128-byte line of a row,
 //     the swizzle is applied on the per-lane SOURCE address (the LDS image of a wave instruction is lane-linear);
-//   * B-tile rows are stored permuted so that after the last K block every lane holds 4*NS consecutive n of one m
-//     (16-byte BF16 stores).
+//   * B-tile rows are stored permuted so that after the last K block every lane holds 8 consecutive n of one m per pair
+//     of N-subtiles and the four lanes of a row write 64 contiguous bytes per store instruction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -161,12 +161,14 @@ __device__ __forceinline__ v8i load_fragment(const uint8_t* tile_rows, int frag_
 }
 
 // B-tile row permutation: LDS row position p (within the BN-row tile) holds global column n0 + perm(p), chosen so that
-// the MFMA row slot i = 4 * lg + r of N-subtile ns lands on column wave_n0 + lg * 4 * NS + ns * 4 + r.
+// the MFMA row slot i = 4 * lg + r of N-subtile ns lands on column wave_n0 + (ns >> 1) * 32 + lg * 8 + (ns & 1) * 4 + r:
+// a lane then holds 8 consecutive BF16 outputs (16 bytes) per pair of N-subtiles, and the four lanes lg = 0..3 of a row
+// write 64 CONTIGUOUS bytes with one store instruction (full 64-byte sectors instead of 16-byte pieces at a 32-byte
+// stride: the epilogue of one tile per CU is not overlapped with anything, its store efficiency is wall time).
 template <int WN>
 __device__ __forceinline__ int b_row_perm(int p) {
-    constexpr int NS = WN / 16;
     const int w = p / WN, q = p % WN, ns = q >> 4, i = q & 15;
-    return w * WN + (i >> 2) * (4 * NS) + ns * 4 + (i & 3);
+    return w * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
@@ -183,12 +185,12 @@ __device__ __forceinline__ float round_bf16(float x) { return bf16_lo(pack_bf16(
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
-template <int MS, int NS, bool INTERLEAVED_ROWS = false>
+template <int MS, int NS, bool INTERLEAVED_ROWS = false, bool NT_STORE = false>
 __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
                                            int m_base, int n_base) {
     const int lane = threadIdx.x & 63, lg = lane >> 4;
-    const int n_lane = n_base + lg * (4 * NS);
-    const bool full_n = (n_lane + 4 * NS <= p.n);
+    const int n_lane = n_base + lg * 8;                     // + (ns >> 1) * 32 + (ns & 1) * 4 + r
+    const bool full_n = (n_lane + (NS / 2 - 1) * 32 + 8 <= p.n) && (NS % 2 == 0);
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
         const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
@@ -208,7 +210,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                         w[2 * j] = zero_row ? 0u : pack_bf16(v[0], v[1]);
                         w[2 * j + 1] = zero_row ? 0u : pack_bf16(v[2], v[3]);
                     }
-                    uint4* dst = reinterpret_cast<uint4*>(drow + n_lane + h * 8);
+                    uint4* dst = reinterpret_cast<uint4*>(drow + n_lane + h * 32);
                     if (p.accumulate && !zero_row) {
                         const uint4 old = *dst;
                         const uint32_t o[4] = {old.x, old.y, old.z, old.w};
@@ -216,14 +218,19 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                         for (int j = 0; j < 4; ++j)
                             w[j] = pack_bf16(bf16_lo(o[j]) + bf16_lo(w[j]), bf16_hi(o[j]) + bf16_hi(w[j]));
                     }
-                    *dst = make_uint4(w[0], w[1], w[2], w[3]);
+                    if constexpr (NT_STORE) {
+                        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(u4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u4*>(dst));
+                    } else {
+                        *dst = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
                 }
             } else {
                 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
                     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int col = n_lane + ns * 4 + r;
+                        const int col = n_lane + (ns >> 1) * 32 + (ns & 1) * 4 + r;
                         if (col < p.n) {
                             float v = zero_row ? 0.f : round_bf16(acc[ms][ns][r]);
                             if (p.accumulate && !zero_row)
@@ -238,7 +245,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
             for (int ns = 0; ns < NS; ++ns) {
                 v4f v = acc[ms][ns];
                 if (zero_row) v = v4f{0.f, 0.f, 0.f, 0.f};
-                const int col = n_lane + ns * 4;
+                const int col = n_lane + (ns >> 1) * 32 + (ns & 1) * 4;
                 if (full_n && p.d_vec_ok) {
                     v4f* dst = reinterpret_cast<v4f*>(drow + col);
                     if (p.accumulate && !zero_row) v += *dst;
@@ -1375,7 +1382,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
-        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        if constexpr (DABL == 13) {
+            if (out[0][0][0] == 123.456f) store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        } else {
+            store_tile<MS, NS, true, DABL == 12>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        }
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -1400,15 +1411,20 @@ void dg_fp8_gemm_duo_kernel(const GemmParams p) {
 // per K block both certifies "block kb has landed" (after a counted vmcnt) and frees the slot of block kb-1.
 // The matrix work (8 MFMAs per wave per K block) is far below the pipe's rate here: weights stream once from HBM.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+// B_AUX: cache-policy bits of the weight stream's LDS-DMA (2 = nt: a weight byte is read by exactly one CU, once).
+// KBS: K blocks per ring stage -- a wave requests KBS x 128 contiguous bytes of each row back to back, which is what
+// gives the HBM controller row-buffer hits on K-major weights whose rows lie K bytes apart.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1>
 __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256;
-    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, STAGE_BYTES = SFB_OFF + SFB_BYTES;
+    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = SFB_OFF + SFB_BYTES;
+    constexpr int STAGE_BYTES = KBS * BLOCK_BYTES;
     constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    constexpr int PIECES = A_ITERS + B_ITERS + 2;              // per wave per K block, scale pieces included
+    constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
+    constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + 2) * KBS;      // per wave per stage, scale pieces included
     constexpr unsigned OOB = 0x80000000u;
     static_assert(BM == 64 && BN == 128, "one 256-byte SFA piece and one SFB value per tile");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
@@ -1471,7 +1487,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 const unsigned oob = j < num_kb ? 0u : OOB;
                 uint8_t* stage = lds + slot_off;
                 #pragma unroll
-                for (int q = 0; q < A_ITERS; ++q) {
+                for (int q = 0; q < (NO_A ? 0 : A_ITERS); ++q) {
                     const int unit = wave + NW * q;
                     const int voff = static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob));
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -1483,7 +1499,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
                                                       (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | oob));
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, 0);
+                        b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, B_AUX & 3);
                 }
                 // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -1494,19 +1510,28 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob), 0, 0, 0);
             };
 
+            auto issue_stage = [&](int slot_off, int sb) {            // stage sb = K blocks sb * KBS .. + KBS - 1
+                #pragma unroll
+                for (int u = 0; u < KBS; ++u)
+                    issue_block(slot_off + u * BLOCK_BYTES, sb * KBS + u);
+            };
             #pragma unroll
             for (int j = 0; j < STAGES - 1; ++j)
-                issue_block(j * STAGE_BYTES, j);
+                issue_stage(j * STAGE_BYTES, j);
 
             int cur = 0, fill = (STAGES - 1) * STAGE_BYTES;
-            for (int kb = 0; kb < num_kb; ++kb) {
-                // block kb: my pieces have landed (the STAGES-2 younger blocks may still fly); then everybody's have,
-                // and everybody is done reading block kb-1, whose slot takes block kb+STAGES-1
+            const int num_sb = (num_kb + KBS - 1) / KBS;
+            for (int sb = 0; sb < num_sb; ++sb) {
+                // stage sb: my pieces have landed (the STAGES-2 younger stages may still fly); then everybody's have,
+                // and everybody is done reading stage sb-1, whose slot takes stage sb+STAGES-1
                 asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((STAGES - 2) * PIECES) : "memory");
                 raw_barrier();
-                issue_block(fill, kb + STAGES - 1);
-
-                const uint8_t* stage = lds + cur;
+                issue_stage(fill, sb + STAGES - 1);
+              #pragma unroll
+              for (int u = 0; u < KBS; ++u) {
+                if (sb * KBS + u >= num_kb)
+                    break;
+                const uint8_t* stage = lds + cur + u * BLOCK_BYTES;
                 const v4f sa = *reinterpret_cast<const v4f*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
                 const float sb = *reinterpret_cast<const float*>(stage + SFB_OFF);
                 const uint8_t* a_tile = stage + (wm * WM) * 128;
@@ -1525,6 +1550,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         acc[ms][ns] += scale * part;
                     }
                 }
+              }
                 fill = cur;
                 cur = (cur == (STAGES - 1) * STAGE_BYTES) ? 0 : cur + STAGE_BYTES;
             }
@@ -1535,10 +1561,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_stream_kernel(const GemmParams p) {
-    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES>(p);
+    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1588,10 +1614,9 @@ __device__ __forceinline__ StagedTile stage_load(const uint8_t* base, int64_t st
 // the LDS row position whose permuted row equals the loaded row, found through a small search-free formula below.
 template <int WN>
 __device__ __forceinline__ int b_row_perm_inv(int n_local) {
-    constexpr int NS = WN / 16;
     const int w = n_local / WN, q = n_local % WN;
-    const int hi = q / (4 * NS), rem = q % (4 * NS), ns = rem >> 2, lo = rem & 3;
-    return w * WN + ns * 16 + hi * 4 + lo;
+    const int pair = q >> 5, lg = (q >> 3) & 3, odd = (q >> 2) & 1, r = q & 3;
+    return w * WN + (pair * 2 + odd) * 16 + lg * 4 + r;
 }
 
 __device__ __forceinline__ void stage_store(uint8_t* tile, const StagedTile& s, int64_t stride_k, bool permute_rows) {
@@ -1697,7 +1722,7 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
                     for (int ns = 0; ns < NS; ++ns)
                         #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int col = imin(t.n0 + wn * WN + lg * (4 * NS) + ns * 4 + r, p.n - 1);
+                            const int col = imin(t.n0 + wn * WN + (ns >> 1) * 32 + lg * 8 + (ns & 1) * 4 + r, p.n - 1);
                             sb_n[ns][r] = sfb_g[static_cast<int64_t>(col) * p.sfb_sn + static_cast<int64_t>(kb) * p.sfb_sk];
                         }
                     #pragma unroll
