@@ -65,10 +65,11 @@ struct Config {
     bool fast;
     KernelFn fn;
     bool ring = false;      // ring kernels read SFA through a buffer descriptor that assumes the MN-major layout
+    bool two_pass = false;  // contiguous layout: BM may be twice the M alignment (halves of two groups => two passes)
 };
 
 const Config kConfigs[] = {
-    {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true},
+    {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true, true},
     {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
@@ -150,12 +151,20 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         const Config& c = kConfigs[i];
         if ((c.fast && !fast_ok) || c.efficiency <= 0.f || (c.ring && p.sfa_sm != 1))
             continue;
-        if (bm_must_divide > 0 && bm_must_divide % c.bm != 0)
+        if (bm_must_divide > 0 && bm_must_divide % c.bm != 0 &&
+            !(c.two_pass && p.gemm_type == dg::kContiguous && c.bm == 2 * bm_must_divide))
             continue;
         const int m_eff = expected_m > 0 ? expected_m : m_for_tiling;
         const int groups = (p.gemm_type == dg::kMasked) ? p.num_groups : 1;
-        const long tiles = static_cast<long>(groups) * ceil_div(m_eff, c.bm) * ceil_div(p.n, c.bn);
+        long tiles = static_cast<long>(groups) * ceil_div(m_eff, c.bm) * ceil_div(p.n, c.bn);
         const long slots = static_cast<long>(num_cus()) * c.blocks_per_cu;
+        if (bm_must_divide > 0 && bm_must_divide % c.bm != 0) {
+            // two-pass tiles (BM = 2 x alignment): tiles whose halves belong to two groups cost twice and land anywhere
+            // in the schedule, so the big tile only pays when there are several rounds to average over
+            if (tiles < 4 * slots)
+                continue;
+            tiles += tiles / 4;
+        }
         const long rounds = (tiles + slots - 1) / slots;
         // A round costs the work of blocks_per_cu co-resident tiles per CU; tiny tiles are HBM/latency dominated.
         const double tile_work = static_cast<double>(c.bm) * c.bn / c.efficiency + 4096.0;
@@ -184,7 +193,8 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs MN-major SFA (sfa_stride_m == 1)";
         return 3;
     }
-    if (bm_must_divide > 0 && bm_must_divide % cfg->bm != 0) {
+    if (bm_must_divide > 0 && bm_must_divide % cfg->bm != 0 &&
+        !(cfg->two_pass && p.gemm_type == dg::kContiguous && cfg->bm == 2 * bm_must_divide)) {
         g_last_error = std::string("config '") + cfg->name + "' does not divide the contiguous-layout M alignment";
         return 3;
     }

@@ -61,8 +61,11 @@ struct Tile {
     int m0, n0;       // first row (within the group's A/D for masked, global otherwise) / first column
     int group;        // B / SFB group (masked: also A / SFA / D group)
     int m_end;        // rows >= m_end are not computed from A (clamped loads)
-    int zero_from;    // rows in [zero_from, m0 + BM) are stored as zeros; rows in [m_end, zero_from) are skipped
+    int zero_from;    // rows in [zero_from, zero_to) are stored as zeros; rows outside [m_begin, m_end) and that range are skipped
+    int m_begin;      // rows < m_begin are not stored by this pass (two-pass tiles of the contiguous layout)
+    int zero_to;
     bool valid;
+    bool second_pass; // the tile needs another pass (its two alignment-sized halves belong to different groups)
 };
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -87,9 +90,10 @@ __device__ __forceinline__ void swizzled_tile(int bid, int nwg, int num_m_tiles,
 struct MaskedWalk { int group = 0; int cum_m_tiles = 0; };
 
 template <int BM, int BN>
-__device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, MaskedWalk& walk) {
+__device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, MaskedWalk& walk, int pass = 0) {
     Tile t;
     t.valid = true;
+    t.second_pass = false;
     if (p.gemm_type == kMasked) {
         // Persistent walk over groups; masked_m lives on the device (README: the CPU never learns the counts).
         int nmt;
@@ -107,7 +111,8 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
         t.m0 = mt * BM;
         t.n0 = nt * BN;
         t.m_end = imin(p.layout[walk.group], p.m);
-        t.zero_from = t.m0 + BM;
+        t.zero_from = t.zero_to = t.m0 + BM;
+        t.m_begin = t.m0;
         return t;
     }
     const int num_tiles = p.num_m_tiles * p.num_n_tiles;
@@ -118,8 +123,42 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
     t.n0 = nt * BN;
     t.group = 0;
     t.m_end = p.m;
-    t.zero_from = t.m0 + BM;
-    if (p.gemm_type == kContiguous) {
+    t.zero_from = t.zero_to = t.m0 + BM;
+    t.m_begin = t.m0;
+    if (p.gemm_type == kContiguous && BM > p.m_alignment) {
+        // A tile of two alignment-sized halves (BM == 2 * m_alignment, checked by the host): the halves may belong to
+        // different groups (=> two passes over the tile, one per half, each with its own B) or be padding (=> zeros).
+        const int half = p.m_alignment, mid = t.m0 + half;
+        const int g0 = p.layout[t.m0], g1 = mid < p.m ? p.layout[mid] : -2;       // -2: the half does not exist
+        const int end1 = imin(mid + half, p.m);
+        const bool c0 = g0 >= 0, c1 = g1 >= 0, has1 = g1 != -2;
+        if (c0 && c1 && g0 != g1) {
+            // two different groups: pass 0 -> first half, pass 1 -> second half
+            t.second_pass = (pass == 0);
+            t.group = pass == 0 ? g0 : g1;
+            t.m_begin = pass == 0 ? t.m0 : mid;
+            t.m_end = pass == 0 ? mid : end1;
+        } else if (c0 && c1) {                      // one group owns both halves
+            t.group = g0;
+            t.m_end = end1;
+        } else if (c0) {                            // second half is padding (zero rows) or does not exist
+            t.group = g0;
+            t.m_end = mid;
+            t.zero_from = mid;
+            t.zero_to = has1 ? end1 : mid;
+        } else if (c1) {                            // first half is padding
+            t.group = g1;
+            t.m_begin = mid;
+            t.m_end = end1;
+            t.zero_from = t.m0;
+            t.zero_to = mid;
+        } else {                                    // nothing to compute
+            t.group = 0;
+            t.m_begin = t.m_end = t.m0;
+            t.zero_from = t.m0;
+            t.zero_to = has1 ? end1 : imin(mid, p.m);
+        }
+    } else if (p.gemm_type == kContiguous) {
         const int g = p.layout[t.m0];
         if (g < 0) { t.m_end = t.m0; t.zero_from = t.m0; }
         t.group = imax(g, 0);
@@ -194,8 +233,8 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
         const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
-        const bool compute_row = row < t.m_end;
-        const bool zero_row = row >= t.zero_from;
+        const bool compute_row = row >= t.m_begin && row < t.m_end;
+        const bool zero_row = row >= t.zero_from && row < t.zero_to;
         if (!compute_row && !zero_row)
             continue;
         if (p.d_dtype == 0) {
@@ -1159,10 +1198,17 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 
     MaskedWalk walk;
     const int num_launched = gridDim.x;
-    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
-        if (!t.valid)
+    bool more_tiles = true;
+    for (int tile_id = blockIdx.x; more_tiles; tile_id += num_launched)
+    for (int pass = 0, passes = 1; pass < passes; ++pass) {
+        // contiguous layout with BM = 2 x alignment: a tile whose halves belong to two groups is walked twice
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
+        if (!t.valid) {
+            more_tiles = false;
             break;
+        }
+        if (t.second_pass)
+            passes = 2;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
 
         float acc[MS][NS][4];
@@ -1387,7 +1433,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         } else {
             store_tile<MS, NS, true, DABL == 12>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         }
-        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+        if (p.dbg != nullptr && tile_id == blockIdx.x && pass == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);

@@ -99,7 +99,7 @@ def test_dense_layouts_vs_oracle(layout, m, n, k):
 
 
 @pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float])
-@pytest.mark.parametrize('cfg', ['auto', 'generic_128x128', 'pipe_128x128', 'duo_256x256', 'ring_256x256'])
+@pytest.mark.parametrize('cfg', ['auto', 'generic_128x128', 'pipe_128x128', 'duo_256x256', 'ring_256x256', 'stream_64x128'])
 def test_accumulate_and_fp32_out(out_dtype, cfg):
     gen.reset_seed(2)
     dg.set_forced_config(cfg)
@@ -192,11 +192,13 @@ def test_back_to_back_launches_and_side_stream():
 @pytest.mark.parametrize('b_k_major', [True, False])
 def test_m_grouped_contiguous_vs_oracle(use_psum, b_k_major):
     gen.reset_seed(6)
-    for actual_ms, n, k in (([100, 0, 130, 256], 256, 384), ([300, 77], 520, 256), ([128] * 8, 4096, 512)):
+    for actual_ms, n, k in (([100, 0, 130, 256], 256, 384), ([300, 77], 520, 256), ([128] * 8, 4096, 512),
+                            ([128, 384, 0, 0, 200, 640], 512, 256)):
         case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, b_k_major, use_psum, actual_ms=actual_ms)
         want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
         oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), use_psum)
-        for cfg in (['auto', 'generic_128x128'] + (['pipe_128x256', 'pipe_128x128', 'pipe_64x256'] if b_k_major else [])):
+        fast = ['pipe_128x256', 'pipe_128x128', 'pipe_64x256'] + ([] if use_psum else ['duo_256x256'])   # duo: two-pass 256-row tiles
+        for cfg in (['auto', 'generic_128x128'] + (fast if b_k_major else [])):
             dg.set_forced_config(cfg)
             case.d.fill_(float('nan'))
             if b_k_major:
