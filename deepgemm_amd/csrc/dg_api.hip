@@ -78,6 +78,7 @@ const Config kConfigs[] = {
     {"pipe_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_pipe_kernel<32, 256, 1, 4, 0>},
     {"pipe_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_pipe_kernel<16, 256, 1, 4, 0>},
     {"stream_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6>, true},
+    {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 12>, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
     // experimental / baseline variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of
     // the heuristic): LDS-DMA piece placement variants and the hipcc-scheduled first version of the fast path.
@@ -139,12 +140,25 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         return nullptr;
     }
     const bool fast_ok = fast_eligible(p);
-    // HBM-bound shapes (decode-sized M: every weight byte is streamed once for <= 64 rows): the deep-ring stream kernel.
+    // HBM-bound shapes (M up to a few 64-row tiles: every weight byte is streamed once or twice): the deep-ring stream
+    // kernels.  A CU sustains only ~25 GB/s of HBM stream (bytes in flight / latency), so the tile count has to cover
+    // the chip: 64 x 128 tiles when there are enough of them, 64 x 32 otherwise (measured: tools/ref_shapes.py).
     const int m_hint = expected_m > 0 ? expected_m : m_for_tiling;
-    if (fast_ok && p.sfa_sm == 1 && m_hint <= 64 && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum)
-        for (int i = 0; i < kNumConfigs; ++i)
-            if (std::strcmp(kConfigs[i].name, "stream_64x128") == 0)
-                return &kConfigs[i];
+    if (fast_ok && p.sfa_sm == 1 && m_hint <= 256 && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum) {
+        const int groups = (p.gemm_type == dg::kMasked) ? p.num_groups : 1;
+        const long tiles128 = static_cast<long>(groups) * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
+        const char* pick = nullptr;
+        if (m_hint <= 64)
+            pick = tiles128 >= 96 ? "stream_64x128" : "stream_64x32";
+        else if (tiles128 < 96)
+            pick = "stream_64x32";
+        else if (tiles128 < 256)
+            pick = "stream_64x128";
+        if (pick != nullptr)
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (std::strcmp(kConfigs[i].name, pick) == 0)
+                    return &kConfigs[i];
+    }
     const Config* best = nullptr;
     double best_cost = 0;
     for (int i = 0; i < kNumConfigs; ++i) {

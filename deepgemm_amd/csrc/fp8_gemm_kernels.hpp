@@ -1472,9 +1472,9 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
     constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + 2) * KBS;      // per wave per stage, scale pieces included
     constexpr unsigned OOB = 0x80000000u;
-    static_assert(BM == 64 && BN == 128, "one 256-byte SFA piece and one SFB value per tile");
+    static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA piece and one SFB value per tile");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
-    static_assert(MS == 4 && NS % 2 == 0, "a lane reads its MS = 4 row scales with one ds_read_b128");
+    static_assert((MS == 4 || MS == 1) && NS % 2 == 0, "a lane reads its MS row scales with one LDS read");
     static_assert((STAGES - 1) * PIECES < 64, "vmcnt is a 6-bit counter");
     static_assert(LDS_BYTES <= 160 * 1024 && STAGES >= 3, "LDS budget");
     static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
@@ -1578,7 +1578,13 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 if (sb * KBS + u >= num_kb)
                     break;
                 const uint8_t* stage = lds + cur + u * BLOCK_BYTES;
-                const v4f sa = *reinterpret_cast<const v4f*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                float sa[MS];
+                if constexpr (MS == 4) {
+                    const v4f q = *reinterpret_cast<const v4f*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                    sa[0] = q[0]; sa[1] = q[1]; sa[2] = q[2]; sa[3] = q[3];
+                } else {
+                    sa[0] = *reinterpret_cast<const float*>(stage + SFA_OFF + (wm * WM + (lane & 15)) * 4);
+                }
                 const float sb = *reinterpret_cast<const float*>(stage + SFB_OFF);
                 const uint8_t* a_tile = stage + (wm * WM) * 128;
                 const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;

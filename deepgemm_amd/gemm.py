@@ -14,7 +14,8 @@ import torch
 
 from ._lib import lib, check, current_stream_ptr, require_device
 from .errors import host_assert
-from .layout import check_major_type_cd, is_k_major, major_check, transform_sf_pair_into_required_layout
+from .layout import (check_major_type_cd, get_mn_major_tma_aligned_tensor, is_k_major, major_check,
+                     transform_sf_pair_into_required_layout)
 from . import runtime
 
 _BF16, _FP32 = 0, 1
@@ -43,6 +44,17 @@ def _as_k_major(t: torch.Tensor, macs: int) -> torch.Tensor:
     check(lib.dg_transpose_fp8(t.data_ptr(), out.data_ptr(), batches, k, mn, t.stride(-1), k,
                                t.stride(0) if t.dim() == 3 else 0, mn * k, current_stream_ptr()))
     return out
+
+
+# Host-overhead diet for decode-sized calls: the reference's checks cost ~20 us of Python per call, more than the kernel of
+# a small GEMM.  A call whose (shape, stride, dtype, device) signature has already passed every check once skips straight
+# to the SF layout step and the C call; anything new, or any failing call, takes the full path below.
+_VALIDATED_DENSE = {}
+_VALIDATED_MASKED = {}
+
+
+def _sig(t: Optional[torch.Tensor]):
+    return None if t is None else (t.shape, t.stride(), t.dtype, t.device)
 
 
 def _dtype_code(d: torch.Tensor) -> int:
@@ -75,6 +87,23 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
                 disable_ue8m0_cast: bool = False) -> None:
     """D = C + A @ B^T with per-128-block FP32 scales; ``a = (A_fp8 [M,K], SFA)``, ``b = (B_fp8 [N,K], SFB)``."""
     (a_data, a_sf), (b_data, b_sf) = a, b
+    same_cd = c is not None and c.data_ptr() == d.data_ptr()
+    key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(c), same_cd,
+           recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),
+           recipe_b if recipe_b is None else tuple(recipe_b))
+    plan = _VALIDATED_DENSE.get(key)
+    if plan is not None:
+        m, n, k, gran_n, sfa_ready = plan
+        if c is not None and not same_cd:
+            d.copy_(c)
+        sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
+        a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
+        check(lib.dg_fp8_gemm_nt(
+            a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), m, n, k,
+            a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
+            sfa.stride(0), sfa.stride(1), b_sf.stride(0), b_sf.stride(1), gran_n,
+            d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
+        return
     major_check(a_data), major_check(b_data)
     check_major_type_cd(d)
     m, k = _check_ab_fp8(a_data, 2)
@@ -87,6 +116,8 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
                                                               None, None, disable_ue8m0_cast)
     require_device(a_data, b_data, sfa, sfb, d)
+    if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
+        _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf)
     a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
     check(lib.dg_fp8_gemm_nt(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
@@ -161,22 +192,32 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
     """``a [G,M,K]``, ``b [G,N,K]``, ``d [G,M,N]``; only ``d[g, :masked_m[g]]`` is written; ``masked_m`` stays on
     the device, ``expected_m`` is a tuning hint."""
     (a_data, a_sf), (b_data, b_sf) = a, b
-    host_assert(is_k_major(a_data) and is_k_major(b_data), 'major_a == cute::UMMA::Major::K and major_b == cute::UMMA::Major::K')
-    host_assert(masked_m.is_contiguous(), 'masked_m.is_contiguous()')
-    num_groups, m, k = _check_ab_fp8(a_data, 3)
-    num_groups_, n, k_ = _check_ab_fp8(b_data, 3)
-    host_assert(d.dim() == 3, 'd.dim() == 3')
-    host_assert(num_groups == num_groups_ == d.size(0) == masked_m.numel(),
-                'num_groups == num_groups_ and num_groups == num_groups__ and num_groups == num_groups___')
-    host_assert((m, n) == tuple(d.shape[1:]) and k == k_, 'm == m_ and n == n_ and k == k_')
-    host_assert(expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0,
-                'expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0')
-    host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
-    host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
-    check_major_type_cd(d)
-    sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                         num_groups, num_groups, disable_ue8m0_cast)
-    require_device(a_data, b_data, sfa, sfb, d, masked_m)
+    key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(masked_m), expected_m > 0,
+           recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),
+           recipe_b if recipe_b is None else tuple(recipe_b))
+    plan = _VALIDATED_MASKED.get(key)
+    if plan is not None:
+        num_groups, m, n, k, sfa_ready = plan
+        sfa, sfb = (a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)), b_sf
+    else:
+        host_assert(is_k_major(a_data) and is_k_major(b_data), 'major_a == cute::UMMA::Major::K and major_b == cute::UMMA::Major::K')
+        host_assert(masked_m.is_contiguous(), 'masked_m.is_contiguous()')
+        num_groups, m, k = _check_ab_fp8(a_data, 3)
+        num_groups_, n, k_ = _check_ab_fp8(b_data, 3)
+        host_assert(d.dim() == 3, 'd.dim() == 3')
+        host_assert(num_groups == num_groups_ == d.size(0) == masked_m.numel(),
+                    'num_groups == num_groups_ and num_groups == num_groups__ and num_groups == num_groups___')
+        host_assert((m, n) == tuple(d.shape[1:]) and k == k_, 'm == m_ and n == n_ and k == k_')
+        host_assert(expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0,
+                    'expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0')
+        host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
+        host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
+        check_major_type_cd(d)
+        sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
+                                                             num_groups, num_groups, disable_ue8m0_cast)
+        require_device(a_data, b_data, sfa, sfb, d, masked_m)
+        if sfb is b_sf and len(_VALIDATED_MASKED) < 4096:
+            _VALIDATED_MASKED[key] = (num_groups, m, n, k, sfa is a_sf)
     check(lib.dg_m_grouped_fp8_gemm_nt_masked(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), masked_m.data_ptr(),
         num_groups, m, n, k, int(expected_m),
