@@ -66,10 +66,12 @@ struct Config {
     KernelFn fn;
     bool ring = false;      // ring kernels read SFA through a buffer descriptor that assumes the MN-major layout
     bool two_pass = false;  // contiguous layout: BM may be twice the M alignment (halves of two groups => two passes)
+    bool persistent = false;  // one workgroup per CU walks the tile list and prefetches the next tile's first K blocks
 };
 
 const Config kConfigs[] = {
     {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true, true},
+    {"duo_p_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 20>, true, true, true},
     {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
@@ -227,6 +229,9 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         const long slots = static_cast<long>(num_cus()) * cfg->blocks_per_cu;
         const long max_tiles = total * p.num_groups;
         grid = max_tiles < slots ? max_tiles : slots;
+    } else if (cfg->persistent) {
+        const long slots = static_cast<long>(num_cus()) * cfg->blocks_per_cu;
+        grid = total < slots ? total : slots;
     } else {
         grid = total;
     }

@@ -1167,6 +1167,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_EARLY = (DABL == 9) ? 0 : A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
+    constexpr bool PERSIST = (DABL == 20);      // persistent launch with cross-tile prologue prefetch
     constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3), LOADPRIO = (DABL == 8 || DABL == 11);
     constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
@@ -1198,18 +1199,101 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 
     MaskedWalk walk;
     const int num_launched = gridDim.x;
-    bool more_tiles = true;
-    for (int tile_id = blockIdx.x; more_tiles; tile_id += num_launched)
-    for (int pass = 0, passes = 1; pass < passes; ++pass) {
-        // contiguous layout with BM = 2 x alignment: a tile whose halves belong to two groups is walked twice
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
-        if (!t.valid) {
-            more_tiles = false;
-            break;
-        }
-        if (t.second_pass)
-            passes = 2;
+    const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+    const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
+    const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
+
+    // Per-piece source offsets (rows + chunk: the bounds-checked part of the address) are kernel invariants held in
+    // VGPRs; the K block goes in the soffset.  Blocks past the end re-read the last K block into a dead slot -- no
+    // out-of-range arithmetic in the loop, the vmcnt counts stay exact, the bytes come from L2.
+    int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
+    #pragma unroll
+    for (int q = 0; q < A_ITERS; ++q)
+        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
+    #pragma unroll
+    for (int q = 0; q < B_ITERS; ++q)
+        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+
+    // Addresses of one tile (plain scalars; the buffer descriptors are built from them where they are used).
+    struct TileMem { const uint8_t* a_base; const uint8_t* b_base; int a_bytes, b_bytes; uint64_t sfa_addr, sfb_addr; int sfa_voff; };
+    auto tile_mem = [&](const Tile& tt) {
+        const int64_t adg = (p.gemm_type == kMasked) ? tt.group : 0;
+        TileMem tm;
+        // every descriptor input goes through readfirstlane: tile coordinates that depend on loaded values (grouped
+        // layouts) are uniform in fact but not provably so, and hipcc would wrap each buffer op in a waterfall loop
+        auto uniform_ptr = [](const uint8_t* ptr) {
+            const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v));
+            const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+            return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
+        };
+        tm.a_base = uniform_ptr(p.a + adg * p.a_sg + static_cast<int64_t>(tt.m0) * p.a_sm);
+        tm.b_base = uniform_ptr(p.b + static_cast<int64_t>(tt.group) * p.b_sg + static_cast<int64_t>(tt.n0) * p.b_sn);
+        tm.a_bytes = __builtin_amdgcn_readfirstlane((imin(tt.m_end - tt.m0, BM) - 1) * lda + p.k);
+        tm.b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - tt.n0, BN) - 1) * ldb + p.k);
+        tm.sfa_addr = reinterpret_cast<uint64_t>(p.sfa + adg * p.sfa_sg);
+        tm.sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(tt.group) * p.sfb_sg +
+                                                 static_cast<int64_t>((tt.n0 + wn * WN) / 128) * p.sfb_sn);
+        tm.sfa_voff = (tt.m0 + wm * WM + (lane & 15) * MS) * 4;
+        return tm;
+    };
+    auto scale_rsrc = [&](uint64_t addr, int extent) {
+        return v4i{__builtin_amdgcn_readfirstlane(static_cast<int>(addr)),
+                   __builtin_amdgcn_readfirstlane(static_cast<int>(addr >> 32) & 0xffff),
+                   __builtin_amdgcn_readfirstlane(extent), 0x00020000};
+    };
+    auto issue_a_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
+        const int unit = wave + NW * q;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
+            imin(j, num_kb - 1) * 128, 0, 0);
+    };
+    auto issue_b_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
+        const int unit = wave + NW * q;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
+            b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+    };
+    // Prologue pieces of a tile: A(0) B(0) A(1) B(1) into ring slots 0 / 1.  Issued at kernel entry for the first tile
+    // and, in the persistent launch, for tile i+1 as soon as tile i's K loop has released the LDS -- i.e. BEFORE tile i's
+    // output stores, so that the cold-start latency of a tile and its predecessor's store tail overlap.  Only LDS-DMA
+    // travels ahead: a VGPR-destination load (the scales) must reach its wait in straight-line code, because hipcc is
+    // free to copy the destination registers at any control-flow join in between -- before the data has arrived.
+    ScaleLandingV<MS> land;
+    auto issue_prologue = [&](const Tile& tt) {
+        const TileMem tm = tile_mem(tt);
+        #pragma unroll
+        for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, 0, 0, q);
+        #pragma unroll
+        for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, 0, 0, q);
+        #pragma unroll
+        for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, A_BYTES, 1, q);
+        #pragma unroll
+        for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, B_BYTES, 1, q);
+    };
+
+    // Tile iteration state: (tile_id, pass); contiguous layout with BM = 2 x alignment: a tile whose halves belong to two
+    // groups is walked twice.
+    int tile_id = blockIdx.x, pass = 0;
+    bool prefetched = false, first_tile = true;
+    Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
+    while (t.valid) {
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+        Tile tn;
+        bool next_prefetched = false;
+        auto fetch_next = [&]() {
+            if (t.second_pass) {
+                pass = 1;
+            } else {
+                tile_id += num_launched;
+                pass = 0;
+            }
+            tn = get_tile<BM, BN>(p, tile_id, walk, pass);
+            if (PERSIST && tn.valid && tn.m_end > tn.m0) {
+                issue_prologue(tn);
+                next_prefetched = true;
+            }
+        };
 
         float acc[MS][NS][4];
         #pragma unroll
@@ -1221,57 +1305,17 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     acc[ms][ns][r] = 0.f;
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
-            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
-                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
-            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
-                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
-            const float* sfa_group = p.sfa + ad_group * p.sfa_sg;
-            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
-                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
-            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
-            const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
-            const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
-            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(sfa_group), sfb_addr = reinterpret_cast<uint64_t>(sfb_wave);
-            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
-                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
-                                  __builtin_amdgcn_readfirstlane(sfa_extent), 0x00020000};
-            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
-                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
-                                  __builtin_amdgcn_readfirstlane(sfb_extent), 0x00020000};
-            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
-
-            // Per-piece source offsets (rows + chunk: the bounds-checked part of the address) are loop invariants held in
-            // VGPRs; the K block goes in the soffset.  Blocks past the end re-read the last K block into a dead slot --
-            // no out-of-range arithmetic in the loop, the vmcnt counts stay exact, the bytes come from L2.
-            int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q)
-                a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q)
-                b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
-            auto issue_a_piece = [&](int slot_off, int j, int q) {
-                const int unit = wave + NW * q;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-                    imin(j, num_kb - 1) * 128, 0, 0);
-            };
-            auto issue_b_piece = [&](int slot_off, int j, int q) {
-                const int unit = wave + NW * q;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
-                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
-            };
+            const TileMem tm = tile_mem(t);
+            const v4i sfa_rsrc = scale_rsrc(tm.sfa_addr, sfa_extent), sfb_rsrc = scale_rsrc(tm.sfb_addr, sfb_extent);
+            const int sfa_voff = tm.sfa_voff;
+            auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
+            auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
             auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
                 const int jj = imin(j, num_kb - 1);         // past the end: the last block's scales again (never consumed)
                 issue_scale_loads_v<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
             float scale[MS], scale_tail = 0.f;
-            ScaleLandingV<MS> land;
             v4f part[DEPTH + 1];
             #pragma unroll
             for (int i = 0; i <= DEPTH; ++i)
@@ -1280,17 +1324,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             for (int ms = 0; ms < MS; ++ms)
                 scale[ms] = 0.f;
 
-            // ---- prologue: SF(0) A(0) B(0) A(1) B(1); block 0 and its scales must land before the first segment ----
+            // ---- block 0 and its scales must land before the first segment ----
+            if (!prefetched)
+                issue_prologue(t);
+            // SF(0) is the newest vector-memory operation and (persistent launch) a predecessor's output stores may be
+            // in flight, retiring out of order with respect to loads: a full drain is the only proof that block 0 is
+            // there.  It also lands block 1 -- a fraction of a microsecond once per tile.
             issue_scales(land, 0);
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
-            wait_landing_v<A_ITERS + B_ITERS, MS>(land);
+            wait_landing_v<0, MS>(land);
             raw_barrier();
             if (DABL != 1 && upper_half)
                 raw_barrier();                      // the upper half runs one segment behind from here on
@@ -1413,13 +1454,16 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             if constexpr (TRACE)
                 if (p.dbg != nullptr)
                     reinterpret_cast<int*>(p.dbg + 8192)[(blockIdx.x * NW + wave) * 64 + lane] = trace_v;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's re-read pieces: the ring is about to be reused
+            __syncthreads();                                    // every wave is done with the LDS
+            fetch_next();                                       // persistent launch: the next tile's prologue flies from here
             #pragma unroll
             for (int i = 0; i < DEPTH; ++i) {
                 const int j = TOTAL - DEPTH + i;
                 promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
             }
-            __syncthreads();
+        } else {
+            fetch_next();
         }
 
         v4f out[MS][NS];
@@ -1433,13 +1477,16 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         } else {
             store_tile<MS, NS, true, DABL == 12>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         }
-        if (p.dbg != nullptr && tile_id == blockIdx.x && pass == 0) {
+        if (p.dbg != nullptr && first_tile && !next_prefetched) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
             dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
         }
+        t = tn;
+        prefetched = next_prefetched;
+        first_tile = false;
     }
 }
 

@@ -12,7 +12,7 @@ from deepgemm_amd.testing import calc_diff, generators as gen
 from gpu_helpers import assert_close_fp32, assert_close_to_oracle, cpu_pair, oracle_dense
 
 pytestmark = pytest.mark.gpu
-FAST = ['stream_64x128', 'stream_64x32', 'duo_256x256', 'ring_256x256', 'pipe_256x256', 'pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'pipe_32x256', 'pipe_16x256',
+FAST = ['stream_64x128', 'stream_64x32', 'duo_256x256', 'duo_p_256x256', 'ring_256x256', 'pipe_256x256', 'pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'pipe_32x256', 'pipe_16x256',
         'pipe_s0_256x256', 'pipe_s1_256x256', 'pipe_s3_256x256', 'naive_256x256']
 
 
@@ -279,6 +279,32 @@ def test_full_size_c2_properties():
         d4 = torch.empty_like(case.d)
         dg.fp8_gemm_nt(case.a, case.b, d4)
         assert torch.equal(d4, case.d), cfg
+
+
+def test_repeatability_full_size():
+    """Same inputs, same configuration, many launches: every output must be bit-identical.  Guards the hand-managed
+    asynchrony (counted vmcnt, raw barriers, asm loads whose destination registers hipcc may copy before they land):
+    a race shows up as a few wrong tiles in a few launches, far below what a single calc_diff check notices."""
+    gen.reset_seed(3)
+    case = gen.generate_normal(4096, 4096, 7168)
+    for cfg in ('duo_256x256', 'duo_p_256x256', 'ring_256x256', 'stream_64x128'):
+        dg.set_forced_config(cfg)
+        first = torch.empty_like(case.d)
+        dg.fp8_gemm_nt(case.a, case.b, first)
+        for _ in range(6 if cfg == 'stream_64x128' else 12):
+            again = torch.empty_like(case.d)
+            dg.fp8_gemm_nt(case.a, case.b, again)
+            assert torch.equal(again, first), cfg
+    # a multi-tile-per-CU problem through the persistent launch
+    case2 = gen.generate_normal(4096, 16384, 1024)
+    want = None
+    for cfg in ('duo_256x256', 'duo_p_256x256', 'duo_p_256x256', 'duo_p_256x256'):
+        dg.set_forced_config(cfg)
+        d = torch.empty_like(case2.d)
+        dg.fp8_gemm_nt(case2.a, case2.b, d)
+        want = d if want is None else want
+        assert torch.equal(d, want), cfg
+    assert calc_diff(want, case2.ref_d) < gen.FP8_MAX_DIFF
 
 
 def test_reference_sweep_subset_gate():
