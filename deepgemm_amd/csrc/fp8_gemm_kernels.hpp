@@ -230,6 +230,51 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
     const int lane = threadIdx.x & 63, lg = lane >> 4;
     const int n_lane = n_base + lg * 8;                     // + (ns >> 1) * 32 + (ns & 1) * 4 + r
     const bool full_n = (n_lane + (NS / 2 - 1) * 32 + 8 <= p.n) && (NS % 2 == 0);
+
+    // Full-line stores (BF16, 64-column wave tile entirely inside N, no accumulation): the output tail of a CU is bound by
+    // the NUMBER of store requests (one per 64-byte run: ~5 cycles each), not by bytes.  Lanes r and r + 8 of a 16-lane row
+    // swap halves through DPP (row_ror:8) so that one store instruction writes 8 rows x 128 contiguous bytes instead of
+    // 16 rows x 64: half the requests for the same bytes.
+    if constexpr (NS == 4) {
+        if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + 64 <= p.n) {
+            const bool lo = (lane & 8) == 0;
+            const int r7 = lane & 7;
+            const int col = n_base + ((lane >> 3) & 1) * 32 + lg * 8;
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+                uint32_t w0[4], w1[4], x[4], y[4];
+                #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    w0[2 * j] = pack_bf16(acc[ms][j][0], acc[ms][j][1]);
+                    w0[2 * j + 1] = pack_bf16(acc[ms][j][2], acc[ms][j][3]);
+                    w1[2 * j] = pack_bf16(acc[ms][2 + j][0], acc[ms][2 + j][1]);
+                    w1[2 * j + 1] = pack_bf16(acc[ms][2 + j][2], acc[ms][2 + j][3]);
+                }
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t send = lo ? w1[j] : w0[j];
+                    uint32_t recv;
+                    // s_nop 1: VALU write -> DPP read of the same VGPR needs two wait states (hipcc pads nothing inside asm)
+                    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(recv) : "v"(send));
+                    x[j] = lo ? w0[j] : recv;
+                    y[j] = lo ? recv : w1[j];
+                }
+                #pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int i = r7 + half * 8;
+                    const int row = INTERLEAVED_ROWS ? m_base + i * MS + ms : m_base + ms * 16 + i;
+                    const bool compute_row = row >= t.m_begin && row < t.m_end;
+                    const bool zero_row = row >= t.zero_from && row < t.zero_to;
+                    if (!compute_row && !zero_row)
+                        continue;
+                    const uint32_t* v = half == 0 ? x : y;
+                    uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+                    *reinterpret_cast<uint4*>(drow + col) = zero_row ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            return;
+        }
+    }
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
         const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
@@ -968,27 +1013,24 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
             for (int i = 0; i <= DEPTH; ++i)
                 part[i] = v4f{0.f, 0.f, 0.f, 0.f};
 
-            // ---- prologue: SF(0) A(0) B(0) | wait, consume SF(0) | SF(1) A(1) B(1) A(2) ----
-            issue_scales(land, 0);
+            // ---- prologue: A(0) B(0) A(1) B(1) | SF(0), full drain (the scale loads must reach their wait in straight-line
+            // code: hipcc may copy their destination registers at any control-flow join in between) ----
             #pragma unroll
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
             #pragma unroll
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
-            wait_landing<A_ITERS + B_ITERS, MS>(land);                // the scales only; the pieces may still fly
-            [[maybe_unused]] int trace_v = 0;                          // RABL 5: lane i = s_memtime at step i of K block 30/31
-            [[maybe_unused]] long long trace_t[4] = {0, 0, 0, 0};
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-                scale[ms] = land.sa[ms] * land.sb;
-            issue_scales(land, 1);
             #pragma unroll
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
             #pragma unroll
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
+            issue_scales(land, 0);
+            wait_landing<0, MS>(land);
             #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(2 * A_BYTES, 2, q);
-            asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((RABL == 5 ? 0 : MS + 1) + 2 * A_ITERS + B_ITERS) : "memory");   // A(0), B(0) landed
+            for (int ms = 0; ms < MS; ++ms)
+                scale[ms] = land.sa[ms] * land.sb;
             raw_barrier();
+            [[maybe_unused]] int trace_v = 0;                          // RABL 5: lane i = s_memtime at step i of K block 30/31
+            [[maybe_unused]] long long trace_t[4] = {0, 0, 0, 0};
 
             // slot offsets (bytes): a_cur is being computed (and re-filled behind barrier P), *_nxt is read behind P
             int a_cur = 0, a_nxt = A_BYTES, b_nxt = B_BYTES;
@@ -998,7 +1040,7 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                 bf[ns] = load_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128, frag_off);
             af[0] = load_fragment(lds + (wm * WM) * 128, frag_off);
 
-            // Issue order per block (vmcnt counts depend on it): SF(kb+1) [end of block kb-1] | A(kb+2) x A_ITERS
+            // Issue order per block (vmcnt counts depend on it): SF(kb+1) [top of block kb] | A(kb+2) x A_ITERS
             // [steps 0, 2, ..] | B(kb+2) x B_ITERS [behind Q] | P_kb waits vmcnt(A_ITERS + B_ITERS).
             constexpr int B_FIRST = (NS > 2 * A_ITERS ? NS : 2 * A_ITERS);
             static_assert(B_FIRST + 2 * (B_ITERS - 1) < P_STEP, "LDS-DMA pieces must be issued in front of barrier P");
@@ -1009,6 +1051,7 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                 const uint8_t* b_next_tile = lds + B_BASE + b_nxt + (wn * WN) * 128;
                 // A(kb+2) goes into the slot that held A(kb-1): the one after a_nxt in ring order
                 const int a_fill = (a_nxt == (A_SLOTS - 1) * A_BYTES) ? 0 : a_nxt + A_BYTES;
+                issue_scales(land, kb + 1);         // consumed at the end of this iteration, behind P's wait
 
                 #pragma unroll
                 for (int i = 0; i < TOTAL; ++i) {
@@ -1039,7 +1082,7 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                     if constexpr (PAD > 0) asm volatile("s_nop %c0" :: "i"(PAD - 1));
                     if (ms == MS - 1)
                         bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
-                    if (RABL != 2 && i % 2 == 0 && i / 2 < A_ITERS && kb > 0)
+                    if (RABL != 2 && i % 2 == 0 && i / 2 < A_ITERS)
                         issue_a_piece(a_fill, kb + 2, i / 2);
                     if (RABL != 1 && i == NS - 1)
                         raw_barrier();                                          // barrier Q: B(kb) is in registers
@@ -1053,7 +1096,6 @@ __device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
                     scale[ms] = land.sa[ms] * land.sb;
                     pin_vgpr(scale[ms]);
                 }
-                issue_scales(land, kb + 2);
                 a_cur = a_nxt;
                 a_nxt = a_fill;
                 b_nxt ^= B_BYTES;
