@@ -190,6 +190,15 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             best_cost = cost;
         }
     }
+    // Several tiles per CU: the persistent variant of the duo kernel (the next tile's first K blocks are fetched and
+    // drained in front of the current tile's stores, which then overlap the next tile's first K block).
+    if (best != nullptr && std::strcmp(best->name, "duo_256x256") == 0 && p.gemm_type != dg::kMasked) {
+        const long tiles = static_cast<long>(ceil_div(m_for_tiling, best->bm)) * ceil_div(p.n, best->bn);
+        if (tiles > num_cus())
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (std::strcmp(kConfigs[i].name, "duo_p_256x256") == 0)
+                    return &kConfigs[i];
+    }
     return best;
 }
 

@@ -1318,6 +1318,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // groups is walked twice.
     int tile_id = blockIdx.x, pass = 0;
     bool prefetched = false, first_tile = true;
+    float scale_pref[MS];                        // scales of a prefetched tile's K block 0 (products, ready to use)
+    #pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+        scale_pref[ms] = 0.f;
     Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
     while (t.valid) {
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
@@ -1332,7 +1336,17 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             }
             tn = get_tile<BM, BN>(p, tile_id, walk, pass);
             if (PERSIST && tn.valid && tn.m_end > tn.m0) {
+                // The next tile's first two K blocks and the scales of its block 0, drained HERE -- in front of this tile's
+                // output stores: once stores are pending they count towards vmcnt, and waiting for "block 0 has landed" at
+                // the top of the next tile would wait for (nearly) all of them.  Drained now, the next tile starts without
+                // any wait and the stores overlap its first K block instead of standing between the two tiles.
+                const TileMem tmn = tile_mem(tn);
                 issue_prologue(tn);
+                issue_scale_loads_v<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff, scale_rsrc(tmn.sfb_addr, sfb_extent), 0);
+                wait_landing_v<0, MS>(land);
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    scale_pref[ms] = land.q[ms / 4][ms % 4] * land.sb;
                 next_prefetched = true;
             }
         };
@@ -1367,13 +1381,17 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 scale[ms] = 0.f;
 
             // ---- block 0 and its scales must land before the first segment ----
-            if (!prefetched)
+            if (!prefetched) {
+                // SF(0) is the newest vector-memory operation: a full drain, which also lands block 1 -- a fraction of a
+                // microsecond once per tile.  (Straight-line from the scale loads to their wait: hipcc may copy the landing
+                // registers at any control-flow join in between.)
                 issue_prologue(t);
-            // SF(0) is the newest vector-memory operation and (persistent launch) a predecessor's output stores may be
-            // in flight, retiring out of order with respect to loads: a full drain is the only proof that block 0 is
-            // there.  It also lands block 1 -- a fraction of a microsecond once per tile.
-            issue_scales(land, 0);
-            wait_landing_v<0, MS>(land);
+                issue_scales(land, 0);
+                wait_landing_v<0, MS>(land);
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    scale_pref[ms] = land.q[ms / 4][ms % 4] * land.sb;
+            }
             raw_barrier();
             if (DABL != 1 && upper_half)
                 raw_barrier();                      // the upper half runs one segment behind from here on
@@ -1413,7 +1431,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 scale_tail = scale[MS - 1];
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
-                    scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                    scale[ms] = kb == 0 ? scale_pref[ms] : land.q[ms / 4][ms % 4] * land.sb;
                     pin_vgpr(scale[ms]);
                 }
                 if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[1]) :: "memory");
@@ -1466,7 +1484,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     for (int q = 0; q < B_ITERS; ++q)
                         issue_b_piece(b_cur, kb + 2, q);
                 }
-                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);       // block kb+1 and its scales: my pieces have landed
+                // Block kb+1 and its scales: my pieces have landed.  (Persistent launch: a predecessor tile's output stores may
+                // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
+                // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
+                // "every load but the newest 8 has landed".)
+                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
                 asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]) :: "memory");
 
                 // ---------------- M_b ----------------
