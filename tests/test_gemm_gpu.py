@@ -253,6 +253,57 @@ def test_m_grouped_masked_vs_oracle(masked_ms, max_m, n, k):
             assert bool(torch.isnan(case.d[g, rows:]).all()), f'{cfg}: rows >= masked_m must not be written'
 
 
+@pytest.mark.parametrize('groups,expected_m,max_m,n,k', [(6, 1024, 4096, 4096, 4096), (32, 20, 4096, 4096, 2048), (8, 48, 64, 4096, 7168)])
+def test_m_grouped_masked_reference_shapes(groups, expected_m, max_m, n, k):
+    """The reference's masked sweep (tests/generators.py:174-187: max_m 4096, masked_m = int(expected_m * U(0.7, 1.3))) and
+    BASELINE config 5's per-rank shape (8 local experts, M <= 64): reference gate on the valid rows, oracle on a row
+    sample, rows >= masked_m untouched (NaN poison)."""
+    gen.reset_seed(groups)
+    case = gen.generate_m_grouped_masked(groups, max_m, expected_m, n, k)
+    case.d.fill_(float('nan'))
+    dg.m_grouped_fp8_gemm_nt_masked(case.a, case.b, case.d, case.masked_m, expected_m)
+    for g, rows in enumerate(case.masked_m.tolist()):
+        rows = int(rows)
+        if rows:
+            assert calc_diff(case.d[g, :rows], case.ref_d[g, :rows]) < gen.FP8_MAX_DIFF, (g, rows, dg.last_config())
+            pick = torch.tensor(sorted(random.sample(range(rows), min(rows, 4))))
+            want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][g][pick.cuda()].cpu(), case.a[1][g][pick.cuda()].cpu(),
+                                                      case.b[0][g].cpu(), case.b[1][g].cpu())
+            assert_close_to_oracle(case.d[g][pick.cuda()], want, f'group {g}')
+        assert bool(torch.isnan(case.d[g, rows:]).all()), f'group {g}: rows >= masked_m must not be written'
+
+
+def test_import_is_fork_safe_and_bench_runs():
+    """(i) importing the package must not initialise the GPU runtime: a forked child can still pick its device (reference
+    tests/test_lazy_init.py:7-20); (ii) bench.py prints one well-formed JSON line carrying roofline and cpu_baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch, deepgemm_amd\n"
+        "assert not torch.cuda.is_initialized()\n"
+        "pids = []\n"
+        "for i in range(4):\n"
+        "    pid = os.fork()\n"
+        "    if pid == 0:\n"
+        "        torch.cuda.set_device(0); torch.zeros(1, device='cuda'); os._exit(0)\n"
+        "    pids.append(pid)\n"
+        "assert all(os.waitpid(p, 0)[1] == 0 for p in pids)\n"
+        "print('fork ok')\n")
+    out = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'fork ok' in out.stdout, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '4', '--warmup', '2'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 4 and line['unit'] == 'TFLOPS' and line['value'] > 0
+    assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1 and line['cpu_baseline']['value'] > 0
+
+
 def test_full_size_c2_properties():
     """BASELINE.json config 2 (4096 x 4096 x 7168): reference gate on the whole output, oracle on sampled rows, and
     size-independent properties that must hold bit-exactly: power-of-two scaling of SFA/SFB and row permutation of A."""
