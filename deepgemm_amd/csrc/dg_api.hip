@@ -114,6 +114,7 @@ const Config kConfigs[] = {
     {"stream_noa_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 64>, true},
     {"dabl12_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 12>, true},
     {"dabl13_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 13>, true},
+    {"e8_ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
@@ -286,6 +287,52 @@ int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* 
     p.sfb_gran_n = sfb_gran_n; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
     return launch_gemm(p, 0, stream);
+}
+
+int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                         int m, int n, int k,
+                         int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                         int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
+    DG_CHECK(m >= 0 && n >= 0 && k > 0);
+    if (m == 0 || n == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr);
+    DG_CHECK(d_dtype == DG_BF16 || d_dtype == DG_FP32);
+    DG_CHECK(d_stride_m >= n);
+    DG_CHECK(sfa_stride_m == 1 && sfb_stride_n == 1);       // MN-major packed scale words (the reference's TMA layout)
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.d = d;
+    p.sfa = reinterpret_cast<const float*>(sfa_packed); p.sfb = reinterpret_cast<const float*>(sfb_packed);
+    p.layout = nullptr;
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = a_stride_m; p.a_sk = a_stride_k; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sm = 1; p.sfa_sk = sfa_stride_kq; p.sfb_sn = 1; p.sfb_sk = sfb_stride_kq;
+    p.d_sm = d_stride_m;
+    p.sfb_gran_n = 128; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
+    p.gemm_type = dg::kNormal; p.m_alignment = 0;
+    p.sfb_gran_n = 128;                                      // only so that the K-major / alignment test below applies
+    if (!fast_eligible(p)) {
+        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs K-major, 16-byte aligned FP8 operands and k % 128 == 0";
+        return 3;
+    }
+    p.num_m_tiles = ceil_div(m, 256);
+    p.num_n_tiles = ceil_div(n, 256);
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    const size_t elem = d_dtype == DG_BF16 ? 2 : 4;
+    p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0;
+    p.dbg = g_debug_buffer;
+    const bool ring_form = g_forced_config == "e8_ring_256x256";       // A/B: the same MFMA in the ring schedule
+    g_last_config = ring_form ? "e8_ring_256x256" : "e8_duo_256x256";
+    const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
+    if (ring_form)
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    else
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, void* d,

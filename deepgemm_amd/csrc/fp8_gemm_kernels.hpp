@@ -1731,6 +1731,449 @@ void dg_fp8_gemm_stream_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// UE8M0 kernel: scales that are powers of two, handed over as packed exponent bytes (the reference's SM100 input format:
+// int32 = four consecutive 128-K blocks of one row, MN-major; recipe (1, 1, 128): one scale per A row and per B row).
+// The scaled MFMA applies 2^(ea + eb - 254) in hardware and accumulates across K blocks in its own FP32 accumulator:
+// no promotion FMAs at all (128 of the FP32-scale path's ~255 instructions per wave per K block).  Verified on hardware
+// (tools/ubench/mfma_scale_probe.hip): a lane's scale byte applies to its own row (lane & 15) and its own 32-K group
+// (lane >> 4); 127 encodes 1.0; opsel picks the byte of the scale VGPR.
+// Structure: the ring kernel's (3-slot A / 2-slot B rings, barriers P and Q, counted vmcnt); with ~3 filler instructions
+// per MFMA a wave sustains the matrix pipe on its own, so no role split is needed.  Scale words for block kb+1 are
+// loaded (inline asm, straight-line to their wait) at the top of block kb: two dwordx4 for the lane's 8 interleaved A rows
+// and four dwords for its B rows.
+// ---------------------------------------------------------------------------------------------------------------
+struct E8Landing { v4i sa[2]; int sb[4]; };
+
+__device__ __forceinline__ void issue_e8_scale_loads(E8Landing& l, const v4i& sfa_rsrc, int sfa_voff, const v4i& sfb_rsrc,
+                                                     int sfb_voff0, int sfb_voff1, int sfb_voff2, int sfb_voff3) {
+    asm volatile(
+        "buffer_load_dwordx4 %0, %6, %7, 0 offen\n\t"
+        "buffer_load_dwordx4 %1, %6, %7, 0 offen offset:16\n\t"
+        "buffer_load_dword %2, %8, %12, 0 offen\n\t"
+        "buffer_load_dword %3, %9, %12, 0 offen\n\t"
+        "buffer_load_dword %4, %10, %12, 0 offen\n\t"
+        "buffer_load_dword %5, %11, %12, 0 offen"
+        : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3])
+        : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff0), "v"(sfb_voff1), "v"(sfb_voff2), "v"(sfb_voff3), "s"(sfb_rsrc)
+        : "memory");
+}
+
+template <int ALLOWED>
+__device__ __forceinline__ void wait_e8_landing(E8Landing& l) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
+    asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]) :: "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void e8_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, TOTAL = MS * NS;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
+    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int P_STEP = TOTAL - NS, SCALE_LOADS = 6;
+    constexpr int B_FIRST = (NS > 2 * A_ITERS ? NS : 2 * A_ITERS);
+    static_assert(MS == 8 && NS == 4, "scale landing registers are written out for a 128 x 64 wave tile");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of LDS-DMA pieces");
+    static_assert(B_FIRST + 2 * (B_ITERS - 1) < P_STEP, "LDS-DMA pieces must be issued in front of barrier P");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
+    const int a_voff = piece_row * MS * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
+    #pragma unroll
+    for (int q = 0; q < A_ITERS; ++q)
+        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
+    #pragma unroll
+    for (int q = 0; q < B_ITERS; ++q)
+        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+    const int num_kq = (num_kb + 3) / 4;
+    const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;   // bytes per packed K column
+
+    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    long long t_loop0 = 0, t_loop1 = 0;
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            // packed scale words: element (row, kq) at base[kq * stride + row] (int32)
+            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg);
+            const uint64_t sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg);
+            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane((num_kq - 1) * sfa_kq_stride + p.m * 4), 0x00020000};
+            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane((num_kq - 1) * sfb_kq_stride + p.n * 4), 0x00020000};
+            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
+            int sfb_voff[NS];
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const int i = lane & 15;
+                sfb_voff[ns] = (t.n0 + wn * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)) * 4;
+            }
+
+            auto issue_a_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
+                    imin(j, num_kb - 1) * 128, 0, 0);
+            };
+            auto issue_b_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
+                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+            };
+            E8Landing land;
+            auto issue_scales = [&](int j) {           // the packed words that contain K block j
+                const int kq = imin(j, num_kb - 1) >> 2;
+                issue_e8_scale_loads(land, sfa_rsrc, sfa_voff + kq * sfa_kq_stride, sfb_rsrc, sfb_voff[0] + kq * sfb_kq_stride,
+                                     sfb_voff[1] + kq * sfb_kq_stride, sfb_voff[2] + kq * sfb_kq_stride,
+                                     sfb_voff[3] + kq * sfb_kq_stride);
+            };
+            int sa_cur[MS], sb_cur[NS];               // byte 0 = the exponent of the current K block
+            auto take_scales = [&](int j) {
+                const int shift = (imin(j, num_kb - 1) & 3) * 8;
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    sa_cur[ms] = static_cast<int>(static_cast<unsigned>(land.sa[ms / 4][ms % 4]) >> shift);
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    sb_cur[ns] = static_cast<int>(static_cast<unsigned>(land.sb[ns]) >> shift);
+            };
+
+            // ---- prologue: A(0) B(0) A(1) B(1) | scales of block 0, full drain ----
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
+            issue_scales(0);
+            wait_e8_landing<0>(land);
+            take_scales(0);
+            raw_barrier();
+
+            int a_cur = 0, a_nxt = A_BYTES, b_nxt = B_BYTES;
+            v8i bf[NS], af[2];
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                bf[ns] = load_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128, frag_off);
+            af[0] = load_fragment(lds + (wm * WM) * 128, frag_off);
+
+            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
+                const uint8_t* b_next_tile = lds + B_BASE + b_nxt + (wn * WN) * 128;
+                const int a_fill = (a_nxt == (A_SLOTS - 1) * A_BYTES) ? 0 : a_nxt + A_BYTES;
+                issue_scales(kb + 1);       // issue order per block: scales(kb+1) | A(kb+2) | B(kb+2) | P waits vmcnt(8)
+
+                #pragma unroll
+                for (int i = 0; i < TOTAL; ++i) {
+                    const int ms = i / NS, ns = i % NS;
+                    if (i == P_STEP) {
+                        // barrier P: block kb+1 and its scale words landed everywhere; every read of A(kb) has returned
+                        wait_e8_landing<A_ITERS + B_ITERS>(land);
+                        raw_barrier();
+                    }
+                    if (ns == 0) {
+                        if (ms + 1 < MS)
+                            af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
+                        else
+                            af[(ms + 1) & 1] = load_fragment(a_next_tile, frag_off);
+                    }
+                    // operand roles are swapped (B rows in the A slot): the A-slot scale is the B row's, the B-slot scale the A row's
+                    acc[ms][ns] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ns], af[ms & 1], acc[ms][ns], 0, 0,
+                                                                                   0, sb_cur[ns], 0, sa_cur[ms]);
+                    if (ms == MS - 1)
+                        bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
+                    if (i % 2 == 0 && i / 2 < A_ITERS)
+                        issue_a_piece(a_fill, kb + 2, i / 2);
+                    if (i == NS - 1)
+                        raw_barrier();                                          // barrier Q: B(kb) is in registers
+                    if (i >= B_FIRST && (i - B_FIRST) % 2 == 0 && (i - B_FIRST) / 2 < B_ITERS)
+                        issue_b_piece(b_nxt ^ B_BYTES, kb + 2, (i - B_FIRST) / 2);   // B(kb)'s slot
+                }
+                take_scales(kb + 1);
+                a_cur = a_nxt;
+                a_nxt = a_fill;
+                b_nxt ^= B_BYTES;
+            }
+            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_stamp(p, NW, 0, t_entry);
+            dbg_stamp(p, NW, 1, t_loop0);
+            dbg_stamp(p, NW, 2, t_loop1);
+            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_e8_kernel(const GemmParams p) {
+    e8_kernel_body<BM, BN, WAVES_M, WAVES_N>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// UE8M0 kernel in the duo schedule: the same role-split segments and wave-half stagger as dg_fp8_gemm_duo_kernel, with
+// the hardware-scaled MFMA of dg_fp8_gemm_e8_kernel in the matrix segments (16 MFMAs, nothing else) and the packed scale
+// words of block kb+1 loaded in L_a(kb), consumed (shifted to byte 0) in L_a(kb+1).
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
+    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW, A_EARLY = A_ITERS / 2;
+    static_assert(MS == 8 && NS == 4, "scale landing registers are written out for a 128 x 64 wave tile");
+    static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+    // The MFMA here is a builtin, free to move: pin the instruction scheduler at every segment boundary so a matrix
+    // segment cannot drift across its barrier into the neighbouring load segment.
+    auto seg_barrier = [] {
+        __builtin_amdgcn_sched_barrier(0);
+        raw_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool upper_half = wave >= NW / 2;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
+    const int a_voff = piece_row * MS * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
+    #pragma unroll
+    for (int q = 0; q < A_ITERS; ++q)
+        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
+    #pragma unroll
+    for (int q = 0; q < B_ITERS; ++q)
+        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+    const int num_kq = (num_kb + 3) / 4;
+    const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;
+    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    long long t_loop0 = 0, t_loop1 = 0;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg);
+            const uint64_t sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg);
+            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane((num_kq - 1) * sfa_kq_stride + p.m * 4), 0x00020000};
+            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
+                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
+                                  __builtin_amdgcn_readfirstlane((num_kq - 1) * sfb_kq_stride + p.n * 4), 0x00020000};
+            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
+            int sfb_voff[NS];
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const int i = lane & 15;
+                sfb_voff[ns] = (t.n0 + wn * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)) * 4;
+            }
+            auto issue_a_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
+                    imin(j, num_kb - 1) * 128, 0, 0);
+            };
+            auto issue_b_piece = [&](int slot_off, int j, int q) {
+                const int unit = wave + NW * q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
+                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+            };
+            E8Landing land;
+            auto issue_scales = [&](int j) {
+                const int kq = imin(j, num_kb - 1) >> 2;
+                issue_e8_scale_loads(land, sfa_rsrc, sfa_voff + kq * sfa_kq_stride, sfb_rsrc, sfb_voff[0] + kq * sfb_kq_stride,
+                                     sfb_voff[1] + kq * sfb_kq_stride, sfb_voff[2] + kq * sfb_kq_stride,
+                                     sfb_voff[3] + kq * sfb_kq_stride);
+            };
+            int sa_cur[MS], sb_cur[NS];
+            auto take_scales = [&](int j) {
+                const int shift = (imin(j, num_kb - 1) & 3) * 8;
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    sa_cur[ms] = static_cast<int>(static_cast<unsigned>(land.sa[ms / 4][ms % 4]) >> shift);
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    sb_cur[ns] = static_cast<int>(static_cast<unsigned>(land.sb[ns]) >> shift);
+            };
+
+            // ---- prologue: A(0) B(0) A(1) B(1) | scale words of block 0, full drain (straight-line load -> wait) ----
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
+            issue_scales(0);
+            wait_e8_landing<0>(land);
+            seg_barrier();
+            if (upper_half)
+                seg_barrier();                      // the upper half runs one segment behind from here on
+
+            int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;
+            v8i bf[NS], af[HS];
+            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
+
+                // ---------------- L_a ----------------
+                seg_barrier();
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                take_scales(kb);                    // the words landed before the previous L_b's wait (or the prologue's)
+                issue_scales(kb + 1);
+                #pragma unroll
+                for (int q = 0; q < A_EARLY; ++q)
+                    issue_a_piece(a_fill, kb + 2, q);
+                __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+                asm volatile("" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
+                             :: "memory");
+
+                // ---------------- M_a ----------------
+                seg_barrier();
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        acc[h][ns] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ns], af[h], acc[h][ns], 0, 0, 0, sb_cur[ns],
+                                                                                      0, sa_cur[h]);
+                asm volatile("" ::: "memory");
+
+                // ---------------- L_b ----------------
+                seg_barrier();
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                #pragma unroll
+                for (int q = A_EARLY; q < A_ITERS; ++q)
+                    issue_a_piece(a_fill, kb + 2, q);
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q)
+                    issue_b_piece(b_cur, kb + 2, q);
+                wait_e8_landing<A_ITERS + B_ITERS>(land);       // block kb+1 and its scale words: my pieces have landed
+                asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]) :: "memory");
+
+                // ---------------- M_b ----------------
+                seg_barrier();
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        acc[HS + h][ns] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ns], af[h], acc[HS + h][ns], 0, 0, 0,
+                                                                                           sb_cur[ns], 0, sa_cur[HS + h]);
+                asm volatile("" ::: "memory");
+
+                const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
+                a_fill = a_cur;
+                a_cur = a_next;
+                b_cur ^= B_BYTES;
+            }
+            if (!upper_half)
+                seg_barrier();              // pairs with the barrier in front of the upper half's last segment
+            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_stamp(p, NW, 0, t_entry);
+            dbg_stamp(p, NW, 1, t_loop0);
+            dbg_stamp(p, NW, 2, t_loop1);
+            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_duo_e8_kernel(const GemmParams p) {
+    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Generic path: any operand majorness / alignment / K tail, both SFB granularities.  128 x 128 tile, 4 waves,
 // register-staged loads written into the same swizzled LDS image.  Correctness first.
 // ---------------------------------------------------------------------------------------------------------------

@@ -81,12 +81,49 @@ def _early_return(m: int, n: int, k: int, d: torch.Tensor, c: Optional[torch.Ten
     return False
 
 
+def _packed_sf_mn_major(sf: torch.Tensor, mn: int, k: int) -> torch.Tensor:
+    """Packed UE8M0 scale words [mn, ceil(k / 512)] int32 -> the MN-major, 16-byte aligned layout (zero-copy if already
+    there): the int32 twin of get_mn_major_tma_aligned_tensor (csrc/jit_kernels/impls/smxx_layout.hpp:120-153)."""
+    host_assert(sf.dtype == torch.int, 'sf.scalar_type() == torch::kInt')
+    host_assert(sf.dim() == 2, 'sf.dim() == 2')
+    host_assert(sf.size(0) == mn and sf.size(1) == -(-k // 512), 'sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4)')
+    return get_mn_major_tma_aligned_tensor(sf.view(torch.float)).view(torch.int)
+
+
+def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a, recipe_b) -> None:
+    """Power-of-two scales handed over as packed exponent bytes (the reference's SM100 format, recipe (1, 1, 128)):
+    hardware-scaled MFMA path, no FP32 promotion."""
+    host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
+    host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
+    host_assert(recipe_a is None and recipe_b is None, 'not recipe_a.has_value() and not recipe_b.has_value()')
+    major_check(a_data), major_check(b_data)
+    check_major_type_cd(d)
+    m, k = _check_ab_fp8(a_data, 2)
+    n, k_ = _check_ab_fp8(b_data, 2)
+    host_assert(d.dim() == 2, 'd.dim() == 2')
+    host_assert((m, n) == tuple(d.shape) and k == k_, 'm == m_ and n == n_ and k == k_')
+    if _early_return(m, n, k, d, c):
+        return
+    host_assert(k % 128 == 0, 'k % 128 == 0')
+    sfa, sfb = _packed_sf_mn_major(a_sf, m, k), _packed_sf_mn_major(b_sf, n, k)
+    require_device(a_data, b_data, sfa, sfb, d)
+    a_data = a_data if a_data.stride(-1) == 1 else _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
+    b_data = b_data if b_data.stride(-1) == 1 else _as_k_major(b_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
+    check(lib.dg_fp8_gemm_nt_ue8m0(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
+        a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
+        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1),
+        d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
+
+
 def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch.Tensor] = None,
                 recipe: Optional[Tuple[int, int, int]] = None, recipe_a: Optional[Tuple[int, int]] = None,
                 recipe_b: Optional[Tuple[int, int]] = None, compiled_dims: str = 'nk',
                 disable_ue8m0_cast: bool = False) -> None:
     """D = C + A @ B^T with per-128-block FP32 scales; ``a = (A_fp8 [M,K], SFA)``, ``b = (B_fp8 [N,K], SFB)``."""
     (a_data, a_sf), (b_data, b_sf) = a, b
+    if a_sf.dtype == torch.int or b_sf.dtype == torch.int:
+        return _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a, recipe_b)
     same_cd = c is not None and c.data_ptr() == d.data_ptr()
     key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(c), same_cd,
            recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),

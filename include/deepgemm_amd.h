@@ -43,6 +43,18 @@ int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* 
                    int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
                    int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
 
+/* Dense GEMM, NT form, power-of-two scales in the reference's packed UE8M0 format (SM100 input format, recipe (1, 1, 128):
+ * sm100_fp8_fp4_gemm_1d1d, impls/sm100_fp8_fp4_gemm_1d1d.hpp:93; packing: deep_gemm/utils/math.py:19-23,
+ * csrc/apis/layout.hpp:48-58).  sfa_packed / sfb_packed: int32, byte j of element (row, kq) = biased exponent of the
+ * scale of K block 4 kq + j of that row of A / B (127 = 1.0); element (row, kq) at ptr[row * stride_mn + kq * stride_kq],
+ * stride_mn must be 1 (MN-major).  The scaled MFMA applies the scales in hardware: no FP32 promotion pass.
+ * A and B must be K-major with 16-byte aligned rows, k % 128 == 0. */
+int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                         int m, int n, int k,
+                         int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                         int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
+
 /* M-grouped contiguous GEMM.  Replaces sm90_m_grouped_fp8_gemm_contiguous_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:147) /
  * sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:161) as called from
  * m_grouped_fp8_fp4_gemm_nt_contiguous (csrc/apis/gemm.hpp:166-232).

@@ -367,3 +367,35 @@ def test_reference_sweep_subset_gate():
             dg.fp8_gemm_nt(case.a, case.b, case.d)
             diff = calc_diff(case.d, case.ref_d)
             assert diff < gen.FP8_MAX_DIFF, (m, n, k, diff, dg.last_config())
+
+
+@pytest.mark.parametrize('m,n,k', [(256, 512, 1024), (300, 520, 1536), (64, 136, 512), (1024, 2048, 7168)])
+def test_packed_ue8m0_scales_hw_path(m, n, k):
+    """Power-of-two scales in the reference's packed UE8M0 format (SM100 input format, recipe (1, 1, 128);
+    deep_gemm/utils/math.py:13-23): hardware-scaled MFMA path against the oracle fed with the same scales as FP32."""
+    from deepgemm_amd.utils.math import pack_ue8m0_to_int, per_block_cast_to_fp8, per_token_cast_to_fp8
+    gen.reset_seed(m + n)
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    ref = (a.float() @ b.float().t()).to(torch.bfloat16)
+    a_q, sfa = per_token_cast_to_fp8(a, use_ue8m0=True)
+    b_q, sfb_blocks = per_block_cast_to_fp8(b, use_ue8m0=True)
+    sfb_rows = sfb_blocks.repeat_interleave(128, dim=0)[:n].contiguous()             # per-row scales of B
+    d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_q, pack_ue8m0_to_int(sfa)), (b_q, pack_ue8m0_to_int(sfb_rows)), d)
+    assert dg.last_config().startswith('e8_')
+    want = torch.empty((m, n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb_rows.cpu(), want, gran_n=1)
+    assert_close_to_oracle(d, want, 'packed ue8m0')
+    assert calc_diff(d, ref) < gen.FP8_MAX_DIFF
+    # the same scales as FP32 tensors through the FP32-scale path give the same result up to summation order
+    d2 = torch.empty_like(d)
+    dg.fp8_gemm_nt((a_q, sfa), (b_q, sfb_blocks), d2)
+    assert calc_diff(d, d2) < 2e-6
+    # FP32 output and accumulation
+    c32 = torch.randn((m, n), device='cuda', dtype=torch.float)
+    d32 = c32.clone()
+    dg.fp8_gemm_nt((a_q, pack_ue8m0_to_int(sfa)), (b_q, pack_ue8m0_to_int(sfb_rows)), d32, c=d32)
+    want32 = torch.empty((m, n), dtype=torch.float)
+    oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb_rows.cpu(), want32, c=c32.cpu(), gran_n=1)
+    assert_close_fp32(d32, want32, 'packed ue8m0 fp32 accumulate')

@@ -105,8 +105,8 @@ def test_validation_messages():
         dg.fp8_gemm_nt((c.a[0], c.a[1][:, :1]), c.b, c.d)                       # SFA with too few K blocks
     with pytest.raises(RuntimeError, match='recipe_a.has_value'):
         dg.fp8_gemm_nt(c.a, c.b, c.d, recipe=(1, 128, 128), recipe_a=(1, 128), recipe_b=(128, 128))
-    with pytest.raises(RuntimeError, match='sfa_dtype == torch::kFloat'):
-        dg.fp8_gemm_nt((c.a[0], c.a[1].to(torch.int)), c.b, c.d)
+    with pytest.raises(RuntimeError, match=r'sfa.scalar_type\(\) == torch::kInt and sfb.scalar_type\(\) == torch::kInt'):
+        dg.fp8_gemm_nt((c.a[0], c.a[1].to(torch.int)), c.b, c.d)          # packed UE8M0 scales come in pairs
     with pytest.raises(RuntimeError, match=r'd.scalar_type\(\) == c'):
         dg.fp8_gemm_nt(c.a, c.b, c.d, c=torch.zeros(32, 64))
     # grouped: A must be K-major, D must be BF16, layout length must match

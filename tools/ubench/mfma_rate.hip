@@ -33,6 +33,7 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     v16f big0, big1;
     for (int i = 0; i < 16; ++i) { big0[i] = 0.f; big1[i] = 0.f; }
     float dummy = 0.f;
+    int sc_a = 127 + (tid & 1), sc_b = 126 + (tid & 3);
     float fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     typedef float v2f_ __attribute__((ext_vector_type(2)));
     v2f_ acc2[16];
@@ -135,6 +136,10 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
                 #pragma unroll
                 for (int r = 0; r < (PAD + (i & 3)) / 4; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(fill[(i + r) & 7]) : "v"(scale));
                 if (BAR && i % 16 == 15) __builtin_amdgcn_s_barrier();
+            } else if constexpr (MODE == 10) {
+                // hardware-scaled form, scales from VGPRs, accumulate in place (8 independent accumulators)
+                accv[i & 7] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i & 3], b[(i >> 2) & 1], accv[i & 7], 0, 0, 0,
+                                                                             sc_a, 0, sc_b);
             } else if constexpr (MODE == 2) {
                 asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"
                              : "+v"(accv[i & 7]) : "v"(a[i & 3]), "v"(b[(i >> 2) & 1]));
@@ -200,6 +205,10 @@ int main() {
     hipMemcpy(d_zer, zer.data(), n * 4, hipMemcpyHostToDevice);
     const int iters = 2000;
     run<3>("warm-up", 512, d_rnd, out, cyc, iters);
+    run<10>("scaled MFMA, accumulate in place, 1 wave", 256, d_rnd, out, cyc, iters);
+    run<10>("scaled MFMA, accumulate in place, 2 waves", 512, d_rnd, out, cyc, iters);
+    run<2>("unscaled MFMA, accumulate in place, 2 waves", 512, d_rnd, out, cyc, iters);
+    return 0;
     run<9, 0, true>("fmac x4, fill 0, barrier/16", 512, d_rnd, out, cyc, iters);
     run<9, 8, true>("fmac x4, fill 2/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
     run<9, 16, true>("fmac x4, fill 4/step indep, barrier/16", 512, d_rnd, out, cyc, iters);
