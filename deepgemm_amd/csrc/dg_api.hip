@@ -67,6 +67,7 @@ struct Config {
     bool ring = false;      // ring kernels read SFA through a buffer descriptor that assumes the MN-major layout
     bool two_pass = false;  // contiguous layout: BM may be twice the M alignment (halves of two groups => two passes)
     bool persistent = false;  // one workgroup per CU walks the tile list and prefetches the next tile's first K blocks
+    bool per_col = false;     // recipe (1, 1, 128): one SFB value per row of B (all other fast kernels: one per 128 rows)
 };
 
 const Config kConfigs[] = {
@@ -81,6 +82,8 @@ const Config kConfigs[] = {
     {"pipe_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_pipe_kernel<16, 256, 1, 4, 0>},
     {"stream_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6>, true},
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 12>, true},
+    {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2>, true, false, false,
+     true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
     // experimental / baseline variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of
     // the heuristic): LDS-DMA piece placement variants and the hipcc-scheduled first version of the fast path.
@@ -122,7 +125,7 @@ constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 bool fast_eligible(const dg::GemmParams& p) {
-    if (p.sfb_gran_n != 128 || p.a_sk != 1 || p.b_sk != 1 || p.k % 128 != 0)
+    if (p.a_sk != 1 || p.b_sk != 1 || p.k % 128 != 0)
         return false;
     if (!aligned16(p.a) || !aligned16(p.b) || p.a_sm % 16 || p.b_sn % 16 || p.a_sg % 16 || p.b_sg % 16)
         return false;
@@ -130,6 +133,13 @@ bool fast_eligible(const dg::GemmParams& p) {
     if (p.a_sm > (1 << 22) || p.b_sn > (1 << 22))
         return false;
     return true;
+}
+
+// Recipe (1, 1, 128) on the fast path: both scale tensors MN-major with 16-byte aligned K-block rows (each block's 256
+// row scales are fetched as one 1 KiB LDS-DMA piece).
+bool per_col_eligible(const dg::GemmParams& p) {
+    return fast_eligible(p) && p.sfb_gran_n == 1 && p.gemm_type == dg::kNormal && p.sfa_sm == 1 && p.sfb_sn == 1 &&
+           aligned16(p.sfa) && aligned16(p.sfb) && p.sfa_sk % 4 == 0 && p.sfb_sk % 4 == 0;
 }
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -141,6 +151,12 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             if (g_forced_config == kConfigs[i].name)
                 return &kConfigs[i];
         return nullptr;
+    }
+    if (p.sfb_gran_n == 1) {
+        const char* pick = per_col_eligible(p) && p.m > 64 ? "pipe_pc_256x256" : "generic_128x128";
+        for (int i = 0; i < kNumConfigs; ++i)
+            if (std::strcmp(kConfigs[i].name, pick) == 0)
+                return &kConfigs[i];
     }
     const bool fast_ok = fast_eligible(p);
     // HBM-bound shapes (M up to a few 64-row tiles: every weight byte is streamed once or twice): the deep-ring stream
@@ -209,6 +225,10 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide);
     if (cfg == nullptr) {
         g_last_error = "no kernel configuration available (forced config '" + g_forced_config + "')";
+        return 3;
+    }
+    if (cfg->fast && (cfg->per_col ? !per_col_eligible(p) : p.sfb_gran_n != 128)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' does not implement this scaling recipe / SF layout";
         return 3;
     }
     if (cfg->fast && !fast_eligible(p)) {

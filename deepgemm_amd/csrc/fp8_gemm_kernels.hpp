@@ -805,6 +805,266 @@ void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Per-column-SFB form of the pipe kernel (recipe (1, 1, 128): one scale per row of A AND per row of B for every 128-K
+// block; the reference's "1D1D" kernel, impls/sm90_fp8_gemm_1d1d.cuh:279-311, used for FP32-accumulating wgrad GEMMs).
+//
+//   final[m][n] += (sfa[m][kb] * sfb[n][kb]) * partial_kb[m][n]
+//
+// Differences from the per-128-column form above:
+//   * the scale product is no longer one value per (lane, M-subtile) but one per accumulator element, so a step carries
+//     two packed multiplies (sfb pair x broadcast sfa) and two packed FMAs instead of four scalar FMAs: the same number
+//     of VALU issues per MFMA;
+//   * both scale vectors of a K block travel with the block's stage as two extra 1 KiB LDS-DMA pieces (256 FP32 row
+//     scales of A, 256 of B: the MN-major SF layouts make each a contiguous run), so the loop holds no register-landing
+//     global loads at all; every wave picks its 8 + 16 values out of LDS at the top of the block.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int SEL>
+__device__ __forceinline__ void mfma_promote_step_pc(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
+                                                     v2f& c01, v2f& c23, v2f sb01, v2f sb23, v2f sa_pair, v2f p01, v2f p23) {
+    v2f t01, t23;
+    if constexpr (SEL == 0)
+        asm volatile(
+            "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+            "v_pk_mul_f32 %3, %7, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %4, %8, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %1, %3, %10, %1\n\t"
+            "v_pk_fma_f32 %2, %4, %11, %2"
+            : "=&v"(part_new), "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
+            : "v"(rows_operand), "v"(cols_operand), "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
+            : "memory");
+    else
+        asm volatile(
+            "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+            "v_pk_mul_f32 %3, %7, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "v_pk_mul_f32 %4, %8, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "v_pk_fma_f32 %1, %3, %10, %1\n\t"
+            "v_pk_fma_f32 %2, %4, %11, %2"
+            : "=&v"(part_new), "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
+            : "v"(rows_operand), "v"(cols_operand), "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
+            : "memory");
+}
+
+template <int SEL>
+__device__ __forceinline__ void promote_only_pc(v2f& c01, v2f& c23, v2f sb01, v2f sb23, v2f sa_pair, v2f p01, v2f p23) {
+    v2f t01, t23;
+    if constexpr (SEL == 0)
+        asm volatile(
+            "s_nop 3\n\t"
+            "v_pk_mul_f32 %2, %4, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %3, %5, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %2, %7, %0\n\t"
+            "v_pk_fma_f32 %1, %3, %8, %1"
+            : "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
+            : "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
+            : "memory");
+    else
+        asm volatile(
+            "s_nop 3\n\t"
+            "v_pk_mul_f32 %2, %4, %6 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "v_pk_mul_f32 %3, %5, %6 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "v_pk_fma_f32 %0, %2, %7, %0\n\t"
+            "v_pk_fma_f32 %1, %3, %8, %1"
+            : "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
+            : "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
+            : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+__device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    constexpr int TOTAL = MS * NS, DEPTH = 3;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_UNITS = BM / 8, B_UNITS = BN / 8;
+    constexpr int A_ITERS = A_UNITS / NW, B_ITERS = B_UNITS / NW;
+    constexpr int SC_BASE = 2 * STAGE_BYTES, SC_STAGE = 2048;      // per stage: 256 row scales of A, 256 of B
+    static_assert(BM == 256 && BN == 256, "one 1 KiB scale piece per operand per K block");
+    static_assert(MS % 2 == 0 && NS % 2 == 0 && NW >= 2 && A_UNITS % NW == 0 && B_UNITS % NW == 0, "tile shape");
+    static_assert(TOTAL >= DEPTH + 1 && (TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
+    static_assert(SPREAD * (A_ITERS + B_ITERS) <= TOTAL, "not enough steps to spread the LDS-DMA pieces");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[SC_BASE + 2 * SC_STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+    // where this lane's scales sit inside a stage's scale block
+    const int sa_lds_off = (wm * WM + (lane & 15)) * 4;                            // + ms * 64
+    const int sb_lds_off = 1024 + (wn * WN + (lane >> 4) * 8) * 4;                 // + (ns >> 1) * 128 + (ns & 1) * 16
+    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    long long t_loop0 = 0, t_loop1 = 0;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        v2f acc[MS][NS][2];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns][0] = acc[ms][ns][1] = v2f{0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
+                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
+                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+            // scale rows: MN-major (stride 1 along m / n), one K block = one contiguous run; lanes past the end of the
+            // last run fall outside the descriptor and fetch zeros (rows / columns that are never stored)
+            const float* sfa_tile = p.sfa + ad_group * p.sfa_sg + t.m0;
+            const float* sfb_tile = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + t.n0;
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(sfa_tile), 0, (num_kb - 1) * sfa_kb_stride + (p.m - t.m0) * 4, 0x00020000);
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(sfb_tile), 0, (num_kb - 1) * sfb_kb_stride + (p.n - t.n0) * 4, 0x00020000);
+
+            auto issue_piece = [&](int stage, int kb, int q) {
+                uint8_t* stage_base = lds + stage * STAGE_BYTES;
+                if (q < A_ITERS) {
+                    const int unit = wave + NW * q;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        a_rsrc, (__attribute__((address_space(3))) void*)(stage_base + unit * 1024), 16, a_voff,
+                        q * (NW * 8) * lda + kb * 128, 0, 0);
+                } else {
+                    const int j = q - A_ITERS, unit = wave + NW * j;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        b_rsrc, (__attribute__((address_space(3))) void*)(stage_base + A_BYTES + unit * 1024), 16,
+                        b_voff, b_row_perm<WN>(j * (NW * 8)) * ldb + kb * 128, 0, 0);
+                }
+            };
+            // waves 0 and 1 carry the block's two scale pieces (lane l: 4 consecutive FP32 scales)
+            auto issue_scale_piece = [&](int stage, int kb) {
+                uint8_t* sc = lds + SC_BASE + stage * SC_STAGE;
+                if (wave == 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(sfa_rsrc, (__attribute__((address_space(3))) void*)sc, 16,
+                                                             lane * 16, kb * sfa_kb_stride, 0, 0);
+                else if (wave == 1)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(sfb_rsrc, (__attribute__((address_space(3))) void*)(sc + 1024),
+                                                             16, lane * 16, kb * sfb_kb_stride, 0, 0);
+            };
+
+            v4f part[DEPTH + 1];
+            #pragma unroll
+            for (int i = 0; i <= DEPTH; ++i)
+                part[i] = v4f{0.f, 0.f, 0.f, 0.f};
+            v2f sa_pair[MS / 2], sa_tail = v2f{0.f, 0.f};
+            v4f sb4[NS], sb_tail[NS];
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                sb_tail[ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+            #pragma unroll
+            for (int q = 0; q < A_ITERS + B_ITERS; ++q)
+                issue_piece(0, 0, q);
+            issue_scale_piece(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            v8i bf[NS], af[2];
+            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            for (int kb = 0; kb < num_kb; ++kb) {
+                const int cur = kb & 1;
+                const bool has_next = kb + 1 < num_kb;
+                const uint8_t* sc = lds + SC_BASE + cur * SC_STAGE;
+                #pragma unroll
+                for (int h = 0; h < MS / 2; ++h)
+                    sa_pair[h] = v2f{*reinterpret_cast<const float*>(sc + sa_lds_off + (2 * h) * 64),
+                                     *reinterpret_cast<const float*>(sc + sa_lds_off + (2 * h + 1) * 64)};
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    sb4[ns] = *reinterpret_cast<const v4f*>(sc + sb_lds_off + (ns >> 1) * 128 + (ns & 1) * 16);
+                if (has_next)
+                    issue_scale_piece(cur ^ 1, kb + 1);
+
+                const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
+                const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
+                bf[0] = load_fragment(b_tile, frag_off);
+                af[0] = load_fragment(a_tile, frag_off);
+
+                #pragma unroll
+                for (int i = 0; i < TOTAL; ++i) {
+                    const int ms = i / NS, ns = i % NS;
+                    const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
+                    const int jms = j / NS, jns = j % NS;
+                    if (ms == 0 && ns + 1 < NS)
+                        bf[ns + 1] = load_fragment(b_tile + (ns + 1) * 2048, frag_off);
+                    if (ns == 0 && ms + 1 < MS)
+                        af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
+                    const v4f& po = part[(i + 1) & DEPTH];
+                    const v2f p01 = v2f{po[0], po[1]}, p23 = v2f{po[2], po[3]};
+                    // i < DEPTH: the previous block's tail steps (last M-subtile) with the previous block's scales
+                    const v4f& sb = (i >= DEPTH) ? sb4[jns] : sb_tail[jns];
+                    const v2f sap = (i >= DEPTH) ? sa_pair[jms >> 1] : sa_tail;
+                    if ((jms & 1) == 0)         // which half of the pair is this M-subtile's row scale
+                        mfma_promote_step_pc<0>(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], acc[jms][jns][1],
+                                                v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, sap, p01, p23);
+                    else
+                        mfma_promote_step_pc<1>(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], acc[jms][jns][1],
+                                                v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, sap, p01, p23);
+                    if (i % SPREAD == SPREAD - 1 && i / SPREAD < A_ITERS + B_ITERS && has_next)
+                        issue_piece(cur ^ 1, kb + 1, i / SPREAD);
+                }
+                sa_tail = sa_pair[(MS - 1) >> 1];
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    sb_tail[ns] = sb4[ns];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            #pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                const int j = TOTAL - DEPTH + i;
+                const v4f& po = part[(TOTAL + i + 1) & DEPTH];
+                promote_only_pc<(MS - 1) & 1>(acc[j / NS][j % NS][0], acc[j / NS][j % NS][1],
+                                              v2f{sb_tail[j % NS][0], sb_tail[j % NS][1]},
+                                              v2f{sb_tail[j % NS][2], sb_tail[j % NS][3]}, sa_tail, v2f{po[0], po[1]},
+                                              v2f{po[2], po[3]});
+            }
+        }
+
+        v4f out[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                out[ms][ns] = v4f{acc[ms][ns][0][0], acc[ms][ns][0][1], acc[ms][ns][1][0], acc[ms][ns][1][1]};
+        store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_stamp(p, NW, 0, t_entry);
+            dbg_stamp(p, NW, 1, t_loop0);
+            dbg_stamp(p, NW, 2, t_loop1);
+            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_pipe_pc_kernel(const GemmParams p) {
+    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Ring kernel: the fast path's production form.  Same tiles, LDS image, LDS-DMA pieces and MFMA+promotion step as
 // the pipe kernel above, but the global->LDS stream is never drained inside the K loop:
 //   * A lives in a 3-slot ring, B in a 2-slot ring (256x256 tile: 3*32 + 2*32 KiB = all 160 KiB of the CU's LDS);

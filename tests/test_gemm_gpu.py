@@ -141,6 +141,32 @@ def test_wgrad_recipe_per_column_sfb():
     assert_close_to_oracle(case.d, want, 'recipe_a/recipe_b')
 
 
+@pytest.mark.parametrize('m,n,k', [(256, 256, 128), (300, 520, 896), (1024, 768, 2048), (65, 4096, 512)])
+@pytest.mark.parametrize('out_dtype,accumulate', [(torch.float, True), (torch.bfloat16, False)])
+def test_per_column_sfb_fast_kernel(m, n, k, out_dtype, accumulate):
+    """Recipe (1, 1, 128) on the LDS-DMA path: both scale vectors of a K block ride along as 1 KiB pieces, the scale
+    product is formed per accumulator element (reference arithmetic: impls/sm90_fp8_gemm_1d1d.cuh:279-311)."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k, accumulate=accumulate, out_dtype=out_dtype, per_token_b=True)
+    c_cpu = case.c.cpu().clone() if accumulate else None
+    want = oracle_dense(case, gran_n=1, c_cpu=c_cpu)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None, recipe=(1, 1, 128))
+    assert dg.last_config() == 'pipe_pc_256x256'
+    if out_dtype == torch.float:
+        assert_close_fp32(case.d, want, 'per-column SFB')
+    else:
+        assert_close_to_oracle(case.d, want, 'per-column SFB')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    # same answer as the layout-agnostic kernel (different summation machinery, same arithmetic order)
+    dg.set_forced_config('generic_128x128')
+    d2 = case.c.clone() if accumulate else torch.empty_like(case.d)
+    if accumulate:
+        d2.copy_(c_cpu.cuda())
+    dg.fp8_gemm_nt(case.a, case.b, d2, c=d2 if accumulate else None, recipe=(1, 1, 128))
+    dg.set_forced_config('auto')
+    assert torch.equal(d2, case.d)
+
+
 def test_k_tail_sub_views_and_wide_d():
     gen.reset_seed(4)
     # K not a multiple of 128 (quantisers zero-pad the last block): generic path
