@@ -410,6 +410,50 @@ int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void*
     return launch_gemm(p, expected_m < m_max ? expected_m : m_max, stream);
 }
 
+int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, float* d,
+                                        int m, int n, const int32_t* ks_host, int num_groups, int ab_layout,
+                                        int64_t a_stride_m, int64_t b_stride_n,
+                                        int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                        void* stream) {
+    DG_CHECK(m >= 0 && n >= 0 && num_groups >= 0);
+    if (m == 0 || n == 0 || num_groups == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr && ks_host != nullptr);
+    DG_CHECK(ab_layout == DG_KGROUPED_BLOCKS || ab_layout == DG_KGROUPED_COLUMNS);
+    for (int g = 0; g < num_groups; ++g)
+        DG_CHECK(ks_host[g] >= 0 && ks_host[g] % 128 == 0);
+    // One dense per-column-SFB launch per non-empty group on the caller's stream: every group is a full M x N output
+    // (hundreds of 256 x 256 tiles), so the launches fill the chip on their own and run back to back.
+    int64_t k_begin = 0;
+    for (int g = 0; g < num_groups; ++g) {
+        const int k = ks_host[g];
+        if (k > 0) {
+            dg::GemmParams p{};
+            if (ab_layout == DG_KGROUPED_BLOCKS) {
+                p.a = static_cast<const uint8_t*>(a) + k_begin * m; p.a_sm = k;
+                p.b = static_cast<const uint8_t*>(b) + k_begin * n; p.b_sn = k;
+            } else {
+                p.a = static_cast<const uint8_t*>(a) + k_begin; p.a_sm = a_stride_m;
+                p.b = static_cast<const uint8_t*>(b) + k_begin; p.b_sn = b_stride_n;
+            }
+            p.a_sk = 1; p.b_sk = 1;
+            p.sfa = sfa + (k_begin / 128) * sfa_stride_k; p.sfb = sfb + (k_begin / 128) * sfb_stride_k;
+            p.d = d + static_cast<int64_t>(g) * m * n;
+            p.layout = nullptr;
+            p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+            p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+            p.d_sm = n;
+            p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1;
+            p.gemm_type = dg::kNormal; p.m_alignment = 0;
+            const int rc = launch_gemm(p, 0, stream);
+            if (rc != 0)
+                return rc;
+        }
+        k_begin += k;
+    }
+    return 0;
+}
+
 int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream) {
     DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
     if (batches == 0 || mn == 0 || sf_k == 0)

@@ -37,6 +37,11 @@ REMAJOR_MIN_MACS = 1 << 27
 def _as_k_major(t: torch.Tensor, macs: int) -> torch.Tensor:
     if t.stride(-1) == 1 or REMAJOR_MIN_MACS <= 0 or macs < REMAJOR_MIN_MACS:
         return t
+    return _remajor(t)
+
+
+def _remajor(t: torch.Tensor) -> torch.Tensor:
+    """An MN-major FP8 operand view ``[.., mn, k]`` (stride 1 along mn) as a fresh K-major tensor (dg_transpose_fp8)."""
     require_device(t)
     mn, k = t.size(-2), t.size(-1)
     batches = t.size(0) if t.dim() == 3 else 1
@@ -261,3 +266,95 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
         a_data.stride(0), a_data.stride(1), a_data.stride(2), b_data.stride(0), b_data.stride(1), b_data.stride(2),
         sfa.stride(0), sfa.stride(1), sfa.stride(2), sfb.stride(0), sfb.stride(1), sfb.stride(2),
         d.stride(0), d.stride(1), current_stream_ptr()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K-grouped contiguous GEMM (MoE weight gradients): d[g] = c[g] + A_g^T-ish products over group g's K range, FP32.
+# Reference: csrc/apis/gemm.hpp:299-400 (operators), :48-69 (argument checks), tests/generators.py:436-477 (layouts).
+# ---------------------------------------------------------------------------------------------------------------------
+_KGROUPED_BLOCKS, _KGROUPED_COLUMNS = 0, 1
+
+
+def _check_k_grouped_args(ks, grouped_layout: torch.Tensor, num_groups: int, use_psum_layout: bool, k_alignment: int) -> int:
+    """csrc/apis/gemm.hpp:48-69; the psum form (K ranges read from the device tensor) is not implemented on gfx950."""
+    host_assert(grouped_layout.is_contiguous(), 'grouped_layout.is_contiguous()')
+    host_assert(grouped_layout.dtype == torch.int, 'grouped_layout.scalar_type() == torch::kInt')
+    host_assert(grouped_layout.numel() == num_groups, 'static_cast<int>(grouped_layout.numel()) == num_groups')
+    host_assert(not use_psum_layout, 'not use_psum_layout')
+    host_assert(ks is not None and len(ks) > 0, 'ks_cpu.has_value() and not ks_cpu.value().empty()')
+    host_assert(len(ks) == num_groups, 'static_cast<int>(ks_cpu.value().size()) == num_groups')
+    for k in ks:
+        host_assert(k % k_alignment == 0, 'k % k_alignment == 0')
+    return int(sum(ks))
+
+
+def _k_grouped_sf(sf: torch.Tensor, mn: int, sum_k: int) -> torch.Tensor:
+    """FP32 per-channel scales of a K-grouped operand as ``[mn, sum_k / 128]`` -> MN-major, 16-byte aligned rows
+    (transform_k_grouped_sf_into_required_layout, csrc/apis/layout.hpp:95-121, FP32 branch)."""
+    host_assert(sf.dim() == 2 and sf.dtype == torch.float, 'sf.dim() == 2 and sf.scalar_type() == torch::kFloat')
+    host_assert(tuple(sf.shape) == (mn, sum_k // 128), 'sf.size(0) == mn and sf.size(1) == sum_k / gran_k')
+    return get_mn_major_tma_aligned_tensor(sf)
+
+
+def _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, layout, a_ld, b_ld) -> None:
+    import ctypes
+    require_device(a_data, b_data, sfa, sfb, d)
+    ks_arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
+    check(lib.dg_k_grouped_fp8_gemm_nt_contiguous(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n,
+        ctypes.cast(ks_arr, ctypes.c_void_p), len(ks), layout, a_ld, b_ld,
+        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr()))
+
+
+def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks, grouped_layout: torch.Tensor,
+                                     c: Optional[torch.Tensor] = None, recipe: Tuple[int, int, int] = (1, 1, 128),
+                                     compiled_dims: str = 'mn', use_psum_layout: bool = False) -> None:
+    """``a[0]``: the groups' K-major ``[M, ks[g]]`` matrices stored one after another (flat), ``a[1]``: ``[M, sum_k / 128]``;
+    same for ``b`` with N; ``d [G, M, N]`` FP32 ``= c + A_g @ B_g^T`` (csrc/apis/gemm.hpp:348-400)."""
+    (a_data, a_sf), (b_data, b_sf) = a, b
+    host_assert(tuple(recipe) == (1, 1, 128), 'recipe == std::make_tuple(1, 1, 128)')
+    host_assert(d.dim() == 3, 'd.dim() == 3')
+    num_groups, m, n = (int(x) for x in d.shape)
+    sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, 128)
+    host_assert(a_data.dtype == torch.float8_e4m3fn and b_data.dtype == torch.float8_e4m3fn,
+                'ab.scalar_type() == torch::kFloat8_e4m3fn')
+    host_assert(a_data.numel() == sum_k * m, 'sum_mk == static_cast<int64_t>(sum_k) * m')
+    host_assert(b_data.numel() == sum_k * n, 'sum_nk == static_cast<int64_t>(sum_k) * n')
+    host_assert(a_data.is_contiguous() and b_data.is_contiguous() and d.is_contiguous(),
+                'a.first.is_contiguous() and b.first.is_contiguous() and d.is_contiguous()')
+    host_assert(c is not None and c.is_contiguous(), 'c.has_value() and c.value().is_contiguous()')
+    host_assert(d.dtype == torch.float, 'd.scalar_type() == torch::kFloat')
+    if _early_return(m, n, sum_k, d, c):
+        return
+    sfa, sfb = _k_grouped_sf(a_sf, m, sum_k), _k_grouped_sf(b_sf, n, sum_k)
+    _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_BLOCKS, 0, 0)
+
+
+def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks, grouped_layout: torch.Tensor,
+                                     c: Optional[torch.Tensor] = None, recipe: Tuple[int, int, int] = (1, 1, 128),
+                                     compiled_dims: str = 'mn', use_psum_layout: bool = False) -> None:
+    """MN-major operands: ``a[0] [sum_k, M]``, ``a[1] [sum_k / 128, M]`` (per-channel scales), ``b`` likewise with N;
+    ``d [G, M, N]`` FP32 ``= c + A_g^T @ B_g`` (csrc/apis/gemm.hpp:299-346).  The FP8 operands are re-majored once by
+    ``dg_transpose_fp8`` (HBM-bound, 2 bytes per element) and every group then is a column range of a K-major matrix."""
+    (a_data, a_sf), (b_data, b_sf) = a, b
+    recipe = tuple(recipe)
+    host_assert(recipe[0] == 1 and recipe[1] == 1, 'std::get<0>(recipe) == 1 and std::get<1>(recipe) == 1')
+    host_assert(recipe[2] == 128, 'gran_k == 128 (gran_k == 32 needs the packed UE8M0 scale format)')
+    host_assert(d.dim() == 3, 'd.dim() == 3')
+    num_groups, m, n = (int(x) for x in d.shape)
+    sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, 128)
+    host_assert(a_data.dim() == 2 and b_data.dim() == 2, 'a.first.dim() == 2 and b.first.dim() == 2')
+    host_assert(a_data.dtype == torch.float8_e4m3fn and b_data.dtype == torch.float8_e4m3fn,
+                'ab.scalar_type() == torch::kFloat8_e4m3fn')
+    host_assert(tuple(a_data.shape) == (sum_k, m) and tuple(b_data.shape) == (sum_k, n),
+                'm == m_ and n == n_ and sum_k == sum_k_ and sum_k == sum_k__')
+    host_assert(a_data.is_contiguous() and b_data.is_contiguous() and d.is_contiguous(),
+                'a.first.is_contiguous() and b.first.is_contiguous() and d.is_contiguous()')
+    host_assert(c is not None and c.is_contiguous(), 'c.has_value() and c.value().is_contiguous()')
+    host_assert(d.dtype == torch.float, 'd.scalar_type() == torch::kFloat')
+    if _early_return(m, n, sum_k, d, c):
+        return
+    host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
+    sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
+    a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))       # [M, sum_k], [N, sum_k]: K-major
+    _k_grouped_launch(a_km, sfa, b_km, sfb, d, m, n, ks, _KGROUPED_COLUMNS, a_km.stride(0), b_km.stride(0))

@@ -170,3 +170,55 @@ def enumerate_m_grouped_masked() -> Iterator[Tuple[int, int, int, int, int]]:
     for groups, expected in MASKED_GROUPS:
         for n, k in GROUPED_NK:
             yield groups, MASKED_MAX_M, expected, n, k
+
+
+@dataclass
+class KGroupedCase:
+    a: tuple                    # operator-ready (fp8, sf) pair in the requested form
+    b: tuple
+    a_groups: List[tuple]       # per non-empty group: (A_g fp8 [m, k_g] K-major, sfa_g [m, k_g / 128]) for checkers
+    b_groups: List[tuple]
+    c: torch.Tensor
+    d: torch.Tensor
+    ref_d: torch.Tensor
+    ks: List[int]
+    grouped_layout: torch.Tensor
+
+
+def generate_k_grouped_contiguous(num_groups: int, m: int, n: int, ks: List[int], k_major: bool,
+                                  device: str = 'cuda') -> KGroupedCase:
+    """tests/generators.py:436-477: ``a [sum_k, m]``, ``b [sum_k, n]`` BF16, per group ``ref_d[g] = c[g] + a_g^T @ b_g``;
+    per-channel FP8 casts per group (128 x 1 blocks along K).  ``k_major`` selects the SM90 operand form (each group's
+    ``[m, k_g]`` transposed block flattened one after another, scales as ``[m, sum_k / 128]`` views) instead of the
+    MN-major ``[sum_k, m]`` form."""
+    assert len(ks) == num_groups and all(k % 128 == 0 for k in ks)
+    from ..utils.math import per_channel_cast_to_fp8
+    sum_k = sum(ks)
+    a = torch.randn((sum_k, m), device=device, dtype=torch.bfloat16)
+    b = torch.randn((sum_k, n), device=device, dtype=torch.bfloat16)
+    c = torch.randn((num_groups, m, n), device=device, dtype=torch.float) * 32
+    ref_d = torch.empty_like(c)
+    a_q = torch.empty((sum_k, m), device=device, dtype=torch.float8_e4m3fn)
+    b_q = torch.empty((sum_k, n), device=device, dtype=torch.float8_e4m3fn)
+    sfa = torch.empty((sum_k // 128, m), device=device, dtype=torch.float)
+    sfb = torch.empty((sum_k // 128, n), device=device, dtype=torch.float)
+    a_groups, b_groups, start = [], [], 0
+    for g, k in enumerate(ks):
+        end = start + k
+        ref_d[g] = c[g] + a[start:end].float().t() @ b[start:end].float()
+        if k > 0:
+            a_q[start:end], sfa[start // 128:end // 128] = per_channel_cast_to_fp8(a[start:end], use_ue8m0=False)
+            b_q[start:end], sfb[start // 128:end // 128] = per_channel_cast_to_fp8(b[start:end], use_ue8m0=False)
+            a_groups.append((a_q[start:end].t().contiguous(), sfa[start // 128:end // 128].t().contiguous()))
+            b_groups.append((b_q[start:end].t().contiguous(), sfb[start // 128:end // 128].t().contiguous()))
+        else:
+            a_groups.append(None), b_groups.append(None)
+        start = end
+    if k_major:
+        flat_a = torch.cat([g[0].reshape(-1) for g in a_groups if g is not None]) if sum_k else a_q.reshape(-1)
+        flat_b = torch.cat([g[0].reshape(-1) for g in b_groups if g is not None]) if sum_k else b_q.reshape(-1)
+        a_op, b_op = (flat_a, sfa.t()), (flat_b, sfb.t())
+    else:
+        a_op, b_op = (a_q, sfa), (b_q, sfb)
+    layout = torch.tensor(ks, device=device, dtype=torch.int32)
+    return KGroupedCase(a_op, b_op, a_groups, b_groups, c, c.clone(), ref_d, list(ks), layout)

@@ -55,6 +55,25 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                          int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
 
+/* K-grouped contiguous GEMM (MoE weight gradients): D[g] += A_g * B_g^T for every group g, where group g owns the K range
+ * [sum(ks[:g]), sum(ks[:g+1])) of both operands.  Replaces sm90_k_grouped_fp8_gemm_1d1d / sm100_k_grouped_fp8_gemm_1d1d as
+ * called from k_grouped_fp8_gemm_nt_contiguous / k_grouped_fp8_gemm_tn_contiguous (csrc/apis/gemm.hpp:299-400).
+ *   ks_host: HOST array of num_groups K extents (the reference's ks_cpu), each a multiple of 128; 0 = empty group, D[g] kept.
+ *   ab_layout DG_KGROUPED_BLOCKS: group g's K-major [m, ks[g]] (resp. [n, ks[g]]) matrix is stored contiguously at element
+ *     offset m * sum(ks[:g]) (resp. n * ...): the reference's SM90 NT operand form; a_stride_m / b_stride_n are ignored.
+ *   ab_layout DG_KGROUPED_COLUMNS: a is one K-major [m, sum_k] matrix with row stride a_stride_m (b: [n, sum_k], b_stride_n)
+ *     and group g is a column range: what an MN-major [sum_k, m] operand (TN form) becomes after dg_transpose_fp8.
+ *   sfa element (row, kb) at sfa[row * sfa_stride_m + kb * sfa_stride_k], kb counted over the whole K axis; same for sfb
+ *   (one scale per row of B per 128-K block: recipe (1, 1, 128)).
+ *   d [num_groups, m, n] FP32, dense; the result is accumulated onto it (the caller copies C into D first). */
+#define DG_KGROUPED_BLOCKS 0
+#define DG_KGROUPED_COLUMNS 1
+int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, float* d,
+                                        int m, int n, const int32_t* ks_host, int num_groups, int ab_layout,
+                                        int64_t a_stride_m, int64_t b_stride_n,
+                                        int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                        void* stream);
+
 /* M-grouped contiguous GEMM.  Replaces sm90_m_grouped_fp8_gemm_contiguous_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:147) /
  * sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:161) as called from
  * m_grouped_fp8_fp4_gemm_nt_contiguous (csrc/apis/gemm.hpp:166-232).

@@ -425,3 +425,43 @@ def test_packed_ue8m0_scales_hw_path(m, n, k):
     want32 = torch.empty((m, n), dtype=torch.float)
     oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb_rows.cpu(), want32, c=c32.cpu(), gran_n=1)
     assert_close_fp32(d32, want32, 'packed ue8m0 fp32 accumulate')
+
+
+@pytest.mark.parametrize('k_major', [True, False])
+@pytest.mark.parametrize('num_groups,m,n,ks', [(3, 256, 384, [256, 0, 512]), (2, 200, 264, [128, 384]),
+                                               (4, 512, 1024, [1024, 896, 1152, 768])])
+def test_k_grouped_contiguous(k_major, num_groups, m, n, ks):
+    """k_grouped_fp8_gemm_{nt,tn}_contiguous (csrc/apis/gemm.hpp:299-400; reference test: tests/test_fp8_fp4.py:193-215):
+    FP32 ``d[g] = c[g] + A_g @ B_g^T`` with per-channel scales; an empty group leaves ``d[g] = c[g]``."""
+    gen.reset_seed(sum(ks) + m)
+    case = gen.generate_k_grouped_contiguous(num_groups, m, n, ks, k_major)
+    fn = dg.k_grouped_fp8_gemm_nt_contiguous if k_major else dg.k_grouped_fp8_gemm_tn_contiguous
+    c_before = case.c.clone()
+    fn(case.a, case.b, case.d, ks, case.grouped_layout, c=case.c)
+    assert torch.equal(case.c, c_before)                       # c is a different buffer here: read, never written
+    for g, k in enumerate(ks):
+        if k == 0:
+            assert torch.equal(case.d[g], case.c[g])
+            continue
+        (a_g, sfa_g), (b_g, sfb_g) = case.a_groups[g], case.b_groups[g]
+        want = torch.empty((m, n), dtype=torch.float)
+        oracle.fp8_gemm_nt(a_g.cpu(), sfa_g.cpu(), b_g.cpu(), sfb_g.cpu(), want, c=case.c[g].cpu(), gran_n=1)
+        assert_close_fp32(case.d[g], want, f'k-grouped group {g}')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    # in place (c is d), the reference test's calling convention
+    d2 = case.c.clone()
+    fn(case.a, case.b, d2, ks, case.grouped_layout, c=d2)
+    assert torch.equal(d2, case.d)
+
+
+def test_k_grouped_argument_checks():
+    gen.reset_seed(1)
+    case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)
+    with pytest.raises(RuntimeError, match='c.has_value'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.ks, case.grouped_layout)
+    with pytest.raises(RuntimeError, match='k % k_alignment == 0'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, [100, 284], case.grouped_layout, c=case.c)
+    with pytest.raises(RuntimeError, match='ks_cpu'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, None, case.grouped_layout, c=case.c)
+    with pytest.raises(RuntimeError, match='recipe'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.ks, case.grouped_layout, c=case.c, recipe=(1, 128, 128))
