@@ -468,6 +468,21 @@ int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int s
     return 0;
 }
 
+int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_k,
+                     int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, void* stream) {
+    DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
+    if (batches == 0 || mn == 0 || sf_k == 0)
+        return 0;
+    DG_CHECK(sf != nullptr && out != nullptr);
+    DG_CHECK(batches <= 65535 && (sf_k + 63) / 64 <= 65535);
+    const int aligned_mn = (mn + 3) / 4 * 4;
+    const dim3 grid((mn + 63) / 64, (sf_k + 63) / 64, batches);
+    hipLaunchKernelGGL(dg::dg_pack_sf_ue8m0_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       sf, out, mn, sf_k, aligned_mn, sf_stride_b, sf_stride_mn, sf_stride_k);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols,
                      int64_t src_ld, int64_t dst_ld, int64_t src_batch_stride, int64_t dst_batch_stride, void* stream) {
     DG_CHECK(batches >= 0 && rows >= 0 && cols >= 0);

@@ -94,6 +94,24 @@ def get_mn_major_tma_aligned_tensor(sf: torch.Tensor) -> torch.Tensor:
     return out.squeeze(0) if sf.dim() == 2 else out
 
 
+def get_mn_major_tma_aligned_packed_ue8m0_tensor(sf: torch.Tensor, psum_layout: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[..., mn, sf_k] FP32 power-of-two scales -> packed UE8M0 words ``[..., mn, ceil(sf_k / 4)]`` int32 with strides
+    ``(packed_k * aligned_mn, 1, aligned_mn)``: four exponent bytes per word, MN-major (the layout the scaled-MFMA kernels
+    read).  Reference: csrc/jit_kernels/impls/smxx_layout.hpp:181-246; mantissa bits are dropped as there (``>> 23``)."""
+    host_assert(sf.dim() in (2, 3), 'dim == 2 or dim == 3')
+    host_assert(sf.dtype == torch.float, 'sf.scalar_type() == torch::kFloat')
+    host_assert(psum_layout is None, 'not psum_layout.has_value() (psum gaps are not skipped on gfx950: pack the whole tensor)')
+    require_device(sf)
+    batched = sf.unsqueeze(0) if sf.dim() == 2 else sf
+    nb, mn, sf_k = batched.shape
+    aligned_mn, packed_k = get_tma_aligned_size(mn, 4), ceil_div(sf_k, 4)
+    out = torch.empty_strided((nb, mn, packed_k), (packed_k * aligned_mn, 1, aligned_mn), dtype=torch.int, device=sf.device)
+    host_assert(nb <= 65535, 'num_sf_batches <= 65535')
+    check(lib.dg_pack_sf_ue8m0(batched.data_ptr(), out.data_ptr(), nb, mn, sf_k,
+                               batched.stride(0), batched.stride(1), batched.stride(2), current_stream_ptr()))
+    return out.squeeze(0) if sf.dim() == 2 else out
+
+
 Recipe = Union[Tuple[int, int, int], Tuple[int, int]]
 
 
@@ -118,8 +136,14 @@ def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe:
     # (FP32, 128, 128): only checked -- csrc/apis/layout.hpp:44-46
     if sf.dtype == torch.float and gran_mn == 128 and gran_k == 128:
         return check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups, False, True, torch.float)
+    # (INT, 1, 128): packed UE8M0 words, only checked and brought to the MN-major layout -- csrc/apis/layout.hpp:60-62
+    if sf.dtype == torch.int and gran_mn == 1 and gran_k == 128:
+        host_assert(sf.dim() == (2 if num_groups is None else 3), 'sf.dim() == static_cast<int>(num_groups.has_value()) + 2')
+        host_assert(sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4),
+                    'sf.size(-2) == ceil_div(mn, gran_mn) and sf.size(-1) == ceil_div(k, gran_k * 4)')
+        return get_mn_major_tma_aligned_tensor(sf.view(torch.float)).view(torch.int)
     raise RuntimeError('Assertion error (layout.py): Unknown SF transformation '
-                       '(packed UE8M0 / gran_k = 32 scales are not supported on gfx950 yet)')
+                       '(gran_k = 32 scales are not supported on gfx950)')
 
 
 def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, recipe_b,

@@ -55,6 +55,14 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                          int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
 
+/* SF packing: FP32 power-of-two scales [batches, mn, sf_k] (element strides given) -> packed UE8M0 words int32
+ * [batches, mn, ceil(sf_k / 4)] in the MN-major layout (strides (ceil(sf_k / 4) * align(mn, 4), 1, align(mn, 4))): byte j
+ * of word (row, kq) = (bits(sf[row][4 kq + j]) >> 23) & 0xff, zero for K blocks past sf_k.  Replaces
+ * get_mn_major_tma_aligned_packed_ue8m0_tensor (csrc/jit_kernels/impls/smxx_layout.hpp:181-246; kernels
+ * deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:56,148; torch twin smxx_layout.hpp:156-179). */
+int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_k,
+                     int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, void* stream);
+
 /* K-grouped contiguous GEMM (MoE weight gradients): D[g] += A_g * B_g^T for every group g, where group g owns the K range
  * [sum(ks[:g]), sum(ks[:g+1])) of both operands.  Replaces sm90_k_grouped_fp8_gemm_1d1d / sm100_k_grouped_fp8_gemm_1d1d as
  * called from k_grouped_fp8_gemm_nt_contiguous / k_grouped_fp8_gemm_tn_contiguous (csrc/apis/gemm.hpp:299-400).

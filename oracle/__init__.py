@@ -7,5 +7,5 @@ from .oracle import (  # noqa: F401
     build, lib,
     e4m3_lut, f32_to_bf16_bits,
     fp8_gemm_nt, m_grouped_fp8_gemm_nt_contiguous, m_grouped_fp8_gemm_nt_masked,
-    transpose_sf, fp8_gemm_nt_blockwise_torch, dequant_matmul_f64,
+    transpose_sf, pack_sf_ue8m0, fp8_gemm_nt_blockwise_torch, dequant_matmul_f64,
 )

@@ -234,3 +234,29 @@ int dgo_transpose_sf(const float* sf, float* out, int batches, int mn, int sf_k)
                     sf[((int64_t) bi * mn + i) * sf_k + j];
     return 0;
 }
+
+/* get_mn_major_tma_aligned_packed_ue8m0_tensor, following the reference's torch statement of it
+ * (csrc/jit_kernels/impls/smxx_layout.hpp:156-179; the CUDA kernels deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:56,148
+ * produce the same words): sf [batches, mn, sf_k] FP32 with element strides (sb, sm, sk) -> int32 words; byte j of word
+ * (b, i, kq) = bits(sf[b][i][4 kq + j]) >> 23 truncated to 8 bits, zero for 4 kq + j >= sf_k; word stored at
+ * out[b * packed_k * aligned_mn + kq * aligned_mn + i].  Padding rows (i >= mn) are not written.
+ */
+int dgo_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_k, int64_t sb, int64_t sm, int64_t sk) {
+    const int64_t aligned_mn = ((int64_t) mn + 3) / 4 * 4;
+    const int packed_k = (sf_k + 3) / 4;
+    for (int bi = 0; bi < batches; ++bi)
+        for (int i = 0; i < mn; ++i)
+            for (int kq = 0; kq < packed_k; ++kq) {
+                uint32_t word = 0;
+                for (int j = 0; j < 4; ++j) {
+                    const int kb = 4 * kq + j;
+                    if (kb < sf_k) {
+                        uint32_t bits;
+                        memcpy(&bits, &sf[bi * sb + i * sm + kb * sk], 4);
+                        word |= ((bits >> 23) & 0xffu) << (8 * j);
+                    }
+                }
+                out[(int64_t) bi * packed_k * aligned_mn + (int64_t) kq * aligned_mn + i] = (int32_t) word;
+            }
+    return 0;
+}

@@ -53,6 +53,8 @@ def lib() -> ctypes.CDLL:
                 _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32]
             handle.dgo_transpose_sf.restype = ctypes.c_int
             handle.dgo_transpose_sf.argtypes = [_vp, _vp, _i32, _i32, _i32]
+            handle.dgo_pack_sf_ue8m0.restype = ctypes.c_int
+            handle.dgo_pack_sf_ue8m0.argtypes = [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64]
             _lib = handle
     return _lib
 
@@ -150,6 +152,22 @@ def transpose_sf(sf: torch.Tensor) -> torch.Tensor:
     storage = torch.zeros(nb * aligned * sf_k, dtype=torch.float32)
     lib().dgo_transpose_sf(batched.data_ptr(), storage.data_ptr(), nb, mn, sf_k)
     out = storage.as_strided((nb, mn, sf_k), (aligned * sf_k, 1, aligned))
+    return out.squeeze(0) if squeeze else out
+
+
+def pack_sf_ue8m0(sf: torch.Tensor) -> torch.Tensor:
+    """[..., mn, sf_k] FP32 (any strides) -> packed UE8M0 words [..., mn, ceil(sf_k / 4)] int32, MN-major with strides
+    (packed_k * aligned_mn, 1, aligned_mn); padding rows zero-filled here."""
+    sf = _cpu(sf, torch.float32)
+    squeeze = sf.dim() == 2
+    batched = sf.unsqueeze(0) if squeeze else sf
+    nb, mn, sf_k = batched.shape
+    aligned, packed_k = (mn + 3) // 4 * 4, (sf_k + 3) // 4
+    storage = torch.zeros(nb * aligned * packed_k, dtype=torch.int32)
+    rc = lib().dgo_pack_sf_ue8m0(batched.data_ptr(), storage.data_ptr(), nb, mn, sf_k,
+                                 batched.stride(0), batched.stride(1), batched.stride(2))
+    assert rc == 0
+    out = storage.as_strided((nb, mn, packed_k), (aligned * packed_k, 1, aligned))
     return out.squeeze(0) if squeeze else out
 
 

@@ -61,3 +61,8 @@ def golden_quantisers():
 @pytest.fixture(scope='session')
 def golden_gemm():
     return Golden('gemm_cases.npz')
+
+
+@pytest.fixture(scope='session')
+def golden_sf_layout():
+    return Golden('sf_layout.npz')

@@ -5,6 +5,9 @@ reference, imported with importlib straight from /root/reference (nothing is cop
   * deep_gemm/utils/math.py      -- per_token / per_block / per_channel casts, ceil_to_ue8m0, pack_ue8m0_to_int
   * deep_gemm/testing/numeric.py -- calc_diff
   * the test oracle expression of tests/generators.py:312, ``(a.float() @ b.float().t()).to(out_dtype)``
+  * tests/test_layout.py:20-44  -- get_mn_major_tma_aligned_packed_ue8m0_tensor_torch_impl, the reference's torch statement
+    of the packed-UE8M0 SF layout (the function's AST node is compiled out of the reference file at generation time; the
+    module itself cannot be imported because it imports the compiled extension)
 The reference's CUDA kernels cannot run here (no NVIDIA GPU, no nvcc, CUTLASS submodule absent), so there are no
 kernel-output goldens; each GEMM fixture instead stores the reference-quantised operands, the reference test result and
 this repository's oracle output with its reference-calc_diff, which pins the oracle at the reference's own gate (< 1e-3).
@@ -110,6 +113,37 @@ def gemm_fixtures():
     print('gemm_cases.npz', len(out), 'arrays')
 
 
+def load_ref_function(rel_path: str, name: str, namespace: dict):
+    """Compiles ONE top-level function out of a reference file that cannot be imported as a whole."""
+    import ast
+    with open(os.path.join(REF, rel_path)) as f:
+        tree = ast.parse(f.read())
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    code = compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF, rel_path), 'exec')
+    exec(code, namespace)
+    return namespace[name]
+
+
+def layout_fixtures():
+    # get_tma_aligned_size lives in the compiled extension; its definition (csrc/utils/math.hpp:23-27) is align(x, 16 / elem)
+    namespace = {'torch': torch, 'align': ref_math.align,
+                 'get_tma_aligned_size': lambda x, elem: ref_math.align(x, 16 // elem)}
+    ref_pack = load_ref_function('tests/test_layout.py', 'get_mn_major_tma_aligned_packed_ue8m0_tensor_torch_impl', namespace)
+    out = {}
+    torch.manual_seed(7)
+    for name, shape in {'p33x7': (33, 7), 'p128x56': (128, 56), 'p3x20x9': (3, 20, 9), 'p2x64x4': (2, 64, 4)}.items():
+        x = torch.randn(shape[:-1] + (shape[-1] * 128,), dtype=torch.bfloat16).reshape(-1, shape[-1] * 128)
+        _, sf = ref_math.per_token_cast_to_fp8(x, use_ue8m0=True)
+        sf = sf.view(shape)
+        packed = ref_pack(sf)
+        out[f'{name}_sf'] = bits(sf)
+        out[f'{name}_packed'] = packed.contiguous().numpy()             # logical [.., mn, packed_k] values
+        out[f'{name}_strides'] = np.array(packed.stride(), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'sf_layout.npz'), **out)
+    print('sf_layout.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     quantiser_fixtures()
     gemm_fixtures()
+    layout_fixtures()

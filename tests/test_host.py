@@ -156,8 +156,13 @@ def test_sf_layout_helpers_on_host():
     assert dg.transform_sf_into_required_layout(sfb, 33 * 128, 7 * 128, (1, 128, 128), is_sfa=False) is sfb
     with pytest.raises(RuntimeError, match='SFB must be contiguous'):
         dg.transform_sf_into_required_layout(torch.rand(33, 14)[:, ::2], 33 * 128, 7 * 128, (128, 128))
+    # packed UE8M0 words (INT, 1, 128): checked and brought to the MN-major layout (csrc/apis/layout.hpp:60-62)
+    packed = dg.transform_sf_into_required_layout(torch.zeros(64, 2, dtype=torch.int), 64, 1024, (1, 128))
+    assert packed.dtype == torch.int and packed.shape == (64, 2) and packed.stride() == (1, 64)
+    with pytest.raises(RuntimeError, match='ceil_div'):
+        dg.transform_sf_into_required_layout(torch.zeros(64, 3, dtype=torch.int), 64, 1024, (1, 128))
     with pytest.raises(RuntimeError, match='Unknown SF transformation'):
-        dg.transform_sf_into_required_layout(torch.zeros(64, 2, dtype=torch.int), 64, 1024, (1, 128))
+        dg.transform_sf_into_required_layout(torch.zeros(64, 8, dtype=torch.int), 64, 1024, (1, 32))
 
 
 def test_generators_follow_reference_conventions():
