@@ -15,6 +15,7 @@ from .gemm import (                                   # noqa: F401
     k_grouped_fp8_gemm_nt_contiguous, k_grouped_fp8_gemm_tn_contiguous,
 )
 from .layout import transform_sf_into_required_layout                 # noqa: F401
+from .quant import fused_per_token_cast_to_fp8                        # noqa: F401
 from . import testing, utils                                          # noqa: F401
 from .utils import *                                                  # noqa: F401,F403
 

@@ -483,6 +483,28 @@ int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_
     return 0;
 }
 
+int dg_per_token_cast_to_fp8(const void* x_bf16, void* out_fp8, float* sf, int m, int n,
+                             int64_t x_stride_m, int64_t out_stride_m, int64_t sf_stride_m, int64_t sf_stride_k,
+                             int use_ue8m0, void* stream) {
+    DG_CHECK(m >= 0 && n >= 0);
+    if (m == 0 || n == 0)
+        return 0;
+    DG_CHECK(x_bf16 != nullptr && out_fp8 != nullptr && sf != nullptr);
+    DG_CHECK(x_stride_m >= n && out_stride_m >= n);
+    const int64_t blocks = static_cast<int64_t>(m) * ((n + 127) / 128);
+    // 16 blocks per 256-thread workgroup and pass; a few passes per workgroup once the chip is covered several times over
+    int64_t grid = (blocks + 15) / 16;
+    const int64_t cap = static_cast<int64_t>(num_cus()) * 32;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(dg::dg_per_token_cast_to_fp8_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint16_t*>(x_bf16),
+                       static_cast<uint8_t*>(out_fp8), sf, m, n, x_stride_m, out_stride_m, sf_stride_m, sf_stride_k,
+                       use_ue8m0 ? 1 : 0);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols,
                      int64_t src_ld, int64_t dst_ld, int64_t src_batch_stride, int64_t dst_batch_stride, void* stream) {
     DG_CHECK(batches >= 0 && rows >= 0 && cols >= 0);

@@ -2667,6 +2667,82 @@ void dg_pack_sf_ue8m0_kernel(const float* __restrict__ sf, int32_t* __restrict__
     }
 }
 
+// Fused per-token quantiser (the producer side of operand A): BF16 [m, n] -> e4m3fn [m, n] + one FP32 scale per
+// 1 x 128 block, the arithmetic of per_token_cast_to_fp8 (deep_gemm/utils/math.py:26-38): amax over the block (ragged
+// tail zero-padded), sf = max(amax, 1e-4) / 448, optionally rounded up to a power of two (ceil_to_ue8m0, :13-16),
+// q = e4m3fn_rne(float(x) * (1.0f / sf)).  HBM-bound: 2 bytes read + 1 byte written per element, one pass (the torch
+// expression makes five).  16 lanes own one block (8 elements = one 16-byte load each), a wave four blocks; the amax is a
+// 4-step DPP-width butterfly inside the 16-lane row.  The scale lands either row-major [m, ceil(n/128)] (reference
+// return value) or directly in the GEMM's MN-major layout, which saves the transpose launch of the GEMM call.
+__global__ __launch_bounds__(256)
+void dg_per_token_cast_to_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ sf,
+                                     int m, int n, int64_t x_sm, int64_t q_sm, int64_t sf_sm, int64_t sf_sk, int use_ue8m0) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int blocks_per_row = (n + 127) / 128;
+    const int64_t total = static_cast<int64_t>(m) * blocks_per_row;
+    const int64_t wave_first = (static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6) * 4;
+    const bool vec_ok = (n % 8 == 0) && (x_sm % 8 == 0) && (q_sm % 8 == 0) &&
+                        (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(q) % 8 == 0);
+    for (int64_t base = wave_first; base < total; base += step) {
+        // every lane of the wave runs the same number of iterations (the butterfly needs all 16 lanes of a row alive)
+        const int64_t c = base + (lane >> 4);
+        const bool live = c < total;
+        const int row = live ? static_cast<int>(c / blocks_per_row) : 0;
+        const int kb = live ? static_cast<int>(c % blocks_per_row) : 0;
+        const int col = kb * 128 + sub * 8;
+        float v[8];
+        if (live && vec_ok && col + 8 <= n) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + row * x_sm + col);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = __uint_as_float(w[i] << 16);
+                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            }
+        } else {
+            #pragma unroll
+            for (int i = 0; i < 8; ++i)
+                v[i] = (live && col + i < n) ? __uint_as_float(static_cast<uint32_t>(x[row * x_sm + col + i]) << 16) : 0.f;
+        }
+        float amax = 0.f;
+        #pragma unroll
+        for (int i = 0; i < 8; ++i)
+            amax = fmaxf(amax, fabsf(v[i]));
+        #pragma unroll
+        for (int d = 1; d < 16; d <<= 1)
+            amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+        float scale = fmaxf(amax, 1e-4f) / 448.0f;
+        if (use_ue8m0) {
+            const uint32_t bits = __float_as_uint(scale);
+            uint32_t e = ((bits >> 23) & 0xffu) + ((bits & 0x7fffffu) != 0 ? 1u : 0u);
+            e = e < 1u ? 1u : (e > 254u ? 254u : e);
+            scale = __uint_as_float(e << 23);
+        }
+        const float inv = 1.0f / scale;
+        if (!live)
+            continue;
+        uint32_t packed[2];
+        #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int word = 0;
+            word = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i] * inv, v[4 * i + 1] * inv, word, false);
+            word = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 2] * inv, v[4 * i + 3] * inv, word, true);
+            packed[i] = static_cast<uint32_t>(word);
+        }
+        if (vec_ok && col + 8 <= n) {
+            *reinterpret_cast<uint2*>(q + row * q_sm + col) = make_uint2(packed[0], packed[1]);
+        } else {
+            #pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (col + i < n)
+                    q[row * q_sm + col + i] = static_cast<uint8_t>(packed[i >> 2] >> (8 * (i & 3)));
+        }
+        if (sub == 0)
+            sf[row * sf_sm + kb * sf_sk] = scale;
+    }
+}
+
 // Operand re-majoring: dst[c][r] = src[r][c] for 1-byte elements (an MN-major FP8 operand -> the K-major form the
 // LDS-DMA kernels consume).  64 x 64 byte patches through LDS; both the global read (16 bytes along c per lane) and the
 // global write (16 bytes along r per lane) are coalesced 16-byte vectors.  HBM-bound: 2 bytes of traffic per element.

@@ -117,6 +117,15 @@ int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void*
  * aligned_mn = align(mn, 4).  Padding slots are not written. */
 int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream);
 
+/* Fused per-token quantiser, the producer of operand A: BF16 x [m, n] (row stride x_stride_m) -> e4m3fn out [m, n] plus
+ * one FP32 scale per 1 x 128 block at sf[row * sf_stride_m + kb * sf_stride_k] (row-major [m, ceil(n/128)] as the reference
+ * returns it, or strides (1, align(m, 4)) to land directly in the GEMM's SFA layout).  Arithmetic of
+ * per_token_cast_to_fp8 (deep_gemm/utils/math.py:26-38; the reference leaves this cast to the caller, README.md:72):
+ * sf = max(amax, 1e-4) / 448, rounded up to a power of two if use_ue8m0 (math.py:13-16), q = e4m3fn(float(x) * (1 / sf)). */
+int dg_per_token_cast_to_fp8(const void* x_bf16, void* out_fp8, float* sf, int m, int n,
+                             int64_t x_stride_m, int64_t out_stride_m, int64_t sf_stride_m, int64_t sf_stride_k,
+                             int use_ue8m0, void* stream);
+
 /* Operand re-majoring for the fast path: dst[b][c][r] = src[b][r][c], 1-byte (FP8) elements, `rows` x `cols` per batch,
  * leading dimensions / batch strides in elements.  Turns an MN-major operand (the SM100 form of fp8_gemm_nn/tn/tt,
  * csrc/apis/gemm.hpp:126-164; UMMA descriptors consume it in place there) into the K-major form the LDS-DMA kernels
