@@ -1466,6 +1466,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    // Early barriers (experiment): a wave in a matrix segment arrives at the segment-end barrier EB steps before its last
+    // MFMA, so the partner half starts its matrix segment while this one still has EB MFMAs to issue -- the matrix pipe
+    // does not idle for the barrier round trip.  (The barrier in front of a load segment only orders LDS traffic, which the
+    // trailing register-only steps do not touch.)
+    constexpr int EB = (DABL == 14) ? 2 : (DABL == 15 ? 4 : (DABL == 16 ? 1 : 0));
     constexpr int A_EARLY = (DABL == 9) ? 0 : A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
@@ -1668,6 +1673,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;     // slots of A(kb), A(kb+2) [= A(kb-1)'s], B(kb)
             v8i bf[NS], af[HS];
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            if (EB > 0) raw_barrier();                          // L_a(0)'s barrier; later ones sit inside M_b
 
             for (int kb = 0; kb < num_kb; ++kb) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
@@ -1675,7 +1681,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 
                 // ---------------- L_a ----------------
                 stamp(kb, 0);
-                raw_barrier();
+                if (EB == 0) raw_barrier();         // EB > 0: executed inside the previous matrix segment / before the loop
                 stamp(kb, 1);
                 // fragment reads first: they complete in the shadow of the slow vector-memory issue that follows
                 if (NO_LDS_READS ? kb == 0 : true) {
@@ -1722,6 +1728,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     const int ns = i % NS, h = i / NS;
                     const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
                     const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
+                    if (EB > 0 && i == SEG - EB) raw_barrier();
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
                 }
                 if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
@@ -1729,7 +1736,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 
                 // ---------------- L_b ----------------
                 stamp(kb, 4);
-                raw_barrier();
+                if (EB == 0) raw_barrier();
                 stamp(kb, 5);
                 if (!NO_LDS_READS) {
                     #pragma unroll
@@ -1749,7 +1756,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
                 // "every load but the newest 8 has landed".)
                 wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
-                asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]) :: "memory");
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    asm volatile("" : "+v"(af[h]) :: "memory");
 
                 // ---------------- M_b ----------------
                 stamp(kb, 6);
@@ -1762,6 +1771,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     const int i = SEG + i2;
                     const int ns = i % NS, h = i2 / NS;
                     const int j = i - DEPTH;
+                    if (EB > 0 && i2 == SEG - EB) raw_barrier();      // the next K block's L_a barrier
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
                 }
                 if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);

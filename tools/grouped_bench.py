@@ -32,13 +32,23 @@ for case_s in args.cases.split(','):
             print(json.dumps({'case': case_s, 'config': cfg, 'error': str(e)[:120]}), flush=True)
             continue
         diff = calc_diff(torch.nan_to_num(case.d), torch.nan_to_num(case.ref_d))
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(args.iters):
-            dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
-        end.record()
-        torch.cuda.synchronize()
-        us = start.elapsed_time(end) / args.iters * 1e3
+        # warm the clocks (the first launches after an idle gap run at a ramping clock), then the median of 5 timed bursts
+        import time
+        t_end = time.time() + 0.3
+        while time.time() < t_end:
+            for _ in range(4):
+                dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
+            torch.cuda.synchronize()
+        bursts = []
+        for _ in range(5):
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            for _ in range(args.iters):
+                dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
+            end.record()
+            torch.cuda.synchronize()
+            bursts.append(start.elapsed_time(end) / args.iters * 1e3)
+        us = sorted(bursts)[2]
         print(json.dumps({'case': case_s, 'm_total': case.m, 'config': cfg, 'kernel': dg.last_config(), 'us': round(us, 1),
                           'tflops': round(2.0 * case.m * n * k / us / 1e6, 1), 'calc_diff': diff}), flush=True)
 dg.set_forced_config('auto')
