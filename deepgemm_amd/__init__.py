@@ -12,7 +12,7 @@ from .runtime import (                                # noqa: F401
 from .gemm import (                                   # noqa: F401
     fp8_gemm_nt, fp8_gemm_nn, fp8_gemm_tn, fp8_gemm_tt,
     m_grouped_fp8_gemm_nt_contiguous, m_grouped_fp8_gemm_nn_contiguous, m_grouped_fp8_gemm_nt_masked,
-    k_grouped_fp8_gemm_nt_contiguous, k_grouped_fp8_gemm_tn_contiguous,
+    k_grouped_fp8_gemm_nt_contiguous, k_grouped_fp8_gemm_tn_contiguous, fp8_gemm_nt_skip_head_mid,
 )
 from .layout import transform_sf_into_required_layout                 # noqa: F401
 from .quant import fused_per_token_cast_to_fp8                        # noqa: F401

@@ -258,6 +258,8 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
+    if (p.head_lr > 0 && ((p.head_lr - p.head_right) % 8 != 0 || p.head_mid % 8 != 0 || p.head_right % 8 != 0))
+        p.d_vec_ok = 0;                  // a 16-byte store would straddle a head split: element-wise stores
     p.dbg = g_debug_buffer;
 
     long grid;
@@ -313,6 +315,36 @@ int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* 
     p.d_sm = d_stride_m;
     p.sfb_gran_n = sfb_gran_n; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
+    return launch_gemm(p, 0, stream);
+}
+
+int dg_fp8_gemm_nt_skip_head_mid(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                 int m, int n, int k,
+                                 int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                                 int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                 int sfb_gran_n, int64_t d_stride_m, int d_dtype,
+                                 int head_left, int head_mid, int head_right, void* stream) {
+    DG_CHECK(m >= 0 && n > 0 && k > 0);
+    if (m == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr);
+    DG_CHECK(a_stride_m == 1 || a_stride_k == 1);
+    DG_CHECK(b_stride_n == 1 || b_stride_k == 1);
+    DG_CHECK(sfb_gran_n == 1 || sfb_gran_n == 128);
+    DG_CHECK(d_dtype == DG_BF16 || d_dtype == DG_FP32);
+    DG_CHECK(head_left >= 0 && head_mid >= 0 && head_right >= 0 && head_left + head_right > 0);
+    DG_CHECK(n % (head_left + head_right) == 0);
+    DG_CHECK(d_stride_m >= n + static_cast<int64_t>(n / (head_left + head_right)) * head_mid);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.sfa = sfa; p.b = static_cast<const uint8_t*>(b); p.sfb = sfb; p.d = d;
+    p.layout = nullptr;
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = a_stride_m; p.a_sk = a_stride_k; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+    p.d_sm = d_stride_m;
+    p.sfb_gran_n = sfb_gran_n; p.d_dtype = d_dtype; p.accumulate = 0;
+    p.gemm_type = dg::kNormal; p.m_alignment = 0;
+    p.head_lr = head_left + head_right; p.head_mid = head_mid; p.head_right = head_right;
     return launch_gemm(p, 0, stream);
 }
 

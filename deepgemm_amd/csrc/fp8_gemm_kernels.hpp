@@ -42,6 +42,8 @@ struct GemmParams {
     int64_t sfb_sg, sfb_sn, sfb_sk;
     int64_t d_sg, d_sm;
     int sfb_gran_n;                 // 128 or 1
+    int head_lr, head_mid, head_right;  // epilogue column map of fp8_gemm_nt_skip_head_mid: D column of GEMM column n is
+                                    // n + (n + head_right) / head_lr * head_mid (head_lr = left + right; 0 = identity)
     int d_dtype;                    // 0 bf16, 1 fp32
     int accumulate;
     int gemm_type;
@@ -221,6 +223,12 @@ __device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 __device__ __forceinline__ float round_bf16(float x) { return bf16_lo(pack_bf16(x, 0.f)); }
 
+// Output column of GEMM column n (reference: epilogue/transform.cuh:15-22, EpilogueHeadSplits::apply_index_n).  Runs of 8
+// columns starting at a multiple of 8 stay contiguous when left, mid and right are multiples of 8 (the vector paths).
+__device__ __forceinline__ int d_col(const GemmParams& p, int n) {
+    return p.head_lr > 0 ? n + (n + p.head_right) / p.head_lr * p.head_mid : n;
+}
+
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
@@ -269,7 +277,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                         continue;
                     const uint32_t* v = half == 0 ? x : y;
                     uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
-                    *reinterpret_cast<uint4*>(drow + col) = zero_row ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<uint4*>(drow + d_col(p, col)) = zero_row ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v[0], v[1], v[2], v[3]);
                 }
             }
             return;
@@ -294,7 +302,7 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                         w[2 * j] = zero_row ? 0u : pack_bf16(v[0], v[1]);
                         w[2 * j + 1] = zero_row ? 0u : pack_bf16(v[2], v[3]);
                     }
-                    uint4* dst = reinterpret_cast<uint4*>(drow + n_lane + h * 32);
+                    uint4* dst = reinterpret_cast<uint4*>(drow + d_col(p, n_lane + h * 32));
                     if (p.accumulate && !zero_row) {
                         const uint4 old = *dst;
                         const uint32_t o[4] = {old.x, old.y, old.z, old.w};
@@ -316,10 +324,11 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                     for (int r = 0; r < 4; ++r) {
                         const int col = n_lane + (ns >> 1) * 32 + (ns & 1) * 4 + r;
                         if (col < p.n) {
+                            const int dc = d_col(p, col);
                             float v = zero_row ? 0.f : round_bf16(acc[ms][ns][r]);
                             if (p.accumulate && !zero_row)
-                                v = v + bf16_lo(static_cast<uint32_t>(drow[col]));
-                            drow[col] = static_cast<uint16_t>(pack_bf16(v, 0.f) & 0xffffu);
+                                v = v + bf16_lo(static_cast<uint32_t>(drow[dc]));
+                            drow[dc] = static_cast<uint16_t>(pack_bf16(v, 0.f) & 0xffffu);
                         }
                     }
             }
@@ -331,14 +340,16 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                 if (zero_row) v = v4f{0.f, 0.f, 0.f, 0.f};
                 const int col = n_lane + (ns >> 1) * 32 + (ns & 1) * 4;
                 if (full_n && p.d_vec_ok) {
-                    v4f* dst = reinterpret_cast<v4f*>(drow + col);
+                    v4f* dst = reinterpret_cast<v4f*>(drow + d_col(p, col));
                     if (p.accumulate && !zero_row) v += *dst;
                     *dst = v;
                 } else {
                     #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (col + r < p.n)
-                            drow[col + r] = (p.accumulate && !zero_row) ? drow[col + r] + v[r] : v[r];
+                        if (col + r < p.n) {
+                            const int dc = d_col(p, col + r);
+                            drow[dc] = (p.accumulate && !zero_row) ? drow[dc] + v[r] : v[r];
+                        }
                 }
             }
         }

@@ -358,3 +358,32 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
     a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))       # [M, sum_k], [N, sum_k]: K-major
     _k_grouped_launch(a_km, sfa, b_km, sfb, d, m, n, ks, _KGROUPED_COLUMNS, a_km.stride(0), b_km.stride(0))
+
+
+def fp8_gemm_nt_skip_head_mid(a: TensorPair, b: TensorPair, d: torch.Tensor, head_splits: Tuple[int, int, int],
+                              recipe: Optional[Tuple[int, int, int]] = None, compiled_dims: str = 'nk',
+                              disable_ue8m0_cast: bool = False) -> None:
+    """``fp8_gemm_nt`` whose N columns are heads of ``left + right`` columns written into a ``d`` that reserves ``mid``
+    untouched columns inside every head: ``d [M, N + N / (left + right) * mid]`` (csrc/apis/attention.hpp:19-73)."""
+    (a_data, a_sf), (b_data, b_sf) = a, b
+    host_assert(is_k_major(a_data) and is_k_major(b_data), 'major_a == cute::UMMA::Major::K and major_b == cute::UMMA::Major::K')
+    check_major_type_cd(d)
+    m, k = _check_ab_fp8(a_data, 2)
+    n, k_ = _check_ab_fp8(b_data, 2)
+    host_assert(d.dim() == 2, 'd.dim() == 2')
+    host_assert(m == d.size(0) and k == k_, 'm == m_ and k == k_')
+    host_assert(n > 0 and k > 0, 'n > 0 and k > 0')
+    host_assert(d.dtype in (torch.bfloat16, torch.float), 'd.scalar_type() == torch::kBFloat16 or d.scalar_type() == torch::kFloat')
+    left, mid, right = (int(x) for x in head_splits)
+    host_assert(n % (left + right) == 0 and d.size(1) == n + n // (left + right) * mid,
+                'n % (left + right) == 0 and n_ == n + n / (left + right) * mid')
+    if m == 0:
+        return
+    sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, None, None, None, None,
+                                                              disable_ue8m0_cast)
+    require_device(a_data, b_data, sfa, sfb, d)
+    check(lib.dg_fp8_gemm_nt_skip_head_mid(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
+        a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
+        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), gran_n,
+        d.stride(0), _dtype_code(d), left, mid, right, current_stream_ptr()))

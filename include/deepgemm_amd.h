@@ -43,6 +43,18 @@ int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* 
                    int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
                    int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
 
+/* Dense GEMM, NT form, with the head-split output map of fp8_gemm_nt_skip_head_mid (csrc/apis/attention.hpp:19-73; column
+ * map epilogue/transform.cuh:15-22): the N columns are heads of (head_left + head_right) columns; in D every head occupies
+ * head_left + head_mid + head_right columns and the middle head_mid columns are left untouched, i.e. GEMM column n lands in
+ * D column n + (n + head_right) / (head_left + head_right) * head_mid.  d is [m, n + n / (left + right) * mid]; no
+ * accumulation.  Other arguments as dg_fp8_gemm_nt. */
+int dg_fp8_gemm_nt_skip_head_mid(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                 int m, int n, int k,
+                                 int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                                 int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                 int sfb_gran_n, int64_t d_stride_m, int d_dtype,
+                                 int head_left, int head_mid, int head_right, void* stream);
+
 /* Dense GEMM, NT form, power-of-two scales in the reference's packed UE8M0 format (SM100 input format, recipe (1, 1, 128):
  * sm100_fp8_fp4_gemm_1d1d, impls/sm100_fp8_fp4_gemm_1d1d.hpp:93; packing: deep_gemm/utils/math.py:19-23,
  * csrc/apis/layout.hpp:48-58).  sfa_packed / sfb_packed: int32, byte j of element (row, kq) = biased exponent of the

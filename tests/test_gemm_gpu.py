@@ -465,3 +465,40 @@ def test_k_grouped_argument_checks():
         dg.k_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, None, case.grouped_layout, c=case.c)
     with pytest.raises(RuntimeError, match='recipe'):
         dg.k_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.ks, case.grouped_layout, c=case.c, recipe=(1, 128, 128))
+
+
+def _apply_skip_head_mid(d: torch.Tensor, head_splits, fill: float):
+    """tests/test_attention.py:19-31 with a recognisable filler in the middle columns."""
+    left, mid, right = head_splits
+    m, n = d.shape
+    heads = n // (left + right)
+    d = d.view(m, heads, -1)
+    pad = torch.full((m, heads, mid), fill, dtype=d.dtype, device=d.device)
+    return torch.cat([d[:, :, :left], pad, d[:, :, left:]], dim=2).reshape(m, -1)
+
+
+@pytest.mark.parametrize('head_splits', [(128, 64, 128), (64, 8, 192), (24, 4, 40)])
+@pytest.mark.parametrize('m,heads,k', [(128, 32, 512), (300, 5, 384), (4096, 8, 512)])
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float])
+def test_gemm_skip_head_mid(head_splits, m, heads, k, out_dtype):
+    """fp8_gemm_nt_skip_head_mid (reference test: tests/test_attention.py:34-53): same values as fp8_gemm_nt, scattered
+    around the reserved middle columns, which must stay untouched."""
+    left, mid, right = head_splits
+    n = heads * (left + right)
+    gen.reset_seed(m + n)
+    case = gen.generate_normal(m, n, k, out_dtype=out_dtype)
+    want = oracle_dense(case)
+    plain = torch.empty_like(case.d)
+    dg.fp8_gemm_nt(case.a, case.b, plain)
+    d = _apply_skip_head_mid(torch.zeros_like(case.d), head_splits, fill=-7.0).contiguous()
+    dg.fp8_gemm_nt_skip_head_mid(case.a, case.b, d, head_splits)
+    assert torch.equal(d, _apply_skip_head_mid(plain, head_splits, fill=-7.0))      # same kernel, same bits, gaps kept
+    got_cols = d.view(m, heads, left + mid + right)
+    compact = torch.cat([got_cols[:, :, :left], got_cols[:, :, left + mid:]], dim=2).reshape(m, n)
+    if out_dtype == torch.float:
+        assert_close_fp32(compact, want, 'skip_head_mid')
+    else:
+        assert_close_to_oracle(compact, want, 'skip_head_mid')
+    assert calc_diff(compact, case.ref_d) < gen.FP8_MAX_DIFF
+    with pytest.raises(RuntimeError, match='left \\+ right'):
+        dg.fp8_gemm_nt_skip_head_mid(case.a, case.b, d[:, :-8], head_splits)
