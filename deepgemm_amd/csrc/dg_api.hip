@@ -123,6 +123,8 @@ const Config kConfigs[] = {
     {"dabl14_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 14>, true},
     {"dabl15_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 15>, true},
     {"dabl16_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 16>, true},
+    {"dabl17_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 17>, true},
+    {"dabl18_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 18>, true},
     {"e8_ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };

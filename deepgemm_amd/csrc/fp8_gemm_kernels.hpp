@@ -1482,7 +1482,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // does not idle for the barrier round trip.  (The barrier in front of a load segment only orders LDS traffic, which the
     // trailing register-only steps do not touch.)
     constexpr int EB = (DABL == 14) ? 2 : (DABL == 15 ? 4 : (DABL == 16 ? 1 : 0));
-    constexpr int A_EARLY = (DABL == 9) ? 0 : A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
+    constexpr int A_EARLY = (DABL == 9) ? 0 : (DABL == 17 ? A_ITERS : (DABL == 18 ? A_ITERS * 3 / 4 : A_ITERS / 2));        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
     constexpr bool PERSIST = (DABL == 20);      // persistent launch with cross-tile prologue prefetch

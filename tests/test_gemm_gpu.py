@@ -502,3 +502,31 @@ def test_gemm_skip_head_mid(head_splits, m, heads, k, out_dtype):
     assert calc_diff(compact, case.ref_d) < gen.FP8_MAX_DIFF
     with pytest.raises(RuntimeError, match='left \\+ right'):
         dg.fp8_gemm_nt_skip_head_mid(case.a, case.b, d[:, :-8], head_splits)
+
+
+def test_hip_graph_capture_and_replay():
+    """The operators never allocate or synchronise once their SF operands are in the kernel's layout, so a sequence of them
+    can be captured into a hipGraph and replayed (reference: CUDA-graph capturable after the first call,
+    jit/kernel_runtime.hpp:139-162)."""
+    gen.reset_seed(11)
+    dense = gen.generate_normal(512, 768, 1024)
+    dense.a = (dense.a[0], dg.get_mn_major_tma_aligned_tensor(dense.a[1]))
+    masked = gen.generate_m_grouped_masked(4, 128, 48, 512, 512)
+    masked_a = (masked.a[0], dg.get_mn_major_tma_aligned_tensor(masked.a[1]))
+    # eager results (also warms every lazily initialised piece of host state)
+    dg.fp8_gemm_nt(dense.a, dense.b, dense.d)
+    dg.m_grouped_fp8_gemm_nt_masked(masked_a, masked.b, masked.d, masked.masked_m, 48)
+    torch.cuda.synchronize()
+    want_dense, want_masked = dense.d.clone(), masked.d.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dg.fp8_gemm_nt(dense.a, dense.b, dense.d)
+        dg.m_grouped_fp8_gemm_nt_masked(masked_a, masked.b, masked.d, masked.masked_m, 48)
+    for _ in range(3):
+        dense.d.zero_(), masked.d.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dense.d, want_dense)
+        for g in range(4):
+            rows = int(masked.masked_m[g])
+            assert torch.equal(masked.d[g, :rows], want_masked[g, :rows])
