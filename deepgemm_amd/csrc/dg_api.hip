@@ -125,6 +125,9 @@ const Config kConfigs[] = {
     {"dabl16_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 16>, true},
     {"dabl17_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 17>, true},
     {"dabl18_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 18>, true},
+    {"dabl19_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 19>, true},
+    {"dabl21_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 21>, true},
+    {"duo_fix_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_fixland_kernel<256, 256, 2, 4, 22>, true, true},
     {"e8_ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };

@@ -1429,10 +1429,24 @@ void dg_fp8_gemm_ring_kernel(const GemmParams p) {
 template <int MS>
 struct ScaleLandingV { v4f q[MS / 4]; float sb; };
 
-template <int MS>
+template <int MS, bool MASKED = false>
 __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
                                                     const v4i& sfb_rsrc, int sfb_voff) {
     static_assert(MS == 8 || MS == 4, "unrolled by hand");
+    if constexpr (MASKED) {
+        // timing experiment: the same loads from the first 16 lanes only (the other lane groups address the same rows)
+        unsigned long long saved;
+        asm volatile(
+            "s_mov_b64 %3, exec\n\t"
+            "s_mov_b64 exec, 0xffff\n\t"
+            "buffer_load_dwordx4 %0, %4, %5, 0 offen\n\t"
+            "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:16\n\t"
+            "buffer_load_dword %2, %6, %7, 0 offen\n\t"
+            "s_mov_b64 exec, %3"
+            : "=&v"(l.q[0]), "=&v"(l.q[1]), "=&v"(l.sb), "=&s"(saved)
+            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+            : "memory");
+    } else
     if constexpr (MS == 8)
         asm volatile(
             "buffer_load_dwordx4 %0, %3, %4, 0 offen\n\t"
@@ -1469,6 +1483,37 @@ __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
         asm volatile("" : "+v"(l.q[0]), "+v"(l.sb) :: "memory");
 }
 
+// Fixed landing registers (kernels compiled with amdgpu_num_vgpr(246); tuples must be even-aligned): v246..v253 = a lane's 8 row scales, v254 = SFB.
+// hipcc never allocates them, so a scale load may stay in flight across the loop back-edge -- with compiler-allocated
+// destinations it may not (hipcc copies them at control-flow joins before the data has landed) -- and the wait moves from
+// the end of L_b to the top of the next block's L_a: one more segment of lead for a load that misses L2 once per K block.
+__device__ __forceinline__ void issue_scale_loads_fixed(const v4i& sfa_rsrc, int sfa_voff, const v4i& sfb_rsrc, int sfb_voff) {
+    asm volatile(
+        "buffer_load_dwordx4 v[246:249], %0, %1, 0 offen\n\t"
+        "buffer_load_dwordx4 v[250:253], %0, %1, 0 offen offset:16\n\t"
+        "buffer_load_dword v254, %2, %3, 0 offen"
+        :: "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+        : "memory", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254");
+}
+
+// scale[ms] = SFA(ms) * SFB out of the fixed landing registers, after "at most ALLOWED newer vector-memory operations".
+template <int ALLOWED>
+__device__ __forceinline__ void take_scales_fixed(float (&scale)[8]) {
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 15));
+    asm volatile(
+        "v_mul_f32 %0, v246, v254\n\t"
+        "v_mul_f32 %1, v247, v254\n\t"
+        "v_mul_f32 %2, v248, v254\n\t"
+        "v_mul_f32 %3, v249, v254\n\t"
+        "v_mul_f32 %4, v250, v254\n\t"
+        "v_mul_f32 %5, v251, v254\n\t"
+        "v_mul_f32 %6, v252, v254\n\t"
+        "v_mul_f32 %7, v253, v254"
+        : "=v"(scale[0]), "=v"(scale[1]), "=v"(scale[2]), "=v"(scale[3]), "=v"(scale[4]), "=v"(scale[5]), "=v"(scale[6]),
+          "=v"(scale[7])
+        :: "memory");
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -1486,6 +1531,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
     constexpr bool PERSIST = (DABL == 20);      // persistent launch with cross-tile prologue prefetch
+    constexpr bool FIXLAND = (DABL == 22);      // scale landing in v246..v254 (kernel built with amdgpu_num_vgpr(246))
+    static_assert(!FIXLAND || MS == 8, "fixed landing registers are laid out for 8 row scales");
     constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3), LOADPRIO = (DABL == 8 || DABL == 11);
     constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
@@ -1643,8 +1690,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
             auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
             auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
-                const int jj = imin(j, num_kb - 1);         // past the end: the last block's scales again (never consumed)
-                issue_scale_loads_v<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
+                const int jj = (DABL == 21) ? 0 : imin(j, num_kb - 1);   // past the end: the last block's scales again (never consumed); DABL 21 (timing): always block 0 = cache resident
+                issue_scale_loads_v<MS, DABL == 19>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
             float scale[MS], scale_tail = 0.f;
@@ -1662,11 +1709,16 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // microsecond once per tile.  (Straight-line from the scale loads to their wait: hipcc may copy the landing
                 // registers at any control-flow join in between.)
                 issue_prologue(t);
-                issue_scales(land, 0);
-                wait_landing_v<0, MS>(land);
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    scale_pref[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                if constexpr (FIXLAND) {
+                    issue_scale_loads_fixed(sfa_rsrc, sfa_voff, sfb_rsrc, 0);
+                    if constexpr (MS == 8) take_scales_fixed<0>(scale_pref);
+                } else {
+                    issue_scales(land, 0);
+                    wait_landing_v<0, MS>(land);
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        scale_pref[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                }
             }
             raw_barrier();
             if (DABL != 1 && upper_half)
@@ -1706,13 +1758,26 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 [[maybe_unused]] long long t_in[3];
                 if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[0]) :: "memory");
                 scale_tail = scale[MS - 1];
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    scale[ms] = kb == 0 ? scale_pref[ms] : land.q[ms / 4][ms % 4] * land.sb;
-                    pin_vgpr(scale[ms]);
+                if constexpr (FIXLAND) {
+                    if (kb == 0) {
+                        #pragma unroll
+                        for (int ms = 0; ms < MS; ++ms)
+                            scale[ms] = scale_pref[ms];
+                    } else {
+                        // the scales of this block were requested a whole block ago; newer: the 8 pieces of block kb+1
+                        if constexpr (MS == 8) take_scales_fixed<A_ITERS + B_ITERS>(scale);
+                    }
+                    const int jj = imin(kb + 1, num_kb - 1);
+                    issue_scale_loads_fixed(sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
+                } else {
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        scale[ms] = kb == 0 ? scale_pref[ms] : land.q[ms / 4][ms % 4] * land.sb;
+                        pin_vgpr(scale[ms]);
+                    }
                 }
                 if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[1]) :: "memory");
-                if (!NO_SCALES) issue_scales(land, kb + 1);
+                if (!NO_SCALES && !FIXLAND) issue_scales(land, kb + 1);
                 if (!NO_DMA) {
                     #pragma unroll
                     for (int q = 0; q < A_EARLY; ++q)
@@ -1766,7 +1831,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
                 // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
                 // "every load but the newest 8 has landed".)
-                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
+                if constexpr (FIXLAND)      // newer than block kb+1's pieces: the scale loads of kb+1 (3) and the pieces of kb+2
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(A_ITERS + B_ITERS + 3, 0));
+                else
+                    wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
                 #pragma unroll
                 for (int h = 0; h < HS; ++h)
                     asm volatile("" : "+v"(af[h]) :: "memory");
@@ -1838,6 +1906,13 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, DABL>(p);
+}
+
+// The same body with v246..v255 withheld from hipcc: the scale landing registers of the FIXLAND schedule.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_num_vgpr(246)))
+void dg_fp8_gemm_duo_fixland_kernel(const GemmParams p) {
     duo_kernel_body<BM, BN, WAVES_M, WAVES_N, DABL>(p);
 }
 
