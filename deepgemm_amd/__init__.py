@@ -15,7 +15,8 @@ from .gemm import (                                   # noqa: F401
     k_grouped_fp8_gemm_nt_contiguous, k_grouped_fp8_gemm_tn_contiguous, fp8_gemm_nt_skip_head_mid,
 )
 from .layout import transform_sf_into_required_layout                 # noqa: F401
-from .quant import fused_per_token_cast_to_fp8                        # noqa: F401
+from .quant import (fused_per_token_cast_to_fp8, fused_per_block_cast_to_fp8,      # noqa: F401
+                    fused_per_channel_cast_to_fp8)
 from . import testing, utils                                          # noqa: F401
 from .utils import *                                                  # noqa: F401,F403
 

@@ -549,6 +549,28 @@ int dg_per_token_cast_to_fp8(const void* x_bf16, void* out_fp8, float* sf, int m
     return 0;
 }
 
+int dg_block_cast_to_fp8(const void* x_bf16, void* out_fp8, float* sf, int rows, int cols,
+                         int64_t x_stride_r, int64_t out_stride_r, int64_t sf_stride_r, int64_t sf_stride_c,
+                         int per_channel, int use_ue8m0, void* stream) {
+    DG_CHECK(rows >= 0 && cols >= 0);
+    if (rows == 0 || cols == 0)
+        return 0;
+    DG_CHECK(x_bf16 != nullptr && out_fp8 != nullptr && sf != nullptr);
+    DG_CHECK(x_stride_r >= cols && out_stride_r >= cols);
+    DG_CHECK((rows + 127) / 128 <= 65535);
+    const dim3 grid((cols + 127) / 128, (rows + 127) / 128);
+    if (per_channel)
+        hipLaunchKernelGGL(dg::dg_block_cast_to_fp8_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint16_t*>(x_bf16), static_cast<uint8_t*>(out_fp8), sf, rows, cols, x_stride_r,
+                           out_stride_r, sf_stride_r, sf_stride_c, use_ue8m0 ? 1 : 0);
+    else
+        hipLaunchKernelGGL(dg::dg_block_cast_to_fp8_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint16_t*>(x_bf16), static_cast<uint8_t*>(out_fp8), sf, rows, cols, x_stride_r,
+                           out_stride_r, sf_stride_r, sf_stride_c, use_ue8m0 ? 1 : 0);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols,
                      int64_t src_ld, int64_t dst_ld, int64_t src_batch_stride, int64_t dst_batch_stride, void* stream) {
     DG_CHECK(batches >= 0 && rows >= 0 && cols >= 0);

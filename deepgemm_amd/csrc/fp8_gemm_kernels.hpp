@@ -2842,6 +2842,120 @@ void dg_per_token_cast_to_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __
     }
 }
 
+// Fused block quantisers of the weight / wgrad side: one 256-thread workgroup casts a 128 x 128 patch of a BF16 matrix in
+// one pass (each thread holds 8 rows x 8 columns).  PER_CHANNEL = false: one scale per 128 x 128 block
+// (per_block_cast_to_fp8, deep_gemm/utils/math.py:51-61; ragged edges count as zeros); PER_CHANNEL = true: one scale per
+// column per 128-row block (per_channel_cast_to_fp8, :41-48: the operand form of the K-grouped GEMM).  Same arithmetic as
+// the per-token kernel above; HBM-bound, 3 bytes per element.
+template <bool PER_CHANNEL>
+__global__ __launch_bounds__(256)
+void dg_block_cast_to_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ sf,
+                                 int rows, int cols, int64_t x_sr, int64_t q_sr, int64_t sf_sr, int64_t sf_sc, int use_ue8m0) {
+    __shared__ float red[4][128];
+    const int tid = threadIdx.x, cg = tid & 15, rg = tid >> 4;           // column group (8 columns), row group (of 16)
+    const int row0 = blockIdx.y * 128, col0 = blockIdx.x * 128 + cg * 8;
+    const bool vec_ok = (cols % 8 == 0) && (x_sr % 8 == 0) && (q_sr % 8 == 0) &&
+                        (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(q) % 8 == 0);
+    float v[8][8];
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + i * 16 + rg;
+        if (row < rows && vec_ok && col0 + 8 <= cols) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + row * x_sr + col0);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[i][2 * j] = __uint_as_float(w[j] << 16);
+                v[i][2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+            }
+        } else {
+            #pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[i][j] = (row < rows && col0 + j < cols) ? __uint_as_float(static_cast<uint32_t>(x[row * x_sr + col0 + j]) << 16) : 0.f;
+        }
+    }
+    // per-column amax over this thread's 8 rows, then over the 16 row groups: lanes 16 / 32 apart, then the 4 waves
+    float cmax[8];
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = 0.f;
+        #pragma unroll
+        for (int i = 0; i < 8; ++i)
+            a = fmaxf(a, fabsf(v[i][j]));
+        a = fmaxf(a, __shfl_xor(a, 16, 64));
+        a = fmaxf(a, __shfl_xor(a, 32, 64));
+        cmax[j] = a;
+    }
+    if ((tid & 63) < 16) {
+        #pragma unroll
+        for (int j = 0; j < 8; ++j)
+            red[tid >> 6][cg * 8 + j] = cmax[j];
+    }
+    __syncthreads();
+    float scale[8];
+    if constexpr (PER_CHANNEL) {
+        #pragma unroll
+        for (int j = 0; j < 8; ++j)
+            scale[j] = fmaxf(fmaxf(red[0][cg * 8 + j], red[1][cg * 8 + j]), fmaxf(red[2][cg * 8 + j], red[3][cg * 8 + j]));
+    } else {
+        float a = 0.f;
+        for (int c = tid & 63; c < 512; c += 64)            // every wave reduces all 4 x 128 partial maxima
+            a = fmaxf(a, red[c >> 7][c & 127]);
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+            a = fmaxf(a, __shfl_xor(a, d, 64));
+        #pragma unroll
+        for (int j = 0; j < 8; ++j)
+            scale[j] = a;
+    }
+    float inv[8];
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float sc = fmaxf(scale[j], 1e-4f) / 448.0f;
+        if (use_ue8m0) {
+            const uint32_t bits = __float_as_uint(sc);
+            uint32_t e = ((bits >> 23) & 0xffu) + ((bits & 0x7fffffu) != 0 ? 1u : 0u);
+            e = e < 1u ? 1u : (e > 254u ? 254u : e);
+            sc = __uint_as_float(e << 23);
+        }
+        scale[j] = sc;
+        inv[j] = 1.0f / sc;
+    }
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + i * 16 + rg;
+        if (row >= rows)
+            continue;
+        uint32_t packed[2];
+        #pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int word = 0;
+            word = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4 * h] * inv[4 * h], v[i][4 * h + 1] * inv[4 * h + 1], word, false);
+            word = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4 * h + 2] * inv[4 * h + 2], v[i][4 * h + 3] * inv[4 * h + 3], word, true);
+            packed[h] = static_cast<uint32_t>(word);
+        }
+        if (vec_ok && col0 + 8 <= cols) {
+            *reinterpret_cast<uint2*>(q + row * q_sr + col0) = make_uint2(packed[0], packed[1]);
+        } else {
+            #pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (col0 + j < cols)
+                    q[row * q_sr + col0 + j] = static_cast<uint8_t>(packed[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+    if constexpr (PER_CHANNEL) {
+        if (rg == 0) {
+            #pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (col0 + j < cols)
+                    sf[blockIdx.y * sf_sr + (col0 + j) * sf_sc] = scale[j];
+        }
+    } else {
+        if (tid == 0)
+            sf[blockIdx.y * sf_sr + blockIdx.x * sf_sc] = scale[0];
+    }
+}
+
 // Operand re-majoring: dst[c][r] = src[r][c] for 1-byte elements (an MN-major FP8 operand -> the K-major form the
 // LDS-DMA kernels consume).  64 x 64 byte patches through LDS; both the global read (16 bytes along c per lane) and the
 // global write (16 bytes along r per lane) are coalesced 16-byte vectors.  HBM-bound: 2 bytes of traffic per element.

@@ -138,6 +138,15 @@ int dg_per_token_cast_to_fp8(const void* x_bf16, void* out_fp8, float* sf, int m
                              int64_t x_stride_m, int64_t out_stride_m, int64_t sf_stride_m, int64_t sf_stride_k,
                              int use_ue8m0, void* stream);
 
+/* Fused block quantisers, one pass: BF16 x [rows, cols] -> e4m3fn out [rows, cols] plus FP32 scales at
+ * sf[rb * sf_stride_r + c * sf_stride_c].  per_channel = 0: one scale per 128 x 128 block, sf [ceil(rows/128), ceil(cols/128)]
+ * (per_block_cast_to_fp8, deep_gemm/utils/math.py:51-61; operand B of the GEMMs); per_channel = 1: one scale per column per
+ * 128-row block, sf [ceil(rows/128), cols] (per_channel_cast_to_fp8, math.py:41-48; operands of the K-grouped GEMM).
+ * Scale arithmetic as dg_per_token_cast_to_fp8. */
+int dg_block_cast_to_fp8(const void* x_bf16, void* out_fp8, float* sf, int rows, int cols,
+                         int64_t x_stride_r, int64_t out_stride_r, int64_t sf_stride_r, int64_t sf_stride_c,
+                         int per_channel, int use_ue8m0, void* stream);
+
 /* Operand re-majoring for the fast path: dst[b][c][r] = src[b][r][c], 1-byte (FP8) elements, `rows` x `cols` per batch,
  * leading dimensions / batch strides in elements.  Turns an MN-major operand (the SM100 form of fp8_gemm_nn/tn/tt,
  * csrc/apis/gemm.hpp:126-164; UMMA descriptors consume it in place there) into the K-major form the LDS-DMA kernels

@@ -61,3 +61,45 @@ def test_fused_cast_feeds_gemm_without_transpose():
     dg.fp8_gemm_nt((a_q.cuda(), sfa.cuda()), b_q, d1)
     dg.fp8_gemm_nt(dg.fused_per_token_cast_to_fp8(a, sf_mn_major=True), b_q, d2)
     assert torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize('m,n', [(128, 128), (200, 300), (256, 384), (4096, 7168), (130, 1000), (5, 3)])
+@pytest.mark.parametrize('use_ue8m0', [False, True])
+def test_fused_per_block_cast_bit_exact(m, n, use_ue8m0):
+    from deepgemm_amd.utils import per_block_cast_to_fp8
+    torch.manual_seed(m + n)
+    x = torch.randn((m, n), device='cuda', dtype=torch.bfloat16) * 0.5
+    if m > 130:
+        x[128:, :min(n, 128)] = 0                                   # an all-zero block: the 1e-4 floor
+    want_q, want_sf = per_block_cast_to_fp8(x.cpu(), use_ue8m0=use_ue8m0)
+    q, sf = dg.fused_per_block_cast_to_fp8(x, use_ue8m0=use_ue8m0)
+    assert q.shape == want_q.shape and sf.shape == want_sf.shape
+    assert torch.equal(_bits(sf.cpu()), _bits(want_sf))
+    assert torch.equal(_bits(q.cpu()), _bits(want_q))
+
+
+@pytest.mark.parametrize('k,n', [(128, 96), (256, 96), (1024, 4096), (384, 1001), (128, 5)])
+@pytest.mark.parametrize('use_ue8m0', [False, True])
+def test_fused_per_channel_cast_bit_exact(k, n, use_ue8m0):
+    from deepgemm_amd.utils import per_channel_cast_to_fp8
+    torch.manual_seed(k + n)
+    x = torch.randn((k, n), device='cuda', dtype=torch.bfloat16)
+    x[:, 0] = 0
+    want_q, want_sf = per_channel_cast_to_fp8(x.cpu(), use_ue8m0=use_ue8m0)
+    q, sf = dg.fused_per_channel_cast_to_fp8(x, use_ue8m0=use_ue8m0)
+    assert q.shape == want_q.shape and sf.shape == want_sf.shape
+    assert torch.equal(_bits(sf.cpu()), _bits(want_sf))
+    assert torch.equal(_bits(q.cpu()), _bits(want_q))
+
+
+def test_fused_block_casts_reference_fixtures(golden_quantisers):
+    g = golden_quantisers
+    for name in ('blk_200x300', 'blk_256x384'):
+        x = g.bf16(f'{name}_x').cuda()
+        for ue in (False, True):
+            q, sf = dg.fused_per_block_cast_to_fp8(x, use_ue8m0=ue)
+            assert torch.equal(_bits(q.cpu()), _bits(g.fp8(f'{name}_ue{int(ue)}_q')))
+            assert torch.equal(_bits(sf.cpu()), _bits(g.raw(f'{name}_ue{int(ue)}_sf')))
+    x = g.bf16('chn_256x96_x').cuda()
+    q, sf = dg.fused_per_channel_cast_to_fp8(x)
+    assert torch.equal(_bits(q.cpu()), _bits(g.fp8('chn_256x96_q'))) and torch.equal(_bits(sf.cpu()), _bits(g.raw('chn_256x96_sf')))
