@@ -334,6 +334,18 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
             }
         } else {
             float* drow = reinterpret_cast<float*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+            if (full_n && p.d_vec_ok && p.accumulate && !zero_row) {
+                // reduce-add: all of the row's loads first, then the adds and stores -- one memory round trip per row
+                // instead of one per 16-byte vector (hipcc cannot hoist a load over the previous vector's store itself)
+                v4f old[NS];
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    old[ns] = *reinterpret_cast<const v4f*>(drow + d_col(p, n_lane + (ns >> 1) * 32 + (ns & 1) * 4));
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    *reinterpret_cast<v4f*>(drow + d_col(p, n_lane + (ns >> 1) * 32 + (ns & 1) * 4)) = acc[ms][ns] + old[ns];
+                continue;
+            }
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 v4f v = acc[ms][ns];
@@ -822,9 +834,10 @@ void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
 //   final[m][n] += (sfa[m][kb] * sfb[n][kb]) * partial_kb[m][n]
 //
 // Differences from the per-128-column form above:
-//   * the scale product is no longer one value per (lane, M-subtile) but one per accumulator element, so a step carries
-//     two packed multiplies (sfb pair x broadcast sfa) and two packed FMAs instead of four scalar FMAs: the same number
-//     of VALU issues per MFMA;
+//   * the scale product is no longer one value per (lane, M-subtile) but one per accumulator element: a step carries four
+//     multiplies (sfb x sfa) and four FMAs.  (First version: two packed multiplies + two packed FMAs, the same VALU issue
+//     count as the per-128 form -- but packed FP32 ops beside MFMAs are slower than two scalar ops each on this part:
+//     4.8 k cycles per K block against 4.0 k, kept as pipe_pcpk_256x256.)
 //   * both scale vectors of a K block travel with the block's stage as two extra 1 KiB LDS-DMA pieces (256 FP32 row
 //     scales of A, 256 of B: the MN-major SF layouts make each a contiguous run), so the loop holds no register-landing
 //     global loads at all; every wave picks its 8 + 16 values out of LDS at the top of the block.
@@ -882,7 +895,46 @@ __device__ __forceinline__ void promote_only_pc(v2f& c01, v2f& c23, v2f sb01, v2
             : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+// The same step with single-rate VALU: 4 products + 4 FMAs.  (v_pk_*_f32 beside MFMAs costs more than two scalar ops
+// each on this part -- MI355X_MICROARCH.md, "price of one filler beside MFMAs" -- so the packed form is the slower one.)
+__device__ __forceinline__ void mfma_promote_step_pc_scalar(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
+                                                            float (&c)[4], const v4f& sb, float sa, const v4f& part_old) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "v_mfma_f32_16x16x128_f8f6f4 %0, %9, %10, 0\n\t"
+        "v_mul_f32 %5, %11, %15\n\t"
+        "v_mul_f32 %6, %12, %15\n\t"
+        "v_mul_f32 %7, %13, %15\n\t"
+        "v_mul_f32 %8, %14, %15\n\t"
+        "v_fmac_f32 %1, %5, %16\n\t"
+        "v_fmac_f32 %2, %6, %17\n\t"
+        "v_fmac_f32 %3, %7, %18\n\t"
+        "v_fmac_f32 %4, %8, %19"
+        : "=&v"(part_new), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(rows_operand), "v"(cols_operand), "v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]), "v"(sa), "v"(part_old[0]),
+          "v"(part_old[1]), "v"(part_old[2]), "v"(part_old[3])
+        : "memory");
+}
+
+__device__ __forceinline__ void promote_only_pc_scalar(float (&c)[4], const v4f& sb, float sa, const v4f& part_old) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "s_nop 3\n\t"
+        "v_mul_f32 %4, %8, %12\n\t"
+        "v_mul_f32 %5, %9, %12\n\t"
+        "v_mul_f32 %6, %10, %12\n\t"
+        "v_mul_f32 %7, %11, %12\n\t"
+        "v_fmac_f32 %0, %4, %13\n\t"
+        "v_fmac_f32 %1, %5, %14\n\t"
+        "v_fmac_f32 %2, %6, %15\n\t"
+        "v_fmac_f32 %3, %7, %16"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]), "v"(sa), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]),
+          "v"(part_old[3])
+        : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false>
 __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
@@ -923,12 +975,17 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             break;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
 
-        v2f acc[MS][NS][2];
+        v2f acc[MS][NS][2];             // packed form
+        float accs[MS][NS][4];          // scalar form (the unused one is dead code)
         #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
             #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
+            for (int ns = 0; ns < NS; ++ns) {
                 acc[ms][ns][0] = acc[ms][ns][1] = v2f{0.f, 0.f};
+                #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    accs[ms][ns][r] = 0.f;
+            }
 
         if (t.m_end > t.m0) {
             const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
@@ -1024,7 +1081,10 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                     // i < DEPTH: the previous block's tail steps (last M-subtile) with the previous block's scales
                     const v4f& sb = (i >= DEPTH) ? sb4[jns] : sb_tail[jns];
                     const v2f sap = (i >= DEPTH) ? sa_pair[jms >> 1] : sa_tail;
-                    if ((jms & 1) == 0)         // which half of the pair is this M-subtile's row scale
+                    if constexpr (!PK)
+                        mfma_promote_step_pc_scalar(part[i & DEPTH], bf[ns], af[ms & 1], accs[jms][jns], sb,
+                                                    (i >= DEPTH) ? sa_pair[jms >> 1][jms & 1] : sa_tail[(MS - 1) & 1], po);
+                    else if ((jms & 1) == 0)         // which half of the pair is this M-subtile's row scale
                         mfma_promote_step_pc<0>(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], acc[jms][jns][1],
                                                 v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, sap, p01, p23);
                     else
@@ -1045,6 +1105,9 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             for (int i = 0; i < DEPTH; ++i) {
                 const int j = TOTAL - DEPTH + i;
                 const v4f& po = part[(TOTAL + i + 1) & DEPTH];
+                if constexpr (!PK)
+                    promote_only_pc_scalar(accs[j / NS][j % NS], sb_tail[j % NS], sa_tail[(MS - 1) & 1], po);
+                else
                 promote_only_pc<(MS - 1) & 1>(acc[j / NS][j % NS][0], acc[j / NS][j % NS][1],
                                               v2f{sb_tail[j % NS][0], sb_tail[j % NS][1]},
                                               v2f{sb_tail[j % NS][2], sb_tail[j % NS][3]}, sa_tail, v2f{po[0], po[1]},
@@ -1057,7 +1120,8 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
         for (int ms = 0; ms < MS; ++ms)
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
-                out[ms][ns] = v4f{acc[ms][ns][0][0], acc[ms][ns][0][1], acc[ms][ns][1][0], acc[ms][ns][1][1]};
+                out[ms][ns] = PK ? v4f{acc[ms][ns][0][0], acc[ms][ns][0][1], acc[ms][ns][1][0], acc[ms][ns][1][1]}
+                                 : v4f{accs[ms][ns][0], accs[ms][ns][1], accs[ms][ns][2], accs[ms][ns][3]};
         store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1069,10 +1133,10 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_pipe_pc_kernel(const GemmParams p) {
-    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD>(p);
+    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, PK>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -19,26 +19,34 @@ ap.add_argument('--configs', default='ring_256x256')
 ap.add_argument('--shape', default='4096x4096x7168')
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--sets', type=int, default=4)
+ap.add_argument('--per-col', action='store_true', help='recipe (1, 1, 128): per-row SFB, FP32 accumulate into D')
 args = ap.parse_args()
 m, n, k = (int(x) for x in args.shape.split('x'))
 cases = []
 for i in range(args.sets):
     gen.reset_seed(i)
-    c = gen.generate_normal(m, n, k)
+    c = gen.generate_normal(m, n, k, accumulate=args.per_col, out_dtype=torch.float if args.per_col else torch.bfloat16,
+                            per_token_b=args.per_col)
     c.a = (c.a[0], dg.get_mn_major_tma_aligned_tensor(c.a[1]))
+    if args.per_col:
+        c.b = (c.b[0], dg.get_mn_major_tma_aligned_tensor(c.b[1]))
     cases.append(c)
 dbg = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device='cuda')
 for cfg in args.configs.split(','):
     dg.set_forced_config(cfg)
     lib.dg_set_debug_buffer(dbg.data_ptr())
+    def call(cc):
+        if args.per_col:
+            dg.fp8_gemm_nt(cc.a, cc.b, cc.d, c=cc.d, recipe=(1, 1, 128))
+        else:
+            dg.fp8_gemm_nt(cc.a, cc.b, cc.d)
     for it in range(5):
-        dg.fp8_gemm_nt(cases[it % len(cases)].a, cases[it % len(cases)].b, cases[it % len(cases)].d)
+        call(cases[it % len(cases)])
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     start.record()
     for it in range(args.iters):
-        cc = cases[it % len(cases)]
-        dg.fp8_gemm_nt(cc.a, cc.b, cc.d)
+        call(cases[it % len(cases)])
     end.record()
     torch.cuda.synchronize()
     wall_us = start.elapsed_time(end) / args.iters * 1e3
