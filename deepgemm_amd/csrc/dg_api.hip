@@ -468,8 +468,59 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
     DG_CHECK(ab_layout == DG_KGROUPED_BLOCKS || ab_layout == DG_KGROUPED_COLUMNS);
     for (int g = 0; g < num_groups; ++g)
         DG_CHECK(ks_host[g] >= 0 && ks_host[g] % 128 == 0);
-    // One dense per-column-SFB launch per non-empty group on the caller's stream: every group is a full M x N output
-    // (hundreds of 256 x 256 tiles), so the launches fill the chip on their own and run back to back.
+    // One launch over all groups when the per-column-SFB LDS-DMA kernel applies: tile order is group-major and the hardware
+    // hands the next workgroup to whichever CU frees up, so groups of different K extents balance without per-group tails.
+    {
+        dg::GemmParams p{};
+        p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.sfa = sfa; p.sfb = sfb; p.d = d;
+        p.layout = nullptr;
+        p.m = m; p.n = n; p.num_groups = num_groups;
+        p.a_sk = 1; p.b_sk = 1;
+        p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+        p.d_sm = n; p.d_sg = static_cast<int64_t>(m) * n;
+        p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1; p.m_alignment = 0;
+        p.kg_blocks = ab_layout == DG_KGROUPED_BLOCKS ? 1 : 0;
+        int64_t sum_k = 0;
+        int k_min = 1 << 30;
+        for (int g = 0; g < num_groups && g <= dg::kMaxKGroups; ++g) {
+            if (g < dg::kMaxKGroups) p.kg_prefix[g] = static_cast<int>(sum_k);
+            sum_k += ks_host[g];
+            if (ks_host[g] > 0 && ks_host[g] < k_min) k_min = ks_host[g];
+        }
+        bool single = num_groups <= dg::kMaxKGroups && sum_k > 0 && sum_k < (1LL << 31) && m > 64 &&
+                      g_forced_config == "auto";
+        if (single) {
+            p.kg_prefix[num_groups] = static_cast<int>(sum_k);
+            // eligibility is that of a dense launch on the most constrained group (smallest row stride in the blocks form)
+            p.gemm_type = dg::kNormal;
+            p.k = k_min;
+            p.a_sm = p.kg_blocks ? k_min : a_stride_m; p.b_sn = p.kg_blocks ? k_min : b_stride_n;
+            single = per_col_eligible(p);
+            if (single && p.kg_blocks)
+                for (int g = 0; g < num_groups; ++g)
+                    single = single && (ks_host[g] % 16 == 0) && (static_cast<int64_t>(p.kg_prefix[g]) * m) % 16 == 0 &&
+                             (static_cast<int64_t>(p.kg_prefix[g]) * n) % 16 == 0;
+        }
+        if (single) {
+            p.gemm_type = dg::kKGrouped;
+            p.a_sm = a_stride_m; p.b_sn = b_stride_n;          // blocks form: the kernel takes k_g as the row stride
+            p.k = static_cast<int>(sum_k);
+            p.num_m_tiles = ceil_div(m, 256);
+            p.num_n_tiles = ceil_div(n, 256);
+            p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+            p.d_vec_ok = aligned16(p.d) && (p.d_sm * 4) % 16 == 0 && (p.d_sg * 4) % 16 == 0;
+            p.dbg = g_debug_buffer;
+            const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * num_groups;
+            if (grid > 0x7fffffffL)
+                return fail(__FILE__, __LINE__, "grid too large");
+            g_last_config = "pipe_pc_256x256";
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>), dim3(static_cast<unsigned>(grid)),
+                               dim3(512), 0, static_cast<hipStream_t>(stream), p);
+            DG_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
+    // Otherwise one dense per-column-SFB launch per non-empty group on the caller's stream.
     int64_t k_begin = 0;
     for (int g = 0; g < num_groups; ++g) {
         const int k = ks_host[g];

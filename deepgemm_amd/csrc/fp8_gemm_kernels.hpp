@@ -26,7 +26,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum GemmType : int { kNormal = 0, kContiguous = 1, kContiguousPsum = 2, kMasked = 3 };
+enum GemmType : int { kNormal = 0, kContiguous = 1, kContiguousPsum = 2, kMasked = 3, kKGrouped = 4 };
+constexpr int kMaxKGroups = 64;
 
 struct GemmParams {
     const uint8_t* a;
@@ -42,6 +43,11 @@ struct GemmParams {
     int64_t sfb_sg, sfb_sn, sfb_sk;
     int64_t d_sg, d_sm;
     int sfb_gran_n;                 // 128 or 1
+    // K-grouped launch (gemm_type kKGrouped, per-column-SFB kernel only): group g owns K range [kg_prefix[g], kg_prefix[g+1])
+    // and writes D[g]; kg_blocks != 0: the operands are the groups' K-major [m, k_g] / [n, k_g] matrices stored one after
+    // another (row stride k_g); 0: column ranges of one K-major matrix (row strides a_sm / b_sn).
+    int kg_blocks;
+    int kg_prefix[kMaxKGroups + 1];
     int head_lr, head_mid, head_right;  // epilogue column map of fp8_gemm_nt_skip_head_mid: D column of GEMM column n is
                                     // n + (n + head_right) / head_lr * head_mid (head_lr = left + right; 0 = identity)
     int d_dtype;                    // 0 bf16, 1 fp32
@@ -118,12 +124,18 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
         return t;
     }
     const int num_tiles = p.num_m_tiles * p.num_n_tiles;
+    int kgroup = 0;
+    if (p.gemm_type == kKGrouped) {                 // group-major tile order: every group is a full M x N output
+        kgroup = tile_id / num_tiles;
+        if (kgroup >= p.num_groups) { t.valid = false; return t; }
+        tile_id -= kgroup * num_tiles;
+    }
     if (tile_id >= num_tiles) { t.valid = false; return t; }
     int mt, nt;
     swizzled_tile(tile_id, num_tiles, p.num_m_tiles, p.num_n_tiles, p.group_m, mt, nt);
     t.m0 = mt * BM;
     t.n0 = nt * BN;
-    t.group = 0;
+    t.group = kgroup;
     t.m_end = p.m;
     t.zero_from = t.zero_to = t.m0 + BM;
     t.m_begin = t.m0;
@@ -953,13 +965,13 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128;
+    int num_kb = p.k / 128;                         // K-grouped launch: set per tile from the group's K extent
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
-    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
-    const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
-    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
+    int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
     const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
     // where this lane's scales sit inside a stage's scale block
     const int sa_lds_off = (wm * WM + (lane & 15)) * 4;                            // + ms * 64
@@ -974,6 +986,26 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
         if (!t.valid)
             break;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+        int64_t kg_a_off = 0, kg_b_off = 0, kg_sf_blocks = 0;      // K-grouped launch: where the group's operands start
+        int k_extent = p.k;
+        if (p.gemm_type == kKGrouped) {
+            const int k_begin = p.kg_prefix[t.group];
+            k_extent = p.kg_prefix[t.group + 1] - k_begin;
+            if (k_extent == 0)
+                continue;                                         // empty group: D[g] stays as it is
+            num_kb = k_extent / 128;
+            kg_sf_blocks = k_begin / 128;
+            if (p.kg_blocks) {
+                lda = ldb = k_extent;
+                a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
+                b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+                kg_a_off = static_cast<int64_t>(k_begin) * p.m;
+                kg_b_off = static_cast<int64_t>(k_begin) * p.n;
+            } else {
+                kg_a_off = kg_b_off = k_begin;
+            }
+        }
+        const int64_t bs_group = (p.gemm_type == kKGrouped) ? 0 : t.group;          // group index into B / SFB
 
         v2f acc[MS][NS][2];             // packed form
         float accs[MS][NS][4];          // scalar form (the unused one is dead code)
@@ -988,17 +1020,17 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             }
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + kg_a_off + static_cast<int64_t>(t.m0) * lda;
+            const uint8_t* b_base = p.b + bs_group * p.b_sg + kg_b_off + static_cast<int64_t>(t.n0) * ldb;
             const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
-                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+                                                                  (a_rows - 1) * lda + k_extent, 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
-                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+                                                                  (b_rows - 1) * ldb + k_extent, 0x00020000);
             // scale rows: MN-major (stride 1 along m / n), one K block = one contiguous run; lanes past the end of the
             // last run fall outside the descriptor and fetch zeros (rows / columns that are never stored)
-            const float* sfa_tile = p.sfa + ad_group * p.sfa_sg + t.m0;
-            const float* sfb_tile = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + t.n0;
+            const float* sfa_tile = p.sfa + ad_group * p.sfa_sg + kg_sf_blocks * p.sfa_sk + t.m0;
+            const float* sfb_tile = p.sfb + bs_group * p.sfb_sg + kg_sf_blocks * p.sfb_sk + t.n0;
             const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(sfa_tile), 0, (num_kb - 1) * sfa_kb_stride + (p.m - t.m0) * 4, 0x00020000);
             const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1122,7 +1154,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = PK ? v4f{acc[ms][ns][0][0], acc[ms][ns][0][1], acc[ms][ns][1][0], acc[ms][ns][1][1]}
                                  : v4f{accs[ms][ns][0], accs[ms][ns][1], accs[ms][ns][2], accs[ms][ns][3]};
-        store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        store_tile<MS, NS>(p, t, (p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
