@@ -465,7 +465,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
     if (m == 0 || n == 0 || num_groups == 0)
         return 0;
     DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr && ks_host != nullptr);
-    DG_CHECK(ab_layout == DG_KGROUPED_BLOCKS || ab_layout == DG_KGROUPED_COLUMNS);
+    DG_CHECK(ab_layout == DG_KGROUPED_BLOCKS || ab_layout == DG_KGROUPED_COLUMNS || ab_layout == DG_KGROUPED_ROWS);
     for (int g = 0; g < num_groups; ++g)
         DG_CHECK(ks_host[g] >= 0 && ks_host[g] % 128 == 0);
     // One launch over all groups when the per-column-SFB LDS-DMA kernel applies: tile order is group-major and the hardware
@@ -480,6 +480,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
         p.d_sm = n; p.d_sg = static_cast<int64_t>(m) * n;
         p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1; p.m_alignment = 0;
         p.kg_blocks = ab_layout == DG_KGROUPED_BLOCKS ? 1 : 0;
+        const bool mn_major = ab_layout == DG_KGROUPED_ROWS;
         int64_t sum_k = 0;
         int k_min = 1 << 30;
         for (int g = 0; g < num_groups && g <= dg::kMaxKGroups; ++g) {
@@ -489,6 +490,37 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
         }
         bool single = num_groups <= dg::kMaxKGroups && sum_k > 0 && sum_k < (1LL << 31) && m > 64 &&
                       g_forced_config == "auto";
+        if (mn_major) {
+            // MN-major operands [sum_k, m] / [sum_k, n] (row pitches a_stride_m / b_stride_n): only the single launch of the
+            // transpose-read kernel takes them; everything else needs the K-major forms (the host layer re-majors)
+            const bool ok = single && aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 &&
+                            a_stride_m >= m && b_stride_n >= n && a_stride_m <= (1 << 22) && b_stride_n <= (1 << 22) &&
+                            sum_k * a_stride_m < (1LL << 31) && sum_k * b_stride_n < (1LL << 31) &&
+                            sfa_stride_m == 1 && sfb_stride_n == 1 && aligned16(sfa) && aligned16(sfb) &&
+                            sfa_stride_k % 4 == 0 && sfb_stride_k % 4 == 0;
+            if (!ok) {
+                g_last_error = "DG_KGROUPED_ROWS needs 16-byte aligned MN-major operands, MN-major scales, m > 64, at most 64 "
+                               "groups and automatic kernel selection; re-major the operands and use DG_KGROUPED_COLUMNS";
+                return 3;
+            }
+            p.a_sm = 1; p.a_sk = a_stride_m; p.b_sn = 1; p.b_sk = b_stride_n;
+            p.kg_prefix[num_groups] = static_cast<int>(sum_k);
+            p.gemm_type = dg::kKGrouped;
+            p.k = static_cast<int>(sum_k);
+            p.num_m_tiles = ceil_div(m, 256);
+            p.num_n_tiles = ceil_div(n, 256);
+            p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+            p.d_vec_ok = aligned16(p.d) && (p.d_sm * 4) % 16 == 0 && (p.d_sg * 4) % 16 == 0;
+            p.dbg = g_debug_buffer;
+            const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * num_groups;
+            if (grid > 0x7fffffffL)
+                return fail(__FILE__, __LINE__, "grid too large");
+            g_last_config = "pipe_pc_mn_256x256";
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false, true>),
+                               dim3(static_cast<unsigned>(grid)), dim3(512), 0, static_cast<hipStream_t>(stream), p);
+            DG_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         if (single) {
             p.kg_prefix[num_groups] = static_cast<int>(sum_k);
             // eligibility is that of a dense launch on the most constrained group (smallest row stride in the blocks form)

@@ -244,10 +244,60 @@ __device__ __forceinline__ int d_col(const GemmParams& p, int n) {
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
-template <int MS, int NS, bool INTERLEAVED_ROWS = false, bool NT_STORE = false>
+// NATURAL_COLS: acc[ms][ns][r] belongs to column n_base + ns*16 + lg*4 + r (B rows in their natural order in the LDS
+// image: the MN-major operand path); only the FP32 vector path and the element-wise paths exist for it.
+template <int MS, int NS, bool INTERLEAVED_ROWS = false, bool NT_STORE = false, bool NATURAL_COLS = false>
 __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
                                            int m_base, int n_base) {
     const int lane = threadIdx.x & 63, lg = lane >> 4;
+    if constexpr (NATURAL_COLS) {
+        const bool full = n_base + NS * 16 <= p.n;
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
+            const bool compute_row = row >= t.m_begin && row < t.m_end;
+            const bool zero_row = row >= t.zero_from && row < t.zero_to;
+            if (!compute_row && !zero_row)
+                continue;
+            if (p.d_dtype != 0 && full && p.d_vec_ok) {
+                float* drow = reinterpret_cast<float*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+                v4f old[NS];
+                if (p.accumulate && !zero_row) {
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        old[ns] = *reinterpret_cast<const v4f*>(drow + d_col(p, n_base + ns * 16 + lg * 4));
+                }
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    v4f v = zero_row ? v4f{0.f, 0.f, 0.f, 0.f} : acc[ms][ns];
+                    if (p.accumulate && !zero_row) v += old[ns];
+                    *reinterpret_cast<v4f*>(drow + d_col(p, n_base + ns * 16 + lg * 4)) = v;
+                }
+                continue;
+            }
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = n_base + ns * 16 + lg * 4 + r;
+                    if (col >= p.n)
+                        continue;
+                    const int64_t off = d_group_off + static_cast<int64_t>(row) * p.d_sm + d_col(p, col);
+                    if (p.d_dtype == 0) {
+                        uint16_t* d16 = reinterpret_cast<uint16_t*>(p.d);
+                        float v = zero_row ? 0.f : round_bf16(acc[ms][ns][r]);
+                        if (p.accumulate && !zero_row)
+                            v = v + bf16_lo(static_cast<uint32_t>(d16[off]));
+                        d16[off] = static_cast<uint16_t>(pack_bf16(v, 0.f) & 0xffffu);
+                    } else {
+                        float* d32 = reinterpret_cast<float*>(p.d);
+                        const float v = zero_row ? 0.f : acc[ms][ns][r];
+                        d32[off] = (p.accumulate && !zero_row) ? d32[off] + v : v;
+                    }
+                }
+        }
+        return;
+    }
     const int n_lane = n_base + lg * 8;                     // + (ns >> 1) * 32 + (ns & 1) * 4 + r
     const bool full_n = (n_lane + (NS / 2 - 1) * 32 + 8 <= p.n) && (NS % 2 == 0);
 
@@ -946,7 +996,36 @@ __device__ __forceinline__ void promote_only_pc_scalar(float (&c)[4], const v4f&
         : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false>
+// gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; expcnt left at "no wait".
+constexpr int waitcnt_imm(int vmcnt, int lgkmcnt) {
+    return (vmcnt & 0xf) | (0x7 << 4) | ((lgkmcnt & 0xf) << 8) | (((vmcnt >> 4) & 0x3) << 14);
+}
+
+// Fragment of an MN-major operand tile ([128 k][256 mn bytes] in LDS, 16-byte chunk c of row k stored at chunk
+// c ^ f(k), f(k) = (k & 7) | ((k >> 4 & 1) << 3)) through the hardware transpose read: in a 16-lane group lanes 2r / 2r+1
+// address the two halves of row r of an [8 k][16 mn] block and lane c receives byte c of every row (probed:
+// tools/ubench/tr_b8_probe.hip).  Four reads give the lane the same 32 K slots a K-major fragment holds:
+// k = 16g .. 16g+15 and 64+16g .. 64+16g+15 (g = lane >> 4).  lane_base = (16g + (i >> 1)) * 256 + (i & 1) * 8 with
+// i = lane & 15; chunk_off = (c ^ ((i >> 1) | ((g & 1) << 3))) << 4 for the fragment's chunk c.
+__device__ __forceinline__ v8i load_fragment_tr(const uint8_t* tile, int lane_base, int chunk_off) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i q0, q1, q2, q3;
+    const int addr = static_cast<int>(reinterpret_cast<uintptr_t>(tile)) + lane_base + chunk_off;
+    asm volatile(
+        "ds_read_b64_tr_b8 %0, %4\n\t"
+        "ds_read_b64_tr_b8 %1, %4 offset:2048\n\t"
+        "ds_read_b64_tr_b8 %2, %4 offset:16384\n\t"
+        "ds_read_b64_tr_b8 %3, %4 offset:18432"
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+        : "v"(addr)
+        : "memory");
+    return v8i{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+}
+
+// MN = true: both FP8 operands are MN-major ([K][M] and [K][N], unit stride along m / n, row pitch a_sk / b_sk): the
+// operand form of the K-grouped TN GEMM.  LDS-DMA pieces are 4 k-rows x 256 bytes, fragments come through
+// load_fragment_tr, A and B rows keep their natural order (=> FP32 output only gets vector stores).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false, bool MN = false>
 __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
@@ -969,13 +1048,19 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
-    int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
-    int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
-    int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    int lda = static_cast<int>(MN ? p.a_sk : p.a_sm), ldb = static_cast<int>(MN ? p.b_sk : p.b_sn);
+    // MN: lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k); u = wave + 8q makes f lane-constant
+    const int mn_swz = ((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3);
+    const int mn_col = (((lane & 15) ^ mn_swz) << 4);
+    int a_voff = MN ? (lane >> 4) * lda + mn_col : (wave * 8 + piece_row) * lda + src_chunk * 16;
+    int b_voff = MN ? (lane >> 4) * ldb + mn_col : b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+    const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
+    const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
     const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
     // where this lane's scales sit inside a stage's scale block
     const int sa_lds_off = (wm * WM + (lane & 15)) * 4;                            // + ms * 64
-    const int sb_lds_off = 1024 + (wn * WN + (lane >> 4) * 8) * 4;                 // + (ns >> 1) * 128 + (ns & 1) * 16
+    const int sb_lds_off = MN ? 1024 + (wn * WN + (lane >> 4) * 4) * 4               // + ns * 64 (natural column order)
+                              : 1024 + (wn * WN + (lane >> 4) * 8) * 4;              // + (ns >> 1) * 128 + (ns & 1) * 16
     const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
 
@@ -995,7 +1080,10 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                 continue;                                         // empty group: D[g] stays as it is
             num_kb = k_extent / 128;
             kg_sf_blocks = k_begin / 128;
-            if (p.kg_blocks) {
+            if constexpr (MN) {
+                kg_a_off = static_cast<int64_t>(k_begin) * lda;
+                kg_b_off = static_cast<int64_t>(k_begin) * ldb;
+            } else if (p.kg_blocks) {
                 lda = ldb = k_extent;
                 a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
                 b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
@@ -1020,13 +1108,15 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             }
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + kg_a_off + static_cast<int64_t>(t.m0) * lda;
-            const uint8_t* b_base = p.b + bs_group * p.b_sg + kg_b_off + static_cast<int64_t>(t.n0) * ldb;
+            const uint8_t* a_base = p.a + ad_group * p.a_sg + kg_a_off + static_cast<int64_t>(t.m0) * (MN ? 1 : lda);
+            const uint8_t* b_base = p.b + bs_group * p.b_sg + kg_b_off + static_cast<int64_t>(t.n0) * (MN ? 1 : ldb);
             const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
-            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
-                                                                  (a_rows - 1) * lda + k_extent, 0x00020000);
-            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
-                                                                  (b_rows - 1) * ldb + k_extent, 0x00020000);
+            // MN: the descriptor ends with the last k-row's valid bytes; a lane past M (N) inside an earlier row reads the
+            // next row's head -- finite bytes that only reach rows / columns which are never stored
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(a_base), 0, MN ? (k_extent - 1) * lda + (p.m - t.m0) : (a_rows - 1) * lda + k_extent, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(b_base), 0, MN ? (k_extent - 1) * ldb + (p.n - t.n0) : (b_rows - 1) * ldb + k_extent, 0x00020000);
             // scale rows: MN-major (stride 1 along m / n), one K block = one contiguous run; lanes past the end of the
             // last run fall outside the descriptor and fetch zeros (rows / columns that are never stored)
             const float* sfa_tile = p.sfa + ad_group * p.sfa_sg + kg_sf_blocks * p.sfa_sk + t.m0;
@@ -1042,12 +1132,12 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                     const int unit = wave + NW * q;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(stage_base + unit * 1024), 16, a_voff,
-                        q * (NW * 8) * lda + kb * 128, 0, 0);
+                        MN ? (kb * 128 + 4 * unit) * lda : q * (NW * 8) * lda + kb * 128, 0, 0);
                 } else {
                     const int j = q - A_ITERS, unit = wave + NW * j;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(stage_base + A_BYTES + unit * 1024), 16,
-                        b_voff, b_row_perm<WN>(j * (NW * 8)) * ldb + kb * 128, 0, 0);
+                        b_voff, MN ? (kb * 128 + 4 * unit) * ldb : b_row_perm<WN>(j * (NW * 8)) * ldb + kb * 128, 0, 0);
                 }
             };
             // waves 0 and 1 carry the block's two scale pieces (lane l: 4 consecutive FP32 scales)
@@ -1090,14 +1180,32 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                                      *reinterpret_cast<const float*>(sc + sa_lds_off + (2 * h + 1) * 64)};
                 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
-                    sb4[ns] = *reinterpret_cast<const v4f*>(sc + sb_lds_off + (ns >> 1) * 128 + (ns & 1) * 16);
+                    sb4[ns] = *reinterpret_cast<const v4f*>(sc + sb_lds_off + (MN ? ns * 64 : (ns >> 1) * 128 + (ns & 1) * 16));
+                if constexpr (MN) {
+                    // the transpose reads below are asm with hand-placed lgkmcnt waits: hipcc's own LDS loads (the scales)
+                    // must be complete before the first of them is issued, or its wait counts would be off
+                    #pragma unroll
+                    for (int h = 0; h < MS / 2; ++h)
+                        asm volatile("" : "+v"(sa_pair[h]));
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        asm volatile("" : "+v"(sb4[ns]));
+                }
                 if (has_next)
                     issue_scale_piece(cur ^ 1, kb + 1);
 
-                const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
-                const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
-                bf[0] = load_fragment(b_tile, frag_off);
-                af[0] = load_fragment(a_tile, frag_off);
+                const uint8_t* a_tile = MN ? lds + cur * STAGE_BYTES : lds + cur * STAGE_BYTES + (wm * WM) * 128;
+                const uint8_t* b_tile = MN ? lds + cur * STAGE_BYTES + A_BYTES : lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
+                auto frag_a = [&](int ms) {
+                    if constexpr (MN) return load_fragment_tr(a_tile, tr_lane_base, ((wm * (WM / 16) + ms) ^ tr_swz) << 4);
+                    else return load_fragment(a_tile + ms * 2048, frag_off);
+                };
+                auto frag_b = [&](int ns) {
+                    if constexpr (MN) return load_fragment_tr(b_tile, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                    else return load_fragment(b_tile + ns * 2048, frag_off);
+                };
+                bf[0] = frag_b(0);
+                af[0] = frag_a(0);
 
                 #pragma unroll
                 for (int i = 0; i < TOTAL; ++i) {
@@ -1105,9 +1213,18 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                     const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
                     const int jms = j / NS, jns = j % NS;
                     if (ms == 0 && ns + 1 < NS)
-                        bf[ns + 1] = load_fragment(b_tile + (ns + 1) * 2048, frag_off);
+                        bf[ns + 1] = frag_b(ns + 1);
                     if (ns == 0 && ms + 1 < MS)
-                        af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
+                        af[(ms + 1) & 1] = frag_a(ms + 1);
+                    if constexpr (MN) {
+                        // everything but the reads just issued (4 per fragment) has landed: the operands of this step
+                        const int fresh = 4 * ((ms == 0 && ns + 1 < NS ? 1 : 0) + (ns == 0 && ms + 1 < MS ? 1 : 0));
+                        if (ms == 0 || ns == 0) {       // the steps that consume a fragment for the first time
+                            if (fresh == 8) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 8));
+                            else if (fresh == 4) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 4));
+                            else __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+                        }
+                    }
                     const v4f& po = part[(i + 1) & DEPTH];
                     const v2f p01 = v2f{po[0], po[1]}, p23 = v2f{po[2], po[3]};
                     // i < DEPTH: the previous block's tail steps (last M-subtile) with the previous block's scales
@@ -1154,7 +1271,8 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = PK ? v4f{acc[ms][ns][0][0], acc[ms][ns][0][1], acc[ms][ns][1][0], acc[ms][ns][1][1]}
                                  : v4f{accs[ms][ns][0], accs[ms][ns][1], accs[ms][ns][2], accs[ms][ns][3]};
-        store_tile<MS, NS>(p, t, (p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        store_tile<MS, NS, false, false, MN>(p, t, (p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg, out, t.m0 + wm * WM,
+                                             t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -1165,10 +1283,10 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false, bool MN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_pipe_pc_kernel(const GemmParams p) {
-    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, PK>(p);
+    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, PK, MN>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1559,11 +1677,6 @@ __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const 
             : "=&v"(l.q[0]), "=&v"(l.sb)
             : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
             : "memory");
-}
-
-// gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; expcnt left at "no wait".
-constexpr int waitcnt_imm(int vmcnt, int lgkmcnt) {
-    return (vmcnt & 0xf) | (0x7 << 4) | ((lgkmcnt & 0xf) << 8) | (((vmcnt >> 4) & 0x3) << 14);
 }
 
 // The wait goes through the builtin so that hipcc's own waitcnt pass sees the LDS counter drained and does not re-wait

@@ -272,7 +272,7 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
 # K-grouped contiguous GEMM (MoE weight gradients): d[g] = c[g] + A_g^T-ish products over group g's K range, FP32.
 # Reference: csrc/apis/gemm.hpp:299-400 (operators), :48-69 (argument checks), tests/generators.py:436-477 (layouts).
 # ---------------------------------------------------------------------------------------------------------------------
-_KGROUPED_BLOCKS, _KGROUPED_COLUMNS = 0, 1
+_KGROUPED_BLOCKS, _KGROUPED_COLUMNS, _KGROUPED_ROWS = 0, 1, 2
 
 
 def _check_k_grouped_args(ks, grouped_layout: torch.Tensor, num_groups: int, use_psum_layout: bool, k_alignment: int) -> int:
@@ -356,6 +356,13 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
         return
     host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
     sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
+    from . import runtime as _rt
+    native = (m > 64 and m % 16 == 0 and n % 16 == 0 and num_groups <= 64 and a_data.data_ptr() % 16 == 0 and
+              b_data.data_ptr() % 16 == 0 and sum_k * max(m, n) < 2 ** 31 and _rt.last_forced_config() == 'auto')
+    if native:
+        # MN-major operands straight into the kernel: LDS-DMA of [k][m] rows, hardware transpose reads for the fragments
+        _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0))
+        return
     a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))       # [M, sum_k], [N, sum_k]: K-major
     _k_grouped_launch(a_km, sfa, b_km, sfb, d, m, n, ks, _KGROUPED_COLUMNS, a_km.stride(0), b_km.stride(0))
 

@@ -83,11 +83,16 @@ int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_
  *     offset m * sum(ks[:g]) (resp. n * ...): the reference's SM90 NT operand form; a_stride_m / b_stride_n are ignored.
  *   ab_layout DG_KGROUPED_COLUMNS: a is one K-major [m, sum_k] matrix with row stride a_stride_m (b: [n, sum_k], b_stride_n)
  *     and group g is a column range: what an MN-major [sum_k, m] operand (TN form) becomes after dg_transpose_fp8.
+ *   ab_layout DG_KGROUPED_ROWS: the MN-major operands themselves, a [sum_k, m] with row pitch a_stride_m (b: [sum_k, n],
+ *     b_stride_n), group g = a row range: the TN form without a re-majoring pass (hardware transpose reads out of LDS).
+ *     Needs 16-byte aligned rows, MN-major scales, m > 64, at most 64 groups; otherwise returns non-zero and the caller
+ *     re-majors (dg_transpose_fp8) and uses DG_KGROUPED_COLUMNS.
  *   sfa element (row, kb) at sfa[row * sfa_stride_m + kb * sfa_stride_k], kb counted over the whole K axis; same for sfb
  *   (one scale per row of B per 128-K block: recipe (1, 1, 128)).
  *   d [num_groups, m, n] FP32, dense; the result is accumulated onto it (the caller copies C into D first). */
 #define DG_KGROUPED_BLOCKS 0
 #define DG_KGROUPED_COLUMNS 1
+#define DG_KGROUPED_ROWS 2
 int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, float* d,
                                         int m, int n, const int32_t* ks_host, int num_groups, int ab_layout,
                                         int64_t a_stride_m, int64_t b_stride_n,

@@ -428,7 +428,7 @@ def test_packed_ue8m0_scales_hw_path(m, n, k):
 
 
 @pytest.mark.parametrize('k_major', [True, False])
-@pytest.mark.parametrize('num_groups,m,n,ks', [(3, 256, 384, [256, 0, 512]), (2, 200, 264, [128, 384]),
+@pytest.mark.parametrize('num_groups,m,n,ks', [(3, 256, 384, [256, 0, 512]), (2, 200, 264, [128, 384]), (2, 304, 272, [256, 384]),
                                                (4, 512, 1024, [1024, 896, 1152, 768])])
 def test_k_grouped_contiguous(k_major, num_groups, m, n, ks):
     """k_grouped_fp8_gemm_{nt,tn}_contiguous (csrc/apis/gemm.hpp:299-400; reference test: tests/test_fp8_fp4.py:193-215):
@@ -439,6 +439,9 @@ def test_k_grouped_contiguous(k_major, num_groups, m, n, ks):
     c_before = case.c.clone()
     fn(case.a, case.b, case.d, ks, case.grouped_layout, c=case.c)
     assert torch.equal(case.c, c_before)                       # c is a different buffer here: read, never written
+    if m > 64 and m % 16 == 0 and n % 16 == 0:
+        # one launch over all groups; MN-major operands go in as they are (hardware transpose reads), no re-majoring pass
+        assert dg.last_config() == ('pipe_pc_256x256' if k_major else 'pipe_pc_mn_256x256')
     for g, k in enumerate(ks):
         if k == 0:
             assert torch.equal(case.d[g], case.c[g])
