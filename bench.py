@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument('--workload', default='dense', choices=['dense', 'contiguous', 'masked'])
     ap.add_argument('--config', default='auto', help='force a kernel configuration (tuning)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--clock-warmup-s', type=float, default=1.0, help='untimed load before the warm-up steps (seconds)')
     ap.add_argument('--sets', type=int, default=4, help='rotating input sets (defeats Infinity-Cache residency)')
     return ap.parse_args()
 
@@ -169,10 +170,22 @@ def main():
     dg.set_forced_config(args.config)
     calls, flops, nbytes, desc, check = make_workload(args.workload, args.sets, world, rank)
 
+    calls[0]()
+    torch.cuda.synchronize()
+    diff = check()                          # parity vs the reference test expression, before anything is timed
+    # Untimed clock warm-up, then the W untimed warm-up steps, then -- without an idle gap in between -- the K timed
+    # steps: the chip needs a few hundred milliseconds of load to reach its sustained clock / power state, and a result
+    # check between warm-up and timing would let it fall back to idle.
+    t_warm = time.perf_counter() + args.clock_warmup_s
+    i = 0
+    while time.perf_counter() < t_warm:
+        for _ in range(16):
+            calls[i % len(calls)]()
+            i += 1
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         calls[i % len(calls)]()
     torch.cuda.synchronize()
-    diff = check()
 
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if distributed:

@@ -127,9 +127,11 @@ const Config kConfigs[] = {
     {"dabl18_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 18>, true},
     {"dabl19_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 19>, true},
     {"dabl21_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 21>, true},
-    {"duo_fix_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_fixland_kernel<256, 256, 2, 4, 22>, true, true},
     {"pipe_pcpk_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>, true, false,
      false, true},      // A/B: packed-FP32 promotion (4.8 k cycles per K block against 4.0 k with scalar VALU)
+    {"duo_pprio_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 26>, true, true, true},
+    {"duo_prio_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 28>, true},
+    {"duo_load_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 29>, true},
     {"e8_ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };

@@ -1692,37 +1692,6 @@ __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
         asm volatile("" : "+v"(l.q[0]), "+v"(l.sb) :: "memory");
 }
 
-// Fixed landing registers (kernels compiled with amdgpu_num_vgpr(246); tuples must be even-aligned): v246..v253 = a lane's 8 row scales, v254 = SFB.
-// hipcc never allocates them, so a scale load may stay in flight across the loop back-edge -- with compiler-allocated
-// destinations it may not (hipcc copies them at control-flow joins before the data has landed) -- and the wait moves from
-// the end of L_b to the top of the next block's L_a: one more segment of lead for a load that misses L2 once per K block.
-__device__ __forceinline__ void issue_scale_loads_fixed(const v4i& sfa_rsrc, int sfa_voff, const v4i& sfb_rsrc, int sfb_voff) {
-    asm volatile(
-        "buffer_load_dwordx4 v[246:249], %0, %1, 0 offen\n\t"
-        "buffer_load_dwordx4 v[250:253], %0, %1, 0 offen offset:16\n\t"
-        "buffer_load_dword v254, %2, %3, 0 offen"
-        :: "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
-        : "memory", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254");
-}
-
-// scale[ms] = SFA(ms) * SFB out of the fixed landing registers, after "at most ALLOWED newer vector-memory operations".
-template <int ALLOWED>
-__device__ __forceinline__ void take_scales_fixed(float (&scale)[8]) {
-    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 15));
-    asm volatile(
-        "v_mul_f32 %0, v246, v254\n\t"
-        "v_mul_f32 %1, v247, v254\n\t"
-        "v_mul_f32 %2, v248, v254\n\t"
-        "v_mul_f32 %3, v249, v254\n\t"
-        "v_mul_f32 %4, v250, v254\n\t"
-        "v_mul_f32 %5, v251, v254\n\t"
-        "v_mul_f32 %6, v252, v254\n\t"
-        "v_mul_f32 %7, v253, v254"
-        : "=v"(scale[0]), "=v"(scale[1]), "=v"(scale[2]), "=v"(scale[3]), "=v"(scale[4]), "=v"(scale[5]), "=v"(scale[6]),
-          "=v"(scale[7])
-        :: "memory");
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -1739,10 +1708,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_EARLY = (DABL == 9) ? 0 : (DABL == 17 ? A_ITERS : (DABL == 18 ? A_ITERS * 3 / 4 : A_ITERS / 2));        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
-    constexpr bool PERSIST = (DABL == 20);      // persistent launch with cross-tile prologue prefetch
-    constexpr bool FIXLAND = (DABL == 22);      // scale landing in v246..v254 (kernel built with amdgpu_num_vgpr(246))
-    static_assert(!FIXLAND || MS == 8, "fixed landing registers are laid out for 8 row scales");
-    constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3), LOADPRIO = (DABL == 8 || DABL == 11);
+    constexpr bool PERSIST = (DABL == 20 || DABL == 26);      // persistent launch with cross-tile prologue prefetch
+    constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3 && DABL != 24 && DABL != 26 && DABL != 28),
+                   LOADPRIO = (DABL == 8 || DABL == 11 || DABL == 25 || DABL == 29);
     constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
@@ -1850,10 +1818,6 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // groups is walked twice.
     int tile_id = blockIdx.x, pass = 0;
     bool prefetched = false, first_tile = true;
-    float scale_pref[MS];                        // scales of a prefetched tile's K block 0 (products, ready to use)
-    #pragma unroll
-    for (int ms = 0; ms < MS; ++ms)
-        scale_pref[ms] = 0.f;
     Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
     while (t.valid) {
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
@@ -1875,10 +1839,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 const TileMem tmn = tile_mem(tn);
                 issue_prologue(tn);
                 issue_scale_loads_v<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff, scale_rsrc(tmn.sfb_addr, sfb_extent), 0);
-                wait_landing_v<0, MS>(land);
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    scale_pref[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                wait_landing_v<0, MS>(land);        // the landed values stay in `land` until the next tile's L_a(0) consumes them
                 next_prefetched = true;
             }
         };
@@ -1918,16 +1879,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // microsecond once per tile.  (Straight-line from the scale loads to their wait: hipcc may copy the landing
                 // registers at any control-flow join in between.)
                 issue_prologue(t);
-                if constexpr (FIXLAND) {
-                    issue_scale_loads_fixed(sfa_rsrc, sfa_voff, sfb_rsrc, 0);
-                    if constexpr (MS == 8) take_scales_fixed<0>(scale_pref);
-                } else {
-                    issue_scales(land, 0);
-                    wait_landing_v<0, MS>(land);
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
-                        scale_pref[ms] = land.q[ms / 4][ms % 4] * land.sb;
-                }
+                issue_scales(land, 0);
+                wait_landing_v<0, MS>(land);
             }
             raw_barrier();
             if (DABL != 1 && upper_half)
@@ -1967,26 +1920,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 [[maybe_unused]] long long t_in[3];
                 if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[0]) :: "memory");
                 scale_tail = scale[MS - 1];
-                if constexpr (FIXLAND) {
-                    if (kb == 0) {
-                        #pragma unroll
-                        for (int ms = 0; ms < MS; ++ms)
-                            scale[ms] = scale_pref[ms];
-                    } else {
-                        // the scales of this block were requested a whole block ago; newer: the 8 pieces of block kb+1
-                        if constexpr (MS == 8) take_scales_fixed<A_ITERS + B_ITERS>(scale);
-                    }
-                    const int jj = imin(kb + 1, num_kb - 1);
-                    issue_scale_loads_fixed(sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
-                } else {
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms) {
-                        scale[ms] = kb == 0 ? scale_pref[ms] : land.q[ms / 4][ms % 4] * land.sb;
-                        pin_vgpr(scale[ms]);
-                    }
+                // block kb's scales landed before the previous L_b's wait (block 0: before the prologue's / the prefetch's)
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                    pin_vgpr(scale[ms]);
                 }
                 if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[1]) :: "memory");
-                if (!NO_SCALES && !FIXLAND) issue_scales(land, kb + 1);
+                if (!NO_SCALES) issue_scales(land, kb + 1);
                 if (!NO_DMA) {
                     #pragma unroll
                     for (int q = 0; q < A_EARLY; ++q)
@@ -2040,10 +1981,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
                 // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
                 // "every load but the newest 8 has landed".)
-                if constexpr (FIXLAND)      // newer than block kb+1's pieces: the scale loads of kb+1 (3) and the pieces of kb+2
-                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(A_ITERS + B_ITERS + 3, 0));
-                else
-                    wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
+                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
                 #pragma unroll
                 for (int h = 0; h < HS; ++h)
                     asm volatile("" : "+v"(af[h]) :: "memory");
@@ -2118,12 +2056,6 @@ void dg_fp8_gemm_duo_kernel(const GemmParams p) {
     duo_kernel_body<BM, BN, WAVES_M, WAVES_N, DABL>(p);
 }
 
-// The same body with v246..v255 withheld from hipcc: the scale landing registers of the FIXLAND schedule.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_num_vgpr(246)))
-void dg_fp8_gemm_duo_fixland_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, DABL>(p);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stream kernel: the HBM-bound end of the path (masked / decode-sized M, small dense M).  A 64 x 128 tile per
