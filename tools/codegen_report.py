@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Static look at what hipcc made of every GEMM kernel in libdeepgemm_amd.so: VGPR / spill counts from the code-object notes
+and, from the disassembly, the number of scratch (spill) instructions between the first and the last MFMA of the kernel --
+the K loop.  A spill inside the K loop costs far more than its instruction: scratch traffic counts towards vmcnt and
+tightens every counted wait.  Used by tests/test_codegen.py.   python tools/codegen_report.py [--json]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'deepgemm_amd', 'csrc', 'libdeepgemm_amd.so')
+LLVM = '/opt/rocm/lib/llvm/bin'
+
+
+def report():
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, 'lib.so')
+        with open(LIB, 'rb') as src, open(local, 'wb') as dst:
+            dst.write(src.read())
+        subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '--offloading', local], cwd=tmp, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        device = [f for f in os.listdir(tmp) if 'amdgcn' in f]
+        assert device, 'no device code object found in the library'
+        obj = os.path.join(tmp, device[0])
+        notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', obj], check=True, capture_output=True, text=True).stdout
+        asm = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', obj], check=True, capture_output=True, text=True).stdout
+    meta = {}
+    name = None
+    for line in notes.splitlines():
+        m = re.search(r'\.name:\s+(\S+)', line)
+        if m:
+            name = m.group(1)
+            meta[name] = {}
+        for key in ('vgpr_count', 'vgpr_spill_count', 'sgpr_spill_count'):
+            m = re.search(r'\.%s:\s+(\d+)' % key, line)
+            if m and name:
+                meta[name][key] = int(m.group(1))
+    kernels = {}
+    cur = None
+    for line in asm.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(\S+)>:', line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        if cur is not None and line.strip():
+            kernels[cur].append(line.split('//')[0].strip())
+    out = []
+    for name, body in kernels.items():
+        if name not in meta or 'gemm' not in name:
+            continue
+        mfma = [i for i, ins in enumerate(body) if ins.startswith('v_mfma')]
+        loop = body[mfma[0]:mfma[-1] + 1] if mfma else []
+        # readable name without a demangler: _ZN2dg22dg_fp8_gemm_duo_kernelILi256ELi256ELi2ELi4ELi0EEEvNS_10GemmParamsE
+        m = re.match(r'_ZN2dg\d+(\w+?)(?:I(.*?)EEv|Ev)', name)
+        pretty = name if not m else m.group(1) + ('<' + ','.join(re.findall(r'L[ib](\d+)E', m.group(2))) + '>' if m.group(2) else '')
+        out.append({'kernel': pretty, 'symbol': name, **meta[name],
+                    'mfma_range_instructions': len(loop),
+                    'scratch_in_mfma_range': sum(1 for ins in loop if ins.startswith('scratch_')),
+                    'lane_ops_in_mfma_range': sum(1 for ins in loop if ins.startswith(('v_readlane', 'v_writelane')))})
+    return out
+
+
+if __name__ == '__main__':
+    rows = report()
+    if '--json' in sys.argv:
+        print(json.dumps(rows))
+    else:
+        for r in sorted(rows, key=lambda r: r['kernel']):
+            print(f"{r['kernel'][:78]:78s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} "
+                  f"range {r['mfma_range_instructions']:5d} scratch-in-range {r['scratch_in_mfma_range']:3d} "
+                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d}")
