@@ -1705,7 +1705,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // does not idle for the barrier round trip.  (The barrier in front of a load segment only orders LDS traffic, which the
     // trailing register-only steps do not touch.)
     constexpr int EB = (DABL == 14) ? 2 : (DABL == 15 ? 4 : (DABL == 16 ? 1 : 0));
-    constexpr int A_EARLY = (DABL == 9) ? 0 : (DABL == 17 ? A_ITERS : (DABL == 18 ? A_ITERS * 3 / 4 : A_ITERS / 2));        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
+    constexpr int A_EARLY = (DABL == 9) ? 0 : (DABL == 17 ? A_ITERS : (DABL == 18 ? A_ITERS * 3 / 4 : A_ITERS / 2));
+    // MP (experiment): this many LDS-DMA pieces per matrix segment ride between its MFMA steps (A pieces in M_a, B pieces in
+    // M_b) instead of in L_b, the longest load segment
+    constexpr int MP = (DABL == 30) ? 1 : (DABL == 31 ? 2 : 0);
+    static_assert(MP == 0 || (A_ITERS - A_EARLY >= MP && B_ITERS >= MP && SEG >= 12), "pieces to move");        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
     constexpr bool PERSIST = (DABL == 20 || DABL == 26);      // persistent launch with cross-tile prologue prefetch
@@ -1956,6 +1960,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
                     if (EB > 0 && i == SEG - EB) raw_barrier();
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                    if (MP > 0 && (i == 3 || (MP > 1 && i == 9)))
+                        issue_a_piece(a_fill, kb + 2, A_EARLY + (i == 3 ? 0 : 1));
                 }
                 if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
                 if (LOADPRIO) __builtin_amdgcn_s_setprio(1);
@@ -1971,17 +1977,17 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 }
                 if (!NO_DMA) {
                     #pragma unroll
-                    for (int q = A_EARLY; q < A_ITERS; ++q)
+                    for (int q = A_EARLY + MP; q < A_ITERS; ++q)
                         issue_a_piece(a_fill, kb + 2, q);
                     #pragma unroll
-                    for (int q = 0; q < B_ITERS; ++q)
+                    for (int q = 0; q < B_ITERS - MP; ++q)
                         issue_b_piece(b_cur, kb + 2, q);
                 }
                 // Block kb+1 and its scales: my pieces have landed.  (Persistent launch: a predecessor tile's output stores may
                 // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
                 // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
                 // "every load but the newest 8 has landed".)
-                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS), MS>(land);
+                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS - MP), MS>(land);       // MP pieces of this block come in M_b
                 #pragma unroll
                 for (int h = 0; h < HS; ++h)
                     asm volatile("" : "+v"(af[h]) :: "memory");
@@ -1999,6 +2005,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     const int j = i - DEPTH;
                     if (EB > 0 && i2 == SEG - EB) raw_barrier();      // the next K block's L_a barrier
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
+                    if (MP > 0 && (i2 == 3 || (MP > 1 && i2 == 9)))
+                        issue_b_piece(b_cur, kb + 2, B_ITERS - MP + (i2 == 3 ? 0 : 1));
                 }
                 if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
                 if (LOADPRIO) __builtin_amdgcn_s_setprio(1);
