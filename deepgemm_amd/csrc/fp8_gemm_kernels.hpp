@@ -2608,6 +2608,9 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 for (int h = 0; h < HS; ++h)
                     af[h] = load_fragment(a_tile + h * 2048, frag_off);
                 take_scales(kb);                    // the words landed before the previous L_b's wait (or the prologue's)
+                // (A packed word covers four K blocks, so three of four of these fetches are redundant -- but issuing them
+                // conditionally puts a control-flow join between the asm loads and their wait, where hipcc copies the landing
+                // registers before the data is there: tried, wrong results.  It would take a 4x unrolled block body.)
                 issue_scales(kb + 1);
                 #pragma unroll
                 for (int q = 0; q < A_EARLY; ++q)
