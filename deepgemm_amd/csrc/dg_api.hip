@@ -180,16 +180,18 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     // kernels.  A CU sustains only ~25 GB/s of HBM stream (bytes in flight / latency), so the tile count has to cover
     // the chip: 64 x 128 tiles when there are enough of them, 64 x 32 otherwise (measured: tools/ref_shapes.py).
     const int m_hint = expected_m > 0 ? expected_m : m_for_tiling;
-    if (fast_ok && p.sfa_sm == 1 && m_hint <= 256 && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum) {
+    if (fast_ok && p.sfa_sm == 1 && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum) {
         const int groups = (p.gemm_type == dg::kMasked) ? p.num_groups : 1;
         const long tiles128 = static_cast<long>(groups) * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
         const char* pick = nullptr;
         if (m_hint <= 64)
             pick = tiles128 >= 96 ? "stream_64x128" : "stream_64x32";
-        else if (tiles128 < 96)
+        else if (m_hint <= 256 && tiles128 < 96)
             pick = "stream_64x32";
-        else if (tiles128 < 256)
+        else if (m_hint <= 256 && tiles128 < 256)
             pick = "stream_64x128";
+        else if (m_hint > 256 && tiles128 <= num_cus())
+            pick = "stream_64x128";     // one resident round of 64 x 128 tiles (512 x 4096 x 7168: 36.9 us against 47.3 on 128 x 256 tiles)
         if (pick != nullptr)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)
