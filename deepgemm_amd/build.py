@@ -13,6 +13,10 @@ SOURCES = ['dg_api.hip']
 HEADERS = ['fp8_gemm_kernels.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
+# DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that DESIGN.md section 5 quotes (tools/cycles.py,
+# tools/sustained.py, tools/trace*.py take their names); they roughly triple the compile time and are never selected.
+if os.environ.get('DG_EXPERIMENTS', '') not in ('', '0'):
+    FLAGS.append('-DDG_EXPERIMENTS')
 
 
 def is_stale() -> bool:

@@ -93,6 +93,7 @@ const Config kConfigs[] = {
     {"pipe_s0_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
     {"pipe_s1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 1>},
     {"pipe_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 3>},
+#ifdef DG_EXPERIMENTS   // timing ablations and rejected variants: DG_EXPERIMENTS=1 python __graft_entry__.py
     {"abl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 1>},
     {"abl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 2>},
     {"abl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 3>},
@@ -134,6 +135,7 @@ const Config kConfigs[] = {
     {"duo_load_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 29>, true},
     {"dabl30_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 30>, true},
     {"dabl31_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 31>, true},
+#endif
     {"e8_ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };

@@ -11,7 +11,7 @@ import deepgemm_amd as dg                                              # noqa: E
 from deepgemm_amd._lib import lib                                       # noqa: E402
 from deepgemm_amd.testing import generators as gen                      # noqa: E402
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else 'rabl5_256x256'
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'rabl5_256x256'     # needs a DG_EXPERIMENTS=1 build
 m, n, k = 4096, 4096, 7168
 gen.reset_seed(0)
 c = gen.generate_normal(m, n, k)
