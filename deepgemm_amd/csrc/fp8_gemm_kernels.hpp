@@ -1792,13 +1792,13 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-            imin(j, num_kb - 1) * 128, 0, 0);
+            (DABL == 32 ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);       // DABL 32 (timing): every piece re-reads K block 0 (L2 resident)
     };
     auto issue_b_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
-            b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+            b_piece_voff[q], (DABL == 32 ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
     };
     // Prologue pieces of a tile: A(0) B(0) A(1) B(1) into ring slots 0 / 1.  Issued at kernel entry for the first tile
     // and, in the persistent launch, for tile i+1 as soon as tile i's K loop has released the LDS -- i.e. BEFORE tile i's
