@@ -87,6 +87,8 @@ const Config kConfigs[] = {
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 12>, true},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>, true, false,
      false, true},
+    {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false, true>, true,
+     false, false, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
     // experimental / baseline variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of
     // the heuristic): LDS-DMA piece placement variants and the hipcc-scheduled first version of the fast path.
@@ -162,6 +164,16 @@ bool per_col_eligible(const dg::GemmParams& p) {
            aligned16(p.sfa) && aligned16(p.sfb) && p.sfa_sk % 4 == 0 && p.sfb_sk % 4 == 0;
 }
 
+// The same recipe with BOTH operands MN-major ([K][M] and [K][N], unit stride along m / n): the transpose-read form of the
+// kernel takes them as they are (dense TN wgrad GEMMs, the TN form of the K-grouped GEMM).
+bool per_col_mn_eligible(const dg::GemmParams& p) {
+    return p.sfb_gran_n == 1 && p.gemm_type == dg::kNormal && p.a_sm == 1 && p.b_sn == 1 && p.k % 128 == 0 &&
+           aligned16(p.a) && aligned16(p.b) && p.a_sk % 16 == 0 && p.b_sk % 16 == 0 && p.a_sk <= (1 << 22) &&
+           p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.a_sk < (1LL << 31) &&
+           static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31) && p.sfa_sm == 1 && p.sfb_sn == 1 && aligned16(p.sfa) &&
+           aligned16(p.sfb) && p.sfa_sk % 4 == 0 && p.sfb_sk % 4 == 0;
+}
+
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
@@ -173,7 +185,8 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         return nullptr;
     }
     if (p.sfb_gran_n == 1) {
-        const char* pick = per_col_eligible(p) && p.m > 64 ? "pipe_pc_256x256" : "generic_128x128";
+        const char* pick = per_col_eligible(p) && p.m > 64 ? "pipe_pc_256x256"
+                         : (per_col_mn_eligible(p) && p.m > 64 ? "pipe_pc_mn_256x256" : "generic_128x128");
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, pick) == 0)
                 return &kConfigs[i];
@@ -249,11 +262,12 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = "no kernel configuration available (forced config '" + g_forced_config + "')";
         return 3;
     }
-    if (cfg->fast && (cfg->per_col ? !per_col_eligible(p) : p.sfb_gran_n != 128)) {
+    const bool mn_form = std::strcmp(cfg->name, "pipe_pc_mn_256x256") == 0;
+    if (cfg->fast && (mn_form ? !per_col_mn_eligible(p) : (cfg->per_col ? !per_col_eligible(p) : p.sfb_gran_n != 128))) {
         g_last_error = std::string("forced config '") + cfg->name + "' does not implement this scaling recipe / SF layout";
         return 3;
     }
-    if (cfg->fast && !fast_eligible(p)) {
+    if (cfg->fast && !mn_form && !fast_eligible(p)) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major 16-byte aligned operands and k % 128 == 0";
         return 3;
     }

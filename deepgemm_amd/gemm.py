@@ -40,6 +40,11 @@ def _as_k_major(t: torch.Tensor, macs: int) -> torch.Tensor:
     return _remajor(t)
 
 
+def _both_mn_major_aligned(a: torch.Tensor, b: torch.Tensor, m: int, n: int) -> bool:
+    return (a.stride(-2) == 1 and b.stride(-2) == 1 and m > 64 and m % 16 == 0 and n % 16 == 0 and
+            a.stride(-1) % 16 == 0 and b.stride(-1) % 16 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
 def _remajor(t: torch.Tensor) -> torch.Tensor:
     """An MN-major FP8 operand view ``[.., mn, k]`` (stride 1 along mn) as a fresh K-major tensor (dg_transpose_fp8)."""
     require_device(t)
@@ -139,7 +144,8 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
         if c is not None and not same_cd:
             d.copy_(c)
         sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
-        a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
+        if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
+            a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
         check(lib.dg_fp8_gemm_nt(
             a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), m, n, k,
             a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
@@ -160,7 +166,9 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     require_device(a_data, b_data, sfa, sfb, d)
     if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
         _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf)
-    a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
+    if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
+        # (recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are, no re-majoring pass)
+        a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
     check(lib.dg_fp8_gemm_nt(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),

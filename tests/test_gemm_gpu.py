@@ -167,6 +167,26 @@ def test_per_column_sfb_fast_kernel(m, n, k, out_dtype, accumulate):
     assert torch.equal(d2, case.d)
 
 
+@pytest.mark.parametrize('m,n,k', [(256, 256, 256), (304, 528, 896), (1024, 768, 2048)])
+def test_per_column_sfb_mn_major_operands(m, n, k):
+    """fp8_gemm_tn with recipe (1, 1, 128) (dense wgrad in the TN form): both operands MN-major go into the kernel as they
+    are (LDS-DMA of k-rows + hardware transpose reads), same result as the K-major form."""
+    gen.reset_seed(m + n + k + 1)
+    case = gen.generate_normal(m, n, k, a_k_major=False, b_k_major=False, accumulate=True, out_dtype=torch.float, per_token_b=True)
+    c_cpu = case.c.cpu().clone()
+    want = oracle_dense(case, gran_n=1, c_cpu=c_cpu)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c, recipe=(1, 1, 128))
+    assert dg.last_config() == 'pipe_pc_mn_256x256'
+    assert_close_fp32(case.d, want, 'per-column SFB, MN-major operands')
+    # the K-major form of the same problem: same arithmetic order, same bits
+    d2 = c_cpu.cuda()
+    a_km = (case.a[0].contiguous(), case.a[1])
+    b_km = (case.b[0].contiguous(), case.b[1])
+    dg.fp8_gemm_nt(a_km, b_km, d2, c=d2, recipe=(1, 1, 128))
+    assert dg.last_config() == 'pipe_pc_256x256'
+    assert torch.equal(d2, case.d)
+
+
 def test_k_tail_sub_views_and_wide_d():
     gen.reset_seed(4)
     # K not a multiple of 128 (quantisers zero-pad the last block): generic path
