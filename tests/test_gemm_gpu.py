@@ -404,6 +404,59 @@ def test_repeatability_full_size():
     assert calc_diff(want, case2.ref_d) < gen.FP8_MAX_DIFF
 
 
+def test_repeatability_other_kernels():
+    """The same bit-repeatability check for the kernels with hand-placed waits that the dense default does not reach: the
+    128-row duo tile, the per-column-SFB kernel in its K-major and transpose-read forms (FP32 accumulate), the K-grouped
+    single launch and the hardware-scaled UE8M0 kernel."""
+    from deepgemm_amd.utils import per_block_cast_to_fp8, per_token_cast_to_fp8
+    from deepgemm_amd.utils.math import pack_ue8m0_to_int
+    gen.reset_seed(5)
+    case = gen.generate_normal(2048, 4096, 3584)
+    dg.set_forced_config('duo_128x256')
+    first = torch.empty_like(case.d)
+    dg.fp8_gemm_nt(case.a, case.b, first)
+    for _ in range(8):
+        again = torch.empty_like(case.d)
+        dg.fp8_gemm_nt(case.a, case.b, again)
+        assert torch.equal(again, first), 'duo_128x256'
+    dg.set_forced_config('auto')
+    for k_major in (True, False):
+        pc = gen.generate_normal(2048, 2304, 3584, a_k_major=k_major, b_k_major=k_major, accumulate=True, out_dtype=torch.float,
+                                 per_token_b=True)
+        c0 = pc.c.clone()
+        outs = []
+        for _ in range(6):
+            d = c0.clone()
+            dg.fp8_gemm_nt(pc.a, pc.b, d, c=d, recipe=(1, 1, 128))
+            outs.append(d)
+        assert dg.last_config() == ('pipe_pc_256x256' if k_major else 'pipe_pc_mn_256x256')
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), dg.last_config()
+    for k_major in (True, False):
+        kg = gen.generate_k_grouped_contiguous(3, 1024, 1280, [1024, 512, 1536], k_major)
+        fn = dg.k_grouped_fp8_gemm_nt_contiguous if k_major else dg.k_grouped_fp8_gemm_tn_contiguous
+        outs = []
+        for _ in range(5):
+            d = kg.c.clone()
+            fn(kg.a, kg.b, d, kg.ks, kg.grouped_layout, c=d)
+            outs.append(d)
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), ('k-grouped', k_major)
+    torch.manual_seed(6)
+    m, n, k = 2048, 2048, 3584
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    a_q, sfa = per_token_cast_to_fp8(a, use_ue8m0=True)
+    b_q, sfb = per_block_cast_to_fp8(b, use_ue8m0=True)
+    pa = dg.get_mn_major_tma_aligned_packed_ue8m0_tensor(sfa)
+    pb = dg.get_mn_major_tma_aligned_packed_ue8m0_tensor(sfb.repeat_interleave(128, dim=0)[:n].contiguous())
+    outs = []
+    for _ in range(8):
+        d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d)
+        outs.append(d)
+    assert dg.last_config().startswith('e8_')
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'e8'
+
+
 def test_reference_sweep_subset_gate():
     """A slice of the reference's dense sweep (tests/generators.py:119-121) at the reference's own gate."""
     gen.reset_seed(0)
