@@ -76,6 +76,9 @@ const Config kConfigs[] = {
     // 128-row duo tile: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise
     // badly at 256 x 256.  Measured per-tile: 116 k cycles vs 167 k for twice the work (L2->LDS bytes per flop are 1.5x).
     {"duo_128x256", 128, 256, 512, 1, 0.78f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4>, true},
+    // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
+    {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 41>, true, true, true},
+    {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 40>, true},
     {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
@@ -157,6 +160,14 @@ bool fast_eligible(const dg::GemmParams& p) {
     return true;
 }
 
+// A K-major, B MN-major ([K][N], unit stride along n): the B_MN forms of the duo kernels.
+bool bmn_eligible(const dg::GemmParams& p) {
+    return p.sfb_gran_n == 128 && p.a_sk == 1 && p.b_sn == 1 && p.b_sk != 1 && p.k % 128 == 0 && p.sfa_sm == 1 &&
+           (p.gemm_type == dg::kNormal || p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) &&
+           aligned16(p.a) && aligned16(p.b) && p.a_sm % 16 == 0 && p.b_sk % 16 == 0 && p.a_sg % 16 == 0 && p.b_sg % 16 == 0 &&
+           p.n % 16 == 0 && p.a_sm <= (1 << 22) && p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
+}
+
 // Recipe (1, 1, 128) on the fast path: both scale tensors MN-major with 16-byte aligned K-block rows (each block's 256
 // row scales are fetched as one 1 KiB LDS-DMA piece).
 bool per_col_eligible(const dg::GemmParams& p) {
@@ -190,6 +201,15 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, pick) == 0)
                 return &kConfigs[i];
+    }
+    if (bmn_eligible(p) && m_for_tiling > 256) {
+        const bool contiguous = p.gemm_type != dg::kNormal;
+        const char* pick = (contiguous || ceil_div(m_for_tiling, 256) * ceil_div(p.n, 256) < num_cus() / 2) ? "duo_bmn_128x256"
+                                                                                                           : "duo_bmn_256x256";
+        if (!contiguous || bm_must_divide % 128 == 0)
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (std::strcmp(kConfigs[i].name, pick) == 0)
+                    return &kConfigs[i];
     }
     const bool fast_ok = fast_eligible(p);
     // HBM-bound shapes (M up to a few 64-row tiles: every weight byte is streamed once or twice): the deep-ring stream
@@ -262,8 +282,15 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = "no kernel configuration available (forced config '" + g_forced_config + "')";
         return 3;
     }
-    const bool mn_form = std::strcmp(cfg->name, "pipe_pc_mn_256x256") == 0;
-    if (cfg->fast && (mn_form ? !per_col_mn_eligible(p) : (cfg->per_col ? !per_col_eligible(p) : p.sfb_gran_n != 128))) {
+    const bool bmn_form = std::strncmp(cfg->name, "duo_bmn_", 8) == 0;
+    if (bmn_form && !bmn_eligible(p)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs K-major A, MN-major 16-byte aligned B and MN-major SFA";
+        return 3;
+    }
+    const bool pc_mn_form = std::strcmp(cfg->name, "pipe_pc_mn_256x256") == 0;
+    const bool mn_form = pc_mn_form || bmn_form;
+    if (cfg->fast && !bmn_form &&
+        (pc_mn_form ? !per_col_mn_eligible(p) : (cfg->per_col ? !per_col_eligible(p) : p.sfb_gran_n != 128))) {
         g_last_error = std::string("forced config '") + cfg->name + "' does not implement this scaling recipe / SF layout";
         return 3;
     }

@@ -259,6 +259,24 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
             const bool zero_row = row >= t.zero_from && row < t.zero_to;
             if (!compute_row && !zero_row)
                 continue;
+            if (p.d_dtype == 0 && full && p.d_vec_ok) {
+                // BF16: a lane's 4 consecutive columns of a subtile = one 8-byte store (the permuted order's 16-byte stores
+                // need 8 consecutive columns per lane, which the natural B row order does not give)
+                uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    uint2* dst = reinterpret_cast<uint2*>(drow + d_col(p, n_base + ns * 16 + lg * 4));
+                    uint32_t w0 = zero_row ? 0u : pack_bf16(acc[ms][ns][0], acc[ms][ns][1]);
+                    uint32_t w1 = zero_row ? 0u : pack_bf16(acc[ms][ns][2], acc[ms][ns][3]);
+                    if (p.accumulate && !zero_row) {
+                        const uint2 old = *dst;
+                        w0 = pack_bf16(bf16_lo(old.x) + bf16_lo(w0), bf16_hi(old.x) + bf16_hi(w0));
+                        w1 = pack_bf16(bf16_lo(old.y) + bf16_lo(w1), bf16_hi(old.y) + bf16_hi(w1));
+                    }
+                    *dst = make_uint2(w0, w1);
+                }
+                continue;
+            }
             if (p.d_dtype != 0 && full && p.d_vec_ok) {
                 float* drow = reinterpret_cast<float*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
                 v4f old[NS];
@@ -1007,19 +1025,29 @@ constexpr int waitcnt_imm(int vmcnt, int lgkmcnt) {
 // tools/ubench/tr_b8_probe.hip).  Four reads give the lane the same 32 K slots a K-major fragment holds:
 // k = 16g .. 16g+15 and 64+16g .. 64+16g+15 (g = lane >> 4).  lane_base = (16g + (i >> 1)) * 256 + (i & 1) * 8 with
 // i = lane & 15; chunk_off = (c ^ ((i >> 1) | ((g & 1) << 3))) << 4 for the fragment's chunk c.
-__device__ __forceinline__ v8i load_fragment_tr(const uint8_t* tile, int lane_base, int chunk_off) {
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    v2i q0, q1, q2, q3;
+// The four 8-byte results land in separate register pairs; they are put together into the MFMA operand only AFTER the
+// wait for them (assemble_fragment_tr): building the 8-register tuple right after the asm would let hipcc copy registers the
+// loads have not written yet.
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+struct FragTr { v2i_t q0, q1, q2, q3; };
+
+__device__ __forceinline__ FragTr load_fragment_tr(const uint8_t* tile, int lane_base, int chunk_off) {
+    FragTr f;
     const int addr = static_cast<int>(reinterpret_cast<uintptr_t>(tile)) + lane_base + chunk_off;
     asm volatile(
         "ds_read_b64_tr_b8 %0, %4\n\t"
         "ds_read_b64_tr_b8 %1, %4 offset:2048\n\t"
         "ds_read_b64_tr_b8 %2, %4 offset:16384\n\t"
         "ds_read_b64_tr_b8 %3, %4 offset:18432"
-        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+        : "=&v"(f.q0), "=&v"(f.q1), "=&v"(f.q2), "=&v"(f.q3)
         : "v"(addr)
         : "memory");
-    return v8i{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+    return f;
+}
+
+__device__ __forceinline__ v8i assemble_fragment_tr(FragTr& f) {
+    asm volatile("" : "+v"(f.q0), "+v"(f.q1), "+v"(f.q2), "+v"(f.q3));      // the values exist from here on
+    return v8i{f.q0[0], f.q0[1], f.q1[0], f.q1[1], f.q2[0], f.q2[1], f.q3[0], f.q3[1]};
 }
 
 // MN = true: both FP8 operands are MN-major ([K][M] and [K][N], unit stride along m / n, row pitch a_sk / b_sk): the
@@ -1196,16 +1224,18 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
 
                 const uint8_t* a_tile = MN ? lds + cur * STAGE_BYTES : lds + cur * STAGE_BYTES + (wm * WM) * 128;
                 const uint8_t* b_tile = MN ? lds + cur * STAGE_BYTES + A_BYTES : lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
+                // MN: transpose reads land in bfq / afq and become MFMA operands (bf / af) at their first use, after the wait
+                [[maybe_unused]] FragTr bfq[NS], afq[2];
                 auto frag_a = [&](int ms) {
-                    if constexpr (MN) return load_fragment_tr(a_tile, tr_lane_base, ((wm * (WM / 16) + ms) ^ tr_swz) << 4);
-                    else return load_fragment(a_tile + ms * 2048, frag_off);
+                    if constexpr (MN) afq[ms & 1] = load_fragment_tr(a_tile, tr_lane_base, ((wm * (WM / 16) + ms) ^ tr_swz) << 4);
+                    else af[ms & 1] = load_fragment(a_tile + ms * 2048, frag_off);
                 };
                 auto frag_b = [&](int ns) {
-                    if constexpr (MN) return load_fragment_tr(b_tile, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
-                    else return load_fragment(b_tile + ns * 2048, frag_off);
+                    if constexpr (MN) bfq[ns] = load_fragment_tr(b_tile, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                    else bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
                 };
-                bf[0] = frag_b(0);
-                af[0] = frag_a(0);
+                frag_b(0);
+                frag_a(0);
 
                 #pragma unroll
                 for (int i = 0; i < TOTAL; ++i) {
@@ -1213,9 +1243,9 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                     const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
                     const int jms = j / NS, jns = j % NS;
                     if (ms == 0 && ns + 1 < NS)
-                        bf[ns + 1] = frag_b(ns + 1);
+                        frag_b(ns + 1);
                     if (ns == 0 && ms + 1 < MS)
-                        af[(ms + 1) & 1] = frag_a(ms + 1);
+                        frag_a(ms + 1);
                     if constexpr (MN) {
                         // everything but the reads just issued (4 per fragment) has landed: the operands of this step
                         const int fresh = 4 * ((ms == 0 && ns + 1 < NS ? 1 : 0) + (ns == 0 && ms + 1 < MS ? 1 : 0));
@@ -1224,6 +1254,8 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                             else if (fresh == 4) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 4));
                             else __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
                         }
+                        if (ms == 0) bf[ns] = assemble_fragment_tr(bfq[ns]);
+                        if (ns == 0) af[ms & 1] = assemble_fragment_tr(afq[ms & 1]);
                     }
                     const v4f& po = part[(i + 1) & DEPTH];
                     const v2f p01 = v2f{po[0], po[1]}, p23 = v2f{po[2], po[3]};
@@ -1712,7 +1744,12 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     static_assert(MP == 0 || (A_ITERS - A_EARLY >= MP && B_ITERS >= MP && SEG >= 12), "pieces to move");        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     constexpr unsigned OOB = 0x80000000u;
     // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
-    constexpr bool PERSIST = (DABL == 20 || DABL == 26);      // persistent launch with cross-tile prologue prefetch
+    constexpr bool PERSIST = (DABL == 20 || DABL == 26 || DABL == 41);      // persistent launch with cross-tile prologue prefetch
+    // B_MN: operand B is MN-major ([K][N], unit stride along n, row pitch b_sk): the nn / tn layouts without the re-majoring
+    // pass.  LDS-DMA pieces are 4 k-rows x 256 bytes, B fragments come through the hardware transpose read, B rows keep
+    // their natural order (=> 8-byte instead of 16-byte BF16 stores).  See load_fragment_tr.
+    constexpr bool B_MN = (DABL == 40 || DABL == 41);
+    static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3 && DABL != 24 && DABL != 26 && DABL != 28),
                    LOADPRIO = (DABL == 8 || DABL == 11 || DABL == 25 || DABL == 29);
     constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
@@ -1759,6 +1796,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     #pragma unroll
     for (int q = 0; q < B_ITERS; ++q)
         b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+    // MN-major B: lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k); u = wave + 8q => f lane-constant
+    const int ldb_mn = static_cast<int>(p.b_sk);
+    const int bmn_voff = (lane >> 4) * ldb_mn + ((((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3)))) << 4);
+    const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
+    const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
 
     // Addresses of one tile (plain scalars; the buffer descriptors are built from them where they are used).
     struct TileMem { const uint8_t* a_base; const uint8_t* b_base; int a_bytes, b_bytes; uint64_t sfa_addr, sfb_addr; int sfa_voff; };
@@ -1774,9 +1816,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
         };
         tm.a_base = uniform_ptr(p.a + adg * p.a_sg + static_cast<int64_t>(tt.m0) * p.a_sm);
-        tm.b_base = uniform_ptr(p.b + static_cast<int64_t>(tt.group) * p.b_sg + static_cast<int64_t>(tt.n0) * p.b_sn);
+        tm.b_base = uniform_ptr(p.b + static_cast<int64_t>(tt.group) * p.b_sg + static_cast<int64_t>(tt.n0) * (B_MN ? 1 : p.b_sn));
         tm.a_bytes = __builtin_amdgcn_readfirstlane((imin(tt.m_end - tt.m0, BM) - 1) * lda + p.k);
-        tm.b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - tt.n0, BN) - 1) * ldb + p.k);
+        tm.b_bytes = __builtin_amdgcn_readfirstlane(B_MN ? (p.k - 1) * ldb_mn + (p.n - tt.n0) : (imin(p.n - tt.n0, BN) - 1) * ldb + p.k);
         tm.sfa_addr = reinterpret_cast<uint64_t>(p.sfa + adg * p.sfa_sg);
         tm.sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(tt.group) * p.sfb_sg +
                                                  static_cast<int64_t>((tt.n0 + wn * WN) / 128) * p.sfb_sn);
@@ -1798,7 +1840,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
-            b_piece_voff[q], (DABL == 32 ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+            B_MN ? bmn_voff : b_piece_voff[q],
+            B_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * ldb_mn : (DABL == 32 ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
     };
     // Prologue pieces of a tile: A(0) B(0) A(1) B(1) into ring slots 0 / 1.  Issued at kernel entry for the first tile
     // and, in the persistent launch, for tile i+1 as soon as tile i's K loop has released the LDS -- i.e. BEFORE tile i's
@@ -1913,10 +1956,15 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 if (EB == 0) raw_barrier();         // EB > 0: executed inside the previous matrix segment / before the loop
                 stamp(kb, 1);
                 // fragment reads first: they complete in the shadow of the slow vector-memory issue that follows
+                [[maybe_unused]] FragTr bfq[NS];
                 if (NO_LDS_READS ? kb == 0 : true) {
                     #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns)
-                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    for (int ns = 0; ns < NS; ++ns) {
+                        if constexpr (B_MN)
+                            bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                        else
+                            bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    }
                     #pragma unroll
                     for (int h = 0; h < HS; ++h)
                         af[h] = load_fragment(a_tile + h * 2048, frag_off);
@@ -1939,6 +1987,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 }
                 if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[2]) :: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (B_MN) {
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        bf[ns] = assemble_fragment_tr(bfq[ns]);
+                }
                 if constexpr (TRACE) {
                     #pragma unroll
                     for (int q = 0; q < 3; ++q) {
@@ -2043,7 +2096,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         if constexpr (DABL == 13) {
             if (out[0][0][0] == 123.456f) store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         } else {
-            store_tile<MS, NS, true, DABL == 12>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+            store_tile<MS, NS, true, DABL == 12, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         }
         if (p.dbg != nullptr && first_tile && !next_prefetched) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

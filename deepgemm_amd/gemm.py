@@ -45,6 +45,12 @@ def _both_mn_major_aligned(a: torch.Tensor, b: torch.Tensor, m: int, n: int) -> 
             a.stride(-1) % 16 == 0 and b.stride(-1) % 16 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
+def _b_mn_major_native(b: torch.Tensor, m: int, n: int) -> bool:
+    """MN-major B ([.., N, K] view with unit stride along N) that the B_MN kernels take as it is (dg_api.hip: bmn_eligible)."""
+    return (b.stride(-2) == 1 and b.stride(-1) != 1 and m > 256 and n % 16 == 0 and
+            b.stride(-1) % 16 == 0 and b.data_ptr() % 16 == 0 and (b.dim() == 2 or b.stride(0) % 16 == 0))
+
+
 def _remajor(t: torch.Tensor) -> torch.Tensor:
     """An MN-major FP8 operand view ``[.., mn, k]`` (stride 1 along mn) as a fresh K-major tensor (dg_transpose_fp8)."""
     require_device(t)
@@ -145,7 +151,9 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
             d.copy_(c)
         sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
         if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
-            a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
+            a_data = _as_k_major(a_data, m * n * k)
+            if not (gran_n == 128 and _b_mn_major_native(b_data, m, n)):
+                b_data = _as_k_major(b_data, m * n * k)
         check(lib.dg_fp8_gemm_nt(
             a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), m, n, k,
             a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
@@ -168,7 +176,9 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
         _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf)
     if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
         # (recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are, no re-majoring pass)
-        a_data, b_data = _as_k_major(a_data, m * n * k), _as_k_major(b_data, m * n * k)
+        a_data = _as_k_major(a_data, m * n * k)
+        if not (gran_n == 128 and _b_mn_major_native(b_data, m, n)):
+            b_data = _as_k_major(b_data, m * n * k)      # (large MN-major B: read natively through transpose reads instead)
     check(lib.dg_fp8_gemm_nt(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
@@ -219,7 +229,8 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
                                                          None, num_groups, disable_ue8m0_cast)
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
-    b_data = _as_k_major(b_data, m * n * k)
+    if not _b_mn_major_native(b_data, m, n):
+        b_data = _as_k_major(b_data, m * n * k)
     check(lib.dg_m_grouped_fp8_gemm_nt_contiguous(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
         num_groups, m, n, k, a_data.stride(0), a_data.stride(1),

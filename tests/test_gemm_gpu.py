@@ -85,7 +85,8 @@ def test_dense_layouts_vs_oracle(layout, m, n, k):
         try:
             d_generic = torch.full_like(case.d, float('nan'))
             dg.fp8_gemm_nt(case.a, case.b, d_generic)
-            assert layout == 'nt' or dg.last_config().startswith('generic')
+            # nn keeps its K-major A: the MN-major B is read natively (transpose reads); tn / tt: the layout-agnostic kernel
+            assert layout == 'nt' or dg.last_config().startswith('duo_bmn' if layout == 'nn' else 'generic'), dg.last_config()
             assert_close_to_oracle(d_generic, want, f'{layout} generic')
         finally:
             dg.gemm.REMAJOR_MIN_MACS = saved
@@ -184,6 +185,28 @@ def test_per_column_sfb_mn_major_operands(m, n, k):
     b_km = (case.b[0].contiguous(), case.b[1])
     dg.fp8_gemm_nt(a_km, b_km, d2, c=d2, recipe=(1, 1, 128))
     assert dg.last_config() == 'pipe_pc_256x256'
+    assert torch.equal(d2, case.d)
+
+
+@pytest.mark.parametrize('m,n,k', [(512, 512, 512), (1040, 784, 896), (4096, 2048, 1024)])
+@pytest.mark.parametrize('out_dtype,accumulate', [(torch.bfloat16, False), (torch.float, True)])
+def test_mn_major_b_native_path(m, n, k, out_dtype, accumulate):
+    """fp8_gemm_nn on large problems: the MN-major B goes into the duo kernels as it is (LDS-DMA of k-rows + hardware
+    transpose reads, natural column order in the epilogue); same bits as the K-major form of the same operand."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k, a_k_major=True, b_k_major=False, accumulate=accumulate, out_dtype=out_dtype)
+    c_cpu = case.c.cpu().clone() if accumulate else None
+    want = oracle_dense(case, c_cpu=c_cpu)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None)
+    assert dg.last_config().startswith('duo_bmn_'), dg.last_config()
+    if out_dtype == torch.float:
+        assert_close_fp32(case.d, want, 'MN-major B')
+    else:
+        assert_close_to_oracle(case.d, want, 'MN-major B')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    d2 = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
+    dg.fp8_gemm_nt(case.a, (case.b[0].contiguous(), case.b[1]), d2, c=d2 if accumulate else None)
+    assert not dg.last_config().startswith('duo_bmn_')
     assert torch.equal(d2, case.d)
 
 
