@@ -79,6 +79,7 @@ const Config kConfigs[] = {
     // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
     {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 41>, true, true, true},
     {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 40>, true},
+    {"duo_bmn2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 40>, true, true},   // contiguous, two-pass
     {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
@@ -204,8 +205,11 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     }
     if (bmn_eligible(p) && m_for_tiling > 256) {
         const bool contiguous = p.gemm_type != dg::kNormal;
-        const char* pick = (contiguous || ceil_div(m_for_tiling, 256) * ceil_div(p.n, 256) < num_cus() / 2) ? "duo_bmn_128x256"
-                                                                                                           : "duo_bmn_256x256";
+        const long tiles256 = static_cast<long>(ceil_div(m_for_tiling, 256)) * ceil_div(p.n, 256);
+        const char* pick = (contiguous || tiles256 < num_cus() / 2) ? "duo_bmn_128x256" : "duo_bmn_256x256";
+        // many rounds of a contiguous layout aligned to 128 rows: the two-pass 256-row tile (same rule as for K-major B)
+        if (p.gemm_type == dg::kContiguous && bm_must_divide == 128 && tiles256 >= 4L * num_cus())
+            pick = "duo_bmn2_256x256";
         if (!contiguous || bm_must_divide % 128 == 0)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)
@@ -282,7 +286,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = "no kernel configuration available (forced config '" + g_forced_config + "')";
         return 3;
     }
-    const bool bmn_form = std::strncmp(cfg->name, "duo_bmn_", 8) == 0;
+    const bool bmn_form = std::strncmp(cfg->name, "duo_bmn", 7) == 0;
     if (bmn_form && !bmn_eligible(p)) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major A, MN-major 16-byte aligned B and MN-major SFA";
         return 3;

@@ -14,7 +14,7 @@ LLVM_OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 
 PRODUCTION = [
     'dg_fp8_gemm_duo_kernel<256,256,2,4,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,20>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0>',
-    'dg_fp8_gemm_duo_kernel<256,256,2,4,41>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,40>',
+    'dg_fp8_gemm_duo_kernel<256,256,2,4,41>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,40>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,40>',
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,12,0,1>',
     'dg_fp8_gemm_pipe_kernel<128,128,2,2,2,0>', 'dg_fp8_gemm_pipe_kernel<64,256,1,4,1,0>', 'dg_fp8_gemm_pipe_kernel<256,256,2,4,2,0>',
     'dg_fp8_gemm_pipe_pc_kernel<256,256,2,4,2,0,0>', 'dg_fp8_gemm_pipe_pc_kernel<256,256,2,4,2,0,1>',
