@@ -177,3 +177,58 @@ def test_generators_follow_reference_conventions():
         start += aligned
     shapes = list(gen.enumerate_normal())
     assert (4096, 4096, 7168, True, True, False, torch.bfloat16, False) in shapes and len(shapes) == 3 * 7 * 2 + 7 * 3
+
+
+def test_newer_operators_exist_and_validate_on_the_host():
+    """K-grouped GEMM, skip_head_mid, packed-UE8M0 layout helper, fused casts: names (incl. the deep_gemm alias) and the
+    argument checks that run before any device work (reference: csrc/apis/gemm.hpp:48-69,299-400, attention.hpp:19-73)."""
+    import deep_gemm
+    for name in ['k_grouped_fp8_gemm_nt_contiguous', 'k_grouped_fp8_gemm_tn_contiguous', 'fp8_gemm_nt_skip_head_mid',
+                 'get_mn_major_tma_aligned_packed_ue8m0_tensor', 'fused_per_token_cast_to_fp8', 'fused_per_block_cast_to_fp8',
+                 'fused_per_channel_cast_to_fp8']:
+        assert hasattr(deep_gemm, name) and hasattr(dg, name), name
+    kg = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True, device='cpu')
+    with pytest.raises(RuntimeError, match='c.has_value'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, kg.ks, kg.grouped_layout)
+    with pytest.raises(RuntimeError, match='k % k_alignment == 0'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, [100, 284], kg.grouped_layout, c=kg.c)
+    with pytest.raises(RuntimeError, match='ks_cpu'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, None, kg.grouped_layout, c=kg.c)
+    with pytest.raises(RuntimeError, match='not use_psum_layout'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, kg.ks, kg.grouped_layout, c=kg.c, use_psum_layout=True)
+    with pytest.raises(RuntimeError, match='num_groups'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, kg.ks, kg.grouped_layout[:1].contiguous(), c=kg.c)
+    with pytest.raises(RuntimeError, match='sum_mk'):
+        dg.k_grouped_fp8_gemm_nt_contiguous((kg.a[0][:-128], kg.a[1]), kg.b, kg.d, kg.ks, kg.grouped_layout, c=kg.c)
+    with pytest.raises(RuntimeError, match='no CPU path'):                  # everything valid: stops at the device check
+        dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, kg.ks, kg.grouped_layout, c=kg.c)
+    kt = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], False, device='cpu')
+    with pytest.raises(RuntimeError, match='gran_k == 128'):
+        dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, kt.ks, kt.grouped_layout, c=kt.c, recipe=(1, 1, 32))
+    with pytest.raises(RuntimeError, match='sum_k'):
+        dg.k_grouped_fp8_gemm_tn_contiguous((kt.a[0][:256], kt.a[1]), kt.b, kt.d, kt.ks, kt.grouped_layout, c=kt.c)
+    # skip_head_mid: the width of d must reserve the middle columns
+    c = _case(32, 256, 256)
+    with pytest.raises(RuntimeError, match=r'left \+ right'):
+        dg.fp8_gemm_nt_skip_head_mid(c.a, c.b, torch.empty(32, 256, dtype=torch.bfloat16), (64, 32, 64))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.fp8_gemm_nt_skip_head_mid(c.a, c.b, torch.empty(32, 256 + 2 * 32, dtype=torch.bfloat16), (64, 32, 64))
+    # fused casts and the pack helper take BF16 / FP32 device tensors only
+    with pytest.raises(RuntimeError, match='kBFloat16'):
+        dg.fused_per_token_cast_to_fp8(torch.zeros(4, 128))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.fused_per_block_cast_to_fp8(torch.zeros(4, 128, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match='gran_k'):
+        dg.fused_per_channel_cast_to_fp8(torch.zeros(100, 128, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match='kFloat'):
+        dg.get_mn_major_tma_aligned_packed_ue8m0_tensor(torch.zeros(4, 4, dtype=torch.int))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.get_mn_major_tma_aligned_packed_ue8m0_tensor(torch.ones(4, 4))
+    # the C ABI of the K-grouped entry: argument checks without a launch
+    lib = _lib.lib
+    ks = (ctypes.c_int32 * 2)(128, 100)
+    rc = lib.dg_k_grouped_fp8_gemm_nt_contiguous(1, 1, 1, 1, 1, 128, 128, ctypes.cast(ks, ctypes.c_void_p), 2, 0, 0, 0, 1, 128, 1, 128, None)
+    assert rc != 0 and b'% 128 == 0' in lib.dg_last_error()
+    rc = lib.dg_k_grouped_fp8_gemm_nt_contiguous(1, 1, 1, 1, 1, 128, 128, ctypes.cast(ks, ctypes.c_void_p), 2, 7, 0, 0, 1, 128, 1, 128, None)
+    assert rc != 0 and b'ab_layout' in lib.dg_last_error()
+    assert lib.dg_k_grouped_fp8_gemm_nt_contiguous(None, None, None, None, None, 0, 128, None, 2, 0, 0, 0, 1, 1, 1, 1, None) == 0
