@@ -10,7 +10,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libdeepgemm_amd.so')
 SOURCES = ['dg_api.hip']
-HEADERS = ['fp8_gemm_kernels.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
+HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
 # DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that DESIGN.md section 5 quotes (tools/cycles.py,
@@ -19,11 +19,25 @@ if os.environ.get('DG_EXPERIMENTS', '') not in ('', '0'):
     FLAGS.append('-DDG_EXPERIMENTS')
 
 
+STAMP_PATH = LIB_PATH + '.flags'      # the flag set the library was built with (DG_EXPERIMENTS toggles must rebuild)
+
+
+def _stamp() -> str:
+    return ' '.join([HIPCC, *FLAGS])
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > built for f in SOURCES + HEADERS)
+    if any(os.path.getmtime(os.path.join(CSRC, f)) > built for f in SOURCES + HEADERS):
+        return True
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read() != _stamp()
+    except OSError:
+        # a library without a stamp (built by hand or shipped prebuilt): trust it unless experiments are asked for
+        return '-DDG_EXPERIMENTS' in FLAGS
 
 
 def build_extension(force: bool = False, verbose: bool = False) -> str:
@@ -34,6 +48,8 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
             print(' '.join(cmd), file=sys.stderr)
         subprocess.check_call(cmd, cwd=CSRC)
         os.replace(tmp, LIB_PATH)
+        with open(STAMP_PATH, 'w') as f:
+            f.write(_stamp())
     return LIB_PATH
 
 

@@ -3,21 +3,32 @@
 // 160 KiB LDS / wave64) and kernel launches.  Kernels are compiled ahead of time for gfx950; there is no JIT.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/deepgemm_amd.h"
 #include "fp8_gemm_kernels.hpp"
+#include "fp8_gemm_quad.hpp"
 
 namespace {
 
+// Error text and the name of the last selected configuration are per calling thread (errno style); the tuning knobs are
+// process-wide like the reference's runtime singletons (csrc/apis/runtime.hpp:12-49) and safe to set from any thread.
 thread_local std::string g_last_error;
-thread_local std::string g_forced_config = "auto";
 thread_local std::string g_last_config = "";
-int g_num_cus_override = 0;
-thread_local long long* g_debug_buffer = nullptr;
+std::atomic<int> g_num_cus_override{0};
+std::atomic<long long*> g_debug_buffer{nullptr};
+std::mutex g_forced_config_mutex;
+std::string g_forced_config = "auto";              // guarded by g_forced_config_mutex
+
+std::string forced_config() {
+    std::lock_guard<std::mutex> lock(g_forced_config_mutex);
+    return g_forced_config;
+}
 
 int fail(const char* file, int line, const char* what) {
     g_last_error = std::string("Assertion error (") + file + ":" + std::to_string(line) + "): " + what;
@@ -40,20 +51,30 @@ int fail(const char* file, int line, const char* what) {
         }                                                                                   \
     } while (0)
 
+// CU count of the CURRENT device, cached per device ordinal (mixed-device nodes, threads bound to different devices).
 int device_cu_count() {
-    static int cached = -1;
-    if (cached < 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            cached = cus;
-        else
-            cached = 256;   // MI355X; only reached when no device is visible (host-only unit tests)
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> cached[kMaxDevices];    // zero-initialised: 0 = not queried yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return 256;                                 // MI355X; only reached when no device is visible (host-only unit tests)
+    if (dev >= 0 && dev < kMaxDevices) {
+        const int known = cached[dev].load(std::memory_order_relaxed);
+        if (known > 0)
+            return known;
     }
-    return cached;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 256;
+    if (dev >= 0 && dev < kMaxDevices)
+        cached[dev].store(cus, std::memory_order_relaxed);
+    return cus;
 }
 
-int num_cus() { return g_num_cus_override > 0 ? g_num_cus_override : device_cu_count(); }
+int num_cus() {
+    const int forced = g_num_cus_override.load(std::memory_order_relaxed);
+    return forced > 0 ? forced : device_cu_count();
+}
 
 using KernelFn = void (*)(const dg::GemmParams);
 
@@ -100,6 +121,16 @@ const Config kConfigs[] = {
     {"pipe_s1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 1>},
     {"pipe_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 3>},
 #ifdef DG_EXPERIMENTS   // timing ablations and rejected variants: DG_EXPERIMENTS=1 python __graft_entry__.py
+    // FP32-scale kernels in the one-wave-per-SIMD schedule of the UE8M0 quad kernel (fp8_gemm_quad.hpp): bit-identical to the
+    // duo kernels and 1.4x SLOWER -- a lone wave pays ~51 cycles per MFMA + 4 FMA step and ~60 more per LDS-DMA piece
+    {"quad_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2>, true, false, true},
+    {"quad_256x128", 256, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<256, 128, 2, 2>, true, true, true},
+    {"quad_v1_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 1>, true, false, true},
+    {"quad_v2_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 2>, true, false, true},
+    {"quad_v3_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 3>, true, false, true},
+    {"quad_v4_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 4>, true, false, true},
+    {"quad_v5_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 5>, true, false, true},
+    {"quad_v6_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 6>, true, false, true},
     {"abl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 1>},
     {"abl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 2>},
     {"abl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 3>},
@@ -143,10 +174,24 @@ const Config kConfigs[] = {
     {"dabl30_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 30>, true},
     {"dabl31_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 31>, true},
 #endif
-    {"e8_ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, true},
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+// Kernels of the packed-UE8M0 entry points (hardware-scaled MFMA); selected in dg_fp8_gemm_nt_ue8m0, forced by name for A/B.
+struct E8Config { const char* name; KernelFn fn; int threads; bool needs_k512; };
+const E8Config kE8Configs[] = {
+    {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, true},
+    {"e8_duo_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>, 512, false},
+    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 512, false},
+#ifdef DG_EXPERIMENTS
+    {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, true},
+    {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, true},
+    {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, true},
+    {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, true},
+#endif
+};
+
 
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
@@ -190,9 +235,10 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
 const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expected_m, int bm_must_divide) {
-    if (g_forced_config != "auto") {
+    const std::string forced = forced_config();
+    if (forced != "auto") {
         for (int i = 0; i < kNumConfigs; ++i)
-            if (g_forced_config == kConfigs[i].name)
+            if (forced == kConfigs[i].name)
                 return &kConfigs[i];
         return nullptr;
     }
@@ -283,7 +329,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) ? p.m_alignment : 0;
     const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide);
     if (cfg == nullptr) {
-        g_last_error = "no kernel configuration available (forced config '" + g_forced_config + "')";
+        g_last_error = "no kernel configuration available (forced config '" + forced_config() + "')";
         return 3;
     }
     const bool bmn_form = std::strncmp(cfg->name, "duo_bmn", 7) == 0;
@@ -320,7 +366,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
     if (p.head_lr > 0 && ((p.head_lr - p.head_right) % 8 != 0 || p.head_mid % 8 != 0 || p.head_right % 8 != 0))
         p.d_vec_ok = 0;                  // a 16-byte store would straddle a head split: element-wise stores
-    p.dbg = g_debug_buffer;
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
 
     long grid;
     const long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
@@ -440,16 +486,24 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0;
-    p.dbg = g_debug_buffer;
-    const bool ring_form = g_forced_config == "e8_ring_256x256";       // A/B: the same MFMA in the ring schedule
-    g_last_config = ring_form ? "e8_ring_256x256" : "e8_duo_256x256";
-    const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
-    if (ring_form)
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
-                           static_cast<hipStream_t>(stream), p);
-    else
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
-                           static_cast<hipStream_t>(stream), p);
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    // Kernel choice: the 4-wave in-place-accumulating kernel whenever whole K quads (4 K blocks = one packed word) cover K;
+    // otherwise the 8-wave duo schedule.  dg_set_forced_config("e8_...") overrides (A/B runs).
+    const std::string forced = forced_config();
+    const E8Config* cfg = nullptr;
+    for (const E8Config& c : kE8Configs)
+        if (forced == c.name)
+            cfg = &c;
+    if (cfg == nullptr)
+        cfg = (k % 512 == 0) ? &kE8Configs[0] : &kE8Configs[1];
+    if (cfg->needs_k512 && k % 512 != 0) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs k % 512 == 0 (whole packed scale words)";
+        return 3;
+    }
+    g_last_config = cfg->name;
+    const long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
+    const long grid = total < num_cus() ? total : num_cus();          // every kernel walks tile_id += gridDim.x
+    hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
     DG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -542,7 +596,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
             if (ks_host[g] > 0 && ks_host[g] < k_min) k_min = ks_host[g];
         }
         bool single = num_groups <= dg::kMaxKGroups && sum_k > 0 && sum_k < (1LL << 31) && m > 64 &&
-                      g_forced_config == "auto";
+                      forced_config() == "auto";
         if (mn_major) {
             // MN-major operands [sum_k, m] / [sum_k, n] (row pitches a_stride_m / b_stride_n): only the single launch of the
             // transpose-read kernel takes them; everything else needs the K-major forms (the host layer re-majors)
@@ -564,7 +618,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
             p.num_n_tiles = ceil_div(n, 256);
             p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
             p.d_vec_ok = aligned16(p.d) && (p.d_sm * 4) % 16 == 0 && (p.d_sg * 4) % 16 == 0;
-            p.dbg = g_debug_buffer;
+            p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
             const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * num_groups;
             if (grid > 0x7fffffffL)
                 return fail(__FILE__, __LINE__, "grid too large");
@@ -594,7 +648,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
             p.num_n_tiles = ceil_div(n, 256);
             p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
             p.d_vec_ok = aligned16(p.d) && (p.d_sm * 4) % 16 == 0 && (p.d_sg * 4) % 16 == 0;
-            p.dbg = g_debug_buffer;
+            p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
             const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * num_groups;
             if (grid > 0x7fffffffL)
                 return fail(__FILE__, __LINE__, "grid too large");
@@ -728,7 +782,7 @@ int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols
 int dg_set_num_cus(int n) {
     if (n < 0)
         return fail(__FILE__, __LINE__, "num_cus >= 0");
-    g_num_cus_override = n;
+    g_num_cus_override.store(n, std::memory_order_relaxed);
     return 0;
 }
 
@@ -741,26 +795,38 @@ int dg_set_forced_config(const char* name) {
         bool known = false;
         for (int i = 0; i < kNumConfigs; ++i)
             known = known || std::strcmp(name, kConfigs[i].name) == 0;
+        for (const E8Config& c : kE8Configs)
+            known = known || std::strcmp(name, c.name) == 0;
         if (!known) {
             g_last_error = std::string("unknown kernel configuration '") + name + "'";
             return 1;
         }
     }
+    std::lock_guard<std::mutex> lock(g_forced_config_mutex);
     g_forced_config = name;
     return 0;
 }
 
 int dg_set_debug_buffer(void* device_buffer) {
-    g_debug_buffer = static_cast<long long*>(device_buffer);
+    g_debug_buffer.store(static_cast<long long*>(device_buffer), std::memory_order_relaxed);
     return 0;
 }
 
 const char* dg_list_configs(void) {
     static std::string joined;
-    if (joined.empty())
+    if (joined.empty()) {
         for (int i = 0; i < kNumConfigs; ++i)
             joined += std::string(i ? "," : "") + kConfigs[i].name;
+        for (const E8Config& c : kE8Configs)
+            joined += std::string(",") + c.name;
+    }
     return joined.c_str();
+}
+
+const char* dg_get_forced_config(void) {
+    thread_local std::string copy;
+    copy = forced_config();
+    return copy.c_str();
 }
 
 const char* dg_last_config(void) { return g_last_config.c_str(); }

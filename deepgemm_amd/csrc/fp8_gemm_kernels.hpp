@@ -137,7 +137,7 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
     t.n0 = nt * BN;
     t.group = kgroup;
     t.m_end = p.m;
-    t.zero_from = t.zero_to = t.m0 + BM;
+    t.zero_from = t.zero_to = imin(t.m0 + BM, p.m);    // zero rows never reach past the end of D (m need not be a multiple of BM)
     t.m_begin = t.m0;
     if (p.gemm_type == kContiguous && BM > p.m_alignment) {
         // A tile of two alignment-sized halves (BM == 2 * m_alignment, checked by the host): the halves may belong to
@@ -241,6 +241,49 @@ __device__ __forceinline__ int d_col(const GemmParams& p, int n) {
     return p.head_lr > 0 ? n + (n + p.head_right) / p.head_lr * p.head_mid : n;
 }
 
+// Full-line BF16 stores of one M-subtile (16 rows) x four N-subtiles (64 columns starting at n_base): the output tail of a
+// CU is bound by the NUMBER of store requests (one per 64-byte run: ~5 cycles each), not by bytes.  Lanes r and r + 8 of a
+// 16-lane row swap halves through DPP (row_ror:8) so that one store instruction writes 8 rows x 128 contiguous bytes
+// instead of 16 rows x 64: half the requests for the same bytes.  Caller: BF16 output, no accumulation, 16-byte aligned
+// rows, n_base + 64 <= n.  acc4[j][r] = D[row(ms, lane & 15)][n_base + (j >> 1) * 32 + lg * 8 + (j & 1) * 4 + r].
+template <int MS, bool INTERLEAVED_ROWS>
+__device__ __forceinline__ void store_rows_full_line(const GemmParams& p, const Tile& t, int64_t d_group_off,
+                                                     const v4f (&acc4)[4], int ms, int m_base, int n_base) {
+    const int lane = threadIdx.x & 63, lg = lane >> 4;
+    const bool lo = (lane & 8) == 0;
+    const int r7 = lane & 7;
+    const int col = n_base + ((lane >> 3) & 1) * 32 + lg * 8;
+    uint32_t w0[4], w1[4], x[4], y[4];
+    #pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        w0[2 * j] = pack_bf16(acc4[j][0], acc4[j][1]);
+        w0[2 * j + 1] = pack_bf16(acc4[j][2], acc4[j][3]);
+        w1[2 * j] = pack_bf16(acc4[2 + j][0], acc4[2 + j][1]);
+        w1[2 * j + 1] = pack_bf16(acc4[2 + j][2], acc4[2 + j][3]);
+    }
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t send = lo ? w1[j] : w0[j];
+        uint32_t recv;
+        // s_nop 1: VALU write -> DPP read of the same VGPR needs two wait states (hipcc pads nothing inside asm)
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(recv) : "v"(send));
+        x[j] = lo ? w0[j] : recv;
+        y[j] = lo ? recv : w1[j];
+    }
+    #pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int i = r7 + half * 8;
+        const int row = INTERLEAVED_ROWS ? m_base + i * MS + ms : m_base + ms * 16 + i;
+        const bool compute_row = row >= t.m_begin && row < t.m_end;
+        const bool zero_row = row >= t.zero_from && row < t.zero_to;
+        if (!compute_row && !zero_row)
+            continue;
+        const uint32_t* v = half == 0 ? x : y;
+        uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
+        *reinterpret_cast<uint4*>(drow + d_col(p, col)) = zero_row ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
@@ -325,41 +368,9 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
     // 16 rows x 64: half the requests for the same bytes.
     if constexpr (NS == 4) {
         if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + 64 <= p.n) {
-            const bool lo = (lane & 8) == 0;
-            const int r7 = lane & 7;
-            const int col = n_base + ((lane >> 3) & 1) * 32 + lg * 8;
             #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-                uint32_t w0[4], w1[4], x[4], y[4];
-                #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    w0[2 * j] = pack_bf16(acc[ms][j][0], acc[ms][j][1]);
-                    w0[2 * j + 1] = pack_bf16(acc[ms][j][2], acc[ms][j][3]);
-                    w1[2 * j] = pack_bf16(acc[ms][2 + j][0], acc[ms][2 + j][1]);
-                    w1[2 * j + 1] = pack_bf16(acc[ms][2 + j][2], acc[ms][2 + j][3]);
-                }
-                #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t send = lo ? w1[j] : w0[j];
-                    uint32_t recv;
-                    // s_nop 1: VALU write -> DPP read of the same VGPR needs two wait states (hipcc pads nothing inside asm)
-                    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(recv) : "v"(send));
-                    x[j] = lo ? w0[j] : recv;
-                    y[j] = lo ? recv : w1[j];
-                }
-                #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int i = r7 + half * 8;
-                    const int row = INTERLEAVED_ROWS ? m_base + i * MS + ms : m_base + ms * 16 + i;
-                    const bool compute_row = row >= t.m_begin && row < t.m_end;
-                    const bool zero_row = row >= t.zero_from && row < t.zero_to;
-                    if (!compute_row && !zero_row)
-                        continue;
-                    const uint32_t* v = half == 0 ? x : y;
-                    uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
-                    *reinterpret_cast<uint4*>(drow + d_col(p, col)) = zero_row ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v[0], v[1], v[2], v[3]);
-                }
-            }
+            for (int ms = 0; ms < MS; ++ms)
+                store_rows_full_line<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
             return;
         }
     }

@@ -58,18 +58,13 @@ def get_theoretical_mk_alignment_for_contiguous_layout(expected_m: Optional[int]
     return _LEGACY_MK_ALIGNMENT
 
 
-_FORCED_CONFIG = 'auto'
-
-
 def set_forced_config(name: str) -> None:
-    """Tuning hook: force a kernel configuration ('auto' restores the heuristic)."""
-    global _FORCED_CONFIG
+    """Tuning hook: force a kernel configuration ('auto' restores the heuristic).  Process-wide, like the knobs above."""
     check(lib.dg_set_forced_config(name.encode()))
-    _FORCED_CONFIG = name
 
 
 def last_forced_config() -> str:
-    return _FORCED_CONFIG
+    return lib.dg_get_forced_config().decode()
 
 
 def list_configs():

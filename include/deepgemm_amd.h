@@ -164,9 +164,11 @@ int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols
 int dg_set_num_cus(int num_cus);
 int dg_get_num_cus(void);
 
-/* Tuning / test hook: force a kernel configuration by name for subsequent calls on this thread
- * ("auto" restores the heuristic).  Unknown names are an error.  dg_list_configs() returns a comma-separated list. */
+/* Tuning / test hook: force a kernel configuration by name for subsequent calls of the process ("auto" restores the
+ * heuristic; like the reference's runtime knobs the setting is process-wide and may be changed from any thread).
+ * Unknown names are an error.  dg_list_configs() returns a comma-separated list, dg_get_forced_config() the current name. */
 int dg_set_forced_config(const char* name);
+const char* dg_get_forced_config(void);
 const char* dg_list_configs(void);
 /* Tuning aid: when non-null, the pipe / ring kernels write 4 int64 s_memtime stamps per wave {kernel entry, K loop
  * begin, K loop end, after the stores} of each block's first tile to device_buffer[(block * waves + wave) * 4 + i].
