@@ -178,20 +178,20 @@ const Config kConfigs[] = {
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
-// Kernels of the packed-UE8M0 entry points (hardware-scaled MFMA); selected in dg_fp8_gemm_nt_ue8m0, forced by name for A/B.
-struct E8Config { const char* name; KernelFn fn; int threads; bool needs_k512; };
+// Kernels of the packed-UE8M0 entry points (hardware-scaled MFMA); selected by launch_e8, forced by name for A/B runs.
+struct E8Config { const char* name; KernelFn fn; int bm, threads; bool whole_quads; bool grouped_ok; };
 const E8Config kE8Configs[] = {
-    {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, true},
-    {"e8_duo_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>, 512, false},
-    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 512, false},
+    {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, 256, true, true},
+    {"e8_quad_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>, 128, 256, false, true},
+    {"e8_duo_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
+    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
 #ifdef DG_EXPERIMENTS
-    {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, true},
-    {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, true},
-    {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, true},
-    {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, true},
+    {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, true, false},
+    {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, 256, true, false},
+    {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, 256, true, false},
+    {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, 256, true, false},
 #endif
 };
-
 
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
@@ -393,6 +393,65 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     return 0;
 }
 
+// Launch of a packed-UE8M0 problem (GemmParams filled by the entry point, scale pointers = packed words).  Kernel choice:
+// the 4-wave in-place-accumulating quad kernels -- 256 x 256 tiles for dense problems of whole K quads that fill the chip and
+// for contiguous layouts with several rounds of two-pass tiles, 128 x 256 tiles otherwise; the 8-wave forms only by name.
+int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
+    if (!fast_eligible(p)) {
+        g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0";
+        return 3;
+    }
+    const bool grouped = p.gemm_type != dg::kNormal;
+    const std::string forced = forced_config();
+    const E8Config* cfg = nullptr;
+    for (const E8Config& c : kE8Configs)
+        if (forced == c.name)
+            cfg = &c;
+    if (cfg == nullptr) {
+        const int m_hint = expected_m > 0 ? expected_m : p.m;
+        const long groups = p.gemm_type == dg::kMasked ? p.num_groups : 1;
+        const long tiles256 = groups * ceil_div(m_hint, 256) * ceil_div(p.n, 256);
+        bool big = p.k % 512 == 0 && m_hint > 128 && 2 * tiles256 >= num_cus();
+        if (p.gemm_type == dg::kContiguous)         // two-pass tiles (halves of two groups): only with rounds to average over
+            big = big && p.m_alignment == 128 && tiles256 >= 4L * num_cus();
+        if (p.gemm_type == dg::kContiguousPsum)
+            big = false;                            // the psum walk is written for tiles that divide the alignment
+        cfg = big ? &kE8Configs[0] : &kE8Configs[1];
+    }
+    if (cfg->whole_quads && p.k % 512 != 0) {
+        g_last_error = std::string("config '") + cfg->name + "' needs k % 512 == 0 (whole packed scale words)";
+        return 3;
+    }
+    if (grouped && !cfg->grouped_ok) {
+        g_last_error = std::string("config '") + cfg->name + "' implements the dense form only";
+        return 3;
+    }
+    if ((p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) && p.m_alignment % cfg->bm != 0 &&
+        !(p.gemm_type == dg::kContiguous && cfg->bm == 2 * p.m_alignment)) {
+        g_last_error = std::string("config '") + cfg->name + "' does not divide the contiguous-layout M alignment";
+        return 3;
+    }
+    g_last_config = cfg->name;
+    p.num_m_tiles = ceil_div(p.m, cfg->bm);
+    p.num_n_tiles = ceil_div(p.n, 256);
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
+    p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
+    if (p.gemm_type == dg::kMasked)
+        total *= p.num_groups;
+    const long grid = total < num_cus() ? total : num_cus();          // every kernel walks tile_id += gridDim.x
+    if (grid <= 0)
+        return 0;
+    hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
+    DG_HIP_CHECK(hipGetLastError());
+    if (getenv("DG_PRINT_CONFIGS") != nullptr)
+        fprintf(stderr, "[deepgemm_amd] ue8m0 type=%d m=%d n=%d k=%d groups=%d -> %s grid=%ld\n", p.gemm_type, p.m, p.n, p.k,
+                p.num_groups, cfg->name, grid);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -481,31 +540,66 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
         g_last_error = "dg_fp8_gemm_nt_ue8m0 needs K-major, 16-byte aligned FP8 operands and k % 128 == 0";
         return 3;
     }
-    p.num_m_tiles = ceil_div(m, 256);
-    p.num_n_tiles = ceil_div(n, 256);
-    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
-    const size_t elem = d_dtype == DG_BF16 ? 2 : 4;
-    p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0;
-    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
-    // Kernel choice: the 4-wave in-place-accumulating kernel whenever whole K quads (4 K blocks = one packed word) cover K;
-    // otherwise the 8-wave duo schedule.  dg_set_forced_config("e8_...") overrides (A/B runs).
-    const std::string forced = forced_config();
-    const E8Config* cfg = nullptr;
-    for (const E8Config& c : kE8Configs)
-        if (forced == c.name)
-            cfg = &c;
-    if (cfg == nullptr)
-        cfg = (k % 512 == 0) ? &kE8Configs[0] : &kE8Configs[1];
-    if (cfg->needs_k512 && k % 512 != 0) {
-        g_last_error = std::string("forced config '") + cfg->name + "' needs k % 512 == 0 (whole packed scale words)";
-        return 3;
-    }
-    g_last_config = cfg->name;
-    const long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
-    const long grid = total < num_cus() ? total : num_cus();          // every kernel walks tile_id += gridDim.x
-    hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
-    DG_HIP_CHECK(hipGetLastError());
-    return 0;
+    return launch_e8(p, 0, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                              void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                              int64_t a_stride_m, int64_t a_stride_k,
+                                              int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                              int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                              int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                              int64_t d_stride_m, int use_psum, int m_alignment, void* stream) {
+    DG_CHECK(m >= 0 && n > 0 && k > 0 && num_groups > 0);
+    if (m == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr && grouped_layout != nullptr);
+    DG_CHECK(a_stride_k == 1 && b_stride_k == 1);       // K-major operands (reference gemm.hpp:181; B is re-majored by the host layer)
+    DG_CHECK(sfa_stride_m == 1 && sfb_stride_n == 1);   // MN-major packed scale words
+    DG_CHECK(m_alignment > 0 && m_alignment % 128 == 0);
+    DG_CHECK(d_stride_m >= n);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.d = d;
+    p.sfa = reinterpret_cast<const float*>(sfa_packed); p.sfb = reinterpret_cast<const float*>(sfb_packed);
+    p.layout = grouped_layout;
+    p.m = m; p.n = n; p.k = k; p.num_groups = num_groups;
+    p.a_sm = a_stride_m; p.a_sk = 1;
+    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = 1;
+    p.sfa_sm = 1; p.sfa_sk = sfa_stride_kq;
+    p.sfb_sg = sfb_stride_g; p.sfb_sn = 1; p.sfb_sk = sfb_stride_kq;
+    p.d_sm = d_stride_m;
+    p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
+    p.gemm_type = use_psum ? dg::kContiguousPsum : dg::kContiguous;
+    p.m_alignment = m_alignment;
+    return launch_e8(p, 0, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                          void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
+                                          int expected_m,
+                                          int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                          int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                          int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                          int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                          int64_t d_stride_g, int64_t d_stride_m, void* stream) {
+    DG_CHECK(expected_m > 0 && m_max > 0 && n > 0 && k > 0 && num_groups > 0);   // reference gemm.hpp:274
+    DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr && masked_m != nullptr);
+    DG_CHECK(a_stride_k == 1 && b_stride_k == 1);       // reference gemm.hpp:263
+    DG_CHECK(sfa_stride_m == 1 && sfb_stride_n == 1);
+    DG_CHECK(d_stride_m >= n);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.d = d;
+    p.sfa = reinterpret_cast<const float*>(sfa_packed); p.sfb = reinterpret_cast<const float*>(sfb_packed);
+    p.layout = masked_m;
+    p.m = m_max; p.n = n; p.k = k; p.num_groups = num_groups;
+    p.a_sg = a_stride_g; p.a_sm = a_stride_m; p.a_sk = 1;
+    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = 1;
+    p.sfa_sg = sfa_stride_g; p.sfa_sm = 1; p.sfa_sk = sfa_stride_kq;
+    p.sfb_sg = sfb_stride_g; p.sfb_sn = 1; p.sfb_sk = sfb_stride_kq;
+    p.d_sg = d_stride_g; p.d_sm = d_stride_m;
+    p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
+    p.gemm_type = dg::kMasked; p.m_alignment = 0;
+    return launch_e8(p, expected_m < m_max ? expected_m : m_max, stream);
 }
 
 int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, void* d,

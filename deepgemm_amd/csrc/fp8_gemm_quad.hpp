@@ -33,33 +33,54 @@ namespace dg {
 
 struct E8LandingQ { v4i sa[2]; int sb[8]; };
 
-// Packed scale words of one K quad: 8 consecutive words of the lane's 8 interleaved A rows (two dwordx4) and one word per
-// N-subtile for its B rows.  K quad in the soffset, the N-subtile in the immediate offset.  NOT valid until the wait.
+// Packed scale words of one K quad: MS consecutive words of the lane's MS interleaved A rows (one or two dwordx4) and one
+// word per N-subtile for its B rows.  K quad in the soffset, the N-subtile in the immediate offset.  NOT valid until the wait.
+template <int MS>
 __device__ __forceinline__ void issue_e8q_scale_loads(E8LandingQ& l, const v4i& sfa_rsrc, int sfa_voff, int sfa_soff,
                                                       const v4i& sfb_rsrc, int sfb_voff, int sfb_soff) {
-    asm volatile(
-        "buffer_load_dwordx4 %0, %10, %11, %12 offen\n\t"
-        "buffer_load_dwordx4 %1, %10, %11, %12 offen offset:16\n\t"
-        "buffer_load_dword %2, %13, %14, %15 offen\n\t"
-        "buffer_load_dword %3, %13, %14, %15 offen offset:16\n\t"
-        "buffer_load_dword %4, %13, %14, %15 offen offset:128\n\t"
-        "buffer_load_dword %5, %13, %14, %15 offen offset:144\n\t"
-        "buffer_load_dword %6, %13, %14, %15 offen offset:256\n\t"
-        "buffer_load_dword %7, %13, %14, %15 offen offset:272\n\t"
-        "buffer_load_dword %8, %13, %14, %15 offen offset:384\n\t"
-        "buffer_load_dword %9, %13, %14, %15 offen offset:400"
-        : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3]), "=&v"(l.sb[4]),
-          "=&v"(l.sb[5]), "=&v"(l.sb[6]), "=&v"(l.sb[7])
-        : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff), "v"(sfb_voff), "s"(sfb_rsrc), "s"(sfb_soff)
-        : "memory");
+    static_assert(MS == 8 || MS == 4, "unrolled by hand");
+    if constexpr (MS == 8)
+        asm volatile(
+            "buffer_load_dwordx4 %0, %10, %11, %12 offen\n\t"
+            "buffer_load_dwordx4 %1, %10, %11, %12 offen offset:16\n\t"
+            "buffer_load_dword %2, %13, %14, %15 offen\n\t"
+            "buffer_load_dword %3, %13, %14, %15 offen offset:16\n\t"
+            "buffer_load_dword %4, %13, %14, %15 offen offset:128\n\t"
+            "buffer_load_dword %5, %13, %14, %15 offen offset:144\n\t"
+            "buffer_load_dword %6, %13, %14, %15 offen offset:256\n\t"
+            "buffer_load_dword %7, %13, %14, %15 offen offset:272\n\t"
+            "buffer_load_dword %8, %13, %14, %15 offen offset:384\n\t"
+            "buffer_load_dword %9, %13, %14, %15 offen offset:400"
+            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3]), "=&v"(l.sb[4]),
+              "=&v"(l.sb[5]), "=&v"(l.sb[6]), "=&v"(l.sb[7])
+            : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff), "v"(sfb_voff), "s"(sfb_rsrc), "s"(sfb_soff)
+            : "memory");
+    else
+        asm volatile(
+            "buffer_load_dwordx4 %0, %9, %10, %11 offen\n\t"
+            "buffer_load_dword %1, %12, %13, %14 offen\n\t"
+            "buffer_load_dword %2, %12, %13, %14 offen offset:16\n\t"
+            "buffer_load_dword %3, %12, %13, %14 offen offset:128\n\t"
+            "buffer_load_dword %4, %12, %13, %14 offen offset:144\n\t"
+            "buffer_load_dword %5, %12, %13, %14 offen offset:256\n\t"
+            "buffer_load_dword %6, %12, %13, %14 offen offset:272\n\t"
+            "buffer_load_dword %7, %12, %13, %14 offen offset:384\n\t"
+            "buffer_load_dword %8, %12, %13, %14 offen offset:400"
+            : "=&v"(l.sa[0]), "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3]), "=&v"(l.sb[4]),
+              "=&v"(l.sb[5]), "=&v"(l.sb[6]), "=&v"(l.sb[7])
+            : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff), "v"(sfb_voff), "s"(sfb_rsrc), "s"(sfb_soff)
+            : "memory");
 }
-constexpr int kE8QScaleLoads = 10;
 
+template <int MS>
 __device__ __forceinline__ void tie_e8q_landing(E8LandingQ& l) {
-    asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]), "+v"(l.sb[4]),
-                      "+v"(l.sb[5]), "+v"(l.sb[6]), "+v"(l.sb[7]) :: "memory");
+    if constexpr (MS == 8)
+        asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]), "+v"(l.sb[4]),
+                          "+v"(l.sb[5]), "+v"(l.sb[6]), "+v"(l.sb[7]) :: "memory");
+    else
+        asm volatile("" : "+v"(l.sa[0]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]), "+v"(l.sb[4]),
+                          "+v"(l.sb[5]), "+v"(l.sb[6]), "+v"(l.sb[7]) :: "memory");
 }
-
 
 // The scaled MFMA accumulating in place, as inline asm: with the builtin hipcc treats every accumulator update as a new
 // value, gives results and inputs different registers and rotates 256 registers back at the loop end through thousands of
@@ -67,6 +88,7 @@ __device__ __forceinline__ void tie_e8q_landing(E8LandingQ& l) {
 // packed scale words (op_sel / op_sel_hi of both scale operands, encoding checked against the builtin's output).
 // Nothing pads hazards inside asm: consecutive steps never touch the same accumulator; the callers keep >= 12 wait states
 // between the last MFMA and the first read of an accumulator, and a few between a VALU write of a scale register and here.
+// (The A / B operands stay in VGPRs: fed from AGPRs the MFMA measured ~1.5x slower.)
 template <int J>
 __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operand, const v8i& cols_operand, int rows_scale,
                                                 int cols_scale) {
@@ -87,16 +109,22 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // QV (timing experiments, DG_EXPERIMENTS builds only; results are garbage):
 //   0 production; 1 no LDS-DMA in the loop; 2 no fragment reads in the loop; 3 neither (matrix stream + barrier);
 //   5 no barrier in the loop.
+// BM = 256: wave tile 128 x 128 (MS = 8), the dense / large contiguous form; BM = 128: wave tile 64 x 128 (MS = 4) for the
+// grouped layouts whose M alignment is 128 rows (contiguous, psum, masked) and for small dense problems.
 template <int BM, int BN, int QV = 0>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int NW = 4, WAVES_N = 2;
     constexpr int WM = BM / 2, WN = BN / 2, MS = WM / 16, NS = WN / 16;
+    constexpr int PRE = (MS - 2) * NS, POST = 2 * NS;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
     constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5);
-    static_assert(MS == 8 && NS == 8, "written for 128 x 128 wave tiles");
-    static_assert(A_ITERS == 8 && B_ITERS == 8, "16 pieces per wave and K block: one per fourth MFMA step");
+    static_assert(NS == 8 && (MS == 8 || MS == 4), "wave tiles 128 x 128 or 64 x 128");
+    constexpr int PRE_STRIDE = PRE / N_PRE, POST_STRIDE = POST / N_POST;
+    static_assert(B_ITERS % 2 == 0 && PRE % N_PRE == 0 && POST % N_POST == 0 && PRE_STRIDE >= 2 && POST_STRIDE >= 2,
+                  "one piece per PRE_STRIDE / POST_STRIDE steps");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
     __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
@@ -104,13 +132,13 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128, num_kq = num_kb / 4;              // host: k % 512 == 0
+    const int num_kb = p.k / 128, num_kq = (num_kb + 3) / 4;
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
     const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
-    // A rows interleaved inside a wave's 128 rows (LDS row position ms * 16 + i holds tile row i * MS + ms): a lane's 8 row
-    // scales are 8 consecutive words of the MN-major scale tensor.  See duo_kernel_body.
+    // A rows interleaved inside a wave's WM rows (LDS row position ms * 16 + i holds tile row i * MS + ms): a lane's MS row
+    // scales are MS consecutive words of the MN-major scale tensor.  See duo_kernel_body.
     auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
     const int a_voff = piece_row * MS * lda + src_chunk * 16;
     const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
@@ -156,8 +184,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
         };
         if (t.m_end <= t.m0) {
             // nothing to compute (padding rows of a contiguous layout): zero rows only.  Kept apart from the main path so that
-            // the accumulators there have ONE definition chain (a join with this path would be resolved by copying all 256 out
-            // of the AGPRs, spills included).
+            // the accumulators there have ONE definition chain (a join with this path would be resolved by copying all of them
+            // out of the AGPRs, spills included).
             v4f zero[MS][4];
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms)
@@ -207,7 +235,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             E8LandingQ cur, nxt;
             auto issue_scales = [&](E8LandingQ& l, int kq) {
                 const int q = imin(kq, num_kq - 1);
-                issue_e8q_scale_loads(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
+                issue_e8q_scale_loads<MS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
             };
 
             // ---- prologue: A(0) B(0) words(0) | A(1) B(1)[first half]; wait for the first group only ----
@@ -222,7 +250,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             for (int q = 0; q < B_ITERS / 2; ++q) issue_b_piece(B_BYTES, 1, q);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
-            tie_e8q_landing(cur);
+            tie_e8q_landing<MS>(cur);
             raw_barrier();
 
             // slots (byte offsets): A(kb), A(kb+1), A(kb+2) [= where A(kb+2) is filled]; B(kb), B(kb+1)
@@ -236,46 +264,49 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
 
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
             asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
-            // One K block with byte J of the scale words.
-            auto block = [&](auto jc, int kb) {
+            // One K block with byte J of the scale words `w`.  LOAD_NEXT: this block issues the loads of the next K quad's
+            // words (block J == 1 of a whole quad); TIE_NEXT: they are waited for at this block's barrier (J == 2).
+            auto block = [&](auto jc, auto load_next, auto tie_next, const E8LandingQ& w, int kb) {
                 constexpr int J = decltype(jc)::value;
+                constexpr bool LOAD_NEXT = decltype(load_next)::value, TIE_NEXT = decltype(tie_next)::value;
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
                 const uint8_t* b_next_tile = lds + B_BASE + (b_cur ^ B_BYTES) + (wn * WN) * 128;
-                // ---- rows 0..5 ----
+                // ---- rows 0 .. MS-3 ----
                 #pragma unroll
-                for (int step = 0; step < 6 * NS; ++step) {
+                for (int step = 0; step < PRE; ++step) {
                     const int ms = step / NS, ns = step % NS;
                     if (ns == 0 && !NO_READS)
                         af[(ms + 2) & 3] = load_fragment(a_tile + (ms + 2) * 2048, frag_off);
-                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], cur.sb[ns], cur.sa[ms / 4][ms % 4]);
-                    if ((step & 3) == 1) {
-                        const int s = step >> 2;               // this wave's slot 0..11: B(kb+1) pieces 4..7, then A(kb+2) 0..7
-                        if (s < B_ITERS / 2)
-                            issue_b_piece(b_cur ^ B_BYTES, kb + 1, B_ITERS / 2 + s);
+                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                    // pieces: one per PRE_STRIDE steps: second half of B(kb+1), then A(kb+2)
+                    if (step % PRE_STRIDE == 1) {
+                        const int q = step / PRE_STRIDE;
+                        if (q < B_ITERS / 2)
+                            issue_b_piece(b_cur ^ B_BYTES, kb + 1, B_ITERS / 2 + q);
                         else
-                            issue_a_piece(a_fill, kb + 2, s - B_ITERS / 2);
+                            issue_a_piece(a_fill, kb + 2, q - B_ITERS / 2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- barrier Z ----
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
-                if (J == 2) tie_e8q_landing(nxt);               // the next K quad's words (issued in block J == 1) are in
+                if (TIE_NEXT) tie_e8q_landing<MS>(nxt);         // the next K quad's words (issued one block earlier) are in
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (J == 1) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
-                // ---- rows 6..7, ns-major ----
+                if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
+                // ---- rows MS-2, MS-1, ns-major ----
                 #pragma unroll
-                for (int step = 0; step < 2 * NS; ++step) {
-                    const int ms = 6 + (step & 1), ns = step >> 1;
-                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], cur.sb[ns], cur.sa[ms / 4][ms % 4]);
+                for (int step = 0; step < POST; ++step) {
+                    const int ms = MS - 2 + (step & 1), ns = step >> 1;
+                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
                     if ((step & 1) && !NO_READS)
                         bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
                     if (step == 4 && !NO_READS) af[0] = load_fragment(a_next_tile, frag_off);
                     if (step == 10 && !NO_READS) af[1] = load_fragment(a_next_tile + 2048, frag_off);
-                    if ((step & 3) == 1)
-                        issue_b_piece(b_cur, kb + 2, step >> 2);    // B(kb)'s slot: its fragments have been in registers since the last block
+                    if (step % POST_STRIDE == 1)
+                        issue_b_piece(b_cur, kb + 2, step / POST_STRIDE);   // B(kb)'s slot: its fragments have been in registers since the last block
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int a_free = a_cur;
@@ -284,23 +315,43 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 a_fill = a_free;
                 b_cur ^= B_BYTES;
             };
-            for (int kb = 0; kb < num_kb; kb += 4) {
-                block(std::integral_constant<int, 0>{}, kb);
-                block(std::integral_constant<int, 1>{}, kb + 1);
-                block(std::integral_constant<int, 2>{}, kb + 2);
-                block(std::integral_constant<int, 3>{}, kb + 3);
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            using Yes = std::true_type; using No = std::false_type;
+            int kb = 0;
+            for (; kb + 4 <= num_kb; kb += 4) {                 // whole K quads: byte select by op_sel, no shifts
+                block(I0{}, No{}, No{}, cur, kb);
+                block(I1{}, Yes{}, No{}, cur, kb + 1);
+                block(I2{}, No{}, Yes{}, cur, kb + 2);
+                block(I3{}, No{}, No{}, cur, kb + 3);
                 cur = nxt;
                 asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> MFMA
+            }
+            // K tail (k % 512 != 0): up to three more blocks out of the last quad's words (loaded by the last whole quad, or by
+            // the prologue when there is none), the byte shifted down by VALU
+            if constexpr (MS == 4)          // (the 256-row form takes whole quads only -- host check: a fifth copy of its 64-step
+                                            // block body pushes hipcc into keeping the accumulators in memory)
+            for (; kb < num_kb; ++kb) {
+                E8LandingQ w;
+                const int shift = (kb & 3) * 8;
+                #pragma unroll
+                for (int q = 0; q < MS / 4; ++q)
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        w.sa[q][e] = static_cast<int>(static_cast<unsigned>(cur.sa[q][e]) >> shift);
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    w.sb[ns] = static_cast<int>(static_cast<unsigned>(cur.sb[ns]) >> shift);
+                asm volatile("s_nop 3" ::: "memory");
+                block(I0{}, No{}, No{}, w, kb);
             }
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA -> accumulator reads; the tail's re-read pieces
             __syncthreads();
         }
-        // Epilogue: the shared store_tile in two halves of four N-subtiles (64 columns) each -- the column map of subtile ns
-        // is wave_n0 + (ns >> 1) * 32 + ..., so subtiles 4..7 are subtiles 0..3 of a tile that starts 64 columns further right.
         if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
             // BF16 full-line stores, one M-subtile at a time: 32 accumulator registers leave the AGPRs, are packed, exchanged and
-            // stored before the next 32 are touched (left alone hipcc reads all 256 up front and spills half of them).
+            // stored before the next 32 are touched (left alone hipcc reads all of them up front and spills half).
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
                 #pragma unroll

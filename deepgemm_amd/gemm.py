@@ -15,7 +15,7 @@ import torch
 from ._lib import lib, check, current_stream_ptr, require_device
 from .errors import host_assert
 from .layout import (check_major_type_cd, get_mn_major_tma_aligned_tensor, is_k_major, major_check,
-                     transform_sf_pair_into_required_layout)
+                     transform_sf_into_required_layout, transform_sf_pair_into_required_layout)
 from . import runtime
 
 _BF16, _FP32 = 0, 1
@@ -132,6 +132,44 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
         d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
 
 
+def _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b):
+    """Both scale tensors as packed UE8M0 words in the MN-major layout (csrc/apis/layout.hpp:58-60: the (INT, 1, gran_k) branch of
+    transform_sf_into_required_layout; default recipe for int scales is (1, 1, 128), csrc/utils/layout.hpp:64-77)."""
+    host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
+    host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
+    host_assert((recipe_a is None) == (recipe_b is None), 'recipe_a.has_value() == recipe_b.has_value()')
+    host_assert(recipe_a is None or (tuple(recipe_a) == (1, 128) and tuple(recipe_b) == (1, 128)),
+                'recipe_a == (1, 128) and recipe_b == (1, 128) for packed UE8M0 scaling factors')
+    host_assert(k % 128 == 0, 'k % 128 == 0')
+    return (transform_sf_into_required_layout(a_sf, m, k, (1, 128), num_groups_a),
+            transform_sf_into_required_layout(b_sf, n, k, (1, 128), num_groups_b))
+
+
+def _m_grouped_masked_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, masked_m, expected_m, recipe, recipe_a, recipe_b) -> None:
+    """m_grouped_fp8_gemm_nt_masked with packed UE8M0 scales (csrc/apis/gemm.hpp:250-297 with int scale tensors)."""
+    host_assert(is_k_major(a_data) and is_k_major(b_data), 'major_a == cute::UMMA::Major::K and major_b == cute::UMMA::Major::K')
+    host_assert(masked_m.is_contiguous(), 'masked_m.is_contiguous()')
+    num_groups, m, k = _check_ab_fp8(a_data, 3)
+    num_groups_, n, k_ = _check_ab_fp8(b_data, 3)
+    host_assert(d.dim() == 3, 'd.dim() == 3')
+    host_assert(num_groups == num_groups_ == d.size(0) == masked_m.numel(),
+                'num_groups == num_groups_ and num_groups == num_groups__ and num_groups == num_groups___')
+    host_assert((m, n) == tuple(d.shape[1:]) and k == k_, 'm == m_ and n == n_ and k == k_')
+    host_assert(expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0,
+                'expected_m > 0 and m > 0 and n > 0 and k > 0 and num_groups > 0')
+    host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
+    host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
+    check_major_type_cd(d)
+    sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups, num_groups)
+    require_device(a_data, b_data, sfa, sfb, d, masked_m)
+    check(lib.dg_m_grouped_fp8_gemm_nt_masked_ue8m0(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), masked_m.data_ptr(),
+        num_groups, m, n, k, int(expected_m),
+        a_data.stride(0), a_data.stride(1), a_data.stride(2), b_data.stride(0), b_data.stride(1), b_data.stride(2),
+        sfa.stride(0), sfa.stride(1), sfa.stride(2), sfb.stride(0), sfb.stride(1), sfb.stride(2),
+        d.stride(0), d.stride(1), current_stream_ptr()))
+
+
 def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch.Tensor] = None,
                 recipe: Optional[Tuple[int, int, int]] = None, recipe_a: Optional[Tuple[int, int]] = None,
                 recipe_b: Optional[Tuple[int, int]] = None, compiled_dims: str = 'nk',
@@ -226,8 +264,20 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     check_major_type_cd(d)
     if m == 0:
         return
-    sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                         None, num_groups, disable_ue8m0_cast)
+    if a_sf.dtype == torch.int or b_sf.dtype == torch.int:
+        # packed UE8M0 scales (SM100 format, recipe (1, 1, 128)): hardware-scaled MFMA kernels
+        sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, num_groups)
+        require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
+        b_km = b_data if b_data.stride(-1) == 1 else _remajor(b_data)
+        check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(
+            a_data.data_ptr(), sfa.data_ptr(), b_km.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
+            num_groups, m, n, k, a_data.stride(0), a_data.stride(1), b_km.stride(0), b_km.stride(1), b_km.stride(2),
+            sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), sfb.stride(2), d.stride(0), int(use_psum_layout),
+            runtime.get_mk_alignment_for_contiguous_layout(), current_stream_ptr()))
+        return
+    sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
+                                                              None, num_groups, disable_ue8m0_cast)
+    host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
     if not _b_mn_major_native(b_data, m, n):
         b_data = _as_k_major(b_data, m * n * k)
@@ -253,6 +303,8 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
     """``a [G,M,K]``, ``b [G,N,K]``, ``d [G,M,N]``; only ``d[g, :masked_m[g]]`` is written; ``masked_m`` stays on
     the device, ``expected_m`` is a tuning hint."""
     (a_data, a_sf), (b_data, b_sf) = a, b
+    if a_sf.dtype == torch.int or b_sf.dtype == torch.int:
+        return _m_grouped_masked_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, masked_m, expected_m, recipe, recipe_a, recipe_b)
     key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(masked_m), expected_m > 0,
            recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),
            recipe_b if recipe_b is None else tuple(recipe_b))
@@ -274,8 +326,9 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
         host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
         host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
         check_major_type_cd(d)
-        sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                             num_groups, num_groups, disable_ue8m0_cast)
+        sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
+                                                                  num_groups, num_groups, disable_ue8m0_cast)
+        host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
         require_device(a_data, b_data, sfa, sfb, d, masked_m)
         if sfb is b_sf and len(_VALIDATED_MASKED) < 4096:
             _VALIDATED_MASKED[key] = (num_groups, m, n, k, sfa is a_sf)

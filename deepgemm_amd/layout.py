@@ -3,8 +3,9 @@
 Mirrors ``csrc/utils/layout.hpp:13-117``, ``csrc/apis/layout.hpp:14-90`` and ``csrc/jit_kernels/impls/smxx_layout.hpp:
 120-153`` of the reference: SFA (1 x 128 granularity) is handed to the kernel MN-major with the MN extent padded to a
 multiple of 4 floats ("TMA aligned" in the reference; on CDNA4 it makes the per-lane SFA reads of a wave contiguous),
-SFB (128 x 128) is only checked.  FP32 scales only: packed-UE8M0 (int) scales are an SM100 input format that is listed
-as "next" in SURVEY.md section 8(f) and rejected here with the reference's own assertion text.
+SFB (128 x 128) is only checked.  Packed UE8M0 scales (int32 words of four exponent bytes, the reference's SM100 input
+format) are brought to the same MN-major layout (``csrc/apis/layout.hpp:58-60``) and feed the hardware-scaled MFMA kernels;
+``get_mn_major_tma_aligned_packed_ue8m0_tensor`` packs FP32 power-of-two scales on the device.
 """
 from typing import Optional, Tuple, Union
 
@@ -41,7 +42,10 @@ def check_major_type_cd(t: torch.Tensor) -> None:
 
 
 def get_default_recipe(sfa_dtype: torch.dtype, sfb_dtype: torch.dtype) -> Tuple[int, int, int]:
-    # gfx950 plays the role of the reference's FP32-scale architecture (csrc/utils/layout.hpp:64-77, arch_major == 9).
+    """csrc/utils/layout.hpp:64-77: FP32 scales => (1, 128, 128) (gfx950 plays the role of the reference's FP32-scale
+    architecture for them); packed UE8M0 (int) scales => (1, 1, 128), the reference's SM100 branch."""
+    if sfa_dtype == torch.int and sfb_dtype == torch.int:
+        return 1, 1, 128
     host_assert(sfa_dtype == torch.float and sfb_dtype == torch.float,
                 'sfa_dtype == torch::kFloat and sfb_dtype == torch::kFloat')
     return 1, 128, 128

@@ -38,21 +38,21 @@ def _with_major(data: torch.Tensor, sf: torch.Tensor, k_major: bool):
     return (data, sf) if k_major else (data.mT.contiguous().mT, sf)
 
 
-def cast_a(x: torch.Tensor, k_major: bool = True):
-    return _with_major(*per_token_cast_to_fp8(x, use_ue8m0=False), k_major)
+def cast_a(x: torch.Tensor, k_major: bool = True, use_ue8m0: bool = False):
+    return _with_major(*per_token_cast_to_fp8(x, use_ue8m0=use_ue8m0), k_major)
 
 
-def cast_b(x: torch.Tensor, k_major: bool = True, per_token: bool = False):
-    quant = per_token_cast_to_fp8(x, use_ue8m0=False) if per_token else per_block_cast_to_fp8(x, use_ue8m0=False)
+def cast_b(x: torch.Tensor, k_major: bool = True, per_token: bool = False, use_ue8m0: bool = False):
+    quant = per_token_cast_to_fp8(x, use_ue8m0=use_ue8m0) if per_token else per_block_cast_to_fp8(x, use_ue8m0=use_ue8m0)
     return _with_major(*quant, k_major)
 
 
-def grouped_cast(x: torch.Tensor, per_block: bool, k_major: bool = True):
+def grouped_cast(x: torch.Tensor, per_block: bool, k_major: bool = True, use_ue8m0: bool = False):
     groups, mn, k = x.shape
     data = torch.empty_like(x, dtype=torch.float8_e4m3fn)
     sf = torch.empty((groups, ceil_div(mn, 128) if per_block else mn, ceil_div(k, 128)), device=x.device, dtype=torch.float)
     for i in range(groups):
-        data[i], sf[i] = per_block_cast_to_fp8(x[i], use_ue8m0=False) if per_block else per_token_cast_to_fp8(x[i], use_ue8m0=False)
+        data[i], sf[i] = per_block_cast_to_fp8(x[i], use_ue8m0=use_ue8m0) if per_block else per_token_cast_to_fp8(x[i], use_ue8m0=use_ue8m0)
     return (data, sf) if k_major else (data.mT.contiguous().mT, sf)
 
 
@@ -68,15 +68,17 @@ class DenseCase:
 
 
 def generate_normal(m: int, n: int, k: int, a_k_major: bool = True, b_k_major: bool = True, accumulate: bool = False,
-                    out_dtype: torch.dtype = torch.bfloat16, per_token_b: bool = False, device: str = 'cuda') -> DenseCase:
-    """tests/generators.py:301-324.  ``per_token_b`` selects the (1, 1, 128) recipe's per-column SFB."""
+                    out_dtype: torch.dtype = torch.bfloat16, per_token_b: bool = False, device: str = 'cuda',
+                    use_ue8m0: bool = False) -> DenseCase:
+    """tests/generators.py:301-324.  ``per_token_b`` selects the (1, 1, 128) recipe's per-column SFB; ``use_ue8m0`` rounds
+    the scales up to powers of two (the reference's SM100 convention, deep_gemm/utils/math.py:13-16)."""
     a = torch.randn((m, k), device=device, dtype=torch.bfloat16)
     b = torch.randn((n, k), device=device, dtype=torch.bfloat16)
     d = torch.randn((m, n), device=device, dtype=out_dtype) * 32 if accumulate else \
         torch.empty((m, n), device=device, dtype=out_dtype)
     c = d if accumulate else None
     ref = (a.float() @ b.float().t() + (c if accumulate else 0)).to(out_dtype)
-    return DenseCase(cast_a(a, a_k_major), cast_b(b, b_k_major, per_token_b), c, d, ref, a, b)
+    return DenseCase(cast_a(a, a_k_major, use_ue8m0), cast_b(b, b_k_major, per_token_b, use_ue8m0), c, d, ref, a, b)
 
 
 @dataclass
@@ -93,7 +95,7 @@ class ContiguousCase:
 
 def generate_m_grouped_contiguous(num_groups: int, expected_m_per_group: int, n: int, k: int, b_k_major: bool = True,
                                   use_psum_layout: bool = False, device: str = 'cuda',
-                                  actual_ms: Optional[List[int]] = None) -> ContiguousCase:
+                                  actual_ms: Optional[List[int]] = None, use_ue8m0: bool = False) -> ContiguousCase:
     """tests/generators.py:327-366: per-group M = int(expected * U(0.7, 1.3)) aligned up, padding rows zeroed / -1."""
     alignment = runtime.get_mk_alignment_for_contiguous_layout()
     if actual_ms is None:
@@ -115,7 +117,8 @@ def generate_m_grouped_contiguous(num_groups: int, expected_m_per_group: int, n:
         a[start + actual:start + aligned] = 0
         ref[start:start + aligned] = (a[start:start + aligned].float() @ b[i].float().t()).to(torch.bfloat16)
         start += aligned
-    return ContiguousCase(m, cast_a(a), grouped_cast(b, per_block=True, k_major=b_k_major), layout, d, ref, actual_ms, aligned_ms)
+    return ContiguousCase(m, cast_a(a, use_ue8m0=use_ue8m0), grouped_cast(b, per_block=True, k_major=b_k_major, use_ue8m0=use_ue8m0),
+                          layout, d, ref, actual_ms, aligned_ms)
 
 
 @dataclass
@@ -128,7 +131,7 @@ class MaskedCase:
 
 
 def generate_m_grouped_masked(num_groups: int, max_m: int, expected_m_per_group: int, n: int, k: int,
-                              device: str = 'cuda', masked_ms: Optional[List[int]] = None) -> MaskedCase:
+                              device: str = 'cuda', masked_ms: Optional[List[int]] = None, use_ue8m0: bool = False) -> MaskedCase:
     """tests/generators.py:380-408."""
     a = torch.randn((num_groups, max_m, k), device=device, dtype=torch.bfloat16)
     b = torch.randn((num_groups, n, k), device=device, dtype=torch.bfloat16)
@@ -138,10 +141,21 @@ def generate_m_grouped_masked(num_groups: int, max_m: int, expected_m_per_group:
         masked_ms = [int(expected_m_per_group * random.uniform(0.7, 1.3)) for _ in range(num_groups)]
     assert max(masked_ms) <= max_m
     masked = torch.tensor(masked_ms, device=device, dtype=torch.int32)
-    a_q = grouped_cast(a, per_block=False)
-    for j, rows in enumerate(masked_ms):
-        a_q[1][j, rows:] = 0
-    return MaskedCase(a_q, grouped_cast(b, per_block=True), masked, d, ref)
+    a_q = grouped_cast(a, per_block=False, use_ue8m0=use_ue8m0)
+    if not use_ue8m0:           # (zero is not a power of two: the packed format keeps the scales of the masked-out rows)
+        for j, rows in enumerate(masked_ms):
+            a_q[1][j, rows:] = 0
+    return MaskedCase(a_q, grouped_cast(b, per_block=True, use_ue8m0=use_ue8m0), masked, d, ref)
+
+
+def packed_ue8m0_operand(data: torch.Tensor, sf: torch.Tensor, mn_rows: Optional[int] = None) -> tuple:
+    """(fp8, FP32 power-of-two scales) -> (fp8, packed UE8M0 int32 words [.., mn, ceil(sf_k / 4)]), the reference's SM100 input
+    format.  ``mn_rows``: the scales are per 128-row block and are broadcast to the ``mn_rows`` rows first (what the reference's
+    transform does for recipe (1, 128, 128), csrc/apis/layout.hpp:52-56)."""
+    from ..layout import get_mn_major_tma_aligned_packed_ue8m0_tensor
+    if mn_rows is not None:
+        sf = sf.repeat_interleave(128, dim=-2)[..., :mn_rows, :].contiguous()
+    return data, get_mn_major_tma_aligned_packed_ue8m0_tensor(sf)
 
 
 def enumerate_normal() -> Iterator[Tuple[int, int, int, bool, bool, bool, torch.dtype, bool]]:

@@ -59,13 +59,36 @@ int dg_fp8_gemm_nt_skip_head_mid(const void* a, const float* sfa, const void* b,
  * sm100_fp8_fp4_gemm_1d1d, impls/sm100_fp8_fp4_gemm_1d1d.hpp:93; packing: deep_gemm/utils/math.py:19-23,
  * csrc/apis/layout.hpp:48-58).  sfa_packed / sfb_packed: int32, byte j of element (row, kq) = biased exponent of the
  * scale of K block 4 kq + j of that row of A / B (127 = 1.0); element (row, kq) at ptr[row * stride_mn + kq * stride_kq],
- * stride_mn must be 1 (MN-major).  The scaled MFMA applies the scales in hardware: no FP32 promotion pass.
+ * stride_mn must be 1 (MN-major).  The scaled MFMA applies the scales in hardware and accumulates in place over K: no FP32
+ * promotion pass (4 waves per 256 x 256 tile, 128 x 128 wave tiles in AGPRs; 128 x 256 tiles for small problems and K tails).
  * A and B must be K-major with 16-byte aligned rows, k % 128 == 0. */
 int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
                          int m, int n, int k,
                          int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                          int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
+
+/* M-grouped GEMMs with packed UE8M0 scales (the reference's SM100 drivers sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d /
+ * _masked_1d1d, impls/sm100_fp8_fp4_gemm_1d1d.hpp:161,244, reached from csrc/apis/gemm.hpp:217-231,280-296 with int scale
+ * tensors).  Tensors and grouped_layout / masked_m as in the FP32-scale entry points below; sfa_packed: one word per row of A
+ * per four K blocks, element (row, kq) at ptr[row * stride_m + kq * stride_kq] (masked: + group * stride_g), stride_m must
+ * be 1; sfb_packed: one word per ROW of B (recipe (1, 1, 128)), element (g, n, kq) at ptr[g * stride_g + n * stride_n +
+ * kq * stride_kq], stride_n must be 1.  A and B K-major with 16-byte aligned rows, k % 128 == 0, m_alignment % 128 == 0. */
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                              void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                              int64_t a_stride_m, int64_t a_stride_k,
+                                              int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                              int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                              int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                              int64_t d_stride_m, int use_psum, int m_alignment, void* stream);
+int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                          void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
+                                          int expected_m,
+                                          int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                          int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                          int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                          int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                          int64_t d_stride_g, int64_t d_stride_m, void* stream);
 
 /* SF packing: FP32 power-of-two scales [batches, mn, sf_k] (element strides given) -> packed UE8M0 words int32
  * [batches, mn, ceil(sf_k / 4)] in the MN-major layout (strides (ceil(sf_k / 4) * align(mn, 4), 1, align(mn, 4))): byte j

@@ -524,6 +524,92 @@ def test_packed_ue8m0_scales_hw_path(m, n, k):
     assert_close_fp32(d32, want32, 'packed ue8m0 fp32 accumulate')
 
 
+E8_DENSE_CONFIGS = ['auto', 'e8_quad_256x256', 'e8_quad_128x256', 'e8_duo_256x256', 'e8_ring_256x256']
+
+
+@pytest.mark.parametrize('m,n,k', [(512, 768, 1024), (300, 520, 896), (4096, 4096, 1536), (129, 4096, 384)])
+def test_packed_ue8m0_every_kernel_and_per_row_sfb(m, n, k):
+    """Packed UE8M0 scales with one scale per ROW of B (recipe (1, 1, 128), the general SM100 form) through every
+    hardware-scaled kernel: oracle with the same scales as FP32 (gran_n = 1), reference gate, and bit-equality between the
+    kernels -- the matrix core accumulates the K blocks in place, in the same order, in all of them."""
+    gen.reset_seed(m + k)
+    case = gen.generate_normal(m, n, k, per_token_b=True, use_ue8m0=True)
+    a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b)
+    want = torch.empty((m, n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want, gran_n=1)
+    first = None
+    for cfg in E8_DENSE_CONFIGS:
+        if cfg == 'e8_quad_256x256' and k % 512 != 0:
+            continue                                    # whole packed words only (the other kernels take the K tail)
+        dg.set_forced_config(cfg)
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(a, b, d)
+        assert dg.last_config().startswith('e8_'), dg.last_config()
+        assert_close_to_oracle(d, want, cfg)
+        assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+        first = d if first is None else first
+        assert torch.equal(d, first), f'{cfg} differs from {E8_DENSE_CONFIGS[0]}'
+    dg.set_forced_config('e8_quad_256x256')
+    if k % 512 != 0:
+        with pytest.raises(RuntimeError, match='k % 512'):
+            dg.fp8_gemm_nt(a, b, torch.empty_like(first))
+
+
+@pytest.mark.parametrize('use_psum', [False, True])
+def test_packed_ue8m0_m_grouped_contiguous(use_psum):
+    """m_grouped_fp8_gemm_nt_contiguous / _nn_contiguous with int scale tensors (csrc/apis/gemm.hpp:217-231): the tests of the
+    FP32-scale form mirrored -- oracle per group, zero padding rows, both tile forms (two-pass 256-row tiles where legal)."""
+    gen.reset_seed(16)
+    for actual_ms, n, k in (([100, 0, 130, 256], 256, 384), ([300, 77], 520, 512), ([128] * 8, 4096, 512),
+                            ([128, 384, 0, 0, 200, 640], 512, 1024)):
+        case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, use_psum, actual_ms=actual_ms, use_ue8m0=True)
+        want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
+        oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), use_psum)
+        a = gen.packed_ue8m0_operand(*case.a)
+        b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+        cfgs = ['auto', 'e8_quad_128x256'] + (['e8_quad_256x256'] if not use_psum and k % 512 == 0 else [])
+        for cfg in cfgs:
+            for nn in (False, True):
+                dg.set_forced_config(cfg)
+                case.d.fill_(float('nan'))
+                if nn:
+                    b_nn = (b[0].mT.contiguous(), b[1])                # [G, K, N] storage; scales stay per row of B
+                    dg.m_grouped_fp8_gemm_nn_contiguous(a, (b_nn[0], b_nn[1].mT), case.d, case.grouped_layout, use_psum_layout=use_psum)
+                else:
+                    dg.m_grouped_fp8_gemm_nt_contiguous(a, b, case.d, case.grouped_layout, use_psum_layout=use_psum)
+                assert dg.last_config().startswith('e8_quad'), dg.last_config()
+                start = 0
+                for actual, aligned in zip(case.actual_ms, case.aligned_ms):
+                    rows = slice(start, start + actual)
+                    assert_close_to_oracle(case.d[rows], want[rows], f'{cfg} nn={nn} rows {rows}')
+                    assert bool((case.d[start + actual:start + aligned] == 0).all()), f'{cfg}: padding rows must be zeros'
+                    start += aligned
+                assert calc_diff(torch.nan_to_num(case.d), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
+
+
+@pytest.mark.parametrize('masked_ms,max_m,n,k', [([5, 0, 64, 33], 64, 256, 384), ([200, 1, 129], 256, 520, 512),
+                                                  ([20] * 6 + [0, 64], 64, 4096, 512), ([700, 130], 1024, 768, 1024)])
+def test_packed_ue8m0_m_grouped_masked(masked_ms, max_m, n, k):
+    """m_grouped_fp8_gemm_nt_masked with int scale tensors (csrc/apis/gemm.hpp:280-296): oracle on the valid rows, NaN poison
+    on the rows >= masked_m."""
+    gen.reset_seed(17)
+    case = gen.generate_m_grouped_masked(len(masked_ms), max_m, 0, n, k, masked_ms=masked_ms, use_ue8m0=True)
+    want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
+    oracle.m_grouped_fp8_gemm_nt_masked(*cpu_pair(case.a), *cpu_pair(case.b), want, case.masked_m.cpu())
+    a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+    expected_m = max(1, int(sum(masked_ms) / len(masked_ms)))
+    for cfg in ['auto', 'e8_quad_128x256'] + (['e8_quad_256x256'] if k % 512 == 0 else []):
+        dg.set_forced_config(cfg)
+        case.d.fill_(float('nan'))
+        dg.m_grouped_fp8_gemm_nt_masked(a, b, case.d, case.masked_m, expected_m)
+        assert dg.last_config().startswith('e8_quad'), dg.last_config()
+        for g, rows in enumerate(masked_ms):
+            if rows:
+                assert_close_to_oracle(case.d[g, :rows], want[g, :rows], f'{cfg} group {g}')
+                assert calc_diff(case.d[g, :rows], case.ref_d[g, :rows]) < gen.FP8_MAX_DIFF
+            assert bool(torch.isnan(case.d[g, rows:]).all()), f'{cfg}: rows >= masked_m must not be written'
+
+
 @pytest.mark.parametrize('k_major', [True, False])
 @pytest.mark.parametrize('num_groups,m,n,ks', [(3, 256, 384, [256, 0, 512]), (2, 200, 264, [128, 384]), (2, 304, 272, [256, 384]),
                                                (4, 512, 1024, [1024, 896, 1152, 768])])
