@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|kgrouped|dense_ue8m0]
 
-A "step" is one pass of the hot path (one GEMM launch) over one batch of synthetic, already HBM-resident input
-(``torch.manual_seed(0)`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
+A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
+(``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
 rotated so that consecutive steps do not hit the 256 MiB Infinity Cache with the same operands.  The dense path does not
 shard ("replicas only"): with N > 1 every rank runs an independent replica and ``value`` is the whole-job
-aggregate (scaling: weak).  Rank 0 prints ONE JSON line carrying ``roofline`` (dominant kernel vs the dense FP8 MFMA
-peak, timed with HIP events on the launch stream) and, at N = 1, ``cpu_baseline`` (the reference's CPU-runnable test
-expression timed on the host cores of this box).
+aggregate (scaling: weak); the masked MoE workload shards its experts over the ranks (RCCL all-to-all dispatch / combine,
+deepgemm_amd/ep.py) and reports the dispatch / GEMM / combine time split.  ``--gpus N`` without a launcher
+(``WORLD_SIZE`` unset) spawns the N ranks itself.  Rank 0 prints ONE JSON line carrying ``roofline`` (dominant kernel vs the
+dense FP8 MFMA peak or the HBM peak, timed with HIP events on the launch stream), at N = 1 ``cpu_baseline`` (the reference's
+CPU-runnable test expression timed on the host cores of this box) and, on the default run, ``secondary``: the same
+measurement, shortened, for the other BASELINE configurations (C3 per layout, C4, C5), the wgrad recipe, the K-grouped
+GEMM and the packed-UE8M0 form of C2.
 """
 import argparse
 import json
@@ -27,14 +31,16 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0']
+SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0']
 
 
 def measured_traffic(kernel: str):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/<round>/traffic.json,
-    FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if the
-    newest committed profile is of a different kernel."""
+    FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if no committed
+    profile is of this kernel."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic*.json')), reverse=True):
         with open(path) as f:
             rec = json.load(f)
         if rec.get('kernel') == kernel:
@@ -47,18 +53,19 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='dense', choices=['dense', 'contiguous', 'masked'])
+    ap.add_argument('--workload', default='dense', choices=WORKLOADS)
     ap.add_argument('--config', default='auto', help='force a kernel configuration (tuning)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the shortened runs of the other configurations')
     ap.add_argument('--clock-warmup-s', type=float, default=1.0, help='untimed load before the warm-up steps (seconds)')
     ap.add_argument('--sets', type=int, default=4, help='rotating input sets (defeats Infinity-Cache residency)')
     return ap.parse_args()
 
 
-def make_ep_workload(sets: int, world: int, rank: int):
+def make_ep_workload(sets: int, world: int, rank: int, phase_events: list):
     """BASELINE configs[4] across ranks: 8 experts per rank (8 * world in total, weights resident on their owner), 48
     token rows per rank routed to top-8 experts => about 48 rows per expert; one step = all-to-all dispatch + local masked
-    grouped GEMM + all-to-all combine (deepgemm_amd/ep.py)."""
+    grouped GEMM + all-to-all combine + top-k weighted reduce on the token's owner (deepgemm_amd/ep.py)."""
     from deepgemm_amd import ep
     from deepgemm_amd.utils.math import per_block_cast_to_fp8, per_token_cast_to_fp8
     per_rank, max_m, tokens, top_k, n, k = 8, 128, 48, 8, 4096, 7168
@@ -72,34 +79,89 @@ def make_ep_workload(sets: int, world: int, rank: int):
     for i in range(sets):
         x = per_token_cast_to_fp8(torch.randn((tokens, k), dtype=torch.bfloat16, device='cuda'), use_ue8m0=False)
         ids = torch.stack([torch.randperm(num_experts, device='cuda')[:top_k] for _ in range(tokens)])
-        calls.append(lambda x=x, ids=ids: ep.ep_m_grouped_fp8_gemm_nt_masked(x, ids, b_local, num_experts, max_m, expected_m=48))
+        weights = torch.softmax(torch.randn((tokens, top_k), device='cuda'), dim=-1)
+        calls.append(lambda x=x, ids=ids, weights=weights: ep.ep_m_grouped_fp8_gemm_nt_masked(
+            x, ids, b_local, num_experts, max_m, expected_m=48, topk_weights=weights, phase_events=phase_events))
     flops = 2.0 * tokens * top_k * n * k
     nbytes = float(b_local[0].numel() + 4 * b_local[1].numel() + tokens * top_k * (k + 4 * k // 128 + 2 * n))
     desc = {'workload': f'EP m_grouped_fp8_gemm_nt_masked: {num_experts} experts / {world} GPUs ({per_rank} per rank), about 48 rows per expert, '
-                        f'N={n} K={k}; step = RCCL all-to-all dispatch + local masked GEMM + all-to-all combine (BASELINE configs[4])',
-            'n': n, 'k': k, 'experts': num_experts}
-    return calls, flops, nbytes, desc, lambda: float('nan')
+                        f'N={n} K={k}; step = RCCL all-to-all dispatch + local masked GEMM + all-to-all combine + top-{top_k} weighted reduce '
+                        '(BASELINE configs[4])',
+            'n': n, 'k': k, 'experts': num_experts, 'top_k': top_k}
+    return calls, flops, nbytes, desc, lambda: float('nan'), 'hbm'
 
 
-def make_workload(name: str, sets: int, world: int = 1, rank: int = 0):
-    """Returns (list of zero-arg callables, flops per step, algorithmic bytes per step, description, checker)."""
+def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_events=None):
+    """Returns (zero-arg callables, flops per step, algorithmic bytes per step, description, checker, roofline bound)."""
     calls, cases = [], []
+    bound = 'mfma'
     if name == 'masked' and world > 1:
-        return make_ep_workload(sets, world, rank)
-    if name == 'dense':
+        return make_ep_workload(sets, world, rank, phase_events)
+    if name in ('dense', 'dense_ue8m0'):
+        m, n, k = 4096, 4096, 7168
+        packed = name == 'dense_ue8m0'
+        for i in range(sets):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k, use_ue8m0=packed)
+            if packed:
+                # power-of-two scales handed over as packed UE8M0 words (the reference's SM100 input format): hardware-scaled MFMA
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+            else:
+                # Producers hand SFA over in the kernel's MN-major layout (zero-copy branch of the reference's layout step,
+                # smxx_layout.hpp:124-125), so a step is exactly one GEMM launch.
+                a, b = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1])), case.b
+            cases.append(case)
+            calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d))
+        flops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (DeepSeek-V3 dense shape, BASELINE configs[1])' +
+                            (', packed UE8M0 scales (power-of-two scales, recipe (1, 1, 128))' if packed else ''),
+                'm': m, 'n': n, 'k': k,
+                'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'pre-transposed (zero-copy branch): FP32, MN-major, handed over by the producer'}
+        check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+    elif name.startswith('c3_'):
+        layout = name[3:]
+        m, n, k = 2048, 7168, 2048
+        for i in range(sets):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k, layout[0] == 'n', layout[1] == 't')
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            cases.append(case)
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        flops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        desc = {'workload': f'fp8_gemm_{layout} M={m} N={n} K={k} (BASELINE configs[2]; whole operator call, majorness from strides)',
+                'm': m, 'n': n, 'k': k}
+        check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+    elif name == 'wgrad':
         m, n, k = 4096, 4096, 7168
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_normal(m, n, k)
-            # Producers hand SFA over in the kernel's MN-major layout (zero-copy branch of the reference's layout step,
-            # smxx_layout.hpp:124-125), so a step is exactly one GEMM launch.
-            case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float, per_token_b=True)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            b = (case.b[0], dg.get_mn_major_tma_aligned_tensor(case.b[1]))
             cases.append(case)
-            calls.append(lambda c=case: dg.fp8_gemm_nt(c.a, c.b, c.d))
+            calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d, c=c.d, recipe=(1, 1, 128)))
         flops = 2.0 * m * n * k
-        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
-        desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (DeepSeek-V3 dense shape, BASELINE configs[1])', 'm': m, 'n': n, 'k': k}
-        check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+        nbytes = m * k + n * k + 4 * (m + n) * (k // 128) + 8 * m * n           # FP32 D read and written
+        desc = {'workload': f'fp8_gemm_nt recipe (1, 1, 128), FP32 accumulate into D, M={m} N={n} K={k} (wgrad form, tests/generators.py:146-153)',
+                'm': m, 'n': n, 'k': k}
+        check = lambda: float('nan')                               # noqa: E731  (D keeps accumulating: parity is the tests' job)
+    elif name == 'kgrouped':
+        import random
+        g, m, n, ek = 8, 4096, 7168, 4096
+        random.seed(0)
+        ks = [max(128, int(ek * random.uniform(0.7, 1.3)) // 128 * 128) for _ in range(g)]
+        for i in range(min(sets, 2)):
+            gen.reset_seed(i)
+            case = gen.generate_k_grouped_contiguous(g, m, n, ks, True)
+            cases.append(case)
+            calls.append(lambda c=case: dg.k_grouped_fp8_gemm_nt_contiguous(c.a, c.b, c.d, c.ks, c.grouped_layout, c=c.d))
+        flops = 2.0 * m * n * sum(ks)
+        nbytes = (m + n) * sum(ks) * (1 + 4 / 128) + 8.0 * g * m * n
+        desc = {'workload': f'k_grouped_fp8_gemm_nt_contiguous G={g} M={m} N={n} sum_k={sum(ks)} (reference sweep entry, tests/generators.py:200-202)',
+                'm': m, 'n': n, 'sum_k': sum(ks), 'groups': g}
+        check = lambda: float('nan')                               # noqa: E731
     elif name == 'contiguous':
         groups, expected, n, k = 8, 512, 4096, 7168
         for i in range(sets):
@@ -115,6 +177,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0):
                 'm': m, 'n': n, 'k': k, 'groups': groups}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     else:
+        bound = 'hbm'
         groups, max_m, expected, n, k = 8, 64, 48, 4096, 7168
         for i in range(sets):
             gen.reset_seed(i)
@@ -131,7 +194,52 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0):
         def check():
             c = cases[0]
             return max(calc_diff(c.d[g, :int(r)], c.ref_d[g, :int(r)]) for g, r in enumerate(c.masked_m.tolist()) if r)
-    return calls, flops, float(nbytes), desc, check
+    return calls, flops, float(nbytes), desc, check, bound
+
+
+def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, traffic=None):
+    tflops, gbs = flops / kernel_s / 1e12, nbytes / kernel_s / 1e9
+    rec = ({'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / PEAK_FP8_TFLOPS} if bound == 'mfma' else
+           {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
+    rec.update({'traffic': traffic, 'kernel': kernel, 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
+                'algorithmic_bytes': nbytes, 'tflops': tflops, 'gbs': gbs})
+    return rec
+
+
+def run_secondary(sets: int):
+    """The other configurations, shortened (about 0.3 s of launches each after a short warm-up): HIP-event time per operator
+    call and its roofline fraction.  For the MN-major layouts of C3 the call includes the re-majoring pass of operand A."""
+    out = []
+    for name in SECONDARY:
+        try:
+            calls, flops, nbytes, desc, check, bound = make_workload(name, 2 if name != 'masked' else sets)
+            calls[0]()
+            torch.cuda.synchronize()
+            diff = check()
+            t_end = time.perf_counter() + 0.25
+            i = 0
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    calls[i % len(calls)]()
+                    i += 1
+                torch.cuda.synchronize()
+            steps = 40 if flops < 4e11 else 10
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            for i in range(steps):
+                calls[i % len(calls)]()
+            end.record()
+            torch.cuda.synchronize()
+            call_s = start.elapsed_time(end) / 1e3 / steps
+            rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
+                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config())}
+            out.append(rec)
+        except Exception as e:                                       # noqa: BLE001  (a secondary line must not take the headline down)
+            out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'[:200]})
+        finally:
+            calls = None
+            torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(workload: str):
@@ -153,22 +261,18 @@ def cpu_baseline(workload: str):
                       f'min of 2 timed runs after 1 warm-up, {best:.2f} s per run, os.cpu_count()={os.cpu_count()}'}
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+def run(rank: int, world: int, local_rank: int, args):
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if not dist.is_initialized():
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     dg.set_forced_config(args.config)
-    calls, flops, nbytes, desc, check = make_workload(args.workload, args.sets, world, rank)
+    phase_events = []
+    calls, flops, nbytes, desc, check, bound = make_workload(args.workload, args.sets, world, rank, phase_events)
 
     calls[0]()
     torch.cuda.synchronize()
@@ -186,6 +290,7 @@ def main():
     for i in range(args.warmup):
         calls[i % len(calls)]()
     torch.cuda.synchronize()
+    phase_events.clear()
 
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if distributed:
@@ -198,42 +303,85 @@ def main():
     end.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    split = None
+    if phase_events:                        # EP step: HIP-event time of dispatch / local GEMM / combine (+ reduce), mean over the steps
+        sums = [0.0, 0.0, 0.0]
+        for e0, e1, e2, e3 in phase_events:
+            sums[0] += e0.elapsed_time(e1)
+            sums[1] += e1.elapsed_time(e2)
+            sums[2] += e2.elapsed_time(e3)
+        split = [s / len(phase_events) * 1e3 for s in sums]
     if distributed:
         dist.barrier()
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        t = torch.tensor([elapsed] + (split or [0.0, 0.0, 0.0]), device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_s = start.elapsed_time(end) / 1e3 / args.steps       # average launch duration of the dominant kernel
+        elapsed = float(t[0].item())
+        if split is not None:
+            split = [float(x) for x in t[1:].tolist()]
+    kernel_s = start.elapsed_time(end) / 1e3 / args.steps       # average launch duration of the dominant kernel (EP: of the whole step)
 
     if rank == 0:
         total_flops = flops * args.steps * world
         value = total_flops / elapsed / 1e12
-        achieved = flops / kernel_s / 1e12
-        mfma_bound = args.workload != 'masked'
-        traffic = measured_traffic(dg.last_config()) if args.workload == 'dense' else None
-        roofline = ({'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP8_TFLOPS, 'traffic': traffic} if mfma_bound else
-                    {'bound': 'hbm', 'achieved': nbytes / kernel_s / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                     'frac': nbytes / kernel_s / 1e9 / PEAK_HBM_GBS, 'traffic': traffic})
-        roofline.update({'kernel': dg.last_config(), 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
-                         'algorithmic_bytes': nbytes, 'tflops': achieved, 'gbs': nbytes / kernel_s / 1e9})
+        traffic = measured_traffic(dg.last_config()) if args.workload.startswith('dense') else None
+        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), traffic)
+        if split is not None:
+            # the roofline of the EP step is that of its local GEMM (HBM-bound on the expert weights)
+            roofline = roofline_record(flops, nbytes, split[1] / 1e6, bound, dg.last_config(), None)
+        headline = args.workload == 'dense'
         line = {
             'metric': 'achieved FP8 TFLOPS (and % of MFMA roofline) for fp8_gemm_nt M=4096 N=4096 K=7168'
-                      if args.workload == 'dense' else f'achieved FP8 TFLOPS for {args.workload} grouped FP8 GEMM',
+                      if headline else f'achieved FP8 TFLOPS for the {args.workload} workload',
             'value': value, 'unit': 'TFLOPS', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'fp8_e4m3 (fp32 accumulate, bf16 out)', 'data': 'synthetic',
-            'config': dict(desc, parallelism=('single GPU' if world == 1 else f'ep{world}' if args.workload == 'masked' else 'replicas only'), kernel=dg.last_config(),
-                           input_sets=len(calls)),
+            'config': dict(desc, parallelism=('single GPU' if world == 1 else f'ep{world}' if args.workload == 'masked' else 'replicas only'),
+                           kernel=dg.last_config(), input_sets=len(calls)),
             'pct_of_mfma_peak': 100.0 * value / world / PEAK_FP8_TFLOPS,
             'calc_diff_vs_reference_expr': diff,
             'roofline': roofline,
         }
+        if split is not None:
+            line['ep_time_split_us'] = {'dispatch_all_to_all': split[0], 'local_masked_gemm': split[1], 'combine_all_to_all_and_topk_reduce': split[2],
+                                        'note': 'HIP events on the launch stream, mean per step, max over ranks'}
+        if world == 1 and headline and not args.no_secondary:
+            line['secondary'] = run_secondary(args.sets)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def _spawned(local_rank: int, world: int, port: int, args):
+    os.environ.update({'RANK': str(local_rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    run(local_rank, world, local_rank, args)
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' in os.environ:          # launched by torch.distributed.run: one process per GPU already exists
+        world = int(os.environ['WORLD_SIZE'])
+        if args.gpus != world:
+            raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+        run(int(os.environ.get('RANK', '0')), world, int(os.environ.get('LOCAL_RANK', '0')), args)
+        return
+    if args.gpus <= 1:
+        run(0, 1, 0, args)
+        return
+    # plain `python bench.py --gpus N`: spawn the N ranks here (as the reference's multi-GPU test does,
+    # tests/test_mega_moe.py:312 + deep_gemm/utils/dist.py:10-35) -- and refuse loudly if the node has fewer GPUs
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_spawned, args=(args.gpus, port, args), nprocs=args.gpus, join=True)
 
 
 if __name__ == '__main__':

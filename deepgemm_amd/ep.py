@@ -111,13 +111,20 @@ def dispatch(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, max_m: i
     return (a, sfa), plan
 
 
-def combine(d: torch.Tensor, plan: DispatchPlan, tokens: int, top_k: int, group=None) -> torch.Tensor:
-    """Returns the result rows to their source ranks: output ``[tokens, top_k, N]`` in the order of ``expert_ids``."""
+def combine(d: torch.Tensor, plan: DispatchPlan, tokens: int, top_k: int, group=None,
+            topk_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Returns the result rows to their source ranks.  Without weights: ``[tokens, top_k, N]`` in the order of ``expert_ids``;
+    with ``topk_weights [tokens, top_k]`` the owner of a token reduces its ``top_k`` rows: ``[tokens, N]`` BF16 =
+    ``sum_j topk_weights[t, j] * row(t, j)`` accumulated in FP32 (the reference's fused kernel does
+    the same reduction in its combine stage, deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:523-595)."""
     rows_out = d[plan.recv_expert, plan.recv_slot]                       # [P_recv, N] in arrival order
     back = _all_to_all_rows(rows_out, plan.recv_splits, plan.send_splits, group)
     out = torch.empty((tokens * top_k, d.size(-1)), dtype=d.dtype, device=d.device)
     out[plan.send_order] = back
-    return out.view(tokens, top_k, d.size(-1))
+    out = out.view(tokens, top_k, d.size(-1))
+    if topk_weights is None:
+        return out
+    return (out.float() * topk_weights.to(torch.float).unsqueeze(-1)).sum(dim=1).to(d.dtype)
 
 
 def _default_local_gemm(a: TensorPair, b: TensorPair, d: torch.Tensor, masked_m: torch.Tensor, expected_m: int) -> None:
@@ -127,15 +134,33 @@ def _default_local_gemm(a: TensorPair, b: TensorPair, d: torch.Tensor, masked_m:
 
 def ep_m_grouped_fp8_gemm_nt_masked(x: TensorPair, expert_ids: torch.Tensor, b_local: TensorPair, num_experts: int,
                                     max_m: int, expected_m: Optional[int] = None, group=None,
-                                    local_gemm: Callable = _default_local_gemm) -> torch.Tensor:
-    """One expert-parallel step: dispatch -> local masked grouped GEMM -> combine.
+                                    local_gemm: Callable = _default_local_gemm,
+                                    topk_weights: Optional[torch.Tensor] = None,
+                                    phase_events: Optional[list] = None) -> torch.Tensor:
+    """One expert-parallel step: dispatch -> local masked grouped GEMM -> combine (-> top-k weighted reduce).
 
     ``b_local = (B [G_local, N, K] fp8, SFB [G_local, N / 128, K / 128])`` are this rank's resident expert weights.
-    Returns ``[T, top_k, N]`` BF16: row ``(t, j)`` is ``x[t] @ B[expert_ids[t, j]]^T``.
+    Returns ``[T, top_k, N]`` BF16 (row ``(t, j)`` is ``x[t] @ B[expert_ids[t, j]]^T``) or, with ``topk_weights``, ``[T, N]``.
+    ``phase_events``: a list that receives one ``(e0, e1, e2, e3)`` tuple of recorded CUDA events per call -- dispatch is
+    ``e0..e1``, the local GEMM ``e1..e2``, combine ``e2..e3`` (bench.py's time split; only on CUDA tensors).
     """
     tokens, top_k = expert_ids.shape
+    marks = []
+
+    def mark():
+        if phase_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+    mark()
     (a, sfa), plan = dispatch(x, expert_ids, num_experts, max_m, group)
+    mark()
     groups, n = b_local[0].size(0), b_local[0].size(1)
     d = torch.empty((groups, max_m, n), dtype=torch.bfloat16, device=a.device)
     local_gemm((a, sfa), b_local, d, plan.masked_m, expected_m if expected_m is not None else max(1, max_m // 2))
-    return combine(d, plan, tokens, top_k, group)
+    mark()
+    out = combine(d, plan, tokens, top_k, group, topk_weights)
+    mark()
+    if phase_events is not None:
+        phase_events.append(tuple(marks))
+    return out

@@ -45,10 +45,15 @@ def _both_mn_major_aligned(a: torch.Tensor, b: torch.Tensor, m: int, n: int) -> 
             a.stride(-1) % 16 == 0 and b.stride(-1) % 16 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
-def _b_mn_major_native(b: torch.Tensor, m: int, n: int) -> bool:
-    """MN-major B ([.., N, K] view with unit stride along N) that the B_MN kernels take as it is (dg_api.hip: bmn_eligible)."""
-    return (b.stride(-2) == 1 and b.stride(-1) != 1 and m > 256 and n % 16 == 0 and
-            b.stride(-1) % 16 == 0 and b.data_ptr() % 16 == 0 and (b.dim() == 2 or b.stride(0) % 16 == 0))
+def _b_mn_major_native(b: torch.Tensor, m: int, n: int, k: int, a: torch.Tensor, m_alignment: int = 128) -> bool:
+    """MN-major B ([.., N, K] view with unit stride along N) that the B_MN kernels take as it is.  Mirrors dg_api.hip's
+    bmn_eligible() and the tile rule of select_config() -- K-major 16-byte aligned A, whole K blocks, 32-bit piece offsets, a
+    contiguous-layout alignment the 128-row tiles divide -- so that whatever passes here finds a kernel there; anything else is
+    re-majored into K-major scratch by the caller."""
+    return (b.stride(-2) == 1 and b.stride(-1) != 1 and m > 256 and n % 16 == 0 and k % 128 == 0 and m_alignment % 128 == 0 and
+            b.stride(-1) % 16 == 0 and b.data_ptr() % 16 == 0 and (b.dim() == 2 or b.stride(0) % 16 == 0) and
+            b.stride(-1) <= (1 << 22) and k * b.stride(-1) < (1 << 31) and
+            a.stride(-1) == 1 and a.stride(-2) % 16 == 0 and a.data_ptr() % 16 == 0 and a.stride(-2) <= (1 << 22))
 
 
 def _remajor(t: torch.Tensor) -> torch.Tensor:
@@ -190,7 +195,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
         sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
         if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
             a_data = _as_k_major(a_data, m * n * k)
-            if not (gran_n == 128 and _b_mn_major_native(b_data, m, n)):
+            if not (gran_n == 128 and sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data)):
                 b_data = _as_k_major(b_data, m * n * k)
         check(lib.dg_fp8_gemm_nt(
             a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), m, n, k,
@@ -215,7 +220,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
         # (recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are, no re-majoring pass)
         a_data = _as_k_major(a_data, m * n * k)
-        if not (gran_n == 128 and _b_mn_major_native(b_data, m, n)):
+        if not (gran_n == 128 and sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data)):
             b_data = _as_k_major(b_data, m * n * k)      # (large MN-major B: read natively through transpose reads instead)
     check(lib.dg_fp8_gemm_nt(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
@@ -279,7 +284,7 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
                                                               None, num_groups, disable_ue8m0_cast)
     host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
-    if not _b_mn_major_native(b_data, m, n):
+    if not (sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data, runtime.get_mk_alignment_for_contiguous_layout())):
         b_data = _as_k_major(b_data, m * n * k)
     check(lib.dg_m_grouped_fp8_gemm_nt_contiguous(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
@@ -347,17 +352,23 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
 _KGROUPED_BLOCKS, _KGROUPED_COLUMNS, _KGROUPED_ROWS = 0, 1, 2
 
 
-def _check_k_grouped_args(ks, grouped_layout: torch.Tensor, num_groups: int, use_psum_layout: bool, k_alignment: int) -> int:
-    """csrc/apis/gemm.hpp:48-69; the psum form (K ranges read from the device tensor) is not implemented on gfx950."""
+def _check_k_grouped_args(ks_cpu, grouped_layout: torch.Tensor, num_groups: int, use_psum_layout: bool, k_alignment: int) -> int:
+    """csrc/apis/gemm.hpp:48-69, same order and condition text.  The psum form (K ranges read from the device tensor, groups
+    starting at multiples of the K alignment, ``ks_cpu`` optional) exists only in the reference's SM100 driver
+    (``sm100_k_grouped_fp8_gemm_1d1d``); asking for it here ends where the reference ends on an architecture without it."""
     host_assert(grouped_layout.is_contiguous(), 'grouped_layout.is_contiguous()')
     host_assert(grouped_layout.dtype == torch.int, 'grouped_layout.scalar_type() == torch::kInt')
     host_assert(grouped_layout.numel() == num_groups, 'static_cast<int>(grouped_layout.numel()) == num_groups')
-    host_assert(not use_psum_layout, 'not use_psum_layout')
-    host_assert(ks is not None and len(ks) > 0, 'ks_cpu.has_value() and not ks_cpu.value().empty()')
-    host_assert(len(ks) == num_groups, 'static_cast<int>(ks_cpu.value().size()) == num_groups')
-    for k in ks:
-        host_assert(k % k_alignment == 0, 'k % k_alignment == 0')
-    return int(sum(ks))
+    if ks_cpu is None or len(ks_cpu) == 0:
+        host_assert(use_psum_layout, 'use_psum_layout')
+    else:
+        host_assert(len(ks_cpu) == num_groups, 'static_cast<int>(ks_cpu.value().size()) == num_groups')
+        for k in ks_cpu:
+            host_assert(k % k_alignment == 0, 'k % k_alignment == 0')
+    if use_psum_layout:
+        raise RuntimeError('Assertion error (gemm.py): Unsupported architecture '
+                           '(the psum layout of the K-grouped GEMM is implemented by the reference for SM100 only)')
+    return int(sum(ks_cpu))
 
 
 def _k_grouped_sf(sf: torch.Tensor, mn: int, sum_k: int) -> torch.Tensor:
@@ -378,13 +389,18 @@ def _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, layout, a_ld, b_ld)
         sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr()))
 
 
-def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks, grouped_layout: torch.Tensor,
+def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks_cpu, grouped_layout: torch.Tensor,
                                      c: Optional[torch.Tensor] = None, recipe: Tuple[int, int, int] = (1, 1, 128),
                                      compiled_dims: str = 'mn', use_psum_layout: bool = False) -> None:
-    """``a[0]``: the groups' K-major ``[M, ks[g]]`` matrices stored one after another (flat), ``a[1]``: ``[M, sum_k / 128]``;
-    same for ``b`` with N; ``d [G, M, N]`` FP32 ``= c + A_g @ B_g^T`` (csrc/apis/gemm.hpp:348-400)."""
+    """``a[0]``: the groups' K-major ``[M, ks_cpu[g]]`` matrices stored one after another (flat), ``a[1]``: ``[M, sum_k / 128]``;
+    same for ``b`` with N; ``d [G, M, N]`` FP32 ``= c + A_g @ B_g^T`` (csrc/apis/gemm.hpp:348-400; keyword names of the
+    ``m.def`` at ``:697-710``)."""
     (a_data, a_sf), (b_data, b_sf) = a, b
+    ks = ks_cpu
     host_assert(tuple(recipe) == (1, 1, 128), 'recipe == std::make_tuple(1, 1, 128)')
+    # No psum on FP8 NT (csrc/apis/gemm.hpp:360)
+    host_assert(not use_psum_layout and ks is not None and len(ks) > 0,
+                'not use_psum_layout and ks_cpu.has_value() and not ks_cpu.value().empty()')
     host_assert(d.dim() == 3, 'd.dim() == 3')
     num_groups, m, n = (int(x) for x in d.shape)
     sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, 128)
@@ -402,13 +418,14 @@ def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_BLOCKS, 0, 0)
 
 
-def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks, grouped_layout: torch.Tensor,
+def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks_cpu, grouped_layout: torch.Tensor,
                                      c: Optional[torch.Tensor] = None, recipe: Tuple[int, int, int] = (1, 1, 128),
                                      compiled_dims: str = 'mn', use_psum_layout: bool = False) -> None:
     """MN-major operands: ``a[0] [sum_k, M]``, ``a[1] [sum_k / 128, M]`` (per-channel scales), ``b`` likewise with N;
     ``d [G, M, N]`` FP32 ``= c + A_g^T @ B_g`` (csrc/apis/gemm.hpp:299-346).  The FP8 operands are re-majored once by
     ``dg_transpose_fp8`` (HBM-bound, 2 bytes per element) and every group then is a column range of a K-major matrix."""
     (a_data, a_sf), (b_data, b_sf) = a, b
+    ks = ks_cpu
     recipe = tuple(recipe)
     host_assert(recipe[0] == 1 and recipe[1] == 1, 'std::get<0>(recipe) == 1 and std::get<1>(recipe) == 1')
     host_assert(recipe[2] == 128, 'gran_k == 128 (gran_k == 32 needs the packed UE8M0 scale format)')
@@ -429,8 +446,11 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
     sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
     from . import runtime as _rt
+    # (mirrors the DG_KGROUPED_ROWS conditions of dg_k_grouped_fp8_gemm_nt_contiguous: anything else is re-majored below)
     native = (m > 64 and m % 16 == 0 and n % 16 == 0 and num_groups <= 64 and a_data.data_ptr() % 16 == 0 and
-              b_data.data_ptr() % 16 == 0 and sum_k * max(m, n) < 2 ** 31 and _rt.last_forced_config() == 'auto')
+              b_data.data_ptr() % 16 == 0 and sum_k * max(m, n) < 2 ** 31 and max(m, n) <= (1 << 22) and
+              sfa.stride(0) == 1 and sfb.stride(0) == 1 and sfa.data_ptr() % 16 == 0 and sfb.data_ptr() % 16 == 0 and
+              sfa.stride(1) % 4 == 0 and sfb.stride(1) % 4 == 0 and _rt.last_forced_config() == 'auto')
     if native:
         # MN-major operands straight into the kernel: LDS-DMA of [k][m] rows, hardware transpose reads for the fragments
         _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0))

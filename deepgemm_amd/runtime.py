@@ -21,6 +21,8 @@ def get_num_sms() -> int:
 
 
 def set_tc_util(new_tc_util: int) -> None:
+    """Stored and otherwise ignored: in the reference it throttles tensor-core utilisation in NVIDIA codegen
+    (csrc/apis/runtime.hpp:22-29); the ahead-of-time gfx950 kernels have no such knob.  Never changes results."""
     _state['tc_util'] = int(new_tc_util)
 
 
@@ -29,6 +31,8 @@ def get_tc_util() -> int:
 
 
 def set_pdl(new_enable_pdl: bool) -> None:
+    """Stored and otherwise ignored: programmatic dependent launch is a CUDA launch attribute
+    (csrc/jit/kernel_runtime.hpp:146); HIP has no equivalent.  Never changes results."""
     _state['pdl'] = bool(new_enable_pdl)
 
 
@@ -37,10 +41,14 @@ def get_pdl() -> bool:
 
 
 def set_ignore_compile_dims(new_value: bool) -> None:
+    """Stored and otherwise ignored: it steers which shape dimensions the reference bakes into JIT-compiled code
+    (csrc/jit_kernels/impls/runtime_utils.hpp:22-31); the kernels here are compiled ahead of time with runtime shapes."""
     _state['ignore_compile_dims'] = bool(new_value)
 
 
 def set_block_size_multiple_of(new_value: Union[int, Tuple[int, int]]) -> None:
+    """Stored and otherwise ignored: a constraint on the reference's heuristic tile search (csrc/apis/runtime.hpp:36-41); the
+    gfx950 tile shapes are a fixed set (dg_list_configs())."""
     _state['block_size_multiple_of'] = (new_value, new_value) if isinstance(new_value, int) else tuple(new_value)
 
 

@@ -18,15 +18,36 @@ PRODUCTION = [
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,12,0,1>',
     'dg_fp8_gemm_pipe_kernel<128,128,2,2,2,0>', 'dg_fp8_gemm_pipe_kernel<64,256,1,4,1,0>', 'dg_fp8_gemm_pipe_kernel<256,256,2,4,2,0>',
     'dg_fp8_gemm_pipe_pc_kernel<256,256,2,4,2,0,0>', 'dg_fp8_gemm_pipe_pc_kernel<256,256,2,4,2,0,1>',
-    'dg_fp8_gemm_duo_e8_kernel<256,256,2,4>',
+    'dg_fp8_gemm_duo_e8_kernel<256,256,2,4>', 'dg_fp8_gemm_quad_e8_kernel<256,256,0>', 'dg_fp8_gemm_quad_e8_kernel<128,256,0>',
 ]
+
+
+def _report_module():
+    spec = importlib.util.spec_from_file_location('codegen_report', os.path.join(ROOT, 'tools', 'codegen_report.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_landing_hazard_checker_on_synthetic_streams():
+    """The checker itself: a read, an overwrite or an address use of a landing register before a covering wait is flagged; a
+    counted wait that leaves only YOUNGER operations outstanding releases the registers; LDS-DMA pieces have no landing registers."""
+    check = _report_module().landing_hazards
+    load = 'buffer_load_dwordx4 v[8:11], v2, s[4:7], 0 offen'
+    dma = 'buffer_load_dwordx4 v3, s[8:11], s20 offen lds'
+    assert check([load, dma, dma, 's_waitcnt vmcnt(2)', 'v_mul_f32_e32 v12, v8, v9']) == []
+    assert [h[1] for h in check([load, dma, 's_waitcnt vmcnt(2)', 'v_mul_f32_e32 v12, v8, v9'])] == ['touch']      # wait too weak
+    assert [h[1] for h in check([load, 'v_mov_b32_e32 v20, v10', 's_waitcnt vmcnt(0)'])] == ['touch']                 # early copy
+    assert [h[1] for h in check([load, 'v_mov_b32_e32 v9, v1', 's_waitcnt vmcnt(0)'])] == ['touch']                  # early overwrite
+    assert [h[1] for h in check([load, 'buffer_load_dword v30, v8, s[4:7], 0 offen', 's_waitcnt vmcnt(0)'])] == ['touch']
+    assert [h[1] for h in check([load, 's_cbranch_scc1 12', 's_waitcnt vmcnt(0)'])] == ['branch']
+    assert check([load, 's_waitcnt vmcnt(0) lgkmcnt(0)', 'v_mov_b32_e32 v20, v10', 's_cbranch_scc1 12']) == []
+    assert check([load, 's_waitcnt lgkmcnt(0)', 'v_add_f32_e32 v1, v2, v3', 's_waitcnt vmcnt(0)', 'v_mov_b32_e32 v20, v8']) == []
 
 
 @pytest.mark.skipif(not os.path.exists(LLVM_OBJDUMP), reason='llvm-objdump of the ROCm toolchain not available')
 def test_no_spill_traffic_inside_the_k_loop_of_production_kernels():
-    spec = importlib.util.spec_from_file_location('codegen_report', os.path.join(ROOT, 'tools', 'codegen_report.py'))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    mod = _report_module()
     rows = {r['kernel']: r for r in mod.report()}
     missing = [k for k in PRODUCTION if k not in rows]
     assert not missing, f'kernels not found in the library: {missing}'
@@ -35,3 +56,7 @@ def test_no_spill_traffic_inside_the_k_loop_of_production_kernels():
         assert r['mfma_range_instructions'] > 0, name
         assert r['scratch_in_mfma_range'] == 0, f'{name}: {r["scratch_in_mfma_range"]} scratch instructions between the first and last MFMA'
         assert r.get('vgpr_spill_count', 0) <= 8, f'{name}: {r.get("vgpr_spill_count")} VGPR spills'
+        # the asm-load rule (DESIGN.md "A latent race"): nothing touches a landing VGPR between its buffer_load and the wait that
+        # covers it, anywhere in the kernel; inside the K loop no branch is taken while such a load is in flight
+        assert not r['landing_touches'], f'{name}: landing registers touched before their wait: {r["landing_touches"][:3]}'
+        assert not r['landing_branches_in_mfma_range'], f'{name}: branch with VGPR-landing loads in flight: {r["landing_branches_in_mfma_range"][:3]}'

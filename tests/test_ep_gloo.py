@@ -50,6 +50,13 @@ def _worker(rank: int, world: int, port: int, num_experts: int, tokens: int, top
                 oracle.fp8_gemm_nt(xq[0][t:t + 1], xq[1][t:t + 1], b_all[e][0], b_all[e][1], want)
                 assert torch.equal(out[t, j], want[0]), (rank, t, j, e)
 
+        # top-k weighted reduce on the token's owner: FP32 accumulation of the combined rows
+        weights = torch.softmax(torch.randn((x.size(0), top_k)), dim=-1)
+        reduced = ep.ep_m_grouped_fp8_gemm_nt_masked(xq, expert_ids, b_local, num_experts, max_m, local_gemm=_oracle_local_gemm,
+                                                     topk_weights=weights)
+        assert reduced.shape == (x.size(0), n) and reduced.dtype == torch.bfloat16
+        assert torch.equal(reduced, (out.float() * weights.unsqueeze(-1)).sum(dim=1).to(torch.bfloat16))
+
         # capacity overflow is an error, not silent truncation
         if rank == 0:
             pass

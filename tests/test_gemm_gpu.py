@@ -372,6 +372,17 @@ def test_import_is_fork_safe_and_bench_runs():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['steps'] == 4 and line['unit'] == 'TFLOPS' and line['value'] > 0
     assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1 and line['cpu_baseline']['value'] > 0
+    assert 'zero-copy' in line['config']['sfa_layout']
+    # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0
+    secondary = line['secondary']
+    assert len(secondary) == 9 and not [s for s in secondary if 'error' in s], secondary
+    for rec in secondary:
+        assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
+    assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
+    # --gpus N without a launcher must not silently run one rank
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '2', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and 'GPU(s) visible' in out.stderr
 
 
 def test_full_size_c2_properties():

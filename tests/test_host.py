@@ -232,3 +232,61 @@ def test_newer_operators_exist_and_validate_on_the_host():
     rc = lib.dg_k_grouped_fp8_gemm_nt_contiguous(1, 1, 1, 1, 1, 128, 128, ctypes.cast(ks, ctypes.c_void_p), 2, 7, 0, 0, 1, 128, 1, 128, None)
     assert rc != 0 and b'ab_layout' in lib.dg_last_error()
     assert lib.dg_k_grouped_fp8_gemm_nt_contiguous(None, None, None, None, None, 0, 128, None, 2, 0, 0, 0, 1, 1, 1, 1, None) == 0
+
+
+def test_every_reference_keyword_by_name():
+    """Drop-in boundary: every operator takes the reference's keyword names (csrc/apis/gemm.hpp:645-717, attention.hpp m.def)
+    -- all of them passed BY NAME on host tensors; a call that gets through the argument checks stops at the device check."""
+    c = _case(128, 256, 256)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.fp8_gemm_nt(a=c.a, b=c.b, d=c.d, c=None, recipe=None, recipe_a=None, recipe_b=None, compiled_dims='nk', disable_ue8m0_cast=False)
+    for name, dims in (('fp8_gemm_nn', 'nk'), ('fp8_gemm_tn', 'mn'), ('fp8_gemm_tt', 'mn')):
+        a = c.a if name[-2] == 'n' else (c.a[0].T.contiguous(), c.a[1].T.contiguous())
+        b = c.b if name[-1] == 't' else (c.b[0].T.contiguous(), c.b[1].T.contiguous())
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            getattr(dg, name)(a=a, b=b, d=c.d, c=None, recipe=None, recipe_a=None, recipe_b=None, compiled_dims=dims, disable_ue8m0_cast=False)
+    g = gen.generate_m_grouped_contiguous(2, 100, 128, 256, device='cpu')
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.m_grouped_fp8_gemm_nt_contiguous(a=g.a, b=g.b, d=g.d, grouped_layout=g.grouped_layout, recipe=None, recipe_a=None, recipe_b=None,
+                                            compiled_dims='nk', disable_ue8m0_cast=False, use_psum_layout=False,
+                                            ensure_zero_padding=True, expected_m_for_psum_layout=None)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.m_grouped_fp8_gemm_nn_contiguous(a=g.a, b=(g.b[0].mT.contiguous(), g.b[1].mT.contiguous()), d=g.d, grouped_layout=g.grouped_layout,
+                                            recipe=None, recipe_a=None, recipe_b=None, compiled_dims='nk', disable_ue8m0_cast=False,
+                                            use_psum_layout=False, ensure_zero_padding=True)
+    mk = gen.generate_m_grouped_masked(2, 64, 0, 128, 256, device='cpu', masked_ms=[3, 64])
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.m_grouped_fp8_gemm_nt_masked(a=mk.a, b=mk.b, d=mk.d, masked_m=mk.masked_m, expected_m=32, recipe=None, recipe_a=None,
+                                        recipe_b=None, compiled_dims='nk', disable_ue8m0_cast=False)
+    kg = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True, device='cpu')
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.k_grouped_fp8_gemm_nt_contiguous(a=kg.a, b=kg.b, d=kg.d, ks_cpu=kg.ks, grouped_layout=kg.grouped_layout, c=kg.c,
+                                            recipe=(1, 1, 128), compiled_dims='mn', use_psum_layout=False)
+    kt = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], False, device='cpu')
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.k_grouped_fp8_gemm_tn_contiguous(a=kt.a, b=kt.b, d=kt.d, ks_cpu=kt.ks, grouped_layout=kt.grouped_layout, c=kt.c,
+                                            recipe=(1, 1, 128), compiled_dims='mn', use_psum_layout=False)
+    # ks_cpu missing: legal only together with the psum layout (csrc/apis/gemm.hpp:66-68), which the reference implements for
+    # SM100 alone -- the call ends where the reference ends on an architecture without that driver
+    for missing in (None, []):
+        with pytest.raises(RuntimeError, match=r'\): use_psum_layout'):
+            dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c)
+        with pytest.raises(RuntimeError, match='Unsupported architecture'):
+            dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c, use_psum_layout=True)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.fp8_gemm_nt_skip_head_mid(a=c.a, b=c.b, d=torch.empty(128, 256 + 2 * 32, dtype=torch.bfloat16), head_splits=(64, 32, 64),
+                                     recipe=None, compiled_dims='nk', disable_ue8m0_cast=False)
+    # int (packed UE8M0) scale tensors: routed by dtype, default recipe (1, 1, 128) (csrc/utils/layout.hpp:64-77)
+    pa, pb = (c.a[0], torch.zeros(128, 1, dtype=torch.int)), (c.b[0], torch.zeros(256, 1, dtype=torch.int))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.fp8_gemm_nt(pa, pb, c.d)
+    with pytest.raises(RuntimeError, match='recipe == .1, 1, 128.'):
+        dg.fp8_gemm_nt(pa, pb, c.d, recipe=(1, 128, 128))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.m_grouped_fp8_gemm_nt_contiguous((g.a[0], torch.zeros(g.m, 1, dtype=torch.int)), (g.b[0], torch.zeros(2, 128, 1, dtype=torch.int)),
+                                            g.d, g.grouped_layout)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        dg.m_grouped_fp8_gemm_nt_masked((mk.a[0], torch.zeros(2, 64, 1, dtype=torch.int)), (mk.b[0], torch.zeros(2, 128, 1, dtype=torch.int)),
+                                        mk.d, mk.masked_m, 32)
+    with pytest.raises(RuntimeError, match='gran_n == 128'):           # per-column FP32 SFB is a dense-only recipe
+        dg.m_grouped_fp8_gemm_nt_masked(mk.a, (mk.b[0], torch.ones(2, 128, 2)), mk.d, mk.masked_m, 32, recipe=(1, 1, 128))

@@ -15,6 +15,62 @@ LIB = os.path.join(ROOT, 'deepgemm_amd', 'csrc', 'libdeepgemm_amd.so')
 LLVM = '/opt/rocm/lib/llvm/bin'
 
 
+_REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+_VMEM = ('buffer_load', 'buffer_store', 'buffer_atomic', 'global_load', 'global_store', 'global_atomic', 'scratch_load',
+         'scratch_store', 'flat_load', 'flat_store')
+
+
+def _vregs(text):
+    regs = set()
+    for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+def landing_hazards(body):
+    """The "asm load" rule, checked on the instruction stream: a vector-memory load that lands in VGPRs makes them valid only
+    after an s_waitcnt whose vmcnt leaves no more operations outstanding than were issued after it (vector-memory operations
+    of a wave retire in order).  Until then no instruction may touch those registers (hipcc treats the destinations of an
+    inline-asm load as ordinary values and has copied them early once, DESIGN.md "A latent race"), and no branch may be taken:
+    the rule the kernels follow is "an asm load reaches its wait in straight-line code".  Returns the violations found in the
+    linear instruction sequence `body`: (index, kind, instruction) with kind 'touch' or 'branch'."""
+    outstanding = []            # per vector-memory operation in issue order: set of landing VGPRs (empty for stores / LDS-DMA)
+    bad = []
+    for idx, ins in enumerate(body):
+        op = ins.split()[0] if ins.split() else ''
+        if op == 's_waitcnt':
+            m = re.search(r'vmcnt\((\d+)\)', ins)
+            if m:
+                keep = int(m.group(1))
+                if len(outstanding) > keep:
+                    outstanding = outstanding[len(outstanding) - keep:] if keep else []
+            continue
+        in_flight = set().union(*outstanding) if outstanding else set()
+        if op.startswith(_VMEM):
+            operands = ins[len(op):]
+            first = operands.split(',')[0]
+            is_load = 'load' in op and not ins.rstrip().endswith(' lds')
+            dst = _vregs(first) if is_load else set()
+            rest = _vregs(operands) - dst if is_load else _vregs(operands)
+            if in_flight & rest or (in_flight & dst):
+                bad.append((idx, 'touch', ins))
+            outstanding.append(dst)
+            continue
+        if in_flight:
+            if op.startswith(('s_cbranch', 's_branch', 's_setpc', 's_endpgm')):
+                # only loads issued by inline asm matter for the branch rule, but the disassembly cannot tell them apart:
+                # report it, the caller decides
+                bad.append((idx, 'branch', ins))
+                outstanding = [set() for _ in outstanding]      # (a new block: stop tracking, the touch rule restarts)
+                continue
+            if in_flight & _vregs(ins[len(op):]):
+                bad.append((idx, 'touch', ins))
+    return bad
+
+
 def report():
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, 'lib.so')
@@ -60,7 +116,9 @@ def report():
         out.append({'kernel': pretty, 'symbol': name, **meta[name],
                     'mfma_range_instructions': len(loop),
                     'scratch_in_mfma_range': sum(1 for ins in loop if ins.startswith('scratch_')),
-                    'lane_ops_in_mfma_range': sum(1 for ins in loop if ins.startswith(('v_readlane', 'v_writelane')))})
+                    'lane_ops_in_mfma_range': sum(1 for ins in loop if ins.startswith(('v_readlane', 'v_writelane'))),
+                    'landing_touches': [h for h in landing_hazards(body) if h[1] == 'touch'],
+                    'landing_branches_in_mfma_range': [h for h in landing_hazards(loop) if h[1] == 'branch']})
     return out
 
 
@@ -72,4 +130,4 @@ if __name__ == '__main__':
         for r in sorted(rows, key=lambda r: r['kernel']):
             print(f"{r['kernel'][:78]:78s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} "
                   f"range {r['mfma_range_instructions']:5d} scratch-in-range {r['scratch_in_mfma_range']:3d} "
-                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d}")
+                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d} landing-touches {len(r['landing_touches']):2d} branches-in-range-with-loads-in-flight {len(r['landing_branches_in_mfma_range']):2d}")
