@@ -13,6 +13,9 @@
 #include "../../include/deepgemm_amd.h"
 #include "fp8_gemm_kernels.hpp"
 #include "fp8_gemm_quad.hpp"
+#ifdef DG_EXPERIMENTS
+#include "fp8_gemm_experiments.hpp"
+#endif
 
 namespace {
 
@@ -93,15 +96,14 @@ struct Config {
 
 const Config kConfigs[] = {
     {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true, true},
-    {"duo_p_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 20>, true, true, true},
+    {"duo_p_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true>, true, true, true},
     // 128-row duo tile: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise
     // badly at 256 x 256.  Measured per-tile: 116 k cycles vs 167 k for twice the work (L2->LDS bytes per flop are 1.5x).
     {"duo_128x256", 128, 256, 512, 1, 0.78f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4>, true},
     // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
-    {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 41>, true, true, true},
-    {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 40>, true},
-    {"duo_bmn2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 40>, true, true},   // contiguous, two-pass
-    {"ring_256x256", 256, 256, 512, 1, 1.05f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
+    {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true>, true, true, true},
+    {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true>, true},
+    {"duo_bmn2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, false, true>, true, true},   // contiguous, two-pass
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
     {"pipe_128x128", 128, 128, 256, 2, 0.80f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 2>},
@@ -112,69 +114,57 @@ const Config kConfigs[] = {
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 12>, true},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>, true, false,
      false, true},
-    {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false, true>, true,
+    {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>, true,
      false, false, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
-    // experimental / baseline variants (only reachable through dg_set_forced_config; efficiency 0 keeps them out of
-    // the heuristic): LDS-DMA piece placement variants and the hipcc-scheduled first version of the fast path.
+#ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
+                        // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
+    {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
     {"pipe_s0_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
     {"pipe_s1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 1>},
     {"pipe_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 3>},
-#ifdef DG_EXPERIMENTS   // timing ablations and rejected variants: DG_EXPERIMENTS=1 python __graft_entry__.py
-    // FP32-scale kernels in the one-wave-per-SIMD schedule of the UE8M0 quad kernel (fp8_gemm_quad.hpp): bit-identical to the
-    // duo kernels and 1.4x SLOWER -- a lone wave pays ~51 cycles per MFMA + 4 FMA step and ~60 more per LDS-DMA piece
-    {"quad_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2>, true, false, true},
-    {"quad_256x128", 256, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<256, 128, 2, 2>, true, true, true},
-    {"quad_v1_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 1>, true, false, true},
-    {"quad_v2_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 2>, true, false, true},
-    {"quad_v3_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 3>, true, false, true},
-    {"quad_v4_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 4>, true, false, true},
-    {"quad_v5_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 5>, true, false, true},
-    {"quad_v6_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 6>, true, false, true},
-    {"abl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 1>},
-    {"abl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 2>},
-    {"abl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 3>},
-    {"abl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 4>},
-    {"abl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0, 5>},
+    {"ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
     {"rabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 1>, true},
     {"rabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 2>, true},
     {"rabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 3>, true},
+    {"rabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 4>, true},
+    {"rabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 5>, true},
     {"ring_p2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 2>, true},
     {"ring_p4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 4>, true},
     {"ring_p8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 8>, true},
-    {"rabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 4>, true},
-    {"rabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 5>, true},
-    {"dabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 1>, true},
-    {"dabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 2>, true},
-    {"dabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 3>, true},
-    {"dabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 4>, true},
-    {"dabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 5>, true},
-    {"dabl6_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 6>, true},
-    {"dabl7_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 7>, true},
-    {"dabl8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 8>, true},
-    {"dabl9_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 9>, true},
-    {"dabl10_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 10>, true},
-    {"dabl11_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 11>, true},
+    {"dabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 1>, true},
+    {"dabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 2>, true},
+    {"dabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 3>, true},
+    {"dabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 4>, true},
+    {"dabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 5>, true},
+    {"dabl6_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 6>, true},
+    {"dabl7_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 7>, true},
+    {"dabl8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 8>, true},
+    {"dabl9_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 9>, true},
+    {"dabl10_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 10>, true},
+    {"dabl11_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 11>, true},
+    {"dabl12_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 12>, true},
+    {"dabl13_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 13>, true},
+    {"dabl14_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 14>, true},
+    {"dabl15_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 15>, true},
+    {"dabl16_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 16>, true},
+    {"dabl17_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 17>, true},
+    {"dabl18_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 18>, true},
+    {"dabl21_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 21>, true},
+    {"dabl30_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 30>, true},
+    {"dabl31_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 31>, true},
+    {"dabl32_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 32>, true},
+    {"duo_pprio_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 26>, true, true, true},
+    {"duo_prio_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<128, 256, 2, 4, 28>, true},
+    {"duo_load_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<128, 256, 2, 4, 29>, true},
     {"stream_noa_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 64>, true},
-    {"dabl12_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 12>, true},
-    {"dabl13_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 13>, true},
-    {"dabl14_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 14>, true},
-    {"dabl15_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 15>, true},
-    {"dabl16_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 16>, true},
-    {"dabl17_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 17>, true},
-    {"dabl18_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 18>, true},
-    {"dabl19_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 19>, true},
-    {"dabl21_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 21>, true},
-    {"pipe_pcpk_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>, true, false,
-     false, true},      // A/B: packed-FP32 promotion (4.8 k cycles per K block against 4.0 k with scalar VALU)
-    {"duo_pprio_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 26>, true, true, true},
-    {"duo_prio_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 28>, true},
-    {"duo_load_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, 29>, true},
-    {"dabl32_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 32>, true},
-    {"dabl30_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 30>, true},
-    {"dabl31_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, 31>, true},
+    // FP32-scale kernels in the one-wave-per-SIMD schedule of the UE8M0 quad kernel: bit-identical to the duo kernels and 1.4x
+    // SLOWER -- a lone wave pays ~51 cycles per MFMA + 4 FMA step and ~60 more per LDS-DMA piece
+    {"quad_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2>, true, false, true},
+    {"quad_256x128", 256, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<256, 128, 2, 2>, true, true, true},
+    {"quad_v1_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 1>, true, false, true},
+    {"quad_v5_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 5>, true, false, true},
 #endif
-    {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -184,8 +174,8 @@ const E8Config kE8Configs[] = {
     {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, 256, true, true},
     {"e8_quad_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>, 128, 256, false, true},
     {"e8_duo_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
-    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
 #ifdef DG_EXPERIMENTS
+    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, true, false},
     {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, 256, true, false},
     {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, 256, true, false},
@@ -717,7 +707,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
             if (grid > 0x7fffffffL)
                 return fail(__FILE__, __LINE__, "grid too large");
             g_last_config = "pipe_pc_mn_256x256";
-            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false, true>),
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>),
                                dim3(static_cast<unsigned>(grid)), dim3(512), 0, static_cast<hipStream_t>(stream), p);
             DG_HIP_CHECK(hipGetLastError());
             return 0;

@@ -157,9 +157,9 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
             t.m_end = end1;
         } else if (c0) {                            // second half is padding (zero rows) or does not exist
             t.group = g0;
-            t.m_end = mid;
-            t.zero_from = mid;
-            t.zero_to = has1 ? end1 : mid;
+            t.m_end = imin(mid, p.m);               // (m need not be a multiple of the alignment: nothing is stored past row m)
+            t.zero_from = t.m_end;
+            t.zero_to = has1 ? end1 : t.m_end;
         } else if (c1) {                            // first half is padding
             t.group = g1;
             t.m_begin = mid;
@@ -460,198 +460,6 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
 }
 
 
-// One 128-K block of a wave tile, software-pipelined by hand: MFMA i+DEPTH is issued before the FP32 promotion of
-// MFMA i, so the matrix pipe never waits for a VALU read of its own result (hipcc serialises the naive form into
-// mfma / s_nop 11 / fma).  sched_group_barrier pins the interleave: 1 MFMA, then 4 VALU FMAs (+ the LDS reads of the
-// next A fragment at the head of each M-subtile).
-template <int MS, int NS, int DEPTH>
-__device__ __forceinline__ void compute_block_pipelined(const uint8_t* a_tile, const uint8_t* b_tile, int frag_off,
-                                                        const float (&scale)[MS], v4f (&acc)[MS][NS]) {
-    constexpr int TOTAL = MS * NS;
-    v8i bf[NS];
-    #pragma unroll
-    for (int ns = 0; ns < NS; ++ns)
-        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
-    v8i af[2];
-    af[0] = load_fragment(a_tile, frag_off);
-    v4f part[DEPTH + 1];
-    #pragma unroll
-    for (int i = 0; i < TOTAL + DEPTH; ++i) {
-        if (i < TOTAL) {
-            const int ms = i / NS, ns = i % NS;
-            if (ns == 0 && ms + 1 < MS)
-                af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
-            part[i % (DEPTH + 1)] = mfma_fp8_k128(bf[ns], af[ms & 1]);
-        }
-        if (i >= DEPTH) {
-            const int j = i - DEPTH, ms = j / NS, ns = j % NS;
-            const v4f pr = part[j % (DEPTH + 1)];
-            #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[ms][ns][r] = __builtin_fmaf(scale[ms], pr[r], acc[ms][ns][r]);
-        }
-        if (i < TOTAL) {
-            if (i % NS == 0 && i / NS + 1 < MS)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the next A fragment's two ds_read_b128
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
-        }
-        if (i >= DEPTH)
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);         // its four promotion FMAs
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Fast path: K-major A and B, K % 128 == 0, 16-byte aligned rows.  LDS-DMA double buffer, one barrier per K block.
-// ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
-void dg_fp8_gemm_fast_kernel(const GemmParams p) {
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_UNITS = BM / 8, B_UNITS = BN / 8;                  // 1 KiB LDS-DMA pieces (8 rows x 128 B)
-    constexpr int A_ITERS = (A_UNITS + NW - 1) / NW, B_ITERS = (B_UNITS + NW - 1) / NW;
-    static_assert(WM % 16 == 0 && WN % 16 == 0 && NS % 2 == 0, "wave tile must be a multiple of 16 x 32");
-    static_assert(128 % WN == 0 || WN % 128 == 0, "a wave must not straddle an SFB block unevenly");
-    static_assert(WN <= 128, "one SFB value per wave");
-
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * STAGE_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128;
-
-    // Per-lane constants of the LDS-DMA source pattern: lane -> (row lane >> 3 of the piece, stored chunk lane & 7).
-    const int piece_row = lane >> 3;
-    const int src_chunk = (lane & 7) ^ piece_row;
-    // Fragment read offsets.
-    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
-
-    MaskedWalk walk;
-    const int num_launched = gridDim.x;
-    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
-        if (!t.valid)
-            break;
-
-        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
-        v4f acc[MS][NS];
-        #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
-
-        if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int m_clamp = t.m_end - 1 - t.m0;               // last loadable local row
-            const int n_clamp = p.n - 1 - t.n0;
-
-            int a_off[A_ITERS], b_off[B_ITERS];
-            #pragma unroll
-            for (int j = 0; j < A_ITERS; ++j) {
-                const int row = imin((wave + NW * j) * 8 + piece_row, m_clamp);
-                a_off[j] = row * static_cast<int>(p.a_sm) + src_chunk * 16;
-            }
-            #pragma unroll
-            for (int j = 0; j < B_ITERS; ++j) {
-                const int row = imin(b_row_perm<WN>((wave + NW * j) * 8 + piece_row), n_clamp);
-                b_off[j] = row * static_cast<int>(p.b_sn) + src_chunk * 16;
-            }
-
-            auto issue_stage = [&](int stage, int kb) {
-                uint8_t* stage_base = lds + stage * STAGE_BYTES;
-                const uint8_t* a_k = a_base + kb * 128;
-                const uint8_t* b_k = b_base + kb * 128;
-                #pragma unroll
-                for (int j = 0; j < A_ITERS; ++j) {
-                    const int unit = wave + NW * j;
-                    if (A_UNITS % NW == 0 || unit < A_UNITS)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(a_k + a_off[j]),
-                            (__attribute__((address_space(3))) void*)(stage_base + unit * 1024), 16, 0, 0);
-                }
-                #pragma unroll
-                for (int j = 0; j < B_ITERS; ++j) {
-                    const int unit = wave + NW * j;
-                    if (B_UNITS % NW == 0 || unit < B_UNITS)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(b_k + b_off[j]),
-                            (__attribute__((address_space(3))) void*)(stage_base + A_BYTES + unit * 1024), 16, 0, 0);
-                }
-            };
-
-            // Scale pointers: one SFA value per lane per M-subtile, one SFB value per wave.
-            const float* sfa_lane[MS];
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-                const int row = t.m0 + imin(wm * WM + ms * 16 + (lane & 15), m_clamp);
-                sfa_lane[ms] = p.sfa + ad_group * p.sfa_sg + static_cast<int64_t>(row) * p.sfa_sm;
-            }
-            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
-                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
-
-            float sa_cur[MS], sa_nxt[MS];
-            float sb_cur, sb_nxt = 0.f;
-            issue_stage(0, 0);
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-                sa_cur[ms] = sfa_lane[ms][0];
-            sb_cur = sfb_wave[0];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-
-            for (int kb = 0; kb < num_kb; ++kb) {
-                const int cur = kb & 1;
-                if (kb + 1 < num_kb) {
-                    issue_stage(cur ^ 1, kb + 1);
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
-                        sa_nxt[ms] = sfa_lane[ms][static_cast<int64_t>(kb + 1) * p.sfa_sk];
-                    sb_nxt = sfb_wave[static_cast<int64_t>(kb + 1) * p.sfb_sk];
-                }
-
-                const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
-                const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
-                if constexpr (PIPE > 0) {
-                    float scale[MS];
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
-                        scale[ms] = sa_cur[ms] * sb_cur;
-                    compute_block_pipelined<MS, NS, PIPE>(a_tile, b_tile, frag_off, scale, acc);
-                } else {
-                    v8i bf[NS];
-                    #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns)
-                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms) {
-                        const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
-                        const float scale = sa_cur[ms] * sb_cur;
-                        #pragma unroll
-                        for (int ns = 0; ns < NS; ++ns) {
-                            const v4f part = mfma_fp8_k128(bf[ns], af);
-                            acc[ms][ns] += scale * part;
-                        }
-                    }
-                }
-
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    sa_cur[ms] = sa_nxt[ms];
-                sb_cur = sb_nxt;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        }
-
-        store_tile<MS, NS>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
 // Fast path, hand-scheduled: same tiles / LDS image / LDS-DMA staging as dg_fp8_gemm_fast_kernel, but the MFMA +
 // FP32-promotion stream is written as one inline-asm statement per 16x16x128 step:
@@ -676,17 +484,6 @@ __device__ __forceinline__ void mfma_promote_step(v4f& part_new, const v8i& rows
         : "memory");
 }
 
-// Ablation helper: the MFMA of a step with a single token VALU op instead of the four promotion FMAs.
-__device__ __forceinline__ void mfma_only_step(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand, float& c,
-                                               const v4f& part_old) {
-    asm volatile(
-        "v_mfma_f32_16x16x128_f8f6f4 %0, %2, %3, 0\n\t"
-        "v_add_f32 %1, %1, %4"
-        : "=&v"(part_new), "+v"(c)
-        : "v"(rows_operand), "v"(cols_operand), "v"(part_old[0])
-        : "memory");
-}
-
 // Forces `x` to be materialised in a VGPR at this point of the instruction stream (scheduling fence for one value).
 __device__ __forceinline__ void pin_vgpr(float& x) { asm volatile("" : "+v"(x)); }
 
@@ -704,10 +501,8 @@ __device__ __forceinline__ void promote_only(float (&c)[4], float scale, const v
         : "memory");
 }
 
-// ABLATE (timing experiments only, results are garbage): 1 = no LDS-DMA / vmcnt / barrier inside the K loop,
-// 2 = additionally no FP32 promotion (bare MFMA stream), 3 = loads and barriers kept but no promotion,
-// 4 = as 2 and no LDS fragment reads in the loop either (pure matrix-pipe rate), 5 = as 4 but with the promotion.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, int ABLATE = 0>
+// SPREAD: LDS-DMA piece placement: 0 = the whole next stage at the head of the K block, n = one piece every n MFMA steps.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
 __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
@@ -836,23 +631,15 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 for (int ms = 0; ms < MS; ++ms)
                     sa_nxt[ms] = load_sfa(ms, kb + 1);
                 if (has_next) {
-                    if constexpr (SPREAD == 0 && (ABLATE == 0 || ABLATE == 3))
+                    if constexpr (SPREAD == 0)
                         issue_stage(cur ^ 1, kb + 1);
                     sb_nxt = sfb_wave[static_cast<int64_t>(kb + 1) * p.sfb_sk];
                 }
 
                 const uint8_t* a_tile = lds + cur * STAGE_BYTES + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
-                if (ABLATE < 4 || kb == 0) {
-                    bf[0] = load_fragment(b_tile, frag_off);
-                    af[0] = load_fragment(a_tile, frag_off);
-                }
-                if (ABLATE >= 4 && kb == 0) {
-                    #pragma unroll
-                    for (int ns = 1; ns < NS; ++ns)
-                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
-                    af[1] = load_fragment(a_tile + 2048, frag_off);
-                }
+                bf[0] = load_fragment(b_tile, frag_off);
+                af[0] = load_fragment(a_tile, frag_off);
 
                 #pragma unroll
                 for (int i = 0; i < TOTAL; ++i) {
@@ -862,15 +649,12 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                     const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;     // i < DEPTH: previous block's tail
                     // Fragment reads ride one step ahead of their first use: B subtile ns+1 during the first M-subtile,
                     // A subtile ms+1 at the head of subtile ms.
-                    if (ABLATE < 4 && ms == 0 && ns + 1 < NS)
+                    if (ms == 0 && ns + 1 < NS)
                         bf[ns + 1] = load_fragment(b_tile + (ns + 1) * 2048, frag_off);
-                    if (ABLATE < 4 && ns == 0 && ms + 1 < MS)
+                    if (ns == 0 && ms + 1 < MS)
                         af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
-                    if constexpr (ABLATE == 2 || ABLATE == 3 || ABLATE == 4)
-                        mfma_only_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], part[(i + 1) & DEPTH]);
-                    else
-                        mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
-                    if constexpr (SPREAD > 0 && (ABLATE == 0 || ABLATE == 3)) {
+                    mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
+                    if constexpr (SPREAD > 0) {
                         // spread the next stage's LDS-DMA pieces over the first steps, one per SPREAD MFMAs
                         if (i % SPREAD == SPREAD - 1 && i / SPREAD < A_ITERS + B_ITERS && has_next)
                             issue_piece(cur ^ 1, kb + 1, i / SPREAD);
@@ -879,10 +663,8 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 static_assert((TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
                 scale_tail = scale[MS - 1];
                 sb_cur = sb_nxt;
-                if constexpr (ABLATE == 0 || ABLATE == 3) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             // drain the ring: steps TOTAL-3 .. TOTAL-1 of the last K block
@@ -912,10 +694,10 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
 
 // The body lives in a __device__ function: it uses gfx950-only types (buffer resources) that the host pass of hipcc
 // cannot name, and a __global__ function whose body the host pass rejects gets no launch stub.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, int ABLATE = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
-    pipe_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, ABLATE>(p);
+    pipe_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -934,57 +716,6 @@ void dg_fp8_gemm_pipe_kernel(const GemmParams p) {
 //     global loads at all; every wave picks its 8 + 16 values out of LDS at the top of the block.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int SEL>
-__device__ __forceinline__ void mfma_promote_step_pc(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
-                                                     v2f& c01, v2f& c23, v2f sb01, v2f sb23, v2f sa_pair, v2f p01, v2f p23) {
-    v2f t01, t23;
-    if constexpr (SEL == 0)
-        asm volatile(
-            "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
-            "v_pk_mul_f32 %3, %7, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-            "v_pk_mul_f32 %4, %8, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-            "v_pk_fma_f32 %1, %3, %10, %1\n\t"
-            "v_pk_fma_f32 %2, %4, %11, %2"
-            : "=&v"(part_new), "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
-            : "v"(rows_operand), "v"(cols_operand), "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
-            : "memory");
-    else
-        asm volatile(
-            "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
-            "v_pk_mul_f32 %3, %7, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-            "v_pk_mul_f32 %4, %8, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-            "v_pk_fma_f32 %1, %3, %10, %1\n\t"
-            "v_pk_fma_f32 %2, %4, %11, %2"
-            : "=&v"(part_new), "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
-            : "v"(rows_operand), "v"(cols_operand), "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
-            : "memory");
-}
-
-template <int SEL>
-__device__ __forceinline__ void promote_only_pc(v2f& c01, v2f& c23, v2f sb01, v2f sb23, v2f sa_pair, v2f p01, v2f p23) {
-    v2f t01, t23;
-    if constexpr (SEL == 0)
-        asm volatile(
-            "s_nop 3\n\t"
-            "v_pk_mul_f32 %2, %4, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-            "v_pk_mul_f32 %3, %5, %6 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-            "v_pk_fma_f32 %0, %2, %7, %0\n\t"
-            "v_pk_fma_f32 %1, %3, %8, %1"
-            : "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
-            : "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
-            : "memory");
-    else
-        asm volatile(
-            "s_nop 3\n\t"
-            "v_pk_mul_f32 %2, %4, %6 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-            "v_pk_mul_f32 %3, %5, %6 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-            "v_pk_fma_f32 %0, %2, %7, %0\n\t"
-            "v_pk_fma_f32 %1, %3, %8, %1"
-            : "+v"(c01), "+v"(c23), "=&v"(t01), "=&v"(t23)
-            : "v"(sb01), "v"(sb23), "v"(sa_pair), "v"(p01), "v"(p23)
-            : "memory");
-}
 
 // The same step with single-rate VALU: 4 products + 4 FMAs.  (v_pk_*_f32 beside MFMAs costs more than two scalar ops
 // each on this part -- MI355X_MICROARCH.md, "price of one filler beside MFMAs" -- so the packed form is the slower one.)
@@ -1064,7 +795,7 @@ __device__ __forceinline__ v8i assemble_fragment_tr(FragTr& f) {
 // MN = true: both FP8 operands are MN-major ([K][M] and [K][N], unit stride along m / n, row pitch a_sk / b_sk): the
 // operand form of the K-grouped TN GEMM.  LDS-DMA pieces are 4 k-rows x 256 bytes, fragments come through
 // load_fragment_tr, A and B rows keep their natural order (=> FP32 output only gets vector stores).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false, bool MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool MN = false>
 __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
@@ -1134,17 +865,14 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
         }
         const int64_t bs_group = (p.gemm_type == kKGrouped) ? 0 : t.group;          // group index into B / SFB
 
-        v2f acc[MS][NS][2];             // packed form
-        float accs[MS][NS][4];          // scalar form (the unused one is dead code)
+        float accs[MS][NS][4];
         #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
             #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                acc[ms][ns][0] = acc[ms][ns][1] = v2f{0.f, 0.f};
+            for (int ns = 0; ns < NS; ++ns)
                 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     accs[ms][ns][r] = 0.f;
-            }
 
         if (t.m_end > t.m0) {
             const uint8_t* a_base = p.a + ad_group * p.a_sg + kg_a_off + static_cast<int64_t>(t.m0) * (MN ? 1 : lda);
@@ -1269,19 +997,10 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                         if (ns == 0) af[ms & 1] = assemble_fragment_tr(afq[ms & 1]);
                     }
                     const v4f& po = part[(i + 1) & DEPTH];
-                    const v2f p01 = v2f{po[0], po[1]}, p23 = v2f{po[2], po[3]};
                     // i < DEPTH: the previous block's tail steps (last M-subtile) with the previous block's scales
                     const v4f& sb = (i >= DEPTH) ? sb4[jns] : sb_tail[jns];
-                    const v2f sap = (i >= DEPTH) ? sa_pair[jms >> 1] : sa_tail;
-                    if constexpr (!PK)
-                        mfma_promote_step_pc_scalar(part[i & DEPTH], bf[ns], af[ms & 1], accs[jms][jns], sb,
-                                                    (i >= DEPTH) ? sa_pair[jms >> 1][jms & 1] : sa_tail[(MS - 1) & 1], po);
-                    else if ((jms & 1) == 0)         // which half of the pair is this M-subtile's row scale
-                        mfma_promote_step_pc<0>(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], acc[jms][jns][1],
-                                                v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, sap, p01, p23);
-                    else
-                        mfma_promote_step_pc<1>(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns][0], acc[jms][jns][1],
-                                                v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, sap, p01, p23);
+                    mfma_promote_step_pc_scalar(part[i & DEPTH], bf[ns], af[ms & 1], accs[jms][jns], sb,
+                                                (i >= DEPTH) ? sa_pair[jms >> 1][jms & 1] : sa_tail[(MS - 1) & 1], po);
                     if (i % SPREAD == SPREAD - 1 && i / SPREAD < A_ITERS + B_ITERS && has_next)
                         issue_piece(cur ^ 1, kb + 1, i / SPREAD);
                 }
@@ -1297,13 +1016,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             for (int i = 0; i < DEPTH; ++i) {
                 const int j = TOTAL - DEPTH + i;
                 const v4f& po = part[(TOTAL + i + 1) & DEPTH];
-                if constexpr (!PK)
-                    promote_only_pc_scalar(accs[j / NS][j % NS], sb_tail[j % NS], sa_tail[(MS - 1) & 1], po);
-                else
-                promote_only_pc<(MS - 1) & 1>(acc[j / NS][j % NS][0], acc[j / NS][j % NS][1],
-                                              v2f{sb_tail[j % NS][0], sb_tail[j % NS][1]},
-                                              v2f{sb_tail[j % NS][2], sb_tail[j % NS][3]}, sa_tail, v2f{po[0], po[1]},
-                                              v2f{po[2], po[3]});
+                promote_only_pc_scalar(accs[j / NS][j % NS], sb_tail[j % NS], sa_tail[(MS - 1) & 1], po);
             }
         }
 
@@ -1312,8 +1025,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
         for (int ms = 0; ms < MS; ++ms)
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
-                out[ms][ns] = PK ? v4f{acc[ms][ns][0][0], acc[ms][ns][0][1], acc[ms][ns][1][0], acc[ms][ns][1][1]}
-                                 : v4f{accs[ms][ns][0], accs[ms][ns][1], accs[ms][ns][2], accs[ms][ns][3]};
+                out[ms][ns] = v4f{accs[ms][ns][0], accs[ms][ns][1], accs[ms][ns][2], accs[ms][ns][3]};
         store_tile<MS, NS, false, false, MN>(p, t, (p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg, out, t.m0 + wm * WM,
                                              t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
@@ -1326,343 +1038,18 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool PK = false, bool MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int SPREAD, bool MN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_pipe_pc_kernel(const GemmParams p) {
-    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, PK, MN>(p);
+    pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, MN>(p);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Ring kernel: the fast path's production form.  Same tiles, LDS image, LDS-DMA pieces and MFMA+promotion step as
-// the pipe kernel above, but the global->LDS stream is never drained inside the K loop:
-//   * A lives in a 3-slot ring, B in a 2-slot ring (256x256 tile: 3*32 + 2*32 KiB = all 160 KiB of the CU's LDS);
-//   * ONE barrier P per K block, placed before the last M-subtile round (step TOTAL-NS), certifies "block kb+1 has
-//     landed" (each wave first waits vmcnt(A_ITERS+B_ITERS): everything but its newest two batches of pieces) and
-//     "block kb's A slot is dead"; behind it the wave issues the LDS-DMA of A(kb+3) into that slot and reads the
-//     first fragments of block kb+1 (A subtile 0, and each B subtile right after its last MFMA of block kb), so the
-//     matrix pipe does not see a restart bubble at the block boundary;
-//   * a second, light barrier Q after the first M-subtile round certifies "every wave holds B(kb) in registers",
-//     behind it the LDS-DMA of B(kb+2) goes into that slot.
-//   A and B are therefore prefetched about two K blocks ahead; the per-row scales ride one block ahead in VGPRs,
-//   loaded by inline-asm buffer loads so that hipcc (which would wait vmcnt(0) at their first use and drain the
-//   LDS-DMA queue with them) never sees a VGPR-destination load in the loop.
-// vmcnt bookkeeping (loads retire in order): issue order is ... SF(kb+1) | A(kb+2) x A_ITERS | B(kb+2) x B_ITERS |
-// P_kb: wait vmcnt(A_ITERS+B_ITERS) => SF(kb+1), A(kb+1), B(kb+1) and everything older have landed.
-// K tail: pieces and scale loads of blocks >= num_kb are still issued (the counts stay exact) with bit 31 set in
-// their voffset, which the buffer descriptor's range check turns into a no-op.
-// ---------------------------------------------------------------------------------------------------------------
-template <int MS>
-struct ScaleLanding { float sa[MS]; float sb; };
-
-// SF loads for one K block: MS row scales (SFA is MN-major here: consecutive M-subtiles are 64 bytes apart) and the
-// wave-uniform SFB value, all through buffer descriptors.  The destinations are NOT valid until wait_landing().
-template <int MS>
-__device__ __forceinline__ void issue_scale_loads(ScaleLanding<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
-                                                  const v4i& sfb_rsrc, int sfb_voff) {
-    static_assert(MS == 2 || MS == 4 || MS == 8, "unrolled by hand");
-    // s_nop 4 opening: the descriptor / soffset SGPRs may have been written by the immediately preceding SALU
-    if constexpr (MS == 8) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "buffer_load_dword %0, %9, %10, 0 offen\n\t"
-            "buffer_load_dword %1, %9, %10, 0 offen offset:64\n\t"
-            "buffer_load_dword %2, %9, %10, 0 offen offset:128\n\t"
-            "buffer_load_dword %3, %9, %10, 0 offen offset:192\n\t"
-            "buffer_load_dword %4, %9, %10, 0 offen offset:256\n\t"
-            "buffer_load_dword %5, %9, %10, 0 offen offset:320\n\t"
-            "buffer_load_dword %6, %9, %10, 0 offen offset:384\n\t"
-            "buffer_load_dword %7, %9, %10, 0 offen offset:448\n\t"
-            "buffer_load_dword %8, %11, %12, 0 offen"
-            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sa[2]), "=&v"(l.sa[3]), "=&v"(l.sa[4]), "=&v"(l.sa[5]),
-              "=&v"(l.sa[6]), "=&v"(l.sa[7]), "=&v"(l.sb)
-            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
-            : "memory");
-    } else if constexpr (MS == 4) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "buffer_load_dword %0, %5, %6, 0 offen\n\t"
-            "buffer_load_dword %1, %5, %6, 0 offen offset:64\n\t"
-            "buffer_load_dword %2, %5, %6, 0 offen offset:128\n\t"
-            "buffer_load_dword %3, %5, %6, 0 offen offset:192\n\t"
-            "buffer_load_dword %4, %7, %8, 0 offen"
-            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sa[2]), "=&v"(l.sa[3]), "=&v"(l.sb)
-            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
-            : "memory");
-    } else {
-        asm volatile(
-            "s_nop 4\n\t"
-            "buffer_load_dword %0, %3, %4, 0 offen\n\t"
-            "buffer_load_dword %1, %3, %4, 0 offen offset:64\n\t"
-            "buffer_load_dword %2, %5, %6, 0 offen"
-            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sb)
-            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
-            : "memory");
-    }
-}
-
-// Waits until at most ALLOWED vector-memory operations of this wave are outstanding and all its LDS reads have
-// returned; names the landing registers so that no consumer of them can be scheduled above the wait.
-template <int ALLOWED, int MS>
-__device__ __forceinline__ void wait_landing(ScaleLanding<MS>& l) {
-    static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
-    if constexpr (MS == 8)
-        asm volatile("s_waitcnt vmcnt(%c9) lgkmcnt(0)"
-                     : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sa[2]), "+v"(l.sa[3]), "+v"(l.sa[4]), "+v"(l.sa[5]),
-                       "+v"(l.sa[6]), "+v"(l.sa[7]), "+v"(l.sb)
-                     : "i"(ALLOWED) : "memory");
-    else if constexpr (MS == 4)
-        asm volatile("s_waitcnt vmcnt(%c5) lgkmcnt(0)"
-                     : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sa[2]), "+v"(l.sa[3]), "+v"(l.sb)
-                     : "i"(ALLOWED) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(%c3) lgkmcnt(0)" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb) : "i"(ALLOWED) : "memory");
-}
-
+// A bare s_barrier: __syncthreads() would add a vmcnt(0) fence and drain the LDS-DMA queue.
 __device__ __forceinline__ void raw_barrier() {
     // A bare s_barrier: __syncthreads() would add a vmcnt(0) fence and drain the LDS-DMA queue.
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-}
-
-// RABL (timing experiments only, results are garbage): 1 = no barriers, 2 = no LDS-DMA pieces in the K loop,
-// 3 = every piece re-reads K block 0 (L2-resident source: isolates HBM / L2-miss effects from issue and LDS-write cost).
-// PAD: idle issue cycles appended to every MFMA step (s_nop), a pacing knob.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int RABL = 0, int PAD = 0>
-__device__ __forceinline__ void ring_kernel_body(const GemmParams& p) {
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
-    constexpr int TOTAL = MS * NS, DEPTH = 3;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
-    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
-    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    constexpr int P_STEP = TOTAL - NS;                 // barrier P sits in front of this step
-    constexpr unsigned OOB = 0x80000000u;        // voffset bit that sends a buffer access out of range
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of LDS-DMA pieces");
-    static_assert(WM % 16 == 0 && WN % 16 == 0 && NS % 2 == 0 && MS % 2 == 0 && MS >= 2, "wave tile shape");
-    static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
-    static_assert(TOTAL >= 2 * NS && TOTAL - DEPTH >= TOTAL - NS, "the ring tail must lie within the last M-subtile");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
-                  "the row permutation of a B piece must be lane-independent");
-
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128;
-    const int piece_row = lane >> 3;
-    const int src_chunk = (lane & 7) ^ piece_row;
-    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
-    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
-    // Per-lane byte offsets of a piece's source rows (row part and 16-byte chunk) -- all in the VOFFSET, which is the
-    // part of a buffer address the descriptor range-checks; only the K block offset travels in the soffset.
-    const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
-    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
-    long long t_loop0 = 0, t_loop1 = 0;
-
-    MaskedWalk walk;
-    const int num_launched = gridDim.x;
-    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
-        if (!t.valid)
-            break;
-        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
-
-        float acc[MS][NS][4];
-        #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[ms][ns][r] = 0.f;
-
-        if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
-            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
-                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
-            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
-                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
-            // Scale descriptors as plain 4 x 32-bit words (inline-asm "s" operands).
-            const float* sfa_group = p.sfa + ad_group * p.sfa_sg;
-            const float* sfb_wave = p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
-                                    static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn;
-            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
-            const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
-            const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
-            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(sfa_group), sfb_addr = reinterpret_cast<uint64_t>(sfb_wave);
-            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
-                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
-                                  __builtin_amdgcn_readfirstlane(sfa_extent), 0x00020000};
-            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
-                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
-                                  __builtin_amdgcn_readfirstlane(sfb_extent), 0x00020000};
-            const int sfa_voff = (t.m0 + wm * WM + (lane & 15)) * 4;
-
-            // One LDS-DMA piece of K block j: A piece q -> rows (wave + NW q) * 8 ... + 7 of A slot j % 3.
-            auto issue_a_piece = [&](int slot_off, int j, int q) {
-                const int unit = wave + NW * q;
-                const int voff = static_cast<int>(static_cast<unsigned>(a_voff) +
-                                                  (static_cast<unsigned>(q * (NW * 8) * lda) | (j < num_kb ? 0u : OOB)));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, voff,
-                    RABL == 3 ? 0 : j * 128, 0, 0);
-            };
-            auto issue_b_piece = [&](int slot_off, int j, int q) {
-                const int unit = wave + NW * q;
-                const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
-                                                  (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | (j < num_kb ? 0u : OOB)));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16, voff,
-                    RABL == 3 ? 0 : j * 128, 0, 0);
-            };
-            auto issue_scales = [&](ScaleLanding<MS>& l, int j) {
-                if constexpr (RABL == 5) {      // trace build: no scale traffic at all, constant scales
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms) l.sa[ms] = 1.f;
-                    l.sb = 1.f;
-                    return;
-                }
-                const unsigned oob = j < num_kb ? 0u : OOB;
-                const int jj = (RABL == 4) ? 0 : j;          // RABL 4: scales always from K block 0 (cache resident)
-                issue_scale_loads<MS>(l, sfa_rsrc, static_cast<int>(static_cast<unsigned>(sfa_voff + jj * sfa_kb_stride) | oob),
-                                      sfb_rsrc, static_cast<int>(static_cast<unsigned>(jj * sfb_kb_stride) | oob));
-            };
-
-            float scale[MS], scale_tail = 0.f;
-            ScaleLanding<MS> land;
-            v4f part[DEPTH + 1];
-            #pragma unroll
-            for (int i = 0; i <= DEPTH; ++i)
-                part[i] = v4f{0.f, 0.f, 0.f, 0.f};
-
-            // ---- prologue: A(0) B(0) A(1) B(1) | SF(0), full drain (the scale loads must reach their wait in straight-line
-            // code: hipcc may copy their destination registers at any control-flow join in between) ----
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
-            issue_scales(land, 0);
-            wait_landing<0, MS>(land);
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-                scale[ms] = land.sa[ms] * land.sb;
-            raw_barrier();
-            [[maybe_unused]] int trace_v = 0;                          // RABL 5: lane i = s_memtime at step i of K block 30/31
-            [[maybe_unused]] long long trace_t[4] = {0, 0, 0, 0};
-
-            // slot offsets (bytes): a_cur is being computed (and re-filled behind barrier P), *_nxt is read behind P
-            int a_cur = 0, a_nxt = A_BYTES, b_nxt = B_BYTES;
-            v8i bf[NS], af[2];
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                bf[ns] = load_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128, frag_off);
-            af[0] = load_fragment(lds + (wm * WM) * 128, frag_off);
-
-            // Issue order per block (vmcnt counts depend on it): SF(kb+1) [top of block kb] | A(kb+2) x A_ITERS
-            // [steps 0, 2, ..] | B(kb+2) x B_ITERS [behind Q] | P_kb waits vmcnt(A_ITERS + B_ITERS).
-            constexpr int B_FIRST = (NS > 2 * A_ITERS ? NS : 2 * A_ITERS);
-            static_assert(B_FIRST + 2 * (B_ITERS - 1) < P_STEP, "LDS-DMA pieces must be issued in front of barrier P");
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
-            for (int kb = 0; kb < num_kb; ++kb) {
-                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
-                const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
-                const uint8_t* b_next_tile = lds + B_BASE + b_nxt + (wn * WN) * 128;
-                // A(kb+2) goes into the slot that held A(kb-1): the one after a_nxt in ring order
-                const int a_fill = (a_nxt == (A_SLOTS - 1) * A_BYTES) ? 0 : a_nxt + A_BYTES;
-                issue_scales(land, kb + 1);         // consumed at the end of this iteration, behind P's wait
-
-                #pragma unroll
-                for (int i = 0; i < TOTAL; ++i) {
-                    const int ms = i / NS, ns = i % NS;
-                    const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;     // step being promoted
-                    const int jms = j / NS, jns = j % NS;
-                    const float jscale = (i >= DEPTH) ? scale[jms] : scale_tail;
-                    if constexpr (RABL == 5) {
-                        asm volatile("s_memtime %0" : "=s"(trace_t[i & 3]));
-                        if (i >= 2) {
-                            const int lane_sel = (kb == 30) ? (i - 2) : ((kb == 31) ? (i + 30) : 63);
-                            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v)
-                                         : "s"(static_cast<int>(trace_t[(i - 2) & 3])), "s"(lane_sel));
-                        }
-                    }
-                    if (i == P_STEP) {
-                        // barrier P: block kb+1 (and its scales) landed everywhere; every read of A(kb) has returned
-                        wait_landing<(RABL == 2 ? 0 : A_ITERS + B_ITERS), MS>(land);
-                        if (RABL != 1) raw_barrier();
-                    }
-                    if (ns == 0) {
-                        if (ms + 1 < MS)
-                            af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
-                        else
-                            af[(ms + 1) & 1] = load_fragment(a_next_tile, frag_off);
-                    }
-                    mfma_promote_step(part[i & DEPTH], bf[ns], af[ms & 1], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
-                    if constexpr (PAD > 0) asm volatile("s_nop %c0" :: "i"(PAD - 1));
-                    if (ms == MS - 1)
-                        bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
-                    if (RABL != 2 && i % 2 == 0 && i / 2 < A_ITERS)
-                        issue_a_piece(a_fill, kb + 2, i / 2);
-                    if (RABL != 1 && i == NS - 1)
-                        raw_barrier();                                          // barrier Q: B(kb) is in registers
-                    if (RABL != 2 && i >= B_FIRST && (i - B_FIRST) % 2 == 0 && (i - B_FIRST) / 2 < B_ITERS)
-                        issue_b_piece(b_nxt ^ B_BYTES, kb + 2, (i - B_FIRST) / 2);   // B(kb)'s slot
-                }
-                // scales of block kb+1 (landed before P); then their landing registers take SF(kb+2)
-                scale_tail = scale[MS - 1];
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    scale[ms] = land.sa[ms] * land.sb;
-                    pin_vgpr(scale[ms]);
-                }
-                a_cur = a_nxt;
-                a_nxt = a_fill;
-                b_nxt ^= B_BYTES;
-            }
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
-            if constexpr (RABL == 5)
-                if (p.dbg != nullptr)
-                    reinterpret_cast<int*>(p.dbg + 8192)[(blockIdx.x * NW + wave) * 64 + lane] = trace_v;
-            // drain: the LDS-DMA no-ops of the K tail, then the last three promotions
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) {
-                const int j = TOTAL - DEPTH + i;
-                promote_only(acc[j / NS][j % NS], scale_tail, part[(TOTAL + i + 1) & DEPTH]);
-            }
-            __syncthreads();        // the next tile's prologue rewrites slots other waves may still be reading
-        }
-
-        v4f out[MS][NS];
-        #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
-        store_tile<MS, NS>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
-        if (p.dbg != nullptr && tile_id == blockIdx.x) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dbg_stamp(p, NW, 0, t_entry);
-            dbg_stamp(p, NW, 1, t_loop0);
-            dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
-        }
-    }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int RABL = 0, int PAD = 0>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
-void dg_fp8_gemm_ring_kernel(const GemmParams p) {
-    ring_kernel_body<BM, BN, WAVES_M, WAVES_N, RABL, PAD>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1680,30 +1067,15 @@ void dg_fp8_gemm_ring_kernel(const GemmParams p) {
 // shadow.  Barrier t (counting the lower half's segments) certifies: t = 4kb: block kb landed everywhere and A(kb-1)
 // is dead; t = 4kb+2: B(kb) is in everybody's registers.  Prefetch distance: A 1.5 K blocks, B 1.
 // ---------------------------------------------------------------------------------------------------------------
-// DABL (timing experiments only): 1 = no stagger between the wave halves, 2 = no s_setprio around the matrix segments.
 // Scale landing registers of the duo kernel: with the A rows of a wave interleaved (LDS row position ms * 16 + i holds
 // tile row i * MS + ms) a lane's MS row scales are MS consecutive floats of the MN-major SFA: MS / 4 dwordx4 loads.
 template <int MS>
 struct ScaleLandingV { v4f q[MS / 4]; float sb; };
 
-template <int MS, bool MASKED = false>
+template <int MS>
 __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
                                                     const v4i& sfb_rsrc, int sfb_voff) {
     static_assert(MS == 8 || MS == 4, "unrolled by hand");
-    if constexpr (MASKED) {
-        // timing experiment: the same loads from the first 16 lanes only (the other lane groups address the same rows)
-        unsigned long long saved;
-        asm volatile(
-            "s_mov_b64 %3, exec\n\t"
-            "s_mov_b64 exec, 0xffff\n\t"
-            "buffer_load_dwordx4 %0, %4, %5, 0 offen\n\t"
-            "buffer_load_dwordx4 %1, %4, %5, 0 offen offset:16\n\t"
-            "buffer_load_dword %2, %6, %7, 0 offen\n\t"
-            "s_mov_b64 exec, %3"
-            : "=&v"(l.q[0]), "=&v"(l.q[1]), "=&v"(l.sb), "=&s"(saved)
-            : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
-            : "memory");
-    } else
     if constexpr (MS == 8)
         asm volatile(
             "buffer_load_dwordx4 %0, %3, %4, 0 offen\n\t"
@@ -1735,7 +1107,13 @@ __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
         asm volatile("" : "+v"(l.q[0]), "+v"(l.sb) :: "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
+// PERSIST: persistent launch (one workgroup per CU walks the tile list) with cross-tile prologue prefetch.
+// B_MN: operand B is MN-major ([K][N], unit stride along n, row pitch b_sk): the nn / tn layouts without the re-majoring
+// pass.  LDS-DMA pieces are 4 k-rows x 256 bytes, B fragments come through the hardware transpose read, B rows keep their
+// natural order (=> 8-byte instead of 16-byte BF16 stores).  See load_fragment_tr.
+// (The timing ablations this kernel was tuned with -- no stagger, priorities, early barriers, pieces between MFMAs, per-step
+// traces ... -- live in fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
@@ -1743,27 +1121,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    // Early barriers (experiment): a wave in a matrix segment arrives at the segment-end barrier EB steps before its last
-    // MFMA, so the partner half starts its matrix segment while this one still has EB MFMAs to issue -- the matrix pipe
-    // does not idle for the barrier round trip.  (The barrier in front of a load segment only orders LDS traffic, which the
-    // trailing register-only steps do not touch.)
-    constexpr int EB = (DABL == 14) ? 2 : (DABL == 15 ? 4 : (DABL == 16 ? 1 : 0));
-    constexpr int A_EARLY = (DABL == 9) ? 0 : (DABL == 17 ? A_ITERS : (DABL == 18 ? A_ITERS * 3 / 4 : A_ITERS / 2));
-    // MP (experiment): this many LDS-DMA pieces per matrix segment ride between its MFMA steps (A pieces in M_a, B pieces in
-    // M_b) instead of in L_b, the longest load segment
-    constexpr int MP = (DABL == 30) ? 1 : (DABL == 31 ? 2 : 0);
-    static_assert(MP == 0 || (A_ITERS - A_EARLY >= MP && B_ITERS >= MP && SEG >= 12), "pieces to move");        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
-    constexpr unsigned OOB = 0x80000000u;
-    // DABL 4: matrix segments and barriers only; 5: no LDS-DMA in the loop; 6: no fragment reads in the loop; 7: no scale loads
-    constexpr bool PERSIST = (DABL == 20 || DABL == 26 || DABL == 41);      // persistent launch with cross-tile prologue prefetch
-    // B_MN: operand B is MN-major ([K][N], unit stride along n, row pitch b_sk): the nn / tn layouts without the re-majoring
-    // pass.  LDS-DMA pieces are 4 k-rows x 256 bytes, B fragments come through the hardware transpose read, B rows keep
-    // their natural order (=> 8-byte instead of 16-byte BF16 stores).  See load_fragment_tr.
-    constexpr bool B_MN = (DABL == 40 || DABL == 41);
+    constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
-    constexpr bool TRACE = (DABL == 3 || DABL == 10 || DABL == 11), NOPRIO = (DABL != 2 && DABL != 3 && DABL != 24 && DABL != 26 && DABL != 28),
-                   LOADPRIO = (DABL == 8 || DABL == 11 || DABL == 25 || DABL == 29);
-    constexpr bool NO_DMA = (DABL == 4 || DABL == 5), NO_LDS_READS = (DABL == 4 || DABL == 6), NO_SCALES = (DABL == 4 || DABL == 7);
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
     static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
@@ -1845,14 +1204,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-            (DABL == 32 ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);       // DABL 32 (timing): every piece re-reads K block 0 (L2 resident)
+            imin(j, num_kb - 1) * 128, 0, 0);
     };
     auto issue_b_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
             B_MN ? bmn_voff : b_piece_voff[q],
-            B_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * ldb_mn : (DABL == 32 ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+            B_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * ldb_mn : imin(j, num_kb - 1) * 128, 0, 0);
     };
     // Prologue pieces of a tile: A(0) B(0) A(1) B(1) into ring slots 0 / 1.  Issued at kernel entry for the first tile
     // and, in the persistent launch, for tile i+1 as soon as tile i's K loop has released the LDS -- i.e. BEFORE tile i's
@@ -1918,8 +1277,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
             auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
             auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
-                const int jj = (DABL == 21) ? 0 : imin(j, num_kb - 1);   // past the end: the last block's scales again (never consumed); DABL 21 (timing): always block 0 = cache resident
-                issue_scale_loads_v<MS, DABL == 19>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
+                const int jj = imin(j, num_kb - 1);   // past the end: the last block's scales again (never consumed)
+                issue_scale_loads_v<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
             float scale[MS], scale_tail = 0.f;
@@ -1941,47 +1300,31 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 wait_landing_v<0, MS>(land);
             }
             raw_barrier();
-            if (DABL != 1 && upper_half)
+            if (upper_half)
                 raw_barrier();                      // the upper half runs one segment behind from here on
 
-            [[maybe_unused]] int trace_v = 0;
-            auto stamp = [&](int kb, int k) {
-                if constexpr (TRACE) {      // trace build: lane 8 * (kb - 28) + k = s_memtime, for K blocks 28 .. 35
-                    long long tt;
-                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt));
-                    const int lane_sel = (kb >= 28 && kb < 32) ? (kb - 28) * 8 + k : 63;
-                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v) : "s"(static_cast<int>(tt)), "s"(lane_sel));
-                }
-            };
             int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;     // slots of A(kb), A(kb+2) [= A(kb-1)'s], B(kb)
             v8i bf[NS], af[HS];
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
-            if (EB > 0) raw_barrier();                          // L_a(0)'s barrier; later ones sit inside M_b
 
             for (int kb = 0; kb < num_kb; ++kb) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
 
                 // ---------------- L_a ----------------
-                stamp(kb, 0);
-                if (EB == 0) raw_barrier();         // EB > 0: executed inside the previous matrix segment / before the loop
-                stamp(kb, 1);
+                raw_barrier();
                 // fragment reads first: they complete in the shadow of the slow vector-memory issue that follows
                 [[maybe_unused]] FragTr bfq[NS];
-                if (NO_LDS_READS ? kb == 0 : true) {
-                    #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns) {
-                        if constexpr (B_MN)
-                            bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
-                        else
-                            bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
-                    }
-                    #pragma unroll
-                    for (int h = 0; h < HS; ++h)
-                        af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    if constexpr (B_MN)
+                        bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                    else
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
                 }
-                [[maybe_unused]] long long t_in[3];
-                if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[0]) :: "memory");
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    af[h] = load_fragment(a_tile + h * 2048, frag_off);
                 scale_tail = scale[MS - 1];
                 // block kb's scales landed before the previous L_b's wait (block 0: before the prologue's / the prefetch's)
                 #pragma unroll
@@ -1989,103 +1332,65 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
                     pin_vgpr(scale[ms]);
                 }
-                if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[1]) :: "memory");
-                if (!NO_SCALES) issue_scales(land, kb + 1);
-                if (!NO_DMA) {
-                    #pragma unroll
-                    for (int q = 0; q < A_EARLY; ++q)
-                        issue_a_piece(a_fill, kb + 2, q);
-                }
-                if constexpr (TRACE) asm volatile("s_memtime %0" : "=s"(t_in[2]) :: "memory");
+                issue_scales(land, kb + 1);
+                #pragma unroll
+                for (int q = 0; q < A_EARLY; ++q)
+                    issue_a_piece(a_fill, kb + 2, q);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if constexpr (B_MN) {
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
                         bf[ns] = assemble_fragment_tr(bfq[ns]);
                 }
-                if constexpr (TRACE) {
-                    #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int lane_sel = (kb >= 28 && kb < 32) ? 32 + (kb - 28) * 4 + q : 63;
-                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(trace_v) : "s"(static_cast<int>(t_in[q])), "s"(lane_sel));
-                    }
-                }
 
                 // ---------------- M_a ----------------
-                stamp(kb, 2);
                 raw_barrier();
-                stamp(kb, 3);
-                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(1);
-                if (LOADPRIO) __builtin_amdgcn_s_setprio(0);
                 #pragma unroll
                 for (int i = 0; i < SEG; ++i) {
                     const int ns = i % NS, h = i / NS;
                     const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
                     const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
-                    if (EB > 0 && i == SEG - EB) raw_barrier();
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
-                    if (MP > 0 && (i == 3 || (MP > 1 && i == 9)))
-                        issue_a_piece(a_fill, kb + 2, A_EARLY + (i == 3 ? 0 : 1));
                 }
-                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
-                if (LOADPRIO) __builtin_amdgcn_s_setprio(1);
 
                 // ---------------- L_b ----------------
-                stamp(kb, 4);
-                if (EB == 0) raw_barrier();
-                stamp(kb, 5);
-                if (!NO_LDS_READS) {
-                    #pragma unroll
-                    for (int h = 0; h < HS; ++h)
-                        af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
-                }
-                if (!NO_DMA) {
-                    #pragma unroll
-                    for (int q = A_EARLY + MP; q < A_ITERS; ++q)
-                        issue_a_piece(a_fill, kb + 2, q);
-                    #pragma unroll
-                    for (int q = 0; q < B_ITERS - MP; ++q)
-                        issue_b_piece(b_cur, kb + 2, q);
-                }
+                raw_barrier();
+                #pragma unroll
+                for (int h = 0; h < HS; ++h)
+                    af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                #pragma unroll
+                for (int q = A_EARLY; q < A_ITERS; ++q)
+                    issue_a_piece(a_fill, kb + 2, q);
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q)
+                    issue_b_piece(b_cur, kb + 2, q);
                 // Block kb+1 and its scales: my pieces have landed.  (Persistent launch: a predecessor tile's output stores may
                 // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
                 // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
                 // "every load but the newest 8 has landed".)
-                wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS - MP), MS>(land);       // MP pieces of this block come in M_b
+                wait_landing_v<A_ITERS + B_ITERS, MS>(land);
                 #pragma unroll
                 for (int h = 0; h < HS; ++h)
                     asm volatile("" : "+v"(af[h]) :: "memory");
 
                 // ---------------- M_b ----------------
-                stamp(kb, 6);
                 raw_barrier();
-                stamp(kb, 7);
-                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(1);
-                if (LOADPRIO) __builtin_amdgcn_s_setprio(0);
                 #pragma unroll
                 for (int i2 = 0; i2 < SEG; ++i2) {
                     const int i = SEG + i2;
                     const int ns = i % NS, h = i2 / NS;
                     const int j = i - DEPTH;
-                    if (EB > 0 && i2 == SEG - EB) raw_barrier();      // the next K block's L_a barrier
                     mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
-                    if (MP > 0 && (i2 == 3 || (MP > 1 && i2 == 9)))
-                        issue_b_piece(b_cur, kb + 2, B_ITERS - MP + (i2 == 3 ? 0 : 1));
                 }
-                if (!NOPRIO && !LOADPRIO) __builtin_amdgcn_s_setprio(0);
-                if (LOADPRIO) __builtin_amdgcn_s_setprio(1);
 
                 const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
                 a_fill = a_cur;             // A(kb+3) will take the slot block kb just finished with
                 a_cur = a_next;
                 b_cur ^= B_BYTES;
             }
-            if (DABL != 1 && !upper_half)
+            if (!upper_half)
                 raw_barrier();              // pairs with the barrier in front of the upper half's last segment
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
-            if constexpr (TRACE)
-                if (p.dbg != nullptr)
-                    reinterpret_cast<int*>(p.dbg + 8192)[(blockIdx.x * NW + wave) * 64 + lane] = trace_v;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's re-read pieces: the ring is about to be reused
             __syncthreads();                                    // every wave is done with the LDS
             fetch_next();                                       // persistent launch: the next tile's prologue flies from here
@@ -2104,11 +1409,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
-        if constexpr (DABL == 13) {
-            if (out[0][0][0] == 123.456f) store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
-        } else {
-            store_tile<MS, NS, true, DABL == 12, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
-        }
+        store_tile<MS, NS, true, false, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && first_tile && !next_prefetched) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -2122,10 +1423,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DABL = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, DABL>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN>(p);
 }
 
 
@@ -2332,196 +1633,6 @@ __device__ __forceinline__ void wait_e8_landing(E8Landing& l) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
     asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]) :: "memory");
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__device__ __forceinline__ void e8_kernel_body(const GemmParams& p) {
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, TOTAL = MS * NS;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
-    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
-    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    constexpr int P_STEP = TOTAL - NS, SCALE_LOADS = 6;
-    constexpr int B_FIRST = (NS > 2 * A_ITERS ? NS : 2 * A_ITERS);
-    static_assert(MS == 8 && NS == 4, "scale landing registers are written out for a 128 x 64 wave tile");
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of LDS-DMA pieces");
-    static_assert(B_FIRST + 2 * (B_ITERS - 1) < P_STEP, "LDS-DMA pieces must be issued in front of barrier P");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128;
-    const int piece_row = lane >> 3;
-    const int src_chunk = (lane & 7) ^ piece_row;
-    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
-    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
-    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
-    const int a_voff = piece_row * MS * lda + src_chunk * 16;
-    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
-    int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
-    #pragma unroll
-    for (int q = 0; q < A_ITERS; ++q)
-        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
-    #pragma unroll
-    for (int q = 0; q < B_ITERS; ++q)
-        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
-    const int num_kq = (num_kb + 3) / 4;
-    const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;   // bytes per packed K column
-
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
-    long long t_loop0 = 0, t_loop1 = 0;
-    MaskedWalk walk;
-    const int num_launched = gridDim.x;
-    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
-        if (!t.valid)
-            break;
-        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
-
-        v4f acc[MS][NS];
-        #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
-
-        if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
-            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
-                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
-            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
-                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
-            // packed scale words: element (row, kq) at base[kq * stride + row] (int32)
-            const uint64_t sfa_addr = reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg);
-            const uint64_t sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg);
-            const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
-                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr >> 32) & 0xffff),
-                                  __builtin_amdgcn_readfirstlane((num_kq - 1) * sfa_kq_stride + p.m * 4), 0x00020000};
-            const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
-                                  __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
-                                  __builtin_amdgcn_readfirstlane((num_kq - 1) * sfb_kq_stride + p.n * 4), 0x00020000};
-            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
-            int sfb_voff[NS];
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                const int i = lane & 15;
-                sfb_voff[ns] = (t.n0 + wn * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)) * 4;
-            }
-
-            auto issue_a_piece = [&](int slot_off, int j, int q) {
-                const int unit = wave + NW * q;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-                    imin(j, num_kb - 1) * 128, 0, 0);
-            };
-            auto issue_b_piece = [&](int slot_off, int j, int q) {
-                const int unit = wave + NW * q;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
-                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
-            };
-            E8Landing land;
-            auto issue_scales = [&](int j) {           // the packed words that contain K block j
-                const int kq = imin(j, num_kb - 1) >> 2;
-                issue_e8_scale_loads(land, sfa_rsrc, sfa_voff + kq * sfa_kq_stride, sfb_rsrc, sfb_voff[0] + kq * sfb_kq_stride,
-                                     sfb_voff[1] + kq * sfb_kq_stride, sfb_voff[2] + kq * sfb_kq_stride,
-                                     sfb_voff[3] + kq * sfb_kq_stride);
-            };
-            int sa_cur[MS], sb_cur[NS];               // byte 0 = the exponent of the current K block
-            auto take_scales = [&](int j) {
-                const int shift = (imin(j, num_kb - 1) & 3) * 8;
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    sa_cur[ms] = static_cast<int>(static_cast<unsigned>(land.sa[ms / 4][ms % 4]) >> shift);
-                #pragma unroll
-                for (int ns = 0; ns < NS; ++ns)
-                    sb_cur[ns] = static_cast<int>(static_cast<unsigned>(land.sb[ns]) >> shift);
-            };
-
-            // ---- prologue: A(0) B(0) A(1) B(1) | scales of block 0, full drain ----
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
-            issue_scales(0);
-            wait_e8_landing<0>(land);
-            take_scales(0);
-            raw_barrier();
-
-            int a_cur = 0, a_nxt = A_BYTES, b_nxt = B_BYTES;
-            v8i bf[NS], af[2];
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                bf[ns] = load_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128, frag_off);
-            af[0] = load_fragment(lds + (wm * WM) * 128, frag_off);
-
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
-            for (int kb = 0; kb < num_kb; ++kb) {
-                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
-                const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
-                const uint8_t* b_next_tile = lds + B_BASE + b_nxt + (wn * WN) * 128;
-                const int a_fill = (a_nxt == (A_SLOTS - 1) * A_BYTES) ? 0 : a_nxt + A_BYTES;
-                issue_scales(kb + 1);       // issue order per block: scales(kb+1) | A(kb+2) | B(kb+2) | P waits vmcnt(8)
-
-                #pragma unroll
-                for (int i = 0; i < TOTAL; ++i) {
-                    const int ms = i / NS, ns = i % NS;
-                    if (i == P_STEP) {
-                        // barrier P: block kb+1 and its scale words landed everywhere; every read of A(kb) has returned
-                        wait_e8_landing<A_ITERS + B_ITERS>(land);
-                        raw_barrier();
-                    }
-                    if (ns == 0) {
-                        if (ms + 1 < MS)
-                            af[(ms + 1) & 1] = load_fragment(a_tile + (ms + 1) * 2048, frag_off);
-                        else
-                            af[(ms + 1) & 1] = load_fragment(a_next_tile, frag_off);
-                    }
-                    // operand roles are swapped (B rows in the A slot): the A-slot scale is the B row's, the B-slot scale the A row's
-                    acc[ms][ns] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ns], af[ms & 1], acc[ms][ns], 0, 0,
-                                                                                   0, sb_cur[ns], 0, sa_cur[ms]);
-                    if (ms == MS - 1)
-                        bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
-                    if (i % 2 == 0 && i / 2 < A_ITERS)
-                        issue_a_piece(a_fill, kb + 2, i / 2);
-                    if (i == NS - 1)
-                        raw_barrier();                                          // barrier Q: B(kb) is in registers
-                    if (i >= B_FIRST && (i - B_FIRST) % 2 == 0 && (i - B_FIRST) / 2 < B_ITERS)
-                        issue_b_piece(b_nxt ^ B_BYTES, kb + 2, (i - B_FIRST) / 2);   // B(kb)'s slot
-                }
-                take_scales(kb + 1);
-                a_cur = a_nxt;
-                a_nxt = a_fill;
-                b_nxt ^= B_BYTES;
-            }
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
-        if (p.dbg != nullptr && tile_id == blockIdx.x) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dbg_stamp(p, NW, 0, t_entry);
-            dbg_stamp(p, NW, 1, t_loop0);
-            dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
-        }
-    }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
-void dg_fp8_gemm_e8_kernel(const GemmParams p) {
-    e8_kernel_body<BM, BN, WAVES_M, WAVES_N>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

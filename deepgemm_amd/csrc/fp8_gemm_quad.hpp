@@ -399,328 +399,4 @@ void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
     quad_e8_kernel_body<BM, BN, QV>(p);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// FP32-scale quad kernel: the same one-wave-per-SIMD schedule for the reference's FP32 scaling factors (promotion
-// acc += (sfa * sfb) * partial in the shadow of the following MFMAs, as in the 8-wave kernels).  The accumulators must be
-// VALU-addressable, i.e. 128 arch VGPRs per wave => a 128 x 256 or 256 x 128 tile on four waves (wave tile 64 x 128 or
-// 128 x 64).  One s_barrier per K block, no matrix-pipe hand-off between waves.  Used where the 256 x 256 tile does not fit
-// the problem: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise badly.
-//
-// Of the wave tile's two fragment sets the smaller one ("R": 4 fragments -- A for the 64-row wave tile, B for the 64-column
-// one) stays resident in VGPRs for the whole K block, the other ("S": 8 fragments) streams through a 4-slot ring, two
-// fragments ahead; ring slots 2 and 3 live in AGPRs (ds_read_b128 writes them there directly, the MFMA reads its operand
-// from them), everything that is carried across the loop edge -- R and ring slots 0, 1 -- in VGPRs (a carried AGPR operand
-// would be loaded into a VGPR and copied: 8 VALU moves per fragment).
-// Schedule per K block (TOTAL = 32 steps; a step = one MFMA + the four FMAs of the step three back):
-//   S-rows 0 .. 5 : S fragment s + 2 read at the head of row s; LDS-DMA: second half of B(kb+1), then A(kb+2)
-//   barrier Z     : vmcnt(A_ITERS) => B(kb+1), A(kb+1) landed; everybody is done with A(kb)'s and B(kb)'s... slots
-//   scale loads of block kb+1 (inline asm, VGPR landing), then S-rows 6, 7 R-major -- steps (r, 6), (r, 7) -- so that R
-//   fragment r is dead after its pair and is re-read from block kb+1 at once; S fragments 0, 1 of block kb+1 follow;
-//   LDS-DMA: first half of B(kb+2); the vmcnt(B_ITERS / 2) at the end of the block lands the scales (straight-line from
-//   their issue: see "A latent race" in DESIGN.md).
-// ---------------------------------------------------------------------------------------------------------------
-template <bool ROWS_AGPR, bool COLS_AGPR, bool NO_FMA = false>
-__device__ __forceinline__ void mfma_promote_step_q(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
-                                                    float (&c)[4], float scale, const v4f& part_old) {
-#define DG_QSTEP_ASM(RC, CC)                                                                                             \
-    asm volatile(                                                                                                        \
-        "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"                                                                  \
-        "v_fmac_f32 %1, %7, %8\n\t"                                                                                      \
-        "v_fmac_f32 %2, %7, %9\n\t"                                                                                      \
-        "v_fmac_f32 %3, %7, %10\n\t"                                                                                     \
-        "v_fmac_f32 %4, %7, %11"                                                                                         \
-        : "=&v"(part_new), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])                                                \
-        : RC(rows_operand), CC(cols_operand), "v"(scale), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]),          \
-          "v"(part_old[3])                                                                                               \
-        : "memory")
-    if constexpr (NO_FMA) {       // timing experiment: the bare MFMA stream (results are garbage)
-        if constexpr (ROWS_AGPR) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=&v"(part_new) : "a"(rows_operand), "v"(cols_operand) : "memory");
-        else if constexpr (COLS_AGPR) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=&v"(part_new) : "v"(rows_operand), "a"(cols_operand) : "memory");
-        else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=&v"(part_new) : "v"(rows_operand), "v"(cols_operand) : "memory");
-        asm volatile("" : "+v"(c[0]) : "v"(part_old[0]), "v"(scale));
-    } else
-    if constexpr (ROWS_AGPR && COLS_AGPR) DG_QSTEP_ASM("a", "a");
-    else if constexpr (ROWS_AGPR) DG_QSTEP_ASM("a", "v");
-    else if constexpr (COLS_AGPR) DG_QSTEP_ASM("v", "a");
-    else DG_QSTEP_ASM("v", "v");
-#undef DG_QSTEP_ASM
-}
-
-// QV (timing experiments, DG_EXPERIMENTS builds only; results are garbage): 1 no LDS-DMA in the loop; 2 no fragment reads;
-// 3 no promotion FMAs; 4 no scale loads; 5 = 1 + 2; 6 = 1 + 2 + 3 (MFMA stream and the barrier only).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int QV = 0>
-__device__ __forceinline__ void quad_kernel_body(const GemmParams& p) {
-    constexpr int NW = 4;
-    static_assert(WAVES_M * WAVES_N == NW, "one wave per SIMD");
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, TOTAL = MS * NS, DEPTH = 3;
-    constexpr bool STREAM_A = MS > NS;                      // the streamed operand S; the other one (R) is resident
-    constexpr int SS = STREAM_A ? MS : NS, RS = STREAM_A ? NS : MS;
-    constexpr int PRE = (SS - 2) * RS, POST = 2 * RS;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
-    constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
-    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
-    constexpr bool NO_DMA = (QV == 1 || QV == 5 || QV == 6), NO_READS = (QV == 2 || QV == 5 || QV == 6), NO_FMA = (QV == 3 || QV == 6), NO_SCALES = (QV == 4);
-    static_assert(SS == 8 && RS == 4, "wave tile 64 x 128 or 128 x 64: 128 accumulator registers");
-    static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
-    static_assert(BM % (8 * NW) == 0 && BN % (16 * NW) == 0, "every wave issues the same number of pieces, B in two halves");
-    static_assert(N_PRE <= PRE && N_POST <= POST, "at most one piece per step");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
-                  "the row permutation of a B piece must be lane-independent");
-
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128;
-    const int piece_row = lane >> 3;
-    const int src_chunk = (lane & 7) ^ piece_row;
-    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
-    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
-    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
-    const int a_voff = piece_row * MS * lda + src_chunk * 16;
-    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
-    int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
-    #pragma unroll
-    for (int q = 0; q < A_ITERS; ++q)
-        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
-    #pragma unroll
-    for (int q = 0; q < B_ITERS; ++q)
-        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
-    const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
-    const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
-    const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
-
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
-    long long t_loop0 = 0, t_loop1 = 0;
-    MaskedWalk walk;
-    const int num_launched = gridDim.x;
-    auto uniform_ptr = [](const uint8_t* ptr) {
-        const uint64_t v = reinterpret_cast<uint64_t>(ptr);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v));
-        const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
-        return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
-    };
-    auto scale_rsrc = [](uint64_t addr, int extent) {
-        return v4i{__builtin_amdgcn_readfirstlane(static_cast<int>(addr)),
-                   __builtin_amdgcn_readfirstlane(static_cast<int>(addr >> 32) & 0xffff),
-                   __builtin_amdgcn_readfirstlane(extent), 0x00020000};
-    };
-
-    int tile_id = blockIdx.x, pass = 0;
-    while (true) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
-        if (!t.valid)
-            break;
-        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
-        const int m_base = t.m0 + wm * WM, n_base = t.n0 + wn * WN;
-
-        float acc[MS][NS][4];
-        #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[ms][ns][r] = 0.f;
-
-        if (t.m_end > t.m0) {
-            const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
-            const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
-            const int a_bytes = __builtin_amdgcn_readfirstlane((imin(t.m_end - t.m0, BM) - 1) * lda + p.k);
-            const int b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - t.n0, BN) - 1) * ldb + p.k);
-            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0, a_bytes, 0x00020000);
-            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0, b_bytes, 0x00020000);
-            const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg), sfa_extent);
-            const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg +
-                                                                       static_cast<int64_t>((t.n0 + wn * WN) / 128) * p.sfb_sn), sfb_extent);
-            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
-
-            auto issue_a_piece = [&](int slot_off, int j, int q) {
-                if (NO_DMA) return;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_piece_voff[q],
-                    imin(j, num_kb - 1) * 128, 0, 0);
-            };
-            auto issue_b_piece = [&](int slot_off, int j, int q) {
-                if (NO_DMA) return;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
-                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
-            };
-            ScaleLandingV<MS> land;
-            auto issue_scales = [&](int j) {
-                const int jj = imin(j, num_kb - 1);             // past the end: the last block's scales again (never consumed)
-                issue_scale_loads_v<MS>(land, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
-            };
-
-            // ---- prologue: A(0) B(0) scales(0) | A(1) B(1)[first half]; wait for the first group only ----
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
-            issue_scales(0);
-            #pragma unroll
-            for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
-            #pragma unroll
-            for (int q = 0; q < B_ITERS / 2; ++q) issue_b_piece(B_BYTES, 1, q);
-            wait_landing_v<(NO_DMA ? 0 : A_ITERS + B_ITERS / 2), MS>(land);
-            raw_barrier();
-
-            int a_cur = 0, a_nxt = A_BYTES, a_fill = 2 * A_BYTES, b_cur = 0;
-            const int a_wave = (wm * WM) * 128, b_wave = B_BASE + (wn * WN) * 128;          // this wave's rows inside a slot
-            v8i rf[RS], sf[4];
-            #pragma unroll
-            for (int r = 0; r < RS; ++r)
-                rf[r] = load_fragment(lds + (STREAM_A ? b_wave : a_wave) + r * 2048, frag_off);
-            sf[0] = load_fragment(lds + (STREAM_A ? a_wave : b_wave), frag_off);
-            sf[1] = load_fragment(lds + (STREAM_A ? a_wave : b_wave) + 2048, frag_off);
-
-            float scale[MS], scale_prev[MS];
-            v4f part[DEPTH + 1];
-            #pragma unroll
-            for (int i = 0; i <= DEPTH; ++i)
-                part[i] = v4f{0.f, 0.f, 0.f, 0.f};
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-                scale[ms] = 0.f;
-
-            // sequence index of a step within a K block -> (s, r): S-rows 0 .. SS-3 row-major, the last two S-rows R-major
-            auto seq_s = [](int i) { return i < PRE ? i / RS : SS - 2 + ((i - PRE) & 1); };
-            auto seq_r = [](int i) { return i < PRE ? i % RS : (i - PRE) >> 1; };
-            // one step: MFMA of sequence index i, promotion of sequence index i - DEPTH (the first steps of a block: of the
-            // previous block's last steps, at that block's scales)
-            auto step = [&](int i, auto s_slot_in_agpr) {
-                constexpr bool S_AGPR = decltype(s_slot_in_agpr)::value;
-                const int s = seq_s(i), r = seq_r(i);
-                const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
-                const int js = seq_s(j), jr = seq_r(j);
-                const int jms = STREAM_A ? js : jr, jns = STREAM_A ? jr : js;
-                const float jscale = (i >= DEPTH) ? scale[jms] : scale_prev[jms];
-                if constexpr (STREAM_A)       // rows operand = B fragment (resident), columns operand = A fragment (streamed)
-                    mfma_promote_step_q<false, S_AGPR, NO_FMA>(part[i & DEPTH], rf[r], sf[s & 3], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
-                else
-                    mfma_promote_step_q<S_AGPR, false, NO_FMA>(part[i & DEPTH], sf[s & 3], rf[r], acc[jms][jns], jscale, part[(i + 1) & DEPTH]);
-            };
-
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
-            for (int kb = 0; kb < num_kb; ++kb) {
-                const uint8_t* s_tile = lds + (STREAM_A ? a_cur + a_wave : b_cur + b_wave);
-                const uint8_t* s_next_tile = lds + (STREAM_A ? a_nxt + a_wave : (b_cur ^ B_BYTES) + b_wave);
-                const uint8_t* r_next_tile = lds + (STREAM_A ? (b_cur ^ B_BYTES) + b_wave : a_nxt + a_wave);
-                // block kb's scales landed before the wait at the end of the previous block (block 0: the prologue's)
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    scale_prev[ms] = scale[ms];
-                    scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
-                    pin_vgpr(scale[ms]);
-                }
-                // ---- S-rows 0 .. SS-3 ----
-                #pragma unroll
-                for (int i = 0; i < PRE; ++i) {
-                    const int s = i / RS;
-                    if (i % RS == 0 && !NO_READS)
-                        sf[(s + 2) & 3] = load_fragment(s_tile + (s + 2) * 2048, frag_off);
-                    step(i, std::false_type{});
-                    // pieces: slot q of N_PRE rides behind step q * PRE / N_PRE: second half of B(kb+1), then A(kb+2)
-                    #pragma unroll
-                    for (int q = 0; q < N_PRE; ++q)
-                        if (q * PRE / N_PRE == i) {
-                            if (q < B_ITERS / 2)
-                                issue_b_piece(b_cur ^ B_BYTES, kb + 1, B_ITERS / 2 + q);
-                            else
-                                issue_a_piece(a_fill, kb + 2, q - B_ITERS / 2);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // ---- barrier Z ----
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
-                raw_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                if (!NO_SCALES) issue_scales(kb + 1);               // older than every piece issued from here on
-                // ---- S-rows SS-2, SS-1, R-major ----
-                #pragma unroll
-                for (int u = 0; u < POST; ++u) {
-                    const int i = PRE + u, r = u >> 1;
-                    step(i, std::false_type{});
-                    if ((u & 1) && !NO_READS)
-                        rf[r] = load_fragment(r_next_tile + r * 2048, frag_off);
-                    if (u == 2 && !NO_READS) sf[0] = load_fragment(s_next_tile, frag_off);
-                    if (u == POST / 2 + 2 && !NO_READS) sf[1] = load_fragment(s_next_tile + 2048, frag_off);
-                    #pragma unroll
-                    for (int q = 0; q < N_POST; ++q)
-                        if (q * POST / N_POST + 1 == u)
-                            issue_b_piece(b_cur, kb + 2, q);        // B(kb)'s slot: free since Z (its last reads were this block's)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                wait_landing_v<(NO_DMA ? 0 : N_POST), MS>(land);    // the scales of block kb+1 are in (only B(kb+2)'s first half may fly)
-                const int a_free = a_cur;
-                a_cur = a_nxt;
-                a_nxt = a_fill;
-                a_fill = a_free;
-                b_cur ^= B_BYTES;
-            }
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's re-read pieces: the ring is about to be reused
-            __syncthreads();
-            #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) {                   // the last three steps' partials
-                const int j = TOTAL - DEPTH + i;
-                const int js = seq_s(j), jr = seq_r(j);
-                const int jms = STREAM_A ? js : jr, jns = STREAM_A ? jr : js;
-                promote_only(acc[jms][jns], scale[jms], part[(TOTAL + i + 1) & DEPTH]);
-            }
-        }
-
-        if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-                #pragma unroll
-                for (int g = 0; g < NS / 4; ++g) {
-                    v4f quad4[4];
-                    #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        quad4[j] = v4f{acc[ms][4 * g + j][0], acc[ms][4 * g + j][1], acc[ms][4 * g + j][2], acc[ms][4 * g + j][3]};
-                    store_rows_full_line<MS, true>(p, t, ad_group * p.d_sg, quad4, ms, m_base, n_base + 64 * g);
-                }
-        } else {
-            auto store_group = [&](auto gc) {
-                constexpr int G = decltype(gc)::value;
-                v4f out[MS][4];
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        out[ms][j] = v4f{acc[ms][4 * G + j][0], acc[ms][4 * G + j][1], acc[ms][4 * G + j][2], acc[ms][4 * G + j][3]};
-                store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, out, m_base, n_base + 64 * G);
-            };
-            store_group(std::integral_constant<int, 0>{});
-            if constexpr (NS == 8)
-                store_group(std::integral_constant<int, 1>{});
-        }
-        if (p.dbg != nullptr && tile_id == static_cast<int>(blockIdx.x) && pass == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dbg_stamp(p, NW, 0, t_entry);
-            dbg_stamp(p, NW, 1, t_loop0);
-            dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
-        }
-        if (t.second_pass) {
-            pass = 1;
-        } else {
-            pass = 0;
-            tile_id += num_launched;
-        }
-    }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int QV = 0>
-__global__ __launch_bounds__(256)
-void dg_fp8_gemm_quad_kernel(const GemmParams p) {
-    quad_kernel_body<BM, BN, WAVES_M, WAVES_N, QV>(p);
-}
-
 }  // namespace dg
