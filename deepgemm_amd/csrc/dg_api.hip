@@ -23,6 +23,7 @@ namespace {
 // process-wide like the reference's runtime singletons (csrc/apis/runtime.hpp:12-49) and safe to set from any thread.
 thread_local std::string g_last_error;
 thread_local std::string g_last_config = "";
+thread_local size_t g_workspace_bytes = 0;          // size of the workspace behind GemmParams::sk_workspace for the call in flight
 std::atomic<int> g_num_cus_override{0};
 std::atomic<long long*> g_debug_buffer{nullptr};
 std::mutex g_forced_config_mutex;
@@ -92,6 +93,7 @@ struct Config {
     bool two_pass = false;  // contiguous layout: BM may be twice the M alignment (halves of two groups => two passes)
     bool persistent = false;  // one workgroup per CU walks the tile list and prefetches the next tile's first K blocks
     bool per_col = false;     // recipe (1, 1, 128): one SFB value per row of B (all other fast kernels: one per 128 rows)
+    bool split_k = false;     // persistent launch whose partial last round is cut along K over the idle CUs (needs a workspace)
 };
 
 const Config kConfigs[] = {
@@ -100,6 +102,10 @@ const Config kConfigs[] = {
     // 128-row duo tile: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise
     // badly at 256 x 256.  Measured per-tile: 116 k cycles vs 167 k for twice the work (L2->LDS bytes per flop are 1.5x).
     {"duo_128x256", 128, 256, 512, 1, 0.78f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4>, true},
+    // the same tile in a persistent launch whose partial last round is split along K (2.25 rounds of tiles cost 2 + ~0.4 instead
+    // of 3): picked instead of duo_128x256 when the caller provides the workspace and the tail is at most half a round
+    {"duo_sk_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true>, true, false, true,
+     false, true},
     // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
     {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true>, true, true, true},
     {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true>, true},
@@ -223,6 +229,18 @@ bool per_col_mn_eligible(const dg::GemmParams& p) {
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// K pieces per tile of the partial last round (0 = no split): as many as the idle workgroup slots allow, at most 8 and at most
+// one per K block.
+long split_k_pieces(long tiles, long slots, long num_kb) {
+    const long tail = tiles % slots;
+    if (tiles <= slots || tail == 0)
+        return 0;
+    long pieces = slots / tail;
+    if (pieces > 8) pieces = 8;
+    if (pieces > num_kb) pieces = num_kb;
+    return pieces >= 2 ? pieces : 0;
+}
+
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
 const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expected_m, int bm_must_divide) {
     const std::string forced = forced_config();
@@ -302,6 +320,19 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             best_cost = cost;
         }
     }
+    // A partial last round of 128 x 256 tiles: split it along K over the idle CUs (needs the caller's workspace).  The split
+    // trades (1 - 1/pieces) of a tile's K loop (~1.05 us per K block) for the partial-tile exchange (~17 us + 1.3 us per piece,
+    // tools/grouped_bench.py on 8 groups x N 4096 with 16..128 tail tiles): K = 7168 gains 8..21 us of ~180, K = 4096 0..7 us of
+    // ~100, K = 2048 loses.
+    if (best != nullptr && std::strcmp(best->name, "duo_128x256") == 0 && p.sk_workspace != nullptr &&
+        p.gemm_type != dg::kMasked) {
+        const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
+        const long pieces = split_k_pieces(tiles, num_cus(), p.k / 128);
+        if (pieces >= 2 && static_cast<long>(p.k / 128) * (pieces - 1) * 100 > (1700 + 130 * pieces) * pieces)
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (std::strcmp(kConfigs[i].name, "duo_sk_128x256") == 0)
+                    return &kConfigs[i];
+    }
     // Several tiles per CU: the persistent variant of the duo kernel (the next tile's first K blocks are fetched and
     // drained in front of the current tile's stores, which then overlap the next tile's first K block).
     // (Dense only: on the two-pass contiguous walk the prefetch of the next tile loses more than the overlap wins.)
@@ -360,6 +391,24 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
 
     long grid;
     const long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
+    p.sk_first_tile = static_cast<int>(total);
+    p.sk_tiles = 0;
+    p.sk_factor = 1;
+    if (cfg->split_k) {
+        if (p.gemm_type == dg::kMasked) {
+            g_last_error = std::string("config '") + cfg->name + "' does not implement the masked layout";
+            return 3;
+        }
+        const long slots = static_cast<long>(num_cus()) * cfg->blocks_per_cu;
+        const long tail = total % slots;
+        const long pieces = split_k_pieces(total, slots, p.k / 128);
+        const size_t need = 4096 + static_cast<size_t>(tail) * pieces * cfg->bm * cfg->bn * sizeof(float);
+        if (total > slots && tail > 0 && pieces >= 2 && p.sk_workspace != nullptr && need <= g_workspace_bytes) {
+            p.sk_first_tile = static_cast<int>(total - tail);
+            p.sk_tiles = static_cast<int>(tail);
+            p.sk_factor = static_cast<int>(pieces);
+        }                                           // otherwise: a plain persistent walk over all tiles
+    }
     if (p.gemm_type == dg::kMasked) {
         const long slots = static_cast<long>(num_cus()) * cfg->blocks_per_cu;
         const long max_tiles = total * p.num_groups;
@@ -592,13 +641,14 @@ int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_pack
     return launch_e8(p, expected_m < m_max ? expected_m : m_max, stream);
 }
 
-int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+int dg_m_grouped_fp8_gemm_nt_contiguous_ws(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
                                         const int32_t* grouped_layout, int num_groups, int m, int n, int k,
                                         int64_t a_stride_m, int64_t a_stride_k,
                                         int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
                                         int64_t sfa_stride_m, int64_t sfa_stride_k,
                                         int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
-                                        int64_t d_stride_m, int use_psum, int m_alignment, void* stream) {
+                                        int64_t d_stride_m, int use_psum, int m_alignment, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
     DG_CHECK(m >= 0 && n > 0 && k > 0 && num_groups > 0);
     if (m == 0)
         return 0;
@@ -619,7 +669,28 @@ int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
     p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
     p.gemm_type = use_psum ? dg::kContiguousPsum : dg::kContiguous;
     p.m_alignment = m_alignment;
+    DG_CHECK(workspace == nullptr || (workspace_bytes >= 4096 && aligned16(workspace)));
+    p.sk_workspace = workspace;
+    g_workspace_bytes = workspace != nullptr ? static_cast<size_t>(workspace_bytes) : 0;
     return launch_gemm(p, 0, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                        const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                        int64_t a_stride_m, int64_t a_stride_k,
+                                        int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                        int64_t sfa_stride_m, int64_t sfa_stride_k,
+                                        int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                        int64_t d_stride_m, int use_psum, int m_alignment, void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_contiguous_ws(a, sfa, b, sfb, d, grouped_layout, num_groups, m, n, k, a_stride_m, a_stride_k,
+                                                  b_stride_g, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_k, sfb_stride_g,
+                                                  sfb_stride_n, sfb_stride_k, d_stride_m, use_psum, m_alignment, nullptr, 0, stream);
+}
+
+int64_t dg_split_k_workspace_bytes(void) {
+    // counters (4 KiB) + the largest tail a launch can have: at most half a round of tiles (128 on 256 CUs), each CU of the round
+    // holding one FP32 partial tile of 128 x 256
+    return 4096 + static_cast<int64_t>(device_cu_count()) * 128 * 256 * static_cast<int64_t>(sizeof(float));
 }
 
 int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void* b, const float* sfb, void* d,

@@ -25,6 +25,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 enum GemmType : int { kNormal = 0, kContiguous = 1, kContiguousPsum = 2, kMasked = 3, kKGrouped = 4 };
 constexpr int kMaxKGroups = 64;
@@ -58,6 +59,11 @@ struct GemmParams {
     int group_m;                    // tile-order swizzle: m-tiles per L2 group
     int d_vec_ok;                   // 16-byte aligned D rows => vector stores
     long long* dbg;                 // tuning aid (normally null): per wave {kernel entry, K loop begin, K loop end, after stores} s_memtime ticks
+    // K-split tail of a persistent launch (duo kernels built with SPLITK): tiles [sk_first_tile, sk_first_tile + sk_tiles) are cut
+    // into sk_factor K pieces; sk_workspace = int32 arrival counters [sk_tiles] (zero between launches) in its first 4 KiB, then
+    // FP32 partial tiles [sk_tiles][sk_factor][BM * BN]
+    void* sk_workspace;
+    int sk_first_tile, sk_tiles, sk_factor;
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
@@ -1111,9 +1117,14 @@ __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
 // B_MN: operand B is MN-major ([K][N], unit stride along n, row pitch b_sk): the nn / tn layouts without the re-majoring
 // pass.  LDS-DMA pieces are 4 k-rows x 256 bytes, B fragments come through the hardware transpose read, B rows keep their
 // natural order (=> 8-byte instead of 16-byte BF16 stores).  See load_fragment_tr.
+// SPLITK (persistent launch only): tail balancing for tile counts just above a multiple of the CU count.  The first
+// p.sk_first_tile tiles are walked as usual; the remaining p.sk_tiles tiles (the partial last round) are cut along K into
+// p.sk_factor pieces, one per otherwise idle CU.  Every piece writes its FP32 partial tile to the workspace, publishes it
+// (agent-scope release, then a relaxed counter increment -- MI355X_MICROARCH.md, "Workgroup dispatch ... visibility") and the
+// LAST arriver of a tile (no spinning: no residency assumption) sums all pieces in fixed order, resets the counter and stores.
 // (The timing ablations this kernel was tuned with -- no stagger, priorities, early barriers, pieces between MFMAs, per-step
 // traces ... -- live in fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
@@ -1123,6 +1134,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
+    static_assert(!SPLITK || (PERSIST && !B_MN), "the K-split tail belongs to the persistent K-major form");
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
     static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
@@ -1138,6 +1150,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const bool upper_half = wave >= NW / 2;
     const int num_kb = p.k / 128;
+    int kb0 = 0, nkb = num_kb;                  // K blocks [kb0, kb0 + nkb) of the current work item (SPLITK: a piece of the K range)
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
@@ -1204,14 +1217,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-            imin(j, num_kb - 1) * 128, 0, 0);
+            (kb0 + imin(j, nkb - 1)) * 128, 0, 0);
     };
     auto issue_b_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
             B_MN ? bmn_voff : b_piece_voff[q],
-            B_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * ldb_mn : imin(j, num_kb - 1) * 128, 0, 0);
+            B_MN ? (imin(j, nkb - 1) * 128 + 4 * unit) * ldb_mn : (kb0 + imin(j, nkb - 1)) * 128, 0, 0);
     };
     // Prologue pieces of a tile: A(0) B(0) A(1) B(1) into ring slots 0 / 1.  Issued at kernel entry for the first tile
     // and, in the persistent launch, for tile i+1 as soon as tile i's K loop has released the LDS -- i.e. BEFORE tile i's
@@ -1235,8 +1248,34 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // groups is walked twice.
     int tile_id = blockIdx.x, pass = 0;
     bool prefetched = false, first_tile = true;
-    Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
+    // SPLITK: virtual tile ids >= sk_first_tile are pieces w = id - sk_first_tile of the tail: tile sk_first_tile + w % sk_tiles,
+    // K piece w / sk_tiles of sk_factor (sk_first_tile is a multiple of the grid size, so a workgroup meets at most one piece)
+    struct Piece { int kb0, nkb, tail, index; bool split; };
+    auto work_of = [&](int id, int ps, Piece& pc) {
+        pc = Piece{0, num_kb, 0, 0, false};
+        if constexpr (SPLITK) {
+            if (id >= p.sk_first_tile) {
+                const int w = id - p.sk_first_tile;
+                if (w >= p.sk_tiles * p.sk_factor) {
+                    Tile none;
+                    none.valid = false;
+                    return none;
+                }
+                pc.tail = w % p.sk_tiles;
+                pc.index = w / p.sk_tiles;
+                pc.kb0 = pc.index * num_kb / p.sk_factor;
+                pc.nkb = (pc.index + 1) * num_kb / p.sk_factor - pc.kb0;
+                pc.split = true;
+                id = p.sk_first_tile + pc.tail;
+            }
+        }
+        return get_tile<BM, BN>(p, id, walk, ps);
+    };
+    Piece piece, piece_next;
+    Tile t = work_of(tile_id, pass, piece);
     while (t.valid) {
+        kb0 = piece.kb0;
+        nkb = piece.nkb;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
         Tile tn;
         bool next_prefetched = false;
@@ -1247,15 +1286,18 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 tile_id += num_launched;
                 pass = 0;
             }
-            tn = get_tile<BM, BN>(p, tile_id, walk, pass);
+            tn = work_of(tile_id, pass, piece_next);
             if (PERSIST && tn.valid && tn.m_end > tn.m0) {
+                kb0 = piece_next.kb0;                   // the prologue pieces and scales below belong to the NEXT work item
+                nkb = piece_next.nkb;
                 // The next tile's first two K blocks and the scales of its block 0, drained HERE -- in front of this tile's
                 // output stores: once stores are pending they count towards vmcnt, and waiting for "block 0 has landed" at
                 // the top of the next tile would wait for (nearly) all of them.  Drained now, the next tile starts without
                 // any wait and the stores overlap its first K block instead of standing between the two tiles.
                 const TileMem tmn = tile_mem(tn);
                 issue_prologue(tn);
-                issue_scale_loads_v<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff, scale_rsrc(tmn.sfb_addr, sfb_extent), 0);
+                issue_scale_loads_v<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
+                                        scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
                 wait_landing_v<0, MS>(land);        // the landed values stay in `land` until the next tile's L_a(0) consumes them
                 next_prefetched = true;
             }
@@ -1277,7 +1319,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
             auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
             auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
-                const int jj = imin(j, num_kb - 1);   // past the end: the last block's scales again (never consumed)
+                const int jj = kb0 + imin(j, nkb - 1);   // past the end: the last block's scales again (never consumed)
                 issue_scale_loads_v<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
@@ -1307,7 +1349,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             v8i bf[NS], af[HS];
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
 
-            for (int kb = 0; kb < num_kb; ++kb) {
+            for (int kb = 0; kb < nkb; ++kb) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
 
@@ -1409,7 +1451,73 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = v4f{acc[ms][ns][0], acc[ms][ns][1], acc[ms][ns][2], acc[ms][ns][3]};
-        store_tile<MS, NS, true, false, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+        bool store = true;
+        if constexpr (SPLITK) {
+            if (piece.split && !(t.m_end > t.m0)) {
+                store = piece.index == 0;               // an all-padding tile: its zero rows are written once
+            } else if (piece.split) {
+                // FP32 partial tile of this K piece: lane-linear 16-byte stores, [subtile][wave][lane].  The partials cross XCDs
+                // (every XCD has its own L2): they are written through (sc0 sc1) and read back past the caches (sc0 sc1), the way
+                // agent-scope atomics travel, so neither side needs an L2 write-back / invalidate -- a release fence here would
+                // also flush the D tiles of the earlier rounds that are still dirty in the L2 (measured: ~20 us per launch).
+                constexpr int kCoherent = 17;               // aux bits of the gfx950 buffer instructions: sc0 | sc1
+                uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 +
+                                      static_cast<int64_t>(piece.tail) * p.sk_factor * (BM * BN * 4);
+                const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, p.sk_factor * (BM * BN * 4), 0x00020000);
+                const int lane_off = (wave * 64 + lane) * 16;
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out[ms][ns]), slab,
+                                                               lane_off, piece.index * (BM * BN * 4) + (ms * NS + ns) * (NW * 1024), kCoherent);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // written through: acknowledged = visible to the other XCDs
+                __syncthreads();
+                int* counters = static_cast<int*>(p.sk_workspace);
+                int* flag = reinterpret_cast<int*>(lds);            // the rings are idle: a tail piece has no successor to prefetch
+                if (threadIdx.x == 0) {
+                    const int arrived = __hip_atomic_fetch_add(counters + piece.tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = arrived == p.sk_factor - 1;
+                    if (last)
+                        __hip_atomic_store(counters + piece.tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    *flag = last;
+                }
+                __syncthreads();
+                store = *flag != 0;
+                if (store) {
+                    // all pieces, mine included, in piece order: the sum does not depend on who arrived last.  One piece = 16
+                    // independent 16-byte loads per lane; the next piece's loads are in flight while this one is added
+                    // (a load -> add chain per subtile would pay the cross-XCD latency 16 x pieces times).
+                    // Two halves of the subtile rows, to stay inside the register file.
+                    constexpr int HM = MS / 2;
+                    #pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        auto load_piece = [&](v4f (&dst)[HM][NS], int s) {
+                            #pragma unroll
+                            for (int ms = 0; ms < HM; ++ms)
+                                #pragma unroll
+                                for (int ns = 0; ns < NS; ++ns)
+                                    dst[ms][ns] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(
+                                        slab, lane_off, s * (BM * BN * 4) + ((half * HM + ms) * NS + ns) * (NW * 1024), kCoherent));
+                        };
+                        v4f cur[HM][NS], nxt[HM][NS];
+                        load_piece(cur, 0);
+                        for (int s = 0; s < p.sk_factor; ++s) {
+                            load_piece(nxt, imin(s + 1, p.sk_factor - 1));
+                            #pragma unroll
+                            for (int ms = 0; ms < HM; ++ms)
+                                #pragma unroll
+                                for (int ns = 0; ns < NS; ++ns) {
+                                    out[half * HM + ms][ns] = s == 0 ? cur[ms][ns] : out[half * HM + ms][ns] + cur[ms][ns];
+                                    cur[ms][ns] = nxt[ms][ns];
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        if (store)
+            store_tile<MS, NS, true, false, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && first_tile && !next_prefetched) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -1418,15 +1526,16 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
         }
         t = tn;
+        piece = piece_next;
         prefetched = next_prefetched;
         first_tile = false;
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK>(p);
 }
 
 

@@ -137,6 +137,24 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
         d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
 
 
+_SPLIT_K_WORKSPACES = {}
+
+
+def _split_k_workspace(device: torch.device, stream: int) -> Optional[torch.Tensor]:
+    """Scratch buffer of the K-split tail (dg_m_grouped_fp8_gemm_nt_contiguous_ws): one zero-filled buffer per device and
+    stream, created on first use and kept (the kernel leaves its arrival counters zero; launches of one stream are ordered, so
+    they can share it).  The C ABI itself never allocates.  ``None`` (= no K split) on a stream that is being captured and
+    has no buffer yet: an allocation made during capture belongs to the graph's private pool and must not outlive it."""
+    key = (device.index, stream)
+    ws = _SPLIT_K_WORKSPACES.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ws = torch.zeros(int(lib.dg_split_k_workspace_bytes()), dtype=torch.uint8, device=device)
+        _SPLIT_K_WORKSPACES[key] = ws
+    return ws
+
+
 def _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b):
     """Both scale tensors as packed UE8M0 words in the MN-major layout (csrc/apis/layout.hpp:58-60: the (INT, 1, gran_k) branch of
     transform_sf_into_required_layout; default recipe for int scales is (1, 1, 128), csrc/utils/layout.hpp:64-77)."""
@@ -286,12 +304,15 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
     if not (sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data, runtime.get_mk_alignment_for_contiguous_layout())):
         b_data = _as_k_major(b_data, m * n * k)
-    check(lib.dg_m_grouped_fp8_gemm_nt_contiguous(
+    stream = current_stream_ptr()
+    workspace = _split_k_workspace(d.device, stream)
+    check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ws(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
         num_groups, m, n, k, a_data.stride(0), a_data.stride(1),
         b_data.stride(0), b_data.stride(1), b_data.stride(2), sfa.stride(0), sfa.stride(1),
         sfb.stride(0), sfb.stride(1), sfb.stride(2), d.stride(0), int(use_psum_layout),
-        runtime.get_mk_alignment_for_contiguous_layout(), current_stream_ptr()))
+        runtime.get_mk_alignment_for_contiguous_layout(), workspace.data_ptr() if workspace is not None else 0,
+        workspace.numel() if workspace is not None else 0, stream))
 
 
 def m_grouped_fp8_gemm_nn_contiguous(a, b, d, grouped_layout, recipe=None, recipe_a=None, recipe_b=None,

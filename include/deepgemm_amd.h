@@ -138,6 +138,23 @@ int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
                                         int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
                                         int64_t d_stride_m, int use_psum, int m_alignment, void* stream);
 
+/* The same with a caller-owned scratch buffer for tail balancing: when the tile count is just above a multiple of the CU count
+ * (BASELINE config 4: 576 tiles of 128 x 256 on 256 CUs = 2.25 rounds) the partial last round is cut along K over the idle CUs,
+ * FP32 partial tiles go through `workspace` and the last arriver of a tile reduces them in a fixed order (deterministic).
+ * workspace: device memory, 16-byte aligned, at least dg_split_k_workspace_bytes() bytes, ZERO-filled once before its first use
+ * (the kernel leaves its counters zero), used by one stream at a time; workspace == NULL gives the entry point above.
+ * (The reference's persistent scheduler has no such step: its tiles are not split; the library never allocates, hence the
+ * caller-owned buffer -- the host layer keeps one per device and stream.) */
+int dg_m_grouped_fp8_gemm_nt_contiguous_ws(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                                           const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                           int64_t a_stride_m, int64_t a_stride_k,
+                                           int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                           int64_t sfa_stride_m, int64_t sfa_stride_k,
+                                           int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                           int64_t d_stride_m, int use_psum, int m_alignment, void* workspace, int64_t workspace_bytes,
+                                           void* stream);
+int64_t dg_split_k_workspace_bytes(void);
+
 /* M-grouped masked GEMM.  Replaces sm90_m_grouped_fp8_gemm_masked_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:224) /
  * sm100_m_grouped_fp8_fp4_gemm_masked_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:244) as called from
  * m_grouped_fp8_fp4_gemm_nt_masked (csrc/apis/gemm.hpp:250-297).

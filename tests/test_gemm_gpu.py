@@ -304,6 +304,111 @@ def test_m_grouped_contiguous_reference_shapes_sampled():
         start += aligned
 
 
+def _split_k_case(actual_ms, n, k, use_psum, alignment):
+    dg.set_mk_alignment_for_contiguous_layout(alignment)
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, use_psum, actual_ms=actual_ms)
+    tiles = (case.a[0].size(0) // 128) * ((n + 255) // 256)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    return case, tiles, cus
+
+
+@pytest.mark.parametrize('use_psum', [False, True])
+@pytest.mark.parametrize('actual_ms,n,k,alignment', [
+    ([520, 500, 640, 400, 512, 700, 384, 512], 2048, 512, 128),      # 280 tiles: 24 tail tiles x 4 K pieces
+    ([300, 77, 1000, 128, 129, 1, 2000, 640], 2304, 384, 128),       # 333 tiles: 77 tail tiles x 3 pieces, ragged groups
+    ([100, 1300, 30, 900, 1500], 4096, 256, 256),                    # alignment 256: all-padding 128-row tiles among the pieces
+    ([512] * 7 + [640], 2048, 896, 128),                             # 264 tiles: 8 tail tiles x 7 pieces (one K block each)
+])
+def test_m_grouped_contiguous_split_k_tail(use_psum, actual_ms, n, k, alignment):
+    """The K-split tail of the persistent 128 x 256 duo kernel (the partial last round cut along K over the idle CUs, FP32
+    partials through the caller's workspace, last arriver reduces in piece order): every row against the oracle, padding rows
+    zero, nothing outside D, bit-repeatable, arrival counters left at zero."""
+    from deepgemm_amd import gemm as gemm_mod
+    gen.reset_seed(11)
+    case, tiles, cus = _split_k_case(actual_ms, n, k, use_psum, alignment)
+    assert tiles > cus and 0 < tiles % cus <= cus // 2, 'the case must leave a partial last round'
+    want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
+    oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), use_psum)
+    m = case.d.size(0)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout, use_psum_layout=use_psum)
+    assert dg.last_config() != 'duo_sk_128x256', 'short K loops: the exchange of partial tiles costs more than the split saves'
+    for cfg in ('duo_sk_128x256',):
+        dg.set_forced_config(cfg)
+        guarded = torch.full((m + 256, n), 777.0, device='cuda', dtype=torch.bfloat16)
+        outs = []
+        for _ in range(4):
+            d = guarded[128:128 + m]
+            d.fill_(float('nan'))
+            dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, d, case.grouped_layout, use_psum_layout=use_psum)
+            outs.append(d.clone())
+        assert dg.last_config() == 'duo_sk_128x256', (cfg, dg.last_config())
+        assert bool((guarded[:128] == 777.0).all()) and bool((guarded[128 + m:] == 777.0).all()), 'wrote outside D'
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'the piece-order reduction must be bit-repeatable'
+        start = 0
+        for actual, aligned in zip(case.actual_ms, case.aligned_ms):
+            assert_close_to_oracle(outs[0][start:start + actual], want[start:start + actual], f'{cfg} rows {start}+{actual}')
+            assert bool((outs[0][start + actual:start + aligned] == 0).all()), f'{cfg}: padding rows must be zeros'
+            start += aligned
+    for ws in gemm_mod._SPLIT_K_WORKSPACES.values():
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'arrival counters must be left at zero'
+    # the plain persistent walk of the same kernel (no workspace: dense entry) and the non-split kernel agree with it to rounding
+    dg.set_forced_config('duo_128x256')
+    plain = torch.empty_like(case.d)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, plain, case.grouped_layout, use_psum_layout=use_psum)
+    assert dg.last_config() == 'duo_128x256'
+    assert calc_diff(torch.nan_to_num(plain), torch.nan_to_num(outs[0])) < 1e-6
+
+
+def test_split_k_tail_full_size_and_small_workspace(monkeypatch):
+    """BASELINE config 4 (8 groups x ~512 rows, N = 4096, K = 7168) with a 2.25-round tile count: the default path takes the
+    K-split tail; with a workspace too small for the partials the same kernel walks all tiles unsplit.  Dense calls (no
+    workspace) forced onto the kernel take the unsplit walk too."""
+    from deepgemm_amd import gemm as gemm_mod
+    gen.reset_seed(12)
+    case, tiles, cus = _split_k_case([520, 500, 640, 400, 512, 700, 384, 512], 4096, 7168, False, 128)
+    assert tiles % cus != 0
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
+    assert dg.last_config() == 'duo_sk_128x256'
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    split = case.d.clone()
+    again = torch.empty_like(case.d)
+    for _ in range(5):
+        dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, again, case.grouped_layout)
+        assert torch.equal(again, split)
+    start = 0
+    for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+        rows = torch.tensor(sorted(random.sample(range(start, start + actual), 6)))
+        want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows.cuda()].cpu(), case.a[1][rows.cuda()].cpu(),
+                                                  case.b[0][g].cpu(), case.b[1][g].cpu())
+        assert_close_to_oracle(split[rows.cuda()], want, f'group {g}')
+        assert bool((split[start + actual:start + aligned] == 0).all())
+        start += aligned
+    # other data through the same workspace: a reducer must never see a stale cached partial of the launch before
+    gen.reset_seed(13)
+    other, _, _ = _split_k_case([520, 500, 640, 400, 512, 700, 384, 512], 4096, 7168, False, 128)
+    dg.m_grouped_fp8_gemm_nt_contiguous(other.a, other.b, other.d, other.grouped_layout)
+    assert calc_diff(other.d, other.ref_d) < gen.FP8_MAX_DIFF
+    other_first = other.d.clone()
+    for _ in range(4):
+        dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, again, case.grouped_layout)
+        dg.m_grouped_fp8_gemm_nt_contiguous(other.a, other.b, other.d, other.grouped_layout)
+        assert torch.equal(again, split) and torch.equal(other.d, other_first)
+    tiny = torch.zeros(8192, dtype=torch.uint8, device='cuda')
+    monkeypatch.setattr(gemm_mod, '_split_k_workspace', lambda device, stream: tiny)
+    dg.set_forced_config('duo_sk_128x256')
+    unsplit = torch.empty_like(case.d)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, unsplit, case.grouped_layout)
+    assert calc_diff(unsplit, case.ref_d) < gen.FP8_MAX_DIFF and calc_diff(unsplit, split) < 1e-6
+    dg.set_forced_config('duo_128x256')
+    plain = torch.empty_like(case.d)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, plain, case.grouped_layout)
+    assert torch.equal(plain, unsplit), 'the unsplit walk accumulates in the same order as the one-tile-per-block kernel'
+    dense = gen.generate_normal(4480, 4096, 1024)
+    dg.set_forced_config('duo_sk_128x256')
+    dg.fp8_gemm_nt(dense.a, dense.b, dense.d)
+    assert dg.last_config() == 'duo_sk_128x256' and calc_diff(dense.d, dense.ref_d) < gen.FP8_MAX_DIFF
+
+
 @pytest.mark.parametrize('masked_ms,max_m,n,k', [([5, 0, 64, 33], 64, 256, 384), ([200, 1, 129], 256, 520, 256),
                                                   ([20] * 6 + [0, 64], 64, 4096, 512)])
 def test_m_grouped_masked_vs_oracle(masked_ms, max_m, n, k):

@@ -16,12 +16,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--cases', default='8x512x4096x7168')
 ap.add_argument('--configs', default='auto')
 ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--ms', default='', help='explicit rows per group, e.g. 512,512,640 (the case then reads GxIGNOREDxNxK)')
 ap.add_argument('--nn', action='store_true', help='B stored MN-major ([G, K, N]): the nn form')
 args = ap.parse_args()
 for case_s in args.cases.split(','):
     g, em, n, k = (int(x) for x in case_s.split('x'))
     gen.reset_seed(0)
-    case = gen.generate_m_grouped_contiguous(g, em, n, k, b_k_major=not args.nn)
+    case = gen.generate_m_grouped_contiguous(g, em, n, k, b_k_major=not args.nn,
+                                             actual_ms=[int(x) for x in args.ms.split(',')] if args.ms else None)
     case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
     for cfg in args.configs.split(','):
         dg.set_forced_config(cfg)
