@@ -110,6 +110,9 @@ const Config kConfigs[] = {
     {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true>, true, true, true},
     {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true>, true},
     {"duo_bmn2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, false, true>, true, true},   // contiguous, two-pass
+    // operand A MN-major ([K][M]; the tt / tn layouts of the dense GEMM): A through row pieces + transpose reads, B K-major / MN-major
+    {"duo_amn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, true>, true, false, true},
+    {"duo_abmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true, false, true>, true, false, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
     {"pipe_128x128", 128, 128, 256, 2, 0.80f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 2>},
@@ -210,6 +213,18 @@ bool bmn_eligible(const dg::GemmParams& p) {
            p.n % 16 == 0 && p.a_sm <= (1 << 22) && p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
 }
 
+// A MN-major ([K][M], unit stride along m), dense problems only; B either K-major (fast_eligible's B half) or MN-major (bmn_eligible's
+// B half): the A_MN forms of the 256 x 256 duo kernel.
+bool amn_eligible(const dg::GemmParams& p) {
+    const bool a_ok = p.a_sm == 1 && p.a_sk != 1 && aligned16(p.a) && p.a_sk % 16 == 0 && p.a_sk <= (1 << 22) &&
+                      static_cast<int64_t>(p.k) * p.a_sk < (1LL << 31);
+    const bool b_k_major = p.b_sk == 1 && aligned16(p.b) && p.b_sn % 16 == 0 && p.b_sn <= (1 << 22);
+    const bool b_mn_major = p.b_sn == 1 && p.b_sk != 1 && aligned16(p.b) && p.b_sk % 16 == 0 && p.n % 16 == 0 &&
+                            p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
+    return p.sfb_gran_n == 128 && p.gemm_type == dg::kNormal && p.k % 128 == 0 && p.sfa_sm == 1 && a_ok &&
+           (b_k_major || b_mn_major);
+}
+
 // Recipe (1, 1, 128) on the fast path: both scale tensors MN-major with 16-byte aligned K-block rows (each block's 256
 // row scales are fetched as one 1 KiB LDS-DMA piece).
 bool per_col_eligible(const dg::GemmParams& p) {
@@ -253,6 +268,12 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     if (p.sfb_gran_n == 1) {
         const char* pick = per_col_eligible(p) && p.m > 64 ? "pipe_pc_256x256"
                          : (per_col_mn_eligible(p) && p.m > 64 ? "pipe_pc_mn_256x256" : "generic_128x128");
+        for (int i = 0; i < kNumConfigs; ++i)
+            if (std::strcmp(kConfigs[i].name, pick) == 0)
+                return &kConfigs[i];
+    }
+    if (amn_eligible(p) && m_for_tiling > 256) {
+        const char* pick = p.b_sk == 1 ? "duo_amn_256x256" : "duo_abmn_256x256";
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, pick) == 0)
                 return &kConfigs[i];
@@ -353,14 +374,20 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = "no kernel configuration available (forced config '" + forced_config() + "')";
         return 3;
     }
+    const bool amn_form = std::strcmp(cfg->name, "duo_amn_256x256") == 0 || std::strcmp(cfg->name, "duo_abmn_256x256") == 0;
+    if (amn_form && !(amn_eligible(p) && (p.b_sk == 1) == (std::strcmp(cfg->name, "duo_amn_256x256") == 0))) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs a dense problem with MN-major 16-byte aligned A, B of the "
+                       "majorness in its name and MN-major SFA";
+        return 3;
+    }
     const bool bmn_form = std::strncmp(cfg->name, "duo_bmn", 7) == 0;
     if (bmn_form && !bmn_eligible(p)) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major A, MN-major 16-byte aligned B and MN-major SFA";
         return 3;
     }
     const bool pc_mn_form = std::strcmp(cfg->name, "pipe_pc_mn_256x256") == 0;
-    const bool mn_form = pc_mn_form || bmn_form;
-    if (cfg->fast && !bmn_form &&
+    const bool mn_form = pc_mn_form || bmn_form || amn_form;
+    if (cfg->fast && !bmn_form && !amn_form &&
         (pc_mn_form ? !per_col_mn_eligible(p) : (cfg->per_col ? !per_col_eligible(p) : p.sfb_gran_n != 128))) {
         g_last_error = std::string("forced config '") + cfg->name + "' does not implement this scaling recipe / SF layout";
         return 3;

@@ -253,20 +253,14 @@ __device__ __forceinline__ int d_col(const GemmParams& p, int n) {
 // instead of 16 rows x 64: half the requests for the same bytes.  Caller: BF16 output, no accumulation, 16-byte aligned
 // rows, n_base + 64 <= n.  acc4[j][r] = D[row(ms, lane & 15)][n_base + (j >> 1) * 32 + lg * 8 + (j & 1) * 4 + r].
 template <int MS, bool INTERLEAVED_ROWS>
-__device__ __forceinline__ void store_rows_full_line(const GemmParams& p, const Tile& t, int64_t d_group_off,
-                                                     const v4f (&acc4)[4], int ms, int m_base, int n_base) {
+__device__ __forceinline__ void store_rows_full_line_packed(const GemmParams& p, const Tile& t, int64_t d_group_off,
+                                                            const uint32_t (&w0)[4], const uint32_t (&w1)[4], int ms, int m_base, int n_base) {
+    // w0 / w1: the lane's 8 BF16 columns n_base + lg * 8 .. + 7 (w0) and n_base + 32 + lg * 8 .. + 7 (w1) of its row
     const int lane = threadIdx.x & 63, lg = lane >> 4;
     const bool lo = (lane & 8) == 0;
     const int r7 = lane & 7;
     const int col = n_base + ((lane >> 3) & 1) * 32 + lg * 8;
-    uint32_t w0[4], w1[4], x[4], y[4];
-    #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        w0[2 * j] = pack_bf16(acc4[j][0], acc4[j][1]);
-        w0[2 * j + 1] = pack_bf16(acc4[j][2], acc4[j][3]);
-        w1[2 * j] = pack_bf16(acc4[2 + j][0], acc4[2 + j][1]);
-        w1[2 * j + 1] = pack_bf16(acc4[2 + j][2], acc4[2 + j][3]);
-    }
+    uint32_t x[4], y[4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t send = lo ? w1[j] : w0[j];
@@ -290,6 +284,50 @@ __device__ __forceinline__ void store_rows_full_line(const GemmParams& p, const 
     }
 }
 
+template <int MS, bool INTERLEAVED_ROWS>
+__device__ __forceinline__ void store_rows_full_line(const GemmParams& p, const Tile& t, int64_t d_group_off,
+                                                     const v4f (&acc4)[4], int ms, int m_base, int n_base) {
+    uint32_t w0[4], w1[4];
+    #pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        w0[2 * j] = pack_bf16(acc4[j][0], acc4[j][1]);
+        w0[2 * j + 1] = pack_bf16(acc4[j][2], acc4[j][3]);
+        w1[2 * j] = pack_bf16(acc4[2 + j][0], acc4[2 + j][1]);
+        w1[2 * j + 1] = pack_bf16(acc4[2 + j][2], acc4[2 + j][3]);
+    }
+    store_rows_full_line_packed<MS, INTERLEAVED_ROWS>(p, t, d_group_off, w0, w1, ms, m_base, n_base);
+}
+
+// The same stores from the NATURAL column order of the MN-major-B kernels (acc4[ns][r] = D[row][n_base + ns * 16 + lg * 4 + r]): the
+// packed words first change lanes so that every lane holds the 8 + 8 consecutive columns the full-line form wants.  With column
+// bits c5 c4 c3 c2 = (ns1 ns0 | lg1 lg0) before and (h | lg1 lg0 | j) after, that is a rotation of (ns0, lg1, lg0): one
+// v_permlane32_swap (register bit <-> lane bit 5) and one v_permlane16_swap (register bit <-> lane bit 4) per register pair --
+// 8 swaps per 16 rows instead of 4x the store requests (measured: the 8-byte-per-lane epilogue took 18.0 k cycles per tile
+// against 9.9 k, tools/c3_diag.py).
+template <int MS, bool INTERLEAVED_ROWS>
+__device__ __forceinline__ void store_rows_full_line_natural(const GemmParams& p, const Tile& t, int64_t d_group_off,
+                                                             const v4f (&acc4)[4], int ms, int m_base, int n_base) {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    uint32_t wn[4][2];
+    #pragma unroll
+    for (int ns = 0; ns < 4; ++ns) {
+        wn[ns][0] = pack_bf16(acc4[ns][0], acc4[ns][1]);
+        wn[ns][1] = pack_bf16(acc4[ns][2], acc4[ns][3]);
+    }
+    #pragma unroll
+    for (int h = 0; h < 2; ++h)
+        #pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            // lanes 32..63 of the even register <-> lanes 0..31 of the odd one, then odd 16-lane rows of the even <-> even rows of the odd
+            const u2 a = __builtin_amdgcn_permlane32_swap(wn[2 * h][d], wn[2 * h + 1][d], false, false);
+            const u2 b = __builtin_amdgcn_permlane16_swap(a[0], a[1], false, false);
+            wn[2 * h][d] = b[0];
+            wn[2 * h + 1][d] = b[1];
+        }
+    const uint32_t w0[4] = {wn[0][0], wn[0][1], wn[1][0], wn[1][1]}, w1[4] = {wn[2][0], wn[2][1], wn[3][0], wn[3][1]};
+    store_rows_full_line_packed<MS, INTERLEAVED_ROWS>(p, t, d_group_off, w0, w1, ms, m_base, n_base);
+}
+
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
@@ -300,6 +338,14 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
                                            int m_base, int n_base) {
     const int lane = threadIdx.x & 63, lg = lane >> 4;
     if constexpr (NATURAL_COLS) {
+        if constexpr (NS == 4) {
+            if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + 64 <= p.n) {
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    store_rows_full_line_natural<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
+                return;
+            }
+        }
         const bool full = n_base + NS * 16 <= p.n;
         #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
@@ -1113,6 +1159,52 @@ __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
         asm volatile("" : "+v"(l.q[0]), "+v"(l.sb) :: "memory");
 }
 
+// Scale landing registers for an MN-major A tile: the hardware transpose read fixes lane i of a fragment to row 16 ms + i of the
+// wave's rows (natural order), so a lane's MS row scales lie 16 floats apart in the MN-major SFA: MS dword loads (immediate
+// offsets) instead of MS / 4 dwordx4.
+template <int MS>
+struct ScaleLandingN { float s[MS]; float sb; };
+
+template <int MS>
+__device__ __forceinline__ void issue_scale_loads_n(ScaleLandingN<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
+                                                    const v4i& sfb_rsrc, int sfb_voff) {
+    static_assert(MS == 8, "unrolled by hand");
+    asm volatile(
+        "buffer_load_dword %0, %9, %10, 0 offen\n\t"
+        "buffer_load_dword %1, %9, %10, 0 offen offset:64\n\t"
+        "buffer_load_dword %2, %9, %10, 0 offen offset:128\n\t"
+        "buffer_load_dword %3, %9, %10, 0 offen offset:192\n\t"
+        "buffer_load_dword %4, %9, %10, 0 offen offset:256\n\t"
+        "buffer_load_dword %5, %9, %10, 0 offen offset:320\n\t"
+        "buffer_load_dword %6, %9, %10, 0 offen offset:384\n\t"
+        "buffer_load_dword %7, %9, %10, 0 offen offset:448\n\t"
+        "buffer_load_dword %8, %11, %12, 0 offen"
+        : "=&v"(l.s[0]), "=&v"(l.s[1]), "=&v"(l.s[2]), "=&v"(l.s[3]), "=&v"(l.s[4]), "=&v"(l.s[5]), "=&v"(l.s[6]),
+          "=&v"(l.s[7]), "=&v"(l.sb)
+        : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+        : "memory");
+}
+
+template <int ALLOWED, int MS>
+__device__ __forceinline__ void wait_landing_n(ScaleLandingN<MS>& l) {
+    static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
+    static_assert(MS == 8, "unrolled by hand");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
+    asm volatile("" : "+v"(l.s[0]), "+v"(l.s[1]), "+v"(l.s[2]), "+v"(l.s[3]), "+v"(l.s[4]), "+v"(l.s[5]), "+v"(l.s[6]),
+                      "+v"(l.s[7]), "+v"(l.sb) :: "memory");
+}
+
+// One name for both landing forms (interleaved rows: dwordx4 loads; natural rows: dword loads).
+template <int MS> __device__ __forceinline__ void issue_scale_loads_any(ScaleLandingV<MS>& l, const v4i& ra, int va, const v4i& rb, int vb) { issue_scale_loads_v<MS>(l, ra, va, rb, vb); }
+template <int MS> __device__ __forceinline__ void issue_scale_loads_any(ScaleLandingN<MS>& l, const v4i& ra, int va, const v4i& rb, int vb) { issue_scale_loads_n<MS>(l, ra, va, rb, vb); }
+template <int ALLOWED, int MS> __device__ __forceinline__ void wait_landing_any(ScaleLandingV<MS>& l) { wait_landing_v<ALLOWED, MS>(l); }
+template <int ALLOWED, int MS> __device__ __forceinline__ void wait_landing_any(ScaleLandingN<MS>& l) { wait_landing_n<ALLOWED, MS>(l); }
+template <int MS> __device__ __forceinline__ float landed_sfa(const ScaleLandingV<MS>& l, int ms) { return l.q[ms / 4][ms % 4]; }
+template <int MS> __device__ __forceinline__ float landed_sfa(const ScaleLandingN<MS>& l, int ms) { return l.s[ms]; }
+template <int MS, bool NATURAL> struct ScaleLandingSel { typedef ScaleLandingV<MS> type; };
+template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> type; };
+
 // PERSIST: persistent launch (one workgroup per CU walks the tile list) with cross-tile prologue prefetch.
 // B_MN: operand B is MN-major ([K][N], unit stride along n, row pitch b_sk): the nn / tn layouts without the re-majoring
 // pass.  LDS-DMA pieces are 4 k-rows x 256 bytes, B fragments come through the hardware transpose read, B rows keep their
@@ -1122,9 +1214,12 @@ __device__ __forceinline__ void wait_landing_v(ScaleLandingV<MS>& l) {
 // p.sk_factor pieces, one per otherwise idle CU.  Every piece writes its FP32 partial tile to the workspace, publishes it
 // (agent-scope release, then a relaxed counter increment -- MI355X_MICROARCH.md, "Workgroup dispatch ... visibility") and the
 // LAST arriver of a tile (no spinning: no residency assumption) sums all pieces in fixed order, resets the counter and stores.
+// A_MN: operand A is MN-major ([K][M], unit stride along m, row pitch a_sk): the tn / tt layouts without the re-majoring pass.
+// Same piece / transpose-read geometry as B_MN; A rows keep their natural order (subtile ms of a wave = rows 16 ms .. 16 ms + 15),
+// so a lane's row scales come as MS dword loads (ScaleLandingN) and the epilogue runs with INTERLEAVED_ROWS = false.
 // (The timing ablations this kernel was tuned with -- no stagger, priorities, early barriers, pieces between MFMAs, per-step
 // traces ... -- live in fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
@@ -1134,7 +1229,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
-    static_assert(!SPLITK || (PERSIST && !B_MN), "the K-split tail belongs to the persistent K-major form");
+    static_assert(!A_MN || (BM == 256 && NW == 8), "MN-major A tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
+    static_assert(!SPLITK || (PERSIST && !B_MN && !A_MN), "the K-split tail belongs to the persistent K-major form");
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
     static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
@@ -1180,8 +1276,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     for (int q = 0; q < B_ITERS; ++q)
         b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
     // MN-major B: lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k); u = wave + 8q => f lane-constant
-    const int ldb_mn = static_cast<int>(p.b_sk);
-    const int bmn_voff = (lane >> 4) * ldb_mn + ((((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3)))) << 4);
+    const int ldb_mn = static_cast<int>(p.b_sk), lda_mn = static_cast<int>(p.a_sk);
+    const int mn_chunk = ((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3))) << 4;
+    const int bmn_voff = (lane >> 4) * ldb_mn + mn_chunk;
+    const int amn_voff = (lane >> 4) * lda_mn + mn_chunk;
     const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
     const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
 
@@ -1198,14 +1296,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
             return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
         };
-        tm.a_base = uniform_ptr(p.a + adg * p.a_sg + static_cast<int64_t>(tt.m0) * p.a_sm);
+        tm.a_base = uniform_ptr(p.a + adg * p.a_sg + static_cast<int64_t>(tt.m0) * (A_MN ? 1 : p.a_sm));
         tm.b_base = uniform_ptr(p.b + static_cast<int64_t>(tt.group) * p.b_sg + static_cast<int64_t>(tt.n0) * (B_MN ? 1 : p.b_sn));
-        tm.a_bytes = __builtin_amdgcn_readfirstlane((imin(tt.m_end - tt.m0, BM) - 1) * lda + p.k);
+        tm.a_bytes = __builtin_amdgcn_readfirstlane(A_MN ? (p.k - 1) * lda_mn + (p.m - tt.m0) : (imin(tt.m_end - tt.m0, BM) - 1) * lda + p.k);
         tm.b_bytes = __builtin_amdgcn_readfirstlane(B_MN ? (p.k - 1) * ldb_mn + (p.n - tt.n0) : (imin(p.n - tt.n0, BN) - 1) * ldb + p.k);
         tm.sfa_addr = reinterpret_cast<uint64_t>(p.sfa + adg * p.sfa_sg);
         tm.sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(tt.group) * p.sfb_sg +
                                                  static_cast<int64_t>((tt.n0 + wn * WN) / 128) * p.sfb_sn);
-        tm.sfa_voff = (tt.m0 + wm * WM + (lane & 15) * MS) * 4;
+        tm.sfa_voff = (tt.m0 + wm * WM + (lane & 15) * (A_MN ? 1 : MS)) * 4;
         return tm;
     };
     auto scale_rsrc = [&](uint64_t addr, int extent) {
@@ -1216,8 +1314,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     auto issue_a_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-            (kb0 + imin(j, nkb - 1)) * 128, 0, 0);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16,
+            A_MN ? amn_voff : a_piece_voff[q],
+            A_MN ? ((kb0 + imin(j, nkb - 1)) * 128 + 4 * unit) * lda_mn : (kb0 + imin(j, nkb - 1)) * 128, 0, 0);
     };
     auto issue_b_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
@@ -1231,7 +1330,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // output stores, so that the cold-start latency of a tile and its predecessor's store tail overlap.  Only LDS-DMA
     // travels ahead: a VGPR-destination load (the scales) must reach its wait in straight-line code, because hipcc is
     // free to copy the destination registers at any control-flow join in between -- before the data has arrived.
-    ScaleLandingV<MS> land;
+    typename ScaleLandingSel<MS, A_MN>::type land;
     auto issue_prologue = [&](const Tile& tt) {
         const TileMem tm = tile_mem(tt);
         #pragma unroll
@@ -1296,9 +1395,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // any wait and the stores overlap its first K block instead of standing between the two tiles.
                 const TileMem tmn = tile_mem(tn);
                 issue_prologue(tn);
-                issue_scale_loads_v<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
-                                        scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
-                wait_landing_v<0, MS>(land);        // the landed values stay in `land` until the next tile's L_a(0) consumes them
+                issue_scale_loads_any<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
+                                          scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
+                wait_landing_any<0, MS>(land);      // the landed values stay in `land` until the next tile's L_a(0) consumes them
                 next_prefetched = true;
             }
         };
@@ -1318,9 +1417,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             const int sfa_voff = tm.sfa_voff;
             auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
             auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
-            auto issue_scales = [&](ScaleLandingV<MS>& l, int j) {
+            auto issue_scales = [&](typename ScaleLandingSel<MS, A_MN>::type& l, int j) {
                 const int jj = kb0 + imin(j, nkb - 1);   // past the end: the last block's scales again (never consumed)
-                issue_scale_loads_v<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
+                issue_scale_loads_any<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
             float scale[MS], scale_tail = 0.f;
@@ -1339,7 +1438,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // registers at any control-flow join in between.)
                 issue_prologue(t);
                 issue_scales(land, 0);
-                wait_landing_v<0, MS>(land);
+                wait_landing_any<0, MS>(land);
             }
             raw_barrier();
             if (upper_half)
@@ -1364,14 +1463,19 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     else
                         bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
                 }
+                [[maybe_unused]] FragTr afq[HS];
                 #pragma unroll
-                for (int h = 0; h < HS; ++h)
-                    af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                for (int h = 0; h < HS; ++h) {
+                    if constexpr (A_MN)
+                        afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + h) ^ tr_swz) << 4);
+                    else
+                        af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                }
                 scale_tail = scale[MS - 1];
                 // block kb's scales landed before the previous L_b's wait (block 0: before the prologue's / the prefetch's)
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
-                    scale[ms] = land.q[ms / 4][ms % 4] * land.sb;
+                    scale[ms] = landed_sfa<MS>(land, ms) * land.sb;
                     pin_vgpr(scale[ms]);
                 }
                 issue_scales(land, kb + 1);
@@ -1383,6 +1487,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
                         bf[ns] = assemble_fragment_tr(bfq[ns]);
+                }
+                if constexpr (A_MN) {
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h)
+                        af[h] = assemble_fragment_tr(afq[h]);
                 }
 
                 // ---------------- M_a ----------------
@@ -1398,8 +1507,12 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // ---------------- L_b ----------------
                 raw_barrier();
                 #pragma unroll
-                for (int h = 0; h < HS; ++h)
-                    af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                for (int h = 0; h < HS; ++h) {
+                    if constexpr (A_MN)
+                        afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + HS + h) ^ tr_swz) << 4);
+                    else
+                        af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                }
                 #pragma unroll
                 for (int q = A_EARLY; q < A_ITERS; ++q)
                     issue_a_piece(a_fill, kb + 2, q);
@@ -1410,10 +1523,14 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
                 // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
                 // "every load but the newest 8 has landed".)
-                wait_landing_v<A_ITERS + B_ITERS, MS>(land);
+                wait_landing_any<A_ITERS + B_ITERS, MS>(land);
                 #pragma unroll
-                for (int h = 0; h < HS; ++h)
-                    asm volatile("" : "+v"(af[h]) :: "memory");
+                for (int h = 0; h < HS; ++h) {
+                    if constexpr (A_MN)
+                        af[h] = assemble_fragment_tr(afq[h]);
+                    else
+                        asm volatile("" : "+v"(af[h]) :: "memory");
+                }
 
                 // ---------------- M_b ----------------
                 raw_barrier();
@@ -1517,7 +1634,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             }
         }
         if (store)
-            store_tile<MS, NS, true, false, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+            store_tile<MS, NS, !A_MN, false, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && first_tile && !next_prefetched) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -1532,10 +1649,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN>(p);
 }
 
 

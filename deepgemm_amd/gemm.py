@@ -67,6 +67,45 @@ def _remajor(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _a_mn_major_self_ok(a: torch.Tensor, m: int, k: int) -> bool:
+    """A's half of dg_api.hip's amn_eligible() + the m > 256 rule of select_config(): a dense MN-major A ([M, K] view with unit
+    stride along M) that the A_MN kernels take as it is."""
+    return (a.dim() == 2 and a.stride(0) == 1 and a.stride(1) != 1 and m > 256 and k % 128 == 0 and a.stride(1) % 16 == 0 and
+            a.data_ptr() % 16 == 0 and a.stride(1) <= (1 << 22) and k * a.stride(1) < (1 << 31))
+
+
+def _b_ok_beside_mn_major_a(b: torch.Tensor, n: int, k: int) -> bool:
+    """B's half of amn_eligible(): K-major, or MN-major with whole 16-byte chunks along N."""
+    if b.data_ptr() % 16 != 0:
+        return False
+    if b.stride(1) == 1:
+        return b.stride(0) % 16 == 0 and b.stride(0) <= (1 << 22)
+    return (b.stride(0) == 1 and n % 16 == 0 and b.stride(1) % 16 == 0 and b.stride(1) <= (1 << 22) and
+            k * b.stride(1) < (1 << 31))
+
+
+def _dense_operands(a_data: torch.Tensor, b_data: torch.Tensor, sfa: torch.Tensor, gran_n: int, m: int, n: int, k: int):
+    """The FP8 operands as the C entry will read them: as they are wherever a kernel takes that majorness natively, re-majored
+    into K-major scratch (dg_transpose_fp8) otherwise.  One place for the cached and the uncached path of fp8_gemm_nt."""
+    macs = m * n * k
+    if gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n):
+        return a_data, b_data       # recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are
+    if gran_n == 128 and sfa.stride(0) == 1:
+        if a_data.stride(-1) != 1 and _a_mn_major_self_ok(a_data, m, k):
+            # large MN-major A: transpose reads (duo_amn / duo_abmn); B as it is when that kernel can take it, else re-majored
+            if _b_ok_beside_mn_major_a(b_data, n, k):
+                return a_data, b_data
+            b_k = _as_k_major(b_data, macs)
+            if _b_ok_beside_mn_major_a(b_k, n, k):
+                return a_data, b_k
+            return _as_k_major(a_data, macs), b_k
+        a_k = _as_k_major(a_data, macs)
+        if _b_mn_major_native(b_data, m, n, k, a_k):
+            return a_k, b_data      # large MN-major B: read natively through transpose reads (duo_bmn)
+        return a_k, _as_k_major(b_data, macs)
+    return _as_k_major(a_data, macs), _as_k_major(b_data, macs)
+
+
 # Host-overhead diet for decode-sized calls: the reference's checks cost ~20 us of Python per call, more than the kernel of
 # a small GEMM.  A call whose (shape, stride, dtype, device) signature has already passed every check once skips straight
 # to the SF layout step and the C call; anything new, or any failing call, takes the full path below.
@@ -211,10 +250,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
         if c is not None and not same_cd:
             d.copy_(c)
         sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
-        if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
-            a_data = _as_k_major(a_data, m * n * k)
-            if not (gran_n == 128 and sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data)):
-                b_data = _as_k_major(b_data, m * n * k)
+        a_data, b_data = _dense_operands(a_data, b_data, sfa, gran_n, m, n, k)
         check(lib.dg_fp8_gemm_nt(
             a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), m, n, k,
             a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
@@ -235,11 +271,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     require_device(a_data, b_data, sfa, sfb, d)
     if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
         _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf)
-    if not (gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n)):
-        # (recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are, no re-majoring pass)
-        a_data = _as_k_major(a_data, m * n * k)
-        if not (gran_n == 128 and sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data)):
-            b_data = _as_k_major(b_data, m * n * k)      # (large MN-major B: read natively through transpose reads instead)
+    a_data, b_data = _dense_operands(a_data, b_data, sfa, gran_n, m, n, k)
     check(lib.dg_fp8_gemm_nt(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),

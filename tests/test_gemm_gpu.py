@@ -79,17 +79,19 @@ def test_dense_layouts_vs_oracle(layout, m, n, k):
     want = oracle_dense(case)
     dg.fp8_gemm_nt(case.a, case.b, case.d)                                   # MN-major operands as strided views
     assert_close_to_oracle(case.d, want, f'{layout} view')
-    if m * n * k >= dg.gemm.REMAJOR_MIN_MACS:                                # large: MN-major operands are re-majored
-        assert not dg.last_config().startswith('generic'), (layout, dg.last_config())
-        saved, dg.gemm.REMAJOR_MIN_MACS = dg.gemm.REMAJOR_MIN_MACS, 0       # ... and the in-place generic path agrees
+    if m * n * k >= dg.gemm.REMAJOR_MIN_MACS:                                # large: MN-major operands go to the fast kernels
+        native = {'nt': '', 'nn': 'duo_bmn_', 'tt': 'duo_amn_', 'tn': 'duo_abmn_'}[layout] if m > 256 else ''
+        assert not dg.last_config().startswith('generic') and dg.last_config().startswith(native), (layout, dg.last_config())
+        saved, dg.gemm.REMAJOR_MIN_MACS = dg.gemm.REMAJOR_MIN_MACS, 0       # ... and the in-place layout-agnostic kernel agrees
+        dg.set_forced_config('generic_128x128')
         try:
             d_generic = torch.full_like(case.d, float('nan'))
             dg.fp8_gemm_nt(case.a, case.b, d_generic)
-            # nn keeps its K-major A: the MN-major B is read natively (transpose reads); tn / tt: the layout-agnostic kernel
-            assert layout == 'nt' or dg.last_config().startswith('duo_bmn' if layout == 'nn' else 'generic'), dg.last_config()
+            assert dg.last_config() == 'generic_128x128'
             assert_close_to_oracle(d_generic, want, f'{layout} generic')
         finally:
             dg.gemm.REMAJOR_MIN_MACS = saved
+            dg.set_forced_config('auto')
     a = case.a if a_k_major else (case.a[0].T, case.a[1].T)
     b = case.b if b_k_major else (case.b[0].T, case.b[1].T)
     assert a[0].is_contiguous() and b[0].is_contiguous()
@@ -208,6 +210,36 @@ def test_mn_major_b_native_path(m, n, k, out_dtype, accumulate):
     dg.fp8_gemm_nt(case.a, (case.b[0].contiguous(), case.b[1]), d2, c=d2 if accumulate else None)
     assert not dg.last_config().startswith('duo_bmn_')
     assert torch.equal(d2, case.d)
+
+
+@pytest.mark.parametrize('m,n,k', [(512, 512, 512), (1040, 784, 896), (4096, 2048, 1024), (304, 272, 256)])
+@pytest.mark.parametrize('b_k_major', [True, False])
+@pytest.mark.parametrize('out_dtype,accumulate', [(torch.bfloat16, False), (torch.float, True)])
+def test_mn_major_a_native_path(m, n, k, b_k_major, out_dtype, accumulate):
+    """fp8_gemm_tt / _tn on large problems: the MN-major A goes into the 256 x 256 duo kernel as it is (LDS-DMA of k-rows +
+    hardware transpose reads, natural row order, per-row dword scale loads) -- with a K-major B (tt) or an MN-major B read the
+    same way (tn); same bits as the K-major form of the same operands."""
+    gen.reset_seed(m + n + k + 7)
+    case = gen.generate_normal(m, n, k, a_k_major=False, b_k_major=b_k_major, accumulate=accumulate, out_dtype=out_dtype)
+    c_cpu = case.c.cpu().clone() if accumulate else None
+    want = oracle_dense(case, c_cpu=c_cpu)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None)
+    assert dg.last_config() == ('duo_amn_256x256' if b_k_major else 'duo_abmn_256x256'), dg.last_config()
+    if out_dtype == torch.float:
+        assert_close_fp32(case.d, want, 'MN-major A')
+    else:
+        assert_close_to_oracle(case.d, want, 'MN-major A')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    d2 = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
+    dg.fp8_gemm_nt((case.a[0].contiguous(), case.a[1]), (case.b[0].contiguous(), case.b[1]), d2, c=d2 if accumulate else None)
+    assert not dg.last_config().startswith('duo_a')
+    assert torch.equal(d2, case.d)
+    # the alias entries hand over the same views
+    d3 = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
+    a_t = (case.a[0].T, case.a[1].T)
+    b_arg = case.b if b_k_major else (case.b[0].T, case.b[1].T)
+    (dg.fp8_gemm_tt if b_k_major else dg.fp8_gemm_tn)(a_t, b_arg, d3, c=d3 if accumulate else None)
+    assert dg.last_config().startswith('duo_a') and torch.equal(d3, case.d)
 
 
 def test_k_tail_sub_views_and_wide_d():
