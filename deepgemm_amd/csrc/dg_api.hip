@@ -94,6 +94,7 @@ struct Config {
     bool persistent = false;  // one workgroup per CU walks the tile list and prefetches the next tile's first K blocks
     bool per_col = false;     // recipe (1, 1, 128): one SFB value per row of B (all other fast kernels: one per 128 rows)
     bool split_k = false;     // persistent launch whose partial last round is cut along K over the idle CUs (needs a workspace)
+    bool k_tail = false;      // handles a partial last K block (k % 128 != 0, k % 16 == 0, k > 128): the duo kernels
 };
 
 const Config kConfigs[] = {
@@ -113,6 +114,16 @@ const Config kConfigs[] = {
     // operand A MN-major ([K][M]; the tt / tn layouts of the dense GEMM): A through row pieces + transpose reads, B K-major / MN-major
     {"duo_amn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, true>, true, false, true},
     {"duo_abmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true, false, true>, true, false, true},
+    // K not a multiple of 128 (whole 16-byte chunks; the dgrad shapes K = 2112, 576): the same kernels with the partial last K
+    // block computed after the loop (dense problems; K-major A; B K-major or MN-major)
+    {"duo_kt_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, true>, true, false,
+     true, false, false, true},
+    {"duo_kt_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, false, false, false, true>, true, false,
+     false, false, false, true},
+    {"duo_bmn_kt_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true, false, false, true>, true, false,
+     true, false, false, true},
+    {"duo_bmn_kt_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true, false, false, true>, true, false,
+     false, false, false, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},
     {"pipe_128x128", 128, 128, 256, 2, 0.80f, true, dg::dg_fp8_gemm_pipe_kernel<128, 128, 2, 2, 2>},
@@ -194,8 +205,11 @@ const E8Config kE8Configs[] = {
 
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
-bool fast_eligible(const dg::GemmParams& p) {
-    if (p.a_sk != 1 || p.b_sk != 1 || p.k % 128 != 0)
+// whole_k_blocks = false: a partial last K block of whole 16-byte chunks is allowed (the duo kernels' tail stage)
+bool k_extent_ok(int k, bool whole_k_blocks) { return whole_k_blocks ? k % 128 == 0 : (k % 16 == 0 && k > 128); }
+
+bool fast_eligible(const dg::GemmParams& p, bool whole_k_blocks = true) {
+    if (p.a_sk != 1 || p.b_sk != 1 || !k_extent_ok(p.k, whole_k_blocks))
         return false;
     if (!aligned16(p.a) || !aligned16(p.b) || p.a_sm % 16 || p.b_sn % 16 || p.a_sg % 16 || p.b_sg % 16)
         return false;
@@ -207,8 +221,8 @@ bool fast_eligible(const dg::GemmParams& p) {
 
 // A K-major, B MN-major ([K][N], unit stride along n): the B_MN forms of the duo kernels.
 bool bmn_eligible(const dg::GemmParams& p) {
-    return p.sfb_gran_n == 128 && p.a_sk == 1 && p.b_sn == 1 && p.b_sk != 1 && p.k % 128 == 0 && p.sfa_sm == 1 &&
-           (p.gemm_type == dg::kNormal || p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) &&
+    return p.sfb_gran_n == 128 && p.a_sk == 1 && p.b_sn == 1 && p.b_sk != 1 && k_extent_ok(p.k, p.gemm_type != dg::kNormal) &&
+           p.sfa_sm == 1 && (p.gemm_type == dg::kNormal || p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) &&
            aligned16(p.a) && aligned16(p.b) && p.a_sm % 16 == 0 && p.b_sk % 16 == 0 && p.a_sg % 16 == 0 && p.b_sg % 16 == 0 &&
            p.n % 16 == 0 && p.a_sm <= (1 << 22) && p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
 }
@@ -282,6 +296,8 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         const bool contiguous = p.gemm_type != dg::kNormal;
         const long tiles256 = static_cast<long>(ceil_div(m_for_tiling, 256)) * ceil_div(p.n, 256);
         const char* pick = (contiguous || tiles256 < num_cus() / 2) ? "duo_bmn_128x256" : "duo_bmn_256x256";
+        if (p.k % 128 != 0)             // (dense only, see bmn_eligible) the forms with the K-tail stage
+            pick = tiles256 < num_cus() / 2 ? "duo_bmn_kt_128x256" : "duo_bmn_kt_256x256";
         // many rounds of a contiguous layout aligned to 128 rows: the two-pass 256-row tile (same rule as for K-major B)
         if (p.gemm_type == dg::kContiguous && bm_must_divide == 128 && tiles256 >= 4L * num_cus())
             pick = "duo_bmn2_256x256";
@@ -291,6 +307,14 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
                     return &kConfigs[i];
     }
     const bool fast_ok = fast_eligible(p);
+    const bool tail_ok = fast_eligible(p, false);       // k % 128 != 0: only the kernels with a tail stage
+    if (!fast_ok && tail_ok && p.sfb_gran_n == 128 && p.sfa_sm == 1 && p.gemm_type == dg::kNormal) {
+        const long tiles256 = static_cast<long>(ceil_div(m_for_tiling, 256)) * ceil_div(p.n, 256);
+        const char* pick = tiles256 < num_cus() / 2 ? "duo_kt_128x256" : "duo_kt_256x256";
+        for (int i = 0; i < kNumConfigs; ++i)
+            if (std::strcmp(kConfigs[i].name, pick) == 0)
+                return &kConfigs[i];
+    }
     // HBM-bound shapes (M up to a few 64-row tiles: every weight byte is streamed once or twice): the deep-ring stream
     // kernels.  A CU sustains only ~25 GB/s of HBM stream (bytes in flight / latency), so the tile count has to cover
     // the chip: 64 x 128 tiles when there are enough of them, 64 x 32 otherwise (measured: tools/ref_shapes.py).
@@ -316,7 +340,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     double best_cost = 0;
     for (int i = 0; i < kNumConfigs; ++i) {
         const Config& c = kConfigs[i];
-        if ((c.fast && !fast_ok) || c.efficiency <= 0.f || (c.ring && p.sfa_sm != 1))
+        if ((c.fast && !(fast_ok || (c.k_tail && tail_ok))) || c.efficiency <= 0.f || (c.ring && p.sfa_sm != 1))
             continue;
         if (bm_must_divide > 0 && bm_must_divide % c.bm != 0 &&
             !(c.two_pass && p.gemm_type == dg::kContiguous && c.bm == 2 * bm_must_divide))
@@ -385,6 +409,14 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major A, MN-major 16-byte aligned B and MN-major SFA";
         return 3;
     }
+    if (p.k % 128 != 0 && cfg->fast && !cfg->k_tail) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs k % 128 == 0";
+        return 3;
+    }
+    if (cfg->k_tail && (p.gemm_type != dg::kNormal || p.sfb_gran_n != 128 || p.sfa_sm != 1)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' implements dense problems with per-128 SFB and MN-major SFA";
+        return 3;
+    }
     const bool pc_mn_form = std::strcmp(cfg->name, "pipe_pc_mn_256x256") == 0;
     const bool mn_form = pc_mn_form || bmn_form || amn_form;
     if (cfg->fast && !bmn_form && !amn_form &&
@@ -392,8 +424,9 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = std::string("forced config '") + cfg->name + "' does not implement this scaling recipe / SF layout";
         return 3;
     }
-    if (cfg->fast && !mn_form && !fast_eligible(p)) {
-        g_last_error = std::string("forced config '") + cfg->name + "' needs K-major 16-byte aligned operands and k % 128 == 0";
+    if (cfg->fast && !mn_form && !fast_eligible(p, !cfg->k_tail)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs K-major 16-byte aligned operands and k % 128 == 0" +
+                       (cfg->k_tail ? " (or k % 16 == 0 and k > 128)" : "");
         return 3;
     }
     if (cfg->ring && p.sfa_sm != 1) {

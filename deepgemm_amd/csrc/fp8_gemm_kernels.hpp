@@ -1219,7 +1219,10 @@ template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> t
 // so a lane's row scales come as MS dword loads (ScaleLandingN) and the epilogue runs with INTERLEAVED_ROWS = false.
 // (The timing ablations this kernel was tuned with -- no stagger, priorities, early barriers, pieces between MFMAs, per-step
 // traces ... -- live in fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false>
+// K_TAIL: K need not be a multiple of 128 (whole 16-byte chunks, K > 128): the partial last K block is computed once per tile after
+// the loop (separate instantiations: the stage costs registers that the tuned whole-block kernels do not have to spare).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
+          bool K_TAIL = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
@@ -1231,6 +1234,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     static_assert(!A_MN || (BM == 256 && NW == 8), "MN-major A tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     static_assert(!SPLITK || (PERSIST && !B_MN && !A_MN), "the K-split tail belongs to the persistent K-major form");
+    static_assert(!K_TAIL || !SPLITK, "K tail and K split are not combined");
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
     static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
@@ -1262,8 +1266,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     MaskedWalk walk;
     const int num_launched = gridDim.x;
     const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
-    const int sfa_extent = (p.m - 1) * 4 + (num_kb - 1) * sfa_kb_stride + 4;
-    const int sfb_extent = (num_kb - 1) * sfb_kb_stride + 4;
+    const int k_tail = K_TAIL ? (p.k & 127) : 0;    // a partial last K block (multiple of 16 bytes): handled after the loop, see below
+    const int num_sf_kb = num_kb + (k_tail != 0);
+    const int sfa_extent = (p.m - 1) * 4 + (num_sf_kb - 1) * sfa_kb_stride + 4;
+    const int sfb_extent = (num_sf_kb - 1) * sfb_kb_stride + 4;
 
     // Per-piece source offsets (rows + chunk: the bounds-checked part of the address) are kernel invariants held in
     // VGPRs; the K block goes in the soffset.  Blocks past the end re-read the last K block into a dead slot -- no
@@ -1552,11 +1558,82 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's re-read pieces: the ring is about to be reused
             __syncthreads();                                    // every wave is done with the LDS
-            fetch_next();                                       // persistent launch: the next tile's prologue flies from here
-            #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) {
-                const int j = TOTAL - DEPTH + i;
-                promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
+            auto promote_pending = [&]() {
+                #pragma unroll
+                for (int i = 0; i < DEPTH; ++i) {
+                    const int j = TOTAL - DEPTH + i;
+                    promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
+                }
+            };
+            if constexpr (K_TAIL) {
+                promote_pending();                              // block order of the promotion: the loop's last steps first
+                if (k_tail != 0) {
+                    // K not a multiple of 128 (dgrad shapes such as K = 2112, 576): the partial last block, once per tile, outside the
+                    // tuned loop and without its role split.  K-major operands: the 16-byte chunks at and beyond k_tail get an offset
+                    // that fails the buffer range check -- an LDS-DMA lane that is out of range writes ZEROS into the LDS (probed:
+                    // tools/ubench/lds_dma_oob_probe.hip), so neither the next row's bytes nor row padding reach the matrix core.
+                    // MN-major operands: k-rows >= K lie beyond the descriptor's extent by themselves.
+                    const int tail_bias = (src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
+                    #pragma unroll
+                    for (int q = 0; q < A_ITERS; ++q) {
+                        const int unit = wave + NW * q;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.a_base), 0, tm.a_bytes, 0x00020000),
+                            (__attribute__((address_space(3))) void*)(lds + unit * 1024), 16,
+                            A_MN ? amn_voff : a_piece_voff[q] + tail_bias,
+                            A_MN ? (num_kb * 128 + 4 * unit) * lda_mn : num_kb * 128, 0, 0);
+                    }
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q) {
+                        const int unit = wave + NW * q;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.b_base), 0, tm.b_bytes, 0x00020000),
+                            (__attribute__((address_space(3))) void*)(lds + B_BASE + unit * 1024), 16,
+                            B_MN ? bmn_voff : b_piece_voff[q] + tail_bias,
+                            B_MN ? (num_kb * 128 + 4 * unit) * ldb_mn : num_kb * 128, 0, 0);
+                    }
+                    issue_scale_loads_any<MS>(land, sfa_rsrc, sfa_voff + num_kb * sfa_kb_stride, sfb_rsrc, num_kb * sfb_kb_stride);
+                    wait_landing_any<0, MS>(land);              // straight-line from the loads; also lands the pieces
+                    __syncthreads();
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        scale[ms] = landed_sfa<MS>(land, ms) * land.sb;
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        if constexpr (B_MN) {
+                            FragTr fq = load_fragment_tr(lds + B_BASE, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            bf[ns] = assemble_fragment_tr(fq);
+                        } else {
+                            bf[ns] = load_fragment(lds + B_BASE + (wn * WN) * 128 + ns * 2048, frag_off);
+                        }
+                    }
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        __builtin_amdgcn_sched_barrier(0);      // one subtile row at a time: hoisted fragment loads would cost 64 registers
+                        v8i a_frag;
+                        if constexpr (A_MN) {
+                            FragTr fq = load_fragment_tr(lds, tr_lane_base, ((wm * MS + ms) ^ tr_swz) << 4);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            a_frag = assemble_fragment_tr(fq);
+                        } else {
+                            a_frag = load_fragment(lds + (wm * WM) * 128 + ms * 2048, frag_off);
+                        }
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns) {
+                            const v4f pr = mfma_fp8_k128(bf[ns], a_frag);
+                            #pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[ms][ns][r] = __builtin_fmaf(scale[ms], pr[r], acc[ms][ns][r]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();                            // the LDS is free again (the next tile's prologue may fly)
+                }
+                fetch_next();
+            } else {
+                fetch_next();                                   // persistent launch: the next tile's prologue flies from here
+                promote_pending();
             }
         } else {
             fetch_next();
@@ -1649,10 +1726,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
+          bool K_TAIL = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL>(p);
 }
 
 

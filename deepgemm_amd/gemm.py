@@ -47,10 +47,10 @@ def _both_mn_major_aligned(a: torch.Tensor, b: torch.Tensor, m: int, n: int) -> 
 
 def _b_mn_major_native(b: torch.Tensor, m: int, n: int, k: int, a: torch.Tensor, m_alignment: int = 128) -> bool:
     """MN-major B ([.., N, K] view with unit stride along N) that the B_MN kernels take as it is.  Mirrors dg_api.hip's
-    bmn_eligible() and the tile rule of select_config() -- K-major 16-byte aligned A, whole K blocks, 32-bit piece offsets, a
+    bmn_eligible() and the tile rule of select_config() -- K-major 16-byte aligned A, whole 16-byte K chunks, 32-bit piece offsets, a
     contiguous-layout alignment the 128-row tiles divide -- so that whatever passes here finds a kernel there; anything else is
     re-majored into K-major scratch by the caller."""
-    return (b.stride(-2) == 1 and b.stride(-1) != 1 and m > 256 and n % 16 == 0 and k % 128 == 0 and m_alignment % 128 == 0 and
+    return (b.stride(-2) == 1 and b.stride(-1) != 1 and m > 256 and n % 16 == 0 and k % 16 == 0 and k > 128 and m_alignment % 128 == 0 and
             b.stride(-1) % 16 == 0 and b.data_ptr() % 16 == 0 and (b.dim() == 2 or b.stride(0) % 16 == 0) and
             b.stride(-1) <= (1 << 22) and k * b.stride(-1) < (1 << 31) and
             a.stride(-1) == 1 and a.stride(-2) % 16 == 0 and a.data_ptr() % 16 == 0 and a.stride(-2) <= (1 << 22))
@@ -70,7 +70,7 @@ def _remajor(t: torch.Tensor) -> torch.Tensor:
 def _a_mn_major_self_ok(a: torch.Tensor, m: int, k: int) -> bool:
     """A's half of dg_api.hip's amn_eligible() + the m > 256 rule of select_config(): a dense MN-major A ([M, K] view with unit
     stride along M) that the A_MN kernels take as it is."""
-    return (a.dim() == 2 and a.stride(0) == 1 and a.stride(1) != 1 and m > 256 and k % 128 == 0 and a.stride(1) % 16 == 0 and
+    return (a.dim() == 2 and a.stride(0) == 1 and a.stride(1) != 1 and m > 256 and k % 16 == 0 and k > 128 and a.stride(1) % 16 == 0 and
             a.data_ptr() % 16 == 0 and a.stride(1) <= (1 << 22) and k * a.stride(1) < (1 << 31))
 
 

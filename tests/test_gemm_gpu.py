@@ -242,6 +242,50 @@ def test_mn_major_a_native_path(m, n, k, b_k_major, out_dtype, accumulate):
     assert dg.last_config().startswith('duo_a') and torch.equal(d3, case.d)
 
 
+@pytest.mark.parametrize('m,n,k', [(512, 512, 576), (1040, 784, 2112), (4096, 1024, 320), (130, 4096, 1088)])
+@pytest.mark.parametrize('b_k_major', [True, False])
+def test_k_tail_fast_path(m, n, k, b_k_major):
+    """K not a multiple of 128 (the reference's dgrad sweep has K = 2112 and 576): the duo kernels compute the partial last block
+    after their K loop -- chunks at and beyond K are masked through the buffer range check (zeros in the LDS), so neither the next
+    row's bytes nor NaN patterns in row padding reach the result.  Same bits as the layout-agnostic kernel."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k, a_k_major=True, b_k_major=b_k_major)
+    # operands inside wider buffers whose padding bytes are FP8 NaNs (0x7f): a kernel that read past K would produce NaNs
+    a_wide = torch.full((m, k + 64), 0x7f, dtype=torch.uint8, device='cuda').view(torch.float8_e4m3fn)
+    a_wide[:, :k].copy_(case.a[0])
+    a = (a_wide[:, :k], case.a[1])
+    if b_k_major:
+        b_wide = torch.full((n, k + 64), 0x7f, dtype=torch.uint8, device='cuda').view(torch.float8_e4m3fn)
+        b_wide[:, :k].copy_(case.b[0])
+        b = (b_wide[:, :k], case.b[1])
+    else:
+        b_wide = torch.full((k + 16, n), 0x7f, dtype=torch.uint8, device='cuda').view(torch.float8_e4m3fn)     # [K][N] storage + NaN rows
+        b_wide[:k].copy_(case.b[0].T)
+        b = (b_wide[:k].T, case.b[1])
+    want = oracle_dense(case)
+    dg.fp8_gemm_nt(a, b, case.d)
+    picked = dg.last_config()
+    assert picked.startswith('duo_kt_' if b_k_major else 'duo_bmn_kt_') or (not b_k_major and m <= 256), picked
+    assert_close_to_oracle(case.d, want, f'k tail {picked}')
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    dg.set_forced_config('generic_128x128')
+    d2 = torch.empty_like(case.d)
+    dg.fp8_gemm_nt(a, b, d2)
+    dg.set_forced_config('auto')
+    assert torch.equal(d2, case.d), picked
+    for cfg in (['duo_kt_256x256', 'duo_kt_128x256'] if b_k_major else (['duo_bmn_kt_256x256', 'duo_bmn_kt_128x256'] if m > 256 else [])):
+        dg.set_forced_config(cfg)
+        d3 = torch.full_like(case.d, float('nan'))
+        dg.fp8_gemm_nt(a, b, d3)
+        assert dg.last_config() == cfg and torch.equal(d3, case.d), cfg
+    # whole K blocks through the tail-capable kernels: the stage is skipped
+    dg.set_forced_config('duo_kt_256x256' if b_k_major else 'duo_bmn_kt_256x256')
+    if b_k_major or m > 256:
+        whole = gen.generate_normal(m, n, 384, a_k_major=True, b_k_major=b_k_major)
+        dg.fp8_gemm_nt(whole.a, whole.b, whole.d)
+        assert_close_to_oracle(whole.d, oracle_dense(whole), 'whole blocks through the tail kernel')
+
+
 def test_k_tail_sub_views_and_wide_d():
     gen.reset_seed(4)
     # K not a multiple of 128 (quantisers zero-pad the last block): generic path

@@ -109,7 +109,16 @@ def report():
         if name not in meta or 'gemm' not in name:
             continue
         mfma = [i for i, ins in enumerate(body) if ins.startswith('v_mfma')]
-        loop = body[mfma[0]:mfma[-1] + 1] if mfma else []
+        # the K loop: from the first MFMA to the first backward branch behind it (kernels with a K-tail stage have more MFMAs after
+        # the loop; spills there cost once per tile, not once per K block); no backward branch found: up to the last MFMA
+        end = mfma[-1] if mfma else 0
+        if mfma:
+            for i in range(mfma[0], mfma[-1]):
+                m_br = re.match(r's_c?branch\w*\s+(\d+)', body[i])
+                if m_br and int(m_br.group(1)) >= 0x8000:
+                    end = max(i, mfma[min(len(mfma) - 1, 15)])
+                    break
+        loop = body[mfma[0]:end + 1] if mfma else []
         # readable name without a demangler: _ZN2dg22dg_fp8_gemm_duo_kernelILi256ELi256ELi2ELi4ELi0EEEvNS_10GemmParamsE
         m = re.match(r'_ZN2dg\d+(\w+?)(?:I(.*?)EEv|Ev)', name)
         pretty = name if not m else m.group(1) + ('<' + ','.join(re.findall(r'L[ib](\d+)E', m.group(2))) + '>' if m.group(2) else '')
