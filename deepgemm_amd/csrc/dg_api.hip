@@ -102,14 +102,16 @@ const Config kConfigs[] = {
     {"duo_p_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true>, true, true, true},
     // 128-row duo tile: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise
     // badly at 256 x 256.  Measured per-tile: 116 k cycles vs 167 k for twice the work (L2->LDS bytes per flop are 1.5x).
-    {"duo_128x256", 128, 256, 512, 1, 0.78f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4>, true},
+    // Every 128-row form runs the two-segment schedule (MERGED: one load + one 16-step matrix segment per K block, 3-slot B
+    // ring): 1.47-1.50 k cycles per K block against 1.60-1.63 k for the four-segment schedule of the 256-row tile, same bits.
+    {"duo_128x256", 128, 256, 512, 1, 0.78f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, false, false, false, false, true>, true},
     // the same tile in a persistent launch whose partial last round is split along K (2.25 rounds of tiles cost 2 + ~0.4 instead
     // of 3): picked instead of duo_128x256 when the caller provides the workspace and the tail is at most half a round
-    {"duo_sk_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true>, true, false, true,
+    {"duo_sk_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true, false, false, true>, true, false, true,
      false, true},
     // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
     {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true>, true, true, true},
-    {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true>, true},
+    {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true, false, false, false, true>, true},
     {"duo_bmn2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, false, true>, true, true},   // contiguous, two-pass
     // operand A MN-major ([K][M]; the tt / tn layouts of the dense GEMM): A through row pieces + transpose reads, B K-major / MN-major
     {"duo_amn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, true>, true, false, true},
@@ -118,11 +120,11 @@ const Config kConfigs[] = {
     // block computed after the loop (dense problems; K-major A; B K-major or MN-major)
     {"duo_kt_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, true>, true, false,
      true, false, false, true},
-    {"duo_kt_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, false, false, false, true>, true, false,
+    {"duo_kt_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, false, false, false, true, true>, true, false,
      false, false, false, true},
     {"duo_bmn_kt_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true, false, false, true>, true, false,
      true, false, false, true},
-    {"duo_bmn_kt_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true, false, false, true>, true, false,
+    {"duo_bmn_kt_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true, false, false, true, true>, true, false,
      false, false, false, true},
     {"pipe_256x256", 256, 256, 512, 1, 1.00f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 2>},
     {"pipe_128x256", 128, 256, 512, 1, 0.66f, true, dg::dg_fp8_gemm_pipe_kernel<128, 256, 2, 4, 2>},

@@ -1221,13 +1221,21 @@ template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> t
 // traces ... -- live in fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
 // K_TAIL: K need not be a multiple of 128 (whole 16-byte chunks, K > 128): the partial last K block is computed once per tile after
 // the loop (separate instantiations: the stage costs registers that the tuned whole-block kernels do not have to spare).
+// MERGED (128-row tiles): TWO segments per K block instead of four -- L: scales, every piece of block kb+2, every fragment of block
+// kb; M: all MS * NS steps -- with a 3-slot B ring (B(kb+2) lands in B(kb-1)'s slot, so no barrier has to separate "B(kb) is in
+// everybody's registers" from the refill).  A 64 x 64 wave tile has the registers for all of its fragments, and with 8-step
+// matrix segments the four barrier round trips and the load segments (longer than the matrix segments they hide behind) cost
+// the 128-row tile 1.43 k cycles per K block against 1.02 k of matrix work; 16-step segments halve the barriers.  Waits: at the
+// end of L "everything but this segment's own loads has landed" (my pieces of block kb+1, certified to the others by the next
+// barrier), at the end of M the scales of block kb+1 (straight-line from their loads, in front of the loop's back edge).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false>
+          bool K_TAIL = false, bool MERGED = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MERGED ? MS : MS / 2;
     constexpr int TOTAL = MS * NS, SEG = HS * NS, DEPTH = 3;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = MERGED ? 3 : 2;
+    constexpr int SCALE_LOADS = A_MN ? MS + 1 : MS / 4 + 1;    // vector-memory operations of one issue_scale_loads_any
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
@@ -1235,6 +1243,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     static_assert(!A_MN || (BM == 256 && NW == 8), "MN-major A tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     static_assert(!SPLITK || (PERSIST && !B_MN && !A_MN), "the K-split tail belongs to the persistent K-major form");
     static_assert(!K_TAIL || !SPLITK, "K tail and K split are not combined");
+    static_assert(!MERGED || (BM == 128 && !A_MN), "the two-segment form needs all fragments of the wave tile in registers");
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
     static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
@@ -1451,6 +1460,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 raw_barrier();                      // the upper half runs one segment behind from here on
 
             int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;     // slots of A(kb), A(kb+2) [= A(kb-1)'s], B(kb)
+            [[maybe_unused]] int b_fill = 2 * B_BYTES;          // MERGED: slot of B(kb+2) [= B(kb-1)'s]
             v8i bf[NS], af[HS];
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
 
@@ -1458,100 +1468,159 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
 
-                // ---------------- L_a ----------------
-                raw_barrier();
-                // fragment reads first: they complete in the shadow of the slow vector-memory issue that follows
-                [[maybe_unused]] FragTr bfq[NS];
-                #pragma unroll
-                for (int ns = 0; ns < NS; ++ns) {
-                    if constexpr (B_MN)
-                        bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
-                    else
-                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
-                }
-                [[maybe_unused]] FragTr afq[HS];
-                #pragma unroll
-                for (int h = 0; h < HS; ++h) {
-                    if constexpr (A_MN)
-                        afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + h) ^ tr_swz) << 4);
-                    else
+                if constexpr (MERGED) {
+                    // ---------------- L ----------------
+                    raw_barrier();
+                    [[maybe_unused]] FragTr bfq[NS];
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        if constexpr (B_MN)
+                            bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                        else
+                            bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    }
+                    #pragma unroll
+                    for (int h = 0; h < MS; ++h)
                         af[h] = load_fragment(a_tile + h * 2048, frag_off);
-                }
-                scale_tail = scale[MS - 1];
-                // block kb's scales landed before the previous L_b's wait (block 0: before the prologue's / the prefetch's)
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    scale[ms] = landed_sfa<MS>(land, ms) * land.sb;
-                    pin_vgpr(scale[ms]);
-                }
-                issue_scales(land, kb + 1);
-                #pragma unroll
-                for (int q = 0; q < A_EARLY; ++q)
-                    issue_a_piece(a_fill, kb + 2, q);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (B_MN) {
+                    scale_tail = scale[MS - 1];
                     #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns)
-                        bf[ns] = assemble_fragment_tr(bfq[ns]);
-                }
-                if constexpr (A_MN) {
+                    for (int ms = 0; ms < MS; ++ms) {
+                        scale[ms] = landed_sfa<MS>(land, ms) * land.sb;
+                        pin_vgpr(scale[ms]);
+                    }
+                    issue_scales(land, kb + 1);
                     #pragma unroll
-                    for (int h = 0; h < HS; ++h)
-                        af[h] = assemble_fragment_tr(afq[h]);
-                }
-
-                // ---------------- M_a ----------------
-                raw_barrier();
-                #pragma unroll
-                for (int i = 0; i < SEG; ++i) {
-                    const int ns = i % NS, h = i / NS;
-                    const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
-                    const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
-                    mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
-                }
-
-                // ---------------- L_b ----------------
-                raw_barrier();
-                #pragma unroll
-                for (int h = 0; h < HS; ++h) {
-                    if constexpr (A_MN)
-                        afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + HS + h) ^ tr_swz) << 4);
-                    else
-                        af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
-                }
-                #pragma unroll
-                for (int q = A_EARLY; q < A_ITERS; ++q)
-                    issue_a_piece(a_fill, kb + 2, q);
-                #pragma unroll
-                for (int q = 0; q < B_ITERS; ++q)
-                    issue_b_piece(b_cur, kb + 2, q);
-                // Block kb+1 and its scales: my pieces have landed.  (Persistent launch: a predecessor tile's output stores may
-                // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
-                // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
-                // "every load but the newest 8 has landed".)
-                wait_landing_any<A_ITERS + B_ITERS, MS>(land);
-                #pragma unroll
-                for (int h = 0; h < HS; ++h) {
-                    if constexpr (A_MN)
-                        af[h] = assemble_fragment_tr(afq[h]);
-                    else
+                    for (int q = 0; q < A_ITERS; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q)
+                        issue_b_piece(b_fill, kb + 2, q);
+                    // my pieces of block kb+1 (issued one K block ago) have landed; this segment's own loads stay in flight
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(A_ITERS + B_ITERS + SCALE_LOADS, 0));
+                    asm volatile("" ::: "memory");
+                    if constexpr (B_MN) {
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            bf[ns] = assemble_fragment_tr(bfq[ns]);
+                    } else {
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            asm volatile("" : "+v"(bf[ns]) :: "memory");
+                    }
+                    #pragma unroll
+                    for (int h = 0; h < MS; ++h)
                         asm volatile("" : "+v"(af[h]) :: "memory");
-                }
 
-                // ---------------- M_b ----------------
-                raw_barrier();
-                #pragma unroll
-                for (int i2 = 0; i2 < SEG; ++i2) {
-                    const int i = SEG + i2;
-                    const int ns = i % NS, h = i2 / NS;
-                    const int j = i - DEPTH;
-                    mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
-                }
+                    // ---------------- M ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int i = 0; i < TOTAL; ++i) {
+                        const int ns = i % NS, h = i / NS;
+                        const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
+                        const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                    }
+                    wait_landing_any<A_ITERS + B_ITERS, MS>(land);      // the scales of block kb+1, in front of the back edge
+                    const int b_next = (b_cur == (B_SLOTS - 1) * B_BYTES) ? 0 : b_cur + B_BYTES;
+                    b_fill = b_cur;
+                    b_cur = b_next;
+                } else {
+                    // ---------------- L_a ----------------
+                    raw_barrier();
+                    // fragment reads first: they complete in the shadow of the slow vector-memory issue that follows
+                    [[maybe_unused]] FragTr bfq[NS];
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        if constexpr (B_MN)
+                            bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                        else
+                            bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    }
+                    [[maybe_unused]] FragTr afq[HS];
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h) {
+                        if constexpr (A_MN)
+                            afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + h) ^ tr_swz) << 4);
+                        else
+                            af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                    }
+                    scale_tail = scale[MS - 1];
+                    // block kb's scales landed before the previous L_b's wait (block 0: before the prologue's / the prefetch's)
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        scale[ms] = landed_sfa<MS>(land, ms) * land.sb;
+                        pin_vgpr(scale[ms]);
+                    }
+                    issue_scales(land, kb + 1);
+                    #pragma unroll
+                    for (int q = 0; q < A_EARLY; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (B_MN) {
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            bf[ns] = assemble_fragment_tr(bfq[ns]);
+                    }
+                    if constexpr (A_MN) {
+                        #pragma unroll
+                        for (int h = 0; h < HS; ++h)
+                            af[h] = assemble_fragment_tr(afq[h]);
+                    }
 
+                    // ---------------- M_a ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int i = 0; i < SEG; ++i) {
+                        const int ns = i % NS, h = i / NS;
+                        const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
+                        const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                    }
+
+                    // ---------------- L_b ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h) {
+                        if constexpr (A_MN)
+                            afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + HS + h) ^ tr_swz) << 4);
+                        else
+                            af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                    }
+                    #pragma unroll
+                    for (int q = A_EARLY; q < A_ITERS; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q)
+                        issue_b_piece(b_cur, kb + 2, q);
+                    // Block kb+1 and its scales: my pieces have landed.  (Persistent launch: a predecessor tile's output stores may
+                    // still be pending in the first K block.  They count towards vmcnt too, which can only make this wait
+                    // stricter -- loads retire in order among themselves, so "at most 8 operations outstanding" still implies
+                    // "every load but the newest 8 has landed".)
+                    wait_landing_any<A_ITERS + B_ITERS, MS>(land);
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h) {
+                        if constexpr (A_MN)
+                            af[h] = assemble_fragment_tr(afq[h]);
+                        else
+                            asm volatile("" : "+v"(af[h]) :: "memory");
+                    }
+
+                    // ---------------- M_b ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int i2 = 0; i2 < SEG; ++i2) {
+                        const int i = SEG + i2;
+                        const int ns = i % NS, h = i2 / NS;
+                        const int j = i - DEPTH;
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
+                    }
+
+                    b_cur ^= B_BYTES;
+                }
                 const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
                 a_fill = a_cur;             // A(kb+3) will take the slot block kb just finished with
                 a_cur = a_next;
-                b_cur ^= B_BYTES;
             }
             if (!upper_half)
                 raw_barrier();              // pairs with the barrier in front of the upper half's last segment
@@ -1679,32 +1748,36 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 __syncthreads();
                 store = *flag != 0;
                 if (store) {
-                    // all pieces, mine included, in piece order: the sum does not depend on who arrived last.  One piece = 16
-                    // independent 16-byte loads per lane; the next piece's loads are in flight while this one is added
-                    // (a load -> add chain per subtile would pay the cross-XCD latency 16 x pieces times).
-                    // Two halves of the subtile rows, to stay inside the register file.
-                    constexpr int HM = MS / 2;
+                    // all pieces, mine included, in piece order: the sum does not depend on who arrived last.  The loads of up to
+                    // two pieces (of one half of the subtile rows: 2 x 32 registers) are issued back to back and added when
+                    // they have all arrived: the partials come from the far side of the fabric (~2 us per dependent round trip),
+                    // so a load -> add chain per piece costs pieces + 1 round trips per half (measured: 17 us + 1.3 us per
+                    // piece for the whole exchange), this form one per two pieces (four at once spill: 77 registers).
+                    constexpr int HM = MS / 2, CHUNK = 2;
                     #pragma unroll
                     for (int half = 0; half < 2; ++half) {
-                        auto load_piece = [&](v4f (&dst)[HM][NS], int s) {
+                        for (int s0 = 0; s0 < p.sk_factor; s0 += CHUNK) {
+                            v4f buf[CHUNK][HM][NS];
                             #pragma unroll
-                            for (int ms = 0; ms < HM; ++ms)
+                            for (int c = 0; c < CHUNK; ++c) {
+                                const int s = imin(s0 + c, p.sk_factor - 1);      // past the end: the last piece again (not added)
                                 #pragma unroll
-                                for (int ns = 0; ns < NS; ++ns)
-                                    dst[ms][ns] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(
-                                        slab, lane_off, s * (BM * BN * 4) + ((half * HM + ms) * NS + ns) * (NW * 1024), kCoherent));
-                        };
-                        v4f cur[HM][NS], nxt[HM][NS];
-                        load_piece(cur, 0);
-                        for (int s = 0; s < p.sk_factor; ++s) {
-                            load_piece(nxt, imin(s + 1, p.sk_factor - 1));
+                                for (int ms = 0; ms < HM; ++ms)
+                                    #pragma unroll
+                                    for (int ns = 0; ns < NS; ++ns)
+                                        buf[c][ms][ns] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(
+                                            slab, lane_off, s * (BM * BN * 4) + ((half * HM + ms) * NS + ns) * (NW * 1024), kCoherent));
+                            }
                             #pragma unroll
-                            for (int ms = 0; ms < HM; ++ms)
-                                #pragma unroll
-                                for (int ns = 0; ns < NS; ++ns) {
-                                    out[half * HM + ms][ns] = s == 0 ? cur[ms][ns] : out[half * HM + ms][ns] + cur[ms][ns];
-                                    cur[ms][ns] = nxt[ms][ns];
+                            for (int c = 0; c < CHUNK; ++c) {
+                                if (s0 + c < p.sk_factor) {
+                                    #pragma unroll
+                                    for (int ms = 0; ms < HM; ++ms)
+                                        #pragma unroll
+                                        for (int ns = 0; ns < NS; ++ns)
+                                            out[half * HM + ms][ns] = (s0 + c == 0) ? buf[c][ms][ns] : out[half * HM + ms][ns] + buf[c][ms][ns];
                                 }
+                            }
                         }
                     }
                 }
@@ -1727,10 +1800,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false>
+          bool K_TAIL = false, bool MERGED = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED>(p);
 }
 
 
