@@ -13,6 +13,7 @@ _i32, _i64, _vp, _cp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c
 # name -> (restype, argtypes); must list every symbol declared in include/deepgemm_amd.h
 SIGNATURES = {
     'dg_fp8_gemm_nt': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i32, _i64, _i32, _i32, _vp]),
+    'dg_fp8_gemm_nt_ws': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i32, _i64, _i32, _i32, _vp, _i64, _vp]),
     'dg_fp8_gemm_nt_skip_head_mid': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i32, _i64, _i32, _i32, _i32, _i32, _vp]),
     'dg_fp8_gemm_nt_ue8m0': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i64, _i32, _i32, _vp]),
     'dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0': (_i32, [_vp] * 6 + [_i32] * 4 + [_i64] * 11 + [_i32, _i32, _vp]),

@@ -109,6 +109,8 @@ const Config kConfigs[] = {
     // of 3): picked instead of duo_128x256 when the caller provides the workspace and the tail is at most half a round
     {"duo_sk_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true, false, false, true>, true, false, true,
      false, true},
+    {"duo_sk_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, true, true, false, false, true>, true,
+     false, true, false, true},
     // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
     {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true>, true, true, true},
     {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true, false, false, false, true>, true},
@@ -261,15 +263,23 @@ bool per_col_mn_eligible(const dg::GemmParams& p) {
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // K pieces per tile of the partial last round (0 = no split): as many as the idle workgroup slots allow, at most 8 and at most
-// one per K block.
+// one per K block.  A launch of fewer tiles than slots is all "last round": every tile is cut (dense problems with few tiles
+// and a long K loop, e.g. the dgrad shape 4096 x 512 x 32768: 64 tiles of 128 x 256).
 long split_k_pieces(long tiles, long slots, long num_kb) {
     const long tail = tiles % slots;
-    if (tiles <= slots || tail == 0)
+    if (tiles <= 0 || tail == 0)
         return 0;
     long pieces = slots / tail;
     if (pieces > 8) pieces = 8;
     if (pieces > num_kb) pieces = num_kb;
     return pieces >= 2 ? pieces : 0;
+}
+
+// Does the split pay?  It trades (1 - 1/pieces) of a tile's K loop (~0.9 us per K block of a 128 x 256 tile) for the partial-tile
+// exchange (~17 us + 1.3 us per piece; tools/grouped_bench.py on 8 groups x N 4096 with 16..128 tail tiles): K = 7168 gains
+// 8..21 us of ~180, K = 4096 0..7 us of ~100, K = 2048 loses.
+bool split_k_pays(long pieces, long num_kb) {
+    return pieces >= 2 && num_kb * (pieces - 1) * 100 > (1700 + 130 * pieces) * pieces;
 }
 
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
@@ -300,6 +310,13 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         const char* pick = (contiguous || tiles256 < num_cus() / 2) ? "duo_bmn_128x256" : "duo_bmn_256x256";
         if (p.k % 128 != 0)             // (dense only, see bmn_eligible) the forms with the K-tail stage
             pick = tiles256 < num_cus() / 2 ? "duo_bmn_kt_128x256" : "duo_bmn_kt_256x256";
+        else if (std::strcmp(pick, "duo_bmn_128x256") == 0 && p.sk_workspace != nullptr &&
+                 (!contiguous || bm_must_divide % 128 == 0)) {
+            // a partial last round (or an under-filled launch) of 128 x 256 tiles: cut it along K over the idle CUs
+            const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
+            if (split_k_pays(split_k_pieces(tiles, num_cus(), p.k / 128), p.k / 128))
+                pick = "duo_sk_bmn_128x256";
+        }
         // many rounds of a contiguous layout aligned to 128 rows: the two-pass 256-row tile (same rule as for K-major B)
         if (p.gemm_type == dg::kContiguous && bm_must_divide == 128 && tiles256 >= 4L * num_cus())
             pick = "duo_bmn2_256x256";
@@ -333,6 +350,21 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             pick = "stream_64x128";
         else if (m_hint > 256 && tiles128 <= num_cus())
             pick = "stream_64x128";     // one resident round of 64 x 128 tiles (512 x 4096 x 7168: 36.9 us against 47.3 on 128 x 256 tiles)
+        // ... unless the K loop is long and the caller lent a workspace: cutting every 128 x 256 tile along K over the idle CUs
+        // beats one deep-ring tile per CU (tools/sweep.py: 4096 x 512 x 32768: 88.6 us against 166.4; 1024 x 1024 x 16384: 41.3 / 79.5;
+        // 1024 x 512 x 8192: 30.5 / 42.8; break-even near K = 7168 -- 512 x 4096 x 7168: 38.7 / 39.7, 4096 x 512 x 4096: 32.6 / 25.3).
+        // Model: stream = 5 us + 0.66 (64 x 128) or 0.36 (64 x 32) us per K block, split = 22 us + 1.05 us per K block of a piece.
+        if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && m_hint > 64) {
+            const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
+            const long num_kb = p.k / 128;
+            const long pieces = split_k_pieces(tiles, num_cus(), num_kb);
+            if (pieces >= 2 && tiles < num_cus()) {
+                const double t_stream = 5.0 + num_kb * (std::strcmp(pick, "stream_64x128") == 0 ? 0.66 : 0.36);
+                const double t_split = 22.0 + static_cast<double>((num_kb + pieces - 1) / pieces) * 1.05;
+                if (t_split < t_stream)
+                    pick = "duo_sk_128x256";
+            }
+        }
         if (pick != nullptr)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)
@@ -367,23 +399,21 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             best_cost = cost;
         }
     }
-    // A partial last round of 128 x 256 tiles: split it along K over the idle CUs (needs the caller's workspace).  The split
-    // trades (1 - 1/pieces) of a tile's K loop (~1.05 us per K block) for the partial-tile exchange (~17 us + 1.3 us per piece,
-    // tools/grouped_bench.py on 8 groups x N 4096 with 16..128 tail tiles): K = 7168 gains 8..21 us of ~180, K = 4096 0..7 us of
-    // ~100, K = 2048 loses.
+    // A partial last round (or an under-filled launch) of 128 x 256 tiles: split it along K over the idle CUs (needs the caller's
+    // workspace; see split_k_pays).
     if (best != nullptr && std::strcmp(best->name, "duo_128x256") == 0 && p.sk_workspace != nullptr &&
         p.gemm_type != dg::kMasked) {
         const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
-        const long pieces = split_k_pieces(tiles, num_cus(), p.k / 128);
-        if (pieces >= 2 && static_cast<long>(p.k / 128) * (pieces - 1) * 100 > (1700 + 130 * pieces) * pieces)
+        if (split_k_pays(split_k_pieces(tiles, num_cus(), p.k / 128), p.k / 128))
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, "duo_sk_128x256") == 0)
                     return &kConfigs[i];
     }
     // Several tiles per CU: the persistent variant of the duo kernel (the next tile's first K blocks are fetched and
     // drained in front of the current tile's stores, which then overlap the next tile's first K block).
-    // (Dense only: on the two-pass contiguous walk the prefetch of the next tile loses more than the overlap wins.)
-    if (best != nullptr && std::strcmp(best->name, "duo_256x256") == 0 && p.gemm_type == dg::kNormal) {
+    // (Dense and masked -- 32 groups x ~192 rows: 2-4 % -- only: on the two-pass contiguous walk the prefetch of the next tile loses
+    // more than the overlap wins.)
+    if (best != nullptr && std::strcmp(best->name, "duo_256x256") == 0 && (p.gemm_type == dg::kNormal || p.gemm_type == dg::kMasked)) {
         // (also with one tile per CU: 98.0 against 99.4 us sustained on 4096 x 4096 x 7168, tools/sustained.py)
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, "duo_p_256x256") == 0)
@@ -406,7 +436,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
                        "majorness in its name and MN-major SFA";
         return 3;
     }
-    const bool bmn_form = std::strncmp(cfg->name, "duo_bmn", 7) == 0;
+    const bool bmn_form = std::strstr(cfg->name, "_bmn") != nullptr;       // duo_bmn_*, duo_sk_bmn_*
     if (bmn_form && !bmn_eligible(p)) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major A, MN-major 16-byte aligned B and MN-major SFA";
         return 3;
@@ -465,7 +495,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         const long tail = total % slots;
         const long pieces = split_k_pieces(total, slots, p.k / 128);
         const size_t need = 4096 + static_cast<size_t>(tail) * pieces * cfg->bm * cfg->bn * sizeof(float);
-        if (total > slots && tail > 0 && pieces >= 2 && p.sk_workspace != nullptr && need <= g_workspace_bytes) {
+        if (tail > 0 && pieces >= 2 && p.sk_workspace != nullptr && need <= g_workspace_bytes) {
             p.sk_first_tile = static_cast<int>(total - tail);
             p.sk_tiles = static_cast<int>(tail);
             p.sk_factor = static_cast<int>(pieces);
@@ -477,7 +507,8 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         grid = max_tiles < slots ? max_tiles : slots;
     } else if (cfg->persistent) {
         const long slots = static_cast<long>(num_cus()) * cfg->blocks_per_cu;
-        grid = total < slots ? total : slots;
+        const long items = static_cast<long>(p.sk_first_tile) + static_cast<long>(p.sk_tiles) * p.sk_factor;     // = total without a split
+        grid = items < slots ? items : slots;
     } else {
         grid = total;
     }
@@ -562,6 +593,16 @@ int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* 
                    int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
                    int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
                    int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
+    return dg_fp8_gemm_nt_ws(a, sfa, b, sfb, d, m, n, k, a_stride_m, a_stride_k, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_k,
+                             sfb_stride_n, sfb_stride_k, sfb_gran_n, d_stride_m, d_dtype, accumulate, nullptr, 0, stream);
+}
+
+int dg_fp8_gemm_nt_ws(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                      int m, int n, int k,
+                      int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                      int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                      int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
     DG_CHECK(m >= 0 && n >= 0 && k >= 0);
     if (m == 0 || n == 0)
         return 0;
@@ -581,6 +622,9 @@ int dg_fp8_gemm_nt(const void* a, const float* sfa, const void* b, const float* 
     p.d_sm = d_stride_m;
     p.sfb_gran_n = sfb_gran_n; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
+    DG_CHECK(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 4096));
+    p.sk_workspace = workspace;
+    g_workspace_bytes = workspace != nullptr ? static_cast<size_t>(workspace_bytes) : 0;
     return launch_gemm(p, 0, stream);
 }
 

@@ -1241,7 +1241,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     static_assert(!A_MN || (BM == 256 && NW == 8), "MN-major A tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
-    static_assert(!SPLITK || (PERSIST && !B_MN && !A_MN), "the K-split tail belongs to the persistent K-major form");
+    static_assert(!SPLITK || (PERSIST && !A_MN), "the K-split tail belongs to the persistent forms");
     static_assert(!K_TAIL || !SPLITK, "K tail and K split are not combined");
     static_assert(!MERGED || (BM == 128 && !A_MN), "the two-segment form needs all fragments of the wave tile in registers");
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
             B_MN ? bmn_voff : b_piece_voff[q],
-            B_MN ? (imin(j, nkb - 1) * 128 + 4 * unit) * ldb_mn : (kb0 + imin(j, nkb - 1)) * 128, 0, 0);
+            B_MN ? ((kb0 + imin(j, nkb - 1)) * 128 + 4 * unit) * ldb_mn : (kb0 + imin(j, nkb - 1)) * 128, 0, 0);
     };
     // Prologue pieces of a tile: A(0) B(0) A(1) B(1) into ring slots 0 / 1.  Issued at kernel entry for the first tile
     // and, in the persistent launch, for tile i+1 as soon as tile i's K loop has released the LDS -- i.e. BEFORE tile i's

@@ -194,6 +194,33 @@ def _split_k_workspace(device: torch.device, stream: int) -> Optional[torch.Tens
     return ws
 
 
+def _dense_split_k_workspace(m: int, n: int, k: int, gran_n: int, device: torch.device) -> Optional[torch.Tensor]:
+    """The K-split scratch buffer for a dense call whose 128 x 256 tiles leave most of the chip idle in their (only or last) round
+    while the K loop is long (dg_api.hip: split_k_pieces / split_k_pays, mirrored here so that ordinary calls neither create nor
+    pass a buffer); None otherwise.  The C side decides for itself whether it splits."""
+    if gran_n != 128 or k % 128 != 0 or m <= 64:
+        return None
+    cus = int(lib.dg_get_num_cus())
+    tail = (-(-m // 128) * -(-n // 256)) % cus
+    if tail == 0:
+        return None
+    num_kb = k // 128
+    pieces = min(8, cus // tail, num_kb)
+    if pieces < 2 or num_kb * (pieces - 1) * 100 <= (1700 + 130 * pieces) * pieces:
+        return None
+    return _split_k_workspace(device, current_stream_ptr())
+
+
+def _call_dense(a_data, sfa, b_data, sfb, d, c, m, n, k, gran_n) -> None:
+    ws = _dense_split_k_workspace(m, n, k, gran_n, d.device)
+    check(lib.dg_fp8_gemm_nt_ws(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
+        a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
+        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), gran_n,
+        d.stride(0), _dtype_code(d), int(c is not None),
+        ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, current_stream_ptr()))
+
+
 def _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b):
     """Both scale tensors as packed UE8M0 words in the MN-major layout (csrc/apis/layout.hpp:58-60: the (INT, 1, gran_k) branch of
     transform_sf_into_required_layout; default recipe for int scales is (1, 1, 128), csrc/utils/layout.hpp:64-77)."""
@@ -251,11 +278,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
             d.copy_(c)
         sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
         a_data, b_data = _dense_operands(a_data, b_data, sfa, gran_n, m, n, k)
-        check(lib.dg_fp8_gemm_nt(
-            a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), m, n, k,
-            a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
-            sfa.stride(0), sfa.stride(1), b_sf.stride(0), b_sf.stride(1), gran_n,
-            d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
+        _call_dense(a_data, sfa, b_data, b_sf, d, c, m, n, k, gran_n)
         return
     major_check(a_data), major_check(b_data)
     check_major_type_cd(d)
@@ -272,11 +295,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
         _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf)
     a_data, b_data = _dense_operands(a_data, b_data, sfa, gran_n, m, n, k)
-    check(lib.dg_fp8_gemm_nt(
-        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
-        a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
-        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), gran_n,
-        d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
+    _call_dense(a_data, sfa, b_data, sfb, d, c, m, n, k, gran_n)
 
 
 def fp8_gemm_nn(a, b, d, c=None, recipe=None, recipe_a=None, recipe_b=None, compiled_dims='nk', disable_ue8m0_cast=False) -> None:

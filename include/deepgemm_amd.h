@@ -155,6 +155,16 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ws(const void* a, const float* sfa, cons
                                            void* stream);
 int64_t dg_split_k_workspace_bytes(void);
 
+/* dg_fp8_gemm_nt with the same caller-owned scratch buffer: a dense problem whose tiles do not fill the chip (or leave a partial
+ * last round) and whose K loop is long -- e.g. the dgrad shape 4096 x 512 x 32768: 64 tiles of 128 x 256 on 256 CUs -- is cut
+ * along K over the idle CUs in the same way.  workspace == NULL gives dg_fp8_gemm_nt. */
+int dg_fp8_gemm_nt_ws(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
+                      int m, int n, int k,
+                      int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                      int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                      int sfb_gran_n, int64_t d_stride_m, int d_dtype, int accumulate,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* M-grouped masked GEMM.  Replaces sm90_m_grouped_fp8_gemm_masked_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:224) /
  * sm100_m_grouped_fp8_fp4_gemm_masked_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:244) as called from
  * m_grouped_fp8_fp4_gemm_nt_masked (csrc/apis/gemm.hpp:250-297).

@@ -435,6 +435,39 @@ def test_m_grouped_contiguous_split_k_tail(use_psum, actual_ms, n, k, alignment)
     assert calc_diff(torch.nan_to_num(plain), torch.nan_to_num(outs[0])) < 1e-6
 
 
+@pytest.mark.parametrize('m,n,k', [(1024, 512, 8192), (4096, 576, 7168), (200, 1024, 16384)])
+@pytest.mark.parametrize('b_k_major', [True, False])
+@pytest.mark.parametrize('out_dtype,accumulate', [(torch.bfloat16, False), (torch.float, True)])
+def test_dense_split_k_under_filled_launch(m, n, k, b_k_major, out_dtype, accumulate):
+    """Dense problems whose 128 x 256 tiles fill a fraction of the chip while the K loop is long (the dgrad shape 4096 x 512 x 32768 is
+    the reference-sweep example): every tile is cut along K over the idle CUs -- the K-split of the contiguous tail with all tiles
+    in the "last round" -- for K-major and MN-major B; oracle, repeatability, reduce-add applied once, same result as the unsplit
+    kernel to rounding."""
+    from deepgemm_amd import gemm as gemm_mod
+    gen.reset_seed(m + n + k + 3)
+    case = gen.generate_normal(m, n, k, a_k_major=True, b_k_major=b_k_major, accumulate=accumulate, out_dtype=out_dtype)
+    c_cpu = case.c.cpu().clone() if accumulate else None
+    want = oracle_dense(case, c_cpu=c_cpu)
+    outs = []
+    for _ in range(4):
+        d = c_cpu.cuda() if accumulate else torch.full_like(case.d, float('nan'))
+        dg.fp8_gemm_nt(case.a, case.b, d, c=d if accumulate else None)
+        outs.append(d)
+    # (an MN-major B of a problem with m <= 256 is re-majored first: the K-major kernel)
+    assert dg.last_config() == ('duo_sk_128x256' if b_k_major or m <= 256 else 'duo_sk_bmn_128x256'), dg.last_config()
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'the piece-order reduction must be bit-repeatable'
+    if out_dtype == torch.float:
+        assert_close_fp32(outs[0], want, 'dense split K')
+    else:
+        assert_close_to_oracle(outs[0], want, 'dense split K')
+    for ws in gemm_mod._SPLIT_K_WORKSPACES.values():
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'arrival counters must be left at zero'
+    dg.set_forced_config('duo_128x256' if b_k_major or m <= 256 else 'duo_bmn_128x256')
+    plain = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
+    dg.fp8_gemm_nt(case.a, case.b, plain, c=plain if accumulate else None)
+    assert calc_diff(plain, outs[0]) < 1e-6
+
+
 def test_split_k_tail_full_size_and_small_workspace(monkeypatch):
     """BASELINE config 4 (8 groups x ~512 rows, N = 4096, K = 7168) with a 2.25-round tile count: the default path takes the
     K-split tail; with a workspace too small for the partials the same kernel walks all tiles unsplit.  Dense calls (no
