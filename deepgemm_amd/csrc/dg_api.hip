@@ -135,7 +135,11 @@ const Config kConfigs[] = {
     {"pipe_32x256", 32, 256, 256, 2, 0.35f, true, dg::dg_fp8_gemm_pipe_kernel<32, 256, 1, 4, 0>},
     {"pipe_16x256", 16, 256, 256, 2, 0.20f, true, dg::dg_fp8_gemm_pipe_kernel<16, 256, 1, 4, 0>},
     {"stream_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6>, true},
-    {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 12>, true},
+    // the same with the non-temporal policy on the weight stream's LDS-DMA: +3-5 % when the weights of one launch exceed the 256 MiB
+    // Infinity Cache anyway (32 experts x 6144 x 7168: 254 -> 245 us), neutral to -8 % below that (they would have stayed resident)
+    {"stream_nt_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2>, true},
+    // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
+    {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4>, true},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>, true, false,
      false, true},
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>, true,
@@ -354,12 +358,15 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // beats one deep-ring tile per CU (tools/sweep.py: 4096 x 512 x 32768: 88.6 us against 166.4; 1024 x 1024 x 16384: 41.3 / 79.5;
         // 1024 x 512 x 8192: 30.5 / 42.8; break-even near K = 7168 -- 512 x 4096 x 7168: 38.7 / 39.7, 4096 x 512 x 4096: 32.6 / 25.3).
         // Model: stream = 5 us + 0.66 (64 x 128) or 0.36 (64 x 32) us per K block, split = 22 us + 1.05 us per K block of a piece.
+        if (pick != nullptr && std::strcmp(pick, "stream_64x128") == 0 &&
+            static_cast<double>(groups) * p.n * p.k >= 200e6)
+            pick = "stream_nt_64x128";
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && m_hint > 64) {
             const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
             const long num_kb = p.k / 128;
             const long pieces = split_k_pieces(tiles, num_cus(), num_kb);
             if (pieces >= 2 && tiles < num_cus()) {
-                const double t_stream = 5.0 + num_kb * (std::strcmp(pick, "stream_64x128") == 0 ? 0.66 : 0.36);
+                const double t_stream = 5.0 + num_kb * (std::strcmp(pick, "stream_64x32") == 0 ? 0.36 : 0.66);
                 const double t_split = 22.0 + static_cast<double>((num_kb + pieces - 1) / pieces) * 1.05;
                 if (t_split < t_stream)
                     pick = "duo_sk_128x256";

@@ -1448,12 +1448,12 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 
             // ---- block 0 and its scales must land before the first segment ----
             if (!prefetched) {
-                // SF(0) is the newest vector-memory operation: a full drain, which also lands block 1 -- a fraction of a
-                // microsecond once per tile.  (Straight-line from the scale loads to their wait: hipcc may copy the landing
-                // registers at any control-flow join in between.)
-                issue_prologue(t);
+                // SF(0) first, then the pieces of blocks 0 and 1: the wait leaves block 1's pieces in flight (the first K block's
+                // own counted wait covers them), so the first segment starts as soon as block 0 is in.  (Straight-line from the
+                // scale loads to their wait: hipcc may copy the landing registers at any control-flow join in between.)
                 issue_scales(land, 0);
-                wait_landing_any<0, MS>(land);
+                issue_prologue(t);
+                wait_landing_any<A_ITERS + B_ITERS, MS>(land);
             }
             raw_barrier();
             if (upper_half)
