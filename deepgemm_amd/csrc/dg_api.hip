@@ -418,9 +418,9 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     }
     // Several tiles per CU: the persistent variant of the duo kernel (the next tile's first K blocks are fetched and
     // drained in front of the current tile's stores, which then overlap the next tile's first K block).
-    // (Dense and masked -- 32 groups x ~192 rows: 2-4 % -- only: on the two-pass contiguous walk the prefetch of the next tile loses
-    // more than the overlap wins.)
-    if (best != nullptr && std::strcmp(best->name, "duo_256x256") == 0 && (p.gemm_type == dg::kNormal || p.gemm_type == dg::kMasked)) {
+    // (Every layout: masked, 32 groups x ~192 rows: 2-4 %; contiguous two-pass walks of 8 x ~4096 / 4 x ~8192 rows: 4-15 % --
+    // 378.8 -> 329.5 us at N 4096, K 2048, tools/grouped_bench.py.)
+    if (best != nullptr && std::strcmp(best->name, "duo_256x256") == 0) {
         // (also with one tile per CU: 98.0 against 99.4 us sustained on 4096 x 4096 x 7168, tools/sustained.py)
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, "duo_p_256x256") == 0)
