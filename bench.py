@@ -13,7 +13,7 @@ deepgemm_amd/ep.py) and reports the dispatch / GEMM / combine time split.  ``--g
 dense FP8 MFMA peak or the HBM peak, timed with HIP events on the launch stream), at N = 1 ``cpu_baseline`` (the reference's
 CPU-runnable test expression timed on the host cores of this box) and, on the default run, ``secondary``: the same
 measurement, shortened, for the other BASELINE configurations (C3 per layout, C4, C5), the wgrad recipe, the K-grouped
-GEMM and the packed-UE8M0 form of C2.
+GEMM, the packed-UE8M0 form of C2 and two dgrad entries of the reference sweep (K tail, K split).
 """
 import argparse
 import json
@@ -31,8 +31,8 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
-WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0']
-SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0']
+WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit']
+SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit']
 
 
 def measured_traffic(kernel: str):
@@ -133,6 +133,23 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         desc = {'workload': f'fp8_gemm_{layout} M={m} N={n} K={k} (BASELINE configs[2]; whole operator call, majorness from strides)',
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+    elif name in ('dgrad_ktail', 'dgrad_ksplit'):
+        # two dgrad entries of the reference's dense sweep (tests/generators.py:139-145: fp8_gemm_nn with m = 4096 and the (n, k) pairs
+        # swapped): K = 2112 is not a multiple of 128 (K-tail stage), n = 512 with K = 32768 fills a quarter of the chip (K split)
+        m, n, k = (4096, 7168, 2112) if name == 'dgrad_ktail' else (4096, 512, 32768)
+        for i in range(sets):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k, True, False)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            cases.append(case)
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        kb = -(-k // 128)
+        flops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * m * kb + 4 * (-(-n // 128)) * kb + 2 * m * n
+        desc = {'workload': f'fp8_gemm_nn M={m} N={n} K={k} (dgrad entry of the reference sweep, tests/generators.py:139-145; '
+                            + ('K tail on the fast path' if name == 'dgrad_ktail' else 'under-filled launch: K split') + ')',
+                'm': m, 'n': n, 'k': k}
+        check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name == 'wgrad':
         m, n, k = 4096, 4096, 7168
         for i in range(sets):
@@ -208,7 +225,7 @@ def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, ke
 
 def run_secondary(sets: int):
     """The other configurations, shortened (about 0.3 s of launches each after a short warm-up): HIP-event time per operator
-    call and its roofline fraction.  For the MN-major layouts of C3 the call includes the re-majoring pass of operand A."""
+    call and its roofline fraction (MN-major operands are read as they are: one kernel per call)."""
     out = []
     for name in SECONDARY:
         try:

@@ -114,7 +114,6 @@ const Config kConfigs[] = {
     // operand B MN-major ([K][N]; the nn / tn layouts): the same kernels with LDS-DMA row pieces + transpose reads for B
     {"duo_bmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true>, true, true, true},
     {"duo_bmn_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, false, true, false, false, false, true>, true},
-    {"duo_bmn2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, false, true>, true, true},   // contiguous, two-pass
     // operand A MN-major ([K][M]; the tt / tn layouts of the dense GEMM): A through row pieces + transpose reads, B K-major / MN-major
     {"duo_amn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, true>, true, false, true},
     {"duo_abmn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, true, false, true>, true, false, true},
@@ -323,7 +322,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         }
         // many rounds of a contiguous layout aligned to 128 rows: the two-pass 256-row tile (same rule as for K-major B)
         if (p.gemm_type == dg::kContiguous && bm_must_divide == 128 && tiles256 >= 4L * num_cus())
-            pick = "duo_bmn2_256x256";
+            pick = "duo_bmn_256x256";     // (persistent, two-pass walk: 4-14 % over the one-tile-per-workgroup launch)
         if (!contiguous || bm_must_divide % 128 == 0)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)

@@ -14,7 +14,7 @@ LLVM_OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 
 PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED> for the duo kernels
     'dg_fp8_gemm_duo_kernel<256,256,2,4,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,0,1>',
-    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,0,1>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,0,1,0,0,0,0>',
+    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,0,1>',
     'dg_fp8_gemm_duo_kernel<128,256,2,4,1,0,1,0,0,1>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,1,1,1,0,0,1>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,1,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,1,0,0>',
     'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,1,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,1,1>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,1,0>',
     'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,1,1>',

@@ -343,7 +343,7 @@ def test_m_grouped_contiguous_vs_oracle(use_psum, b_k_major):
         want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
         oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), use_psum)
         fast = ['pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'duo_128x256'] + ([] if use_psum else ['duo_256x256', 'duo_p_256x256'])   # duo: two-pass 256-row tiles
-        fast_nn = (['duo_bmn_128x256'] + ([] if use_psum else ['duo_bmn2_256x256'])) if n % 16 == 0 else []   # MN-major B read natively
+        fast_nn = (['duo_bmn_128x256'] + ([] if use_psum else ['duo_bmn_256x256'])) if n % 16 == 0 else []   # MN-major B read natively
         for cfg in (['auto', 'generic_128x128'] + (fast if b_k_major else fast_nn)):
             dg.set_forced_config(cfg)
             case.d.fill_(float('nan'))
