@@ -587,9 +587,9 @@ def test_import_is_fork_safe_and_bench_runs():
     assert line['n_gpus'] == 1 and line['steps'] == 4 and line['unit'] == 'TFLOPS' and line['value'] > 0
     assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1 and line['cpu_baseline']['value'] > 0
     assert 'zero-copy' in line['config']['sfa_layout']
-    # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0
+    # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0, two dgrad entries
     secondary = line['secondary']
-    assert len(secondary) == 9 and not [s for s in secondary if 'error' in s], secondary
+    assert len(secondary) == 11 and not [s for s in secondary if 'error' in s], secondary
     for rec in secondary:
         assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
     assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
