@@ -3,6 +3,7 @@
 // 160 KiB LDS / wave64) and kernel launches.  Kernels are compiled ahead of time for gfx950; there is no JIT.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -357,6 +358,21 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // beats one deep-ring tile per CU (tools/sweep.py: 4096 x 512 x 32768: 88.6 us against 166.4; 1024 x 1024 x 16384: 41.3 / 79.5;
         // 1024 x 512 x 8192: 30.5 / 42.8; break-even near K = 7168 -- 512 x 4096 x 7168: 38.7 / 39.7, 4096 x 512 x 4096: 32.6 / 25.3).
         // Model: stream = 5 us + 0.66 (64 x 128) or 0.36 (64 x 32) us per K block, split = 22 us + 1.05 us per K block of a piece.
+        // Decode-sized M with MORE 64 x 128 tiles than CUs: the second round of one-tile-per-CU stream tiles is mostly idle, while the
+        // 128 x 256 duo tile (two-segment schedule, 3 x 32 KiB weight ring) covers the same columns in half as many tiles and reaches
+        // the HBM floor -- 6 experts x 6144 x 7168: 72.1 -> 48.0 us, x 7168 x 3072: 37.2 -> 26.4 (tools/masked_bench.py); with at most
+        // one round (C5: 256 tiles) or many rounds (32 experts: HBM-bound either way) the stream tile stays.  Model (us): stream
+        // 5 + rounds x K blocks x 0.62, duo 6 + rounds x K blocks x 0.80, both floored by the weight bytes at 5.8 TB/s.
+        if (pick != nullptr && m_hint <= 64 && std::strcmp(pick, "stream_64x128") == 0 && tiles128 > num_cus()) {
+            const long slots = num_cus();
+            const long num_kb = p.k / 128;
+            const long rounds_s = (tiles128 + slots - 1) / slots;
+            const long rounds_d = (static_cast<long>(groups) * ceil_div(p.n, 256) + slots - 1) / slots;
+            const double floor_us = static_cast<double>(groups) * p.n * p.k / 5.8e6;
+            const double t_s = std::max(floor_us, 5.0 + rounds_s * num_kb * 0.62), t_d = std::max(floor_us, 6.0 + rounds_d * num_kb * 0.80);
+            if (t_d < 0.9 * t_s)
+                pick = "duo_128x256";
+        }
         if (pick != nullptr && std::strcmp(pick, "stream_64x128") == 0 &&
             static_cast<double>(groups) * p.n * p.k >= 200e6)
             pick = "stream_nt_64x128";
