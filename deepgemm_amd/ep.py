@@ -7,7 +7,7 @@ GEMM are independent problems that share nothing but the token stream, so rank `
 one step is
 
   1. *dispatch*: every (token row, expert) pair travels to the expert's owner: ``K`` FP8 bytes + ``K / 128`` FP32 scales
-     per row, variable split sizes exchanged first with a tiny int64 all-to-all (this replaces the in-kernel count
+     per row in ONE payload all-to-all, variable split sizes exchanged first with a tiny int64 all-to-all (this replaces the in-kernel count
      exchange of the reference's fused kernel, deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:357-405);
   2. *local GEMM*: received rows are packed per local expert into the masked layout ``[G_local, M_max, K]`` with the
      row counts in a device tensor ``masked_m`` (the kernel reads them on the device) and
@@ -85,9 +85,16 @@ def dispatch(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, max_m: i
     send_splits = send_counts.sum(dim=1).tolist()
     recv_splits = recv_counts.sum(dim=1).tolist()
 
+    # one payload per row: K FP8 bytes followed by the row's K / 128 FP32 scales as bytes -- a single all-to-all instead of one for
+    # the data and one for the scales (at decode sizes every collective is latency, not bandwidth)
     rows = flat_row[order]
-    payload = _all_to_all_rows(x_fp8.view(torch.uint8)[rows], send_splits, recv_splits, group).view(torch.float8_e4m3fn)
-    payload_sf = _all_to_all_rows(x_sf[rows], send_splits, recv_splits, group)
+    k, sf_bytes = x_fp8.size(1), 4 * x_sf.size(1)
+    packed = torch.empty((rows.numel(), k + sf_bytes), dtype=torch.uint8, device=device)
+    packed[:, :k] = x_fp8.view(torch.uint8)[rows]
+    packed[:, k:] = x_sf.contiguous().view(torch.uint8).view(tokens, sf_bytes)[rows]
+    received = _all_to_all_rows(packed, send_splits, recv_splits, group)
+    payload = received[:, :k].contiguous().view(torch.float8_e4m3fn)
+    payload_sf = received[:, k:].contiguous().view(torch.float)
 
     # received rows arrive rank by rank, inside a rank expert by expert: recover (local expert, slot) of every row
     recv_expert = torch.repeat_interleave(torch.arange(per_rank, device=device).repeat(world), recv_counts.reshape(-1))
@@ -102,7 +109,6 @@ def dispatch(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, max_m: i
     pos_in_run = torch.arange(payload.size(0), device=device) - torch.repeat_interleave(flat_run_begin, recv_counts.reshape(-1))
     recv_slot = run_start + pos_in_run
 
-    k = x_fp8.size(1)
     a = torch.zeros((per_rank, max_m, k), dtype=torch.float8_e4m3fn, device=device)
     sfa = torch.zeros((per_rank, max_m, x_sf.size(1)), dtype=torch.float, device=device)
     a.view(torch.uint8)[recv_expert, recv_slot] = payload.view(torch.uint8)
