@@ -435,6 +435,34 @@ def test_m_grouped_contiguous_split_k_tail(use_psum, actual_ms, n, k, alignment)
     assert calc_diff(torch.nan_to_num(plain), torch.nan_to_num(outs[0])) < 1e-6
 
 
+def test_m_grouped_contiguous_nn_split_k_tail():
+    """m_grouped_fp8_gemm_nn_contiguous (MN-major B read natively) with a partial last round and a long K loop: the K-split tail of
+    the MN-major-B form (duo_sk_bmn_128x256) -- reference gate on all rows, oracle on a row sample per group, padding rows zero,
+    bit-repeatable."""
+    gen.reset_seed(21)
+    actual_ms = [520, 500, 640, 400, 512, 700, 384, 512]
+    dg.set_mk_alignment_for_contiguous_layout(128)
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, 2048, 7168, False, False, actual_ms=actual_ms)
+    tiles = (case.a[0].size(0) // 128) * (2048 // 256)
+    assert tiles % torch.cuda.get_device_properties(0).multi_processor_count != 0
+    outs = []
+    for _ in range(3):
+        d = torch.full_like(case.d, float('nan'))
+        dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, d, case.grouped_layout)
+        outs.append(d)
+    assert dg.last_config() == 'duo_sk_bmn_128x256', dg.last_config()
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    assert calc_diff(torch.nan_to_num(outs[0]), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
+    start = 0
+    for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+        rows = torch.tensor(sorted(random.sample(range(start, start + actual), 6)))
+        want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows.cuda()].cpu(), case.a[1][rows.cuda()].cpu(),
+                                                  case.b[0][g].cpu(), case.b[1][g].cpu())
+        assert_close_to_oracle(outs[0][rows.cuda()], want, f'group {g}')
+        assert bool((outs[0][start + actual:start + aligned] == 0).all())
+        start += aligned
+
+
 @pytest.mark.parametrize('m,n,k', [(1024, 512, 8192), (4096, 576, 7168), (200, 1024, 16384)])
 @pytest.mark.parametrize('b_k_major', [True, False])
 @pytest.mark.parametrize('out_dtype,accumulate', [(torch.bfloat16, False), (torch.float, True)])
