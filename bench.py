@@ -13,7 +13,7 @@ deepgemm_amd/ep.py) and reports the dispatch / GEMM / combine time split.  ``--g
 dense FP8 MFMA peak or the HBM peak, timed with HIP events on the launch stream), at N = 1 ``cpu_baseline`` (the reference's
 CPU-runnable test expression timed on the host cores of this box) and, on the default run, ``secondary``: the same
 measurement, shortened, for the other BASELINE configurations (C3 per layout, C4, C5), the wgrad recipe, the K-grouped
-GEMM, the packed-UE8M0 form of C2 and two dgrad entries of the reference sweep (K tail, K split).
+GEMM, the packed-UE8M0 forms of C2 and C5 and two dgrad entries of the reference sweep (K tail, K split).
 """
 import argparse
 import json
@@ -31,8 +31,8 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
-WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit']
-SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit']
+WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0']
+SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0']
 
 
 def measured_traffic(kernel: str):
@@ -195,17 +195,22 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     else:
         bound = 'hbm'
+        packed = name == 'masked_ue8m0'
         groups, max_m, expected, n, k = 8, 64, 48, 4096, 7168
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_m_grouped_masked(groups, max_m, expected, n, k, masked_ms=None)
-            case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            case = gen.generate_m_grouped_masked(groups, max_m, expected, n, k, masked_ms=None, use_ue8m0=packed)
+            if packed:      # power-of-two scales as packed UE8M0 words (the reference's SM100 input format): hardware-scaled MFMA
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+            else:
+                a, b = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1])), case.b
             cases.append(case)
-            calls.append(lambda c=case: dg.m_grouped_fp8_gemm_nt_masked(c.a, c.b, c.d, c.masked_m, expected))
+            calls.append(lambda a=a, b=b, c=case: dg.m_grouped_fp8_gemm_nt_masked(a, b, c.d, c.masked_m, expected))
         valid = int(cases[0].masked_m.sum().item())
         flops = 2.0 * valid * n * k
         nbytes = count_bytes(cases[0].a, cases[0].d) * valid / (max_m * groups) + count_bytes(cases[0].b)
-        desc = {'workload': f'm_grouped_fp8_gemm_nt_masked G={groups} (64 experts / 8 GPUs) M<=64 N={n} K={k} (BASELINE configs[4], one rank)',
+        desc = {'workload': f'm_grouped_fp8_gemm_nt_masked G={groups} (64 experts / 8 GPUs) M<=64 N={n} K={k} (BASELINE configs[4], one rank)' +
+                            (', packed UE8M0 scales' if packed else ''),
                 'valid_m': valid, 'n': n, 'k': k, 'groups': groups}
 
         def check():
@@ -229,7 +234,7 @@ def run_secondary(sets: int):
     out = []
     for name in SECONDARY:
         try:
-            calls, flops, nbytes, desc, check, bound = make_workload(name, 2 if name != 'masked' else sets)
+            calls, flops, nbytes, desc, check, bound = make_workload(name, 2 if not name.startswith('masked') else sets)
             calls[0]()
             torch.cuda.synchronize()
             diff = check()

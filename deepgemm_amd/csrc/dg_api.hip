@@ -197,17 +197,20 @@ const Config kConfigs[] = {
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 // Kernels of the packed-UE8M0 entry points (hardware-scaled MFMA); selected by launch_e8, forced by name for A/B runs.
-struct E8Config { const char* name; KernelFn fn; int bm, threads; bool whole_quads; bool grouped_ok; };
+struct E8Config { const char* name; KernelFn fn; int bm, bn, threads; bool whole_quads; bool grouped_ok; bool stream; };
 const E8Config kE8Configs[] = {
-    {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, 256, true, true},
-    {"e8_quad_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>, 128, 256, false, true},
-    {"e8_duo_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
+    {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, 256, 256, true, true, false},
+    {"e8_quad_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>, 128, 256, 256, false, true, false},
+    {"e8_duo_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
+    // decode-sized M (masked / dense, M <= 64 per group): the deep-ring stream tile with the quad's words riding in every stage
+    {"e8_stream_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, true>, 64, 128, 256, false, true, true},
+    {"e8_stream_nt_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, true>, 64, 128, 256, false, true, true},
 #ifdef DG_EXPERIMENTS
-    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 512, false, false},
-    {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, true, false},
-    {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, 256, true, false},
-    {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, 256, true, false},
-    {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, 256, true, false},
+    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
+    {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
+    {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, 256, 256, true, false, false},
+    {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, 256, 256, true, false, false},
+    {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, 256, 256, true, false, false},
 #endif
 };
 
@@ -571,6 +574,24 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
         if (p.gemm_type == dg::kContiguousPsum)
             big = false;                            // the psum walk is written for tiles that divide the alignment
         cfg = big ? &kE8Configs[0] : &kE8Configs[1];
+        // decode-sized M with a round of 64 x 128 tiles to fill the chip (the rule of the FP32-scale stream kernel): weights stream
+        // once, five K blocks in flight per CU; non-temporal weight policy when the launch's weights exceed the Infinity Cache
+        const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
+        if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && m_hint <= 64 && tiles128 >= 96 && p.sfa_sm == 1 && p.sfb_sn == 1) {
+            bool stream = true;
+            if (tiles128 > num_cus()) {         // more stream tiles than CUs: the round model of select_config (128 x 256 tile = the quad form)
+                const long slots = num_cus(), num_kb = p.k / 128;
+                const long rounds_s = (tiles128 + slots - 1) / slots, rounds_d = (groups * ceil_div(p.n, 256) + slots - 1) / slots;
+                const double floor_us = static_cast<double>(groups) * p.n * p.k / 5.8e6;
+                stream = !(std::max(floor_us, 6.0 + rounds_d * num_kb * 0.80) < 0.9 * std::max(floor_us, 5.0 + rounds_s * num_kb * 0.62));
+            }
+            if (stream)
+                cfg = static_cast<double>(groups) * p.n * p.k >= 200e6 ? &kE8Configs[4] : &kE8Configs[3];
+        }
+    }
+    if (cfg->stream && (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum)) {
+        g_last_error = std::string("config '") + cfg->name + "' does not implement the contiguous layouts";
+        return 3;
     }
     if (cfg->whole_quads && p.k % 512 != 0) {
         g_last_error = std::string("config '") + cfg->name + "' needs k % 512 == 0 (whole packed scale words)";
@@ -587,7 +608,7 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     }
     g_last_config = cfg->name;
     p.num_m_tiles = ceil_div(p.m, cfg->bm);
-    p.num_n_tiles = ceil_div(p.n, 256);
+    p.num_n_tiles = ceil_div(p.n, cfg->bn);
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;

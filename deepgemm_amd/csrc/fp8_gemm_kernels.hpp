@@ -1818,17 +1818,22 @@ void dg_fp8_gemm_duo_kernel(const GemmParams p) {
 // B_AUX: cache-policy bits of the weight stream's LDS-DMA (2 = nt: a weight byte is read by exactly one CU, once).
 // KBS: K blocks per ring stage -- a wave requests KBS x 128 contiguous bytes of each row back to back, which is what
 // gives the HBM controller row-buffer hits on K-major weights whose rows lie K bytes apart.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1>
+// E8: packed UE8M0 scales (one int32 word of four exponent bytes per row of A and per ROW of B per four K blocks; p.sfa / p.sfb hold the
+// words, strides per K quad): every stage carries the words of its K block's quad (64 for A, BN for B), the block's byte is
+// shifted down by VALU and the hardware-scaled MFMA accumulates in place -- the decode-sized form of the packed-UE8M0 path.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false>
 __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256;
+    constexpr int SFB_PIECES = E8 ? (BN + 63) / 64 : 1;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256 * SFB_PIECES;
     constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = SFB_OFF + SFB_BYTES;
     constexpr int STAGE_BYTES = KBS * BLOCK_BYTES;
     constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
-    constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + 2) * KBS;      // per wave per stage, scale pieces included
+    constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + 1 + SFB_PIECES) * KBS;      // per wave per stage, scale pieces included
+    static_assert(!E8 || (MS == 4 && KBS == 1), "packed-scale form: 64-row tiles, one K block per stage");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA piece and one SFB value per tile");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
@@ -1878,12 +1883,15 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                                                                   (b_rows - 1) * ldb + p.k, 0x00020000);
             // SFA of the tile's rows: MN-major, rows m0 .. m0+63 are 256 contiguous bytes per K block
             const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+            // (E8: the strides are per K quad and the "K block" index of a scale row is j >> 2)
+            const int num_sf_k = E8 ? (num_kb + 3) / 4 : num_kb;
             float* sfa_tile = const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0;
             const int sfa_rows = imin(p.m - t.m0, BM);
-            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_kb - 1) * sfa_kb_stride + sfa_rows * 4, 0x00020000);
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_sf_k - 1) * sfa_kb_stride + sfa_rows * 4, 0x00020000);
             float* sfb_tile = const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg +
-                              static_cast<int64_t>(t.n0 / 128) * p.sfb_sn;
-            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_kb - 1) * sfb_kb_stride + 4, 0x00020000);
+                              (E8 ? static_cast<int64_t>(t.n0) : static_cast<int64_t>(t.n0 / 128) * p.sfb_sn);
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_sf_k - 1) * sfb_kb_stride + (E8 ? imin(p.n - t.n0, BN) * 4 : 4),
+                                                                  0x00020000);
 
             // All pieces of K block j into ring slot j % STAGES (slot_off in bytes).  Blocks past the end are issued as
             // out-of-range no-ops so that the vmcnt arithmetic stays exact.
@@ -1906,12 +1914,21 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, B_AUX & 3);
                 }
                 // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
+                const int jsf = E8 ? j >> 2 : j;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     sfa_rsrc, (__attribute__((address_space(3))) void*)(stage + SFA_OFF), 4,
-                    static_cast<int>(static_cast<unsigned>(lane * 4 + j * sfa_kb_stride) | oob), 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF), 4,
-                    static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob), 0, 0, 0);
+                    static_cast<int>(static_cast<unsigned>(lane * 4 + jsf * sfa_kb_stride) | oob), 0, 0, 0);
+                if constexpr (E8) {
+                    #pragma unroll
+                    for (int r = 0; r < SFB_PIECES; ++r)        // the words of the tile's BN weight rows: 64 per piece
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF + r * 256), 4,
+                            static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + jsf * sfb_kb_stride) | oob), 0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF), 4,
+                        static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob), 0, 0, 0);
+                }
             };
 
             auto issue_stage = [&](int slot_off, int sb) {            // stage sb = K blocks sb * KBS .. + KBS - 1
@@ -1936,6 +1953,34 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 if (sb * KBS + u >= num_kb)
                     break;
                 const uint8_t* stage = lds + cur + u * BLOCK_BYTES;
+                if constexpr (E8) {
+                    const int shift = ((sb * KBS + u) & 3) * 8;         // this block's byte of the quad's words
+                    const v4i qa = *reinterpret_cast<const v4i*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                    int ea[MS], eb[NS];
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        ea[ms] = static_cast<int>(static_cast<unsigned>(qa[ms]) >> shift);
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        // the weight row in MFMA row slot i = lane & 15 of N-subtile ns (see b_row_perm)
+                        const int col = b_row_perm<WN>(wn * WN + ns * 16 + (lane & 15));
+                        eb[ns] = static_cast<int>(*reinterpret_cast<const unsigned*>(stage + SFB_OFF + col * 4) >> shift);
+                    }
+                    const uint8_t* a_tile = stage + (wm * WM) * 128;
+                    const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;
+                    v8i bf[NS];
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            acc[ms][ns] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ns], af, acc[ms][ns], 0, 0, 0, eb[ns], 0, ea[ms]);
+                    }
+                    continue;
+                }
                 float sa[MS];
                 if constexpr (MS == 4) {
                     const v4f q = *reinterpret_cast<const v4f*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
@@ -1971,10 +2016,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_stream_kernel(const GemmParams p) {
-    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS>(p);
+    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

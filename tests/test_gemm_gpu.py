@@ -615,9 +615,9 @@ def test_import_is_fork_safe_and_bench_runs():
     assert line['n_gpus'] == 1 and line['steps'] == 4 and line['unit'] == 'TFLOPS' and line['value'] > 0
     assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1 and line['cpu_baseline']['value'] > 0
     assert 'zero-copy' in line['config']['sfa_layout']
-    # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0, two dgrad entries
+    # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0 (C2, C5), two dgrad entries
     secondary = line['secondary']
-    assert len(secondary) == 11 and not [s for s in secondary if 'error' in s], secondary
+    assert len(secondary) == 12 and not [s for s in secondary if 'error' in s], secondary
     for rec in secondary:
         assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
     assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
@@ -851,11 +851,11 @@ def test_packed_ue8m0_m_grouped_masked(masked_ms, max_m, n, k):
     oracle.m_grouped_fp8_gemm_nt_masked(*cpu_pair(case.a), *cpu_pair(case.b), want, case.masked_m.cpu())
     a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
     expected_m = max(1, int(sum(masked_ms) / len(masked_ms)))
-    for cfg in ['auto', 'e8_quad_128x256'] + (['e8_quad_256x256'] if k % 512 == 0 else []):
+    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128'] + (['e8_quad_256x256'] if k % 512 == 0 else []):
         dg.set_forced_config(cfg)
         case.d.fill_(float('nan'))
         dg.m_grouped_fp8_gemm_nt_masked(a, b, case.d, case.masked_m, expected_m)
-        assert dg.last_config().startswith('e8_quad'), dg.last_config()
+        assert dg.last_config().startswith('e8_'), dg.last_config()
         for g, rows in enumerate(masked_ms):
             if rows:
                 assert_close_to_oracle(case.d[g, :rows], want[g, :rows], f'{cfg} group {g}')
