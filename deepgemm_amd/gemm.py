@@ -84,6 +84,14 @@ def _b_ok_beside_mn_major_a(b: torch.Tensor, n: int, k: int) -> bool:
             k * b.stride(1) < (1 << 31))
 
 
+def _few_tiles_long_k(m: int, n: int, k: int) -> bool:
+    """The MN-major-A kernels exist for 256 x 256 tiles only and are never K-split: a problem whose 256 x 256 tiles cover less than
+    half the chip while the K loop is long (wgrad of a narrow layer: 576 x 4096 x 7168 = 48 tiles) is better served by re-majoring A
+    (a few microseconds) and the 128 x 256 tiles of the K-major-A kernels, which the K split can spread over the idle CUs."""
+    cus = int(lib.dg_get_num_cus())
+    return -(-m // 256) * -(-n // 256) * 2 < cus and k >= 4096
+
+
 def _dense_operands(a_data: torch.Tensor, b_data: torch.Tensor, sfa: torch.Tensor, gran_n: int, m: int, n: int, k: int):
     """The FP8 operands as the C entry will read them: as they are wherever a kernel takes that majorness natively, re-majored
     into K-major scratch (dg_transpose_fp8) otherwise.  One place for the cached and the uncached path of fp8_gemm_nt."""
@@ -91,7 +99,7 @@ def _dense_operands(a_data: torch.Tensor, b_data: torch.Tensor, sfa: torch.Tenso
     if gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n):
         return a_data, b_data       # recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are
     if gran_n == 128 and sfa.stride(0) == 1:
-        if a_data.stride(-1) != 1 and _a_mn_major_self_ok(a_data, m, k):
+        if a_data.stride(-1) != 1 and _a_mn_major_self_ok(a_data, m, k) and not _few_tiles_long_k(m, n, k):
             # large MN-major A: transpose reads (duo_amn / duo_abmn); B as it is when that kernel can take it, else re-majored
             if _b_ok_beside_mn_major_a(b_data, n, k):
                 return a_data, b_data
