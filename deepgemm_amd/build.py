@@ -21,9 +21,25 @@ if os.environ.get('DG_EXPERIMENTS', '') not in ('', '0'):
 
 STAMP_PATH = LIB_PATH + '.flags'      # the flag set the library was built with (DG_EXPERIMENTS toggles must rebuild)
 
+# The fast kernels rely on properties of hipcc's code generation that the language does not promise (registers written by inline-asm
+# loads are not touched before the hand-placed wait; no spill inside a K loop).  tests/test_codegen.py checks them on the built
+# library; they were validated with this toolchain.  Another version still builds -- with a warning to re-run that test.
+VALIDATED_HIP_VERSIONS = ('7.2',)
+
+
+def _hipcc_version() -> str:
+    try:
+        out = subprocess.run([HIPCC, '--version'], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return 'unknown'
+    for line in out.splitlines():
+        if line.startswith('HIP version:'):
+            return line.split(':', 1)[1].strip()
+    return 'unknown'
+
 
 def _stamp() -> str:
-    return ' '.join([HIPCC, *FLAGS])
+    return ' '.join([HIPCC, _hipcc_version(), *FLAGS])
 
 
 def is_stale() -> bool:
@@ -44,6 +60,10 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         tmp = LIB_PATH + f'.{os.getpid()}.tmp'
         cmd = [HIPCC, *FLAGS, *SOURCES, '-o', tmp]
+        version = _hipcc_version()
+        if not version.startswith(VALIDATED_HIP_VERSIONS):
+            print(f'deepgemm_amd: building with HIP {version}; the kernels\' code-generation assumptions were validated with '
+                  f'{", ".join(VALIDATED_HIP_VERSIONS)} -- run tests/test_codegen.py on the result', file=sys.stderr)
         if verbose:
             print(' '.join(cmd), file=sys.stderr)
         subprocess.check_call(cmd, cwd=CSRC)
