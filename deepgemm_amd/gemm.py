@@ -158,6 +158,15 @@ def _packed_sf_mn_major(sf: torch.Tensor, mn: int, k: int) -> torch.Tensor:
     return get_mn_major_tma_aligned_tensor(sf.view(torch.float)).view(torch.int)
 
 
+def _unpack_ue8m0(sf_packed: torch.Tensor, k: int) -> torch.Tensor:
+    """Packed UE8M0 words [mn, ceil(k / 512)] (byte j of word q = exponent of K block 4 q + j, 127 = 1.0) -> FP32 scales
+    [mn, ceil(k / 128)] = 2^(e - 127), exactly."""
+    shifts = torch.tensor([0, 8, 16, 24], dtype=torch.int32, device=sf_packed.device)
+    exps = (sf_packed.unsqueeze(-1) >> shifts) & 0xff                       # [mn, kq, 4]
+    exps = exps.reshape(sf_packed.size(0), -1)[:, :-(-k // 128)]
+    return (exps << 23).view(torch.float).contiguous()
+
+
 def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a, recipe_b) -> None:
     """Power-of-two scales handed over as packed exponent bytes (the reference's SM100 format, recipe (1, 1, 128)):
     hardware-scaled MFMA path, no FP32 promotion."""
@@ -172,7 +181,16 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
     host_assert((m, n) == tuple(d.shape) and k == k_, 'm == m_ and n == n_ and k == k_')
     if _early_return(m, n, k, d, c):
         return
-    host_assert(k % 128 == 0, 'k % 128 == 0')
+    if k % 128 != 0:
+        # A partial last K block (the reference's SM100 kernels take any K: TMA zero-fills): the hardware-scaled kernels need whole
+        # blocks, so the exponents are expanded to FP32 scales -- exactly, they are powers of two -- and the recipe (1, 1, 128) path
+        # computes the same sums (layout-agnostic kernel: correct, not fast).  `c` has been folded into `d` by _early_return.
+        host_assert(a_sf.dim() == 2 and b_sf.dim() == 2 and a_sf.size(0) == m and b_sf.size(0) == n and
+                    a_sf.size(1) == -(-k // 512) and b_sf.size(1) == -(-k // 512),
+                    'sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4)')
+        fp8_gemm_nt((a_data, _unpack_ue8m0(a_sf, k)), (b_data, _unpack_ue8m0(b_sf, k)), d, d if c is not None else None,
+                    recipe=(1, 1, 128))
+        return
     sfa, sfb = _packed_sf_mn_major(a_sf, m, k), _packed_sf_mn_major(b_sf, n, k)
     require_device(a_data, b_data, sfa, sfb, d)
     a_data = a_data if a_data.stride(-1) == 1 else _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)

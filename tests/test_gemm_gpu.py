@@ -840,6 +840,25 @@ def test_packed_ue8m0_m_grouped_contiguous(use_psum):
                 assert calc_diff(torch.nan_to_num(case.d), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
 
 
+@pytest.mark.parametrize('m,n,k', [(256, 384, 576), (130, 264, 2112)])
+def test_packed_ue8m0_k_tail(m, n, k):
+    """Packed UE8M0 scales with K not a multiple of 128 (the reference's SM100 kernels take any K): the exponents are expanded to
+    exact FP32 scales and the recipe (1, 1, 128) path computes the result -- oracle parity, accumulation included."""
+    gen.reset_seed(m + k)
+    for accumulate in (False, True):
+        case = gen.generate_normal(m, n, k, use_ue8m0=True, accumulate=accumulate, out_dtype=torch.float if accumulate else torch.bfloat16)
+        c_cpu = case.c.cpu().clone() if accumulate else None
+        want = oracle_dense(case, c_cpu=c_cpu)
+        a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+        assert a[1].dtype == torch.int and a[1].shape == (m, -(-k // 512))
+        dg.fp8_gemm_nt(a, b, case.d, c=case.c if accumulate else None)
+        if accumulate:
+            assert_close_fp32(case.d, want, 'packed scales, K tail, accumulate')
+        else:
+            assert_close_to_oracle(case.d, want, 'packed scales, K tail')
+        assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+
+
 @pytest.mark.parametrize('masked_ms,max_m,n,k', [([5, 0, 64, 33], 64, 256, 384), ([200, 1, 129], 256, 520, 512),
                                                   ([20] * 6 + [0, 64], 64, 4096, 512), ([700, 130], 1024, 768, 1024)])
 def test_packed_ue8m0_m_grouped_masked(masked_ms, max_m, n, k):
