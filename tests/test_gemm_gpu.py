@@ -585,6 +585,40 @@ def test_m_grouped_masked_reference_shapes(groups, expected_m, max_m, n, k):
         assert bool(torch.isnan(case.d[g, rows:]).all()), f'group {g}: rows >= masked_m must not be written'
 
 
+@pytest.mark.parametrize('num_sms', [40, 200])
+def test_set_num_sms_limits_the_persistent_kernels(num_sms):
+    """set_num_sms (csrc/apis/runtime.hpp:12-41): the persistent launches, the masked walk and the K split size their grids and their
+    piece counts from it; results do not depend on it (K-split sums: to rounding)."""
+    gen.reset_seed(31)
+    dense = gen.generate_normal(1024, 1024, 1024)
+    skinny = gen.generate_normal(1024, 512, 8192)
+    masked = gen.generate_m_grouped_masked(6, 256, 0, 512, 512, masked_ms=[200, 3, 0, 256, 77, 130])
+    contig = gen.generate_m_grouped_contiguous(4, 0, 1024, 1024, actual_ms=[300, 77, 512, 129])
+
+    def run_all():
+        outs = []
+        for case, call in ((dense, lambda c, d: dg.fp8_gemm_nt(c.a, c.b, d)), (skinny, lambda c, d: dg.fp8_gemm_nt(c.a, c.b, d)),
+                           (masked, lambda c, d: dg.m_grouped_fp8_gemm_nt_masked(c.a, c.b, d, c.masked_m, 128)),
+                           (contig, lambda c, d: dg.m_grouped_fp8_gemm_nt_contiguous(c.a, c.b, d, c.grouped_layout))):
+            d = torch.zeros_like(case.d)
+            call(case, d)
+            outs.append((d, dg.last_config()))
+        return outs
+    want = run_all()
+    dg.set_num_sms(num_sms)
+    try:
+        assert dg.get_num_sms() == num_sms
+        got = run_all()
+    finally:
+        dg.set_num_sms(0)
+    for (d0, cfg0), (d1, cfg1) in zip(want, got):
+        if 'sk' in cfg0 or 'sk' in cfg1 or cfg0 != cfg1:
+            assert calc_diff(d1, d0) < 1e-6, (cfg0, cfg1)
+        else:
+            assert torch.equal(d1, d0), (cfg0, cfg1)
+    assert calc_diff(got[0][0], dense.ref_d) < gen.FP8_MAX_DIFF and calc_diff(got[1][0], skinny.ref_d) < gen.FP8_MAX_DIFF
+
+
 def test_import_is_fork_safe_and_bench_runs():
     """(i) importing the package must not initialise the GPU runtime: a forked child can still pick its device (reference
     tests/test_lazy_init.py:7-20); (ii) bench.py prints one well-formed JSON line carrying roofline and cpu_baseline."""
