@@ -282,11 +282,12 @@ long split_k_pieces(long tiles, long slots, long num_kb) {
     return pieces >= 2 ? pieces : 0;
 }
 
-// Does the split pay?  It trades (1 - 1/pieces) of a tile's K loop (~0.9 us per K block of a 128 x 256 tile) for the partial-tile
-// exchange (~17 us + 1.3 us per piece; tools/grouped_bench.py on 8 groups x N 4096 with 16..128 tail tiles): K = 7168 gains
-// 8..21 us of ~180, K = 4096 0..7 us of ~100, K = 2048 loses.
+// Does the split pay?  It trades (1 - 1/pieces) of a tile's K loop (~1 us per K block of a 128 x 256 tile) for the partial-tile
+// exchange: the FP32 partials go to the workspace and a second kernel sums them (~11 us + 1 us per piece with the kernel
+// boundary; the single-kernel form with a last-arriver reduction cost 17 us + 1.3 us per piece).  tools/grouped_bench.py,
+// 8 groups x N 4096 with 16..128 tail tiles: K = 7168 gains 15..25 us of ~175, K = 4096 5..12 us of ~100, K = 2048 about even.
 bool split_k_pays(long pieces, long num_kb) {
-    return pieces >= 2 && num_kb * (pieces - 1) * 100 > (1700 + 130 * pieces) * pieces;
+    return pieces >= 2 && num_kb * (pieces - 1) * 100 > (1100 + 100 * pieces) * pieces;
 }
 
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
@@ -360,7 +361,8 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // ... unless the K loop is long and the caller lent a workspace: cutting every 128 x 256 tile along K over the idle CUs
         // beats one deep-ring tile per CU (tools/sweep.py: 4096 x 512 x 32768: 88.6 us against 166.4; 1024 x 1024 x 16384: 41.3 / 79.5;
         // 1024 x 512 x 8192: 30.5 / 42.8; break-even near K = 7168 -- 512 x 4096 x 7168: 38.7 / 39.7, 4096 x 512 x 4096: 32.6 / 25.3).
-        // Model: stream = 5 us + 0.66 (64 x 128) or 0.36 (64 x 32) us per K block, split = 22 us + 1.05 us per K block of a piece.
+        // Model: stream = 5 us + 0.66 (64 x 128) or 0.36 (64 x 32) us per K block, split = 16 us + 1.05 us per K block of a piece
+        // (two-phase exchange: 1024 x 512 x 8192 21.8 us, 1024 x 1024 x 16384 33.2, 512 x 4096 x 7168 31.3, 4096 x 512 x 4096 25.2 / stream 24.2).
         // Decode-sized M with MORE 64 x 128 tiles than CUs: the second round of one-tile-per-CU stream tiles is mostly idle, while the
         // 128 x 256 duo tile (two-segment schedule, 3 x 32 KiB weight ring) covers the same columns in half as many tiles and reaches
         // the HBM floor -- 6 experts x 6144 x 7168: 72.1 -> 48.0 us, x 7168 x 3072: 37.2 -> 26.4 (tools/masked_bench.py); with at most
@@ -385,7 +387,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             const long pieces = split_k_pieces(tiles, num_cus(), num_kb);
             if (pieces >= 2 && tiles < num_cus()) {
                 const double t_stream = 5.0 + num_kb * (std::strcmp(pick, "stream_64x32") == 0 ? 0.36 : 0.66);
-                const double t_split = 22.0 + static_cast<double>((num_kb + pieces - 1) / pieces) * 1.05;
+                const double t_split = 16.0 + static_cast<double>((num_kb + pieces - 1) / pieces) * 1.05;
                 if (t_split < t_stream)
                     pick = "duo_sk_128x256";
             }
@@ -544,6 +546,13 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0,
                        static_cast<hipStream_t>(stream), p);
     DG_HIP_CHECK(hipGetLastError());
+    if (cfg->split_k && p.sk_tiles > 0 && p.sk_factor >= 2) {
+        // second phase of the K split: the partial tiles' sum and the output stores, one workgroup per (tile, M-subtile row)
+        const KernelFn reduce = bmn_form ? dg::dg_split_k_reduce_kernel<128, 256, 2, 4, true>
+                                         : dg::dg_split_k_reduce_kernel<128, 256, 2, 4, false>;
+        hipLaunchKernelGGL(reduce, dim3(static_cast<unsigned>(p.sk_tiles * 4)), dim3(512), 0, static_cast<hipStream_t>(stream), p);
+        DG_HIP_CHECK(hipGetLastError());
+    }
     if (getenv("DG_PRINT_CONFIGS") != nullptr)
         fprintf(stderr, "[deepgemm_amd] type=%d m=%d n=%d k=%d groups=%d -> %s grid=%ld\n", p.gemm_type, p.m, p.n, p.k,
                 p.num_groups, cfg->name, grid);

@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace dg {
 
@@ -333,22 +334,26 @@ __device__ __forceinline__ void store_rows_full_line_natural(const GemmParams& p
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
 // NATURAL_COLS: acc[ms][ns][r] belongs to column n_base + ns*16 + lg*4 + r (B rows in their natural order in the LDS
 // image: the MN-major operand path); only the FP32 vector path and the element-wise paths exist for it.
+// ms_only >= 0: only that M-subtile is stored (the K-split reduction kernel works on one subtile row per workgroup).
 template <int MS, int NS, bool INTERLEAVED_ROWS = false, bool NT_STORE = false, bool NATURAL_COLS = false>
 __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
-                                           int m_base, int n_base) {
+                                           int m_base, int n_base, int ms_only = -1) {
     const int lane = threadIdx.x & 63, lg = lane >> 4;
     if constexpr (NATURAL_COLS) {
         if constexpr (NS == 4) {
             if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + 64 <= p.n) {
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms)
-                    store_rows_full_line_natural<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
+                    if (ms_only < 0 || ms == ms_only)
+                        store_rows_full_line_natural<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
                 return;
             }
         }
         const bool full = n_base + NS * 16 <= p.n;
         #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
+            if (ms_only >= 0 && ms != ms_only)
+                continue;
             const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
             const bool compute_row = row >= t.m_begin && row < t.m_end;
             const bool zero_row = row >= t.zero_from && row < t.zero_to;
@@ -422,12 +427,15 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
         if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + 64 <= p.n) {
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms)
-                store_rows_full_line<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
+                if (ms_only < 0 || ms == ms_only)
+                    store_rows_full_line<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
             return;
         }
     }
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
+        if (ms_only >= 0 && ms != ms_only)
+            continue;
         const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + ms : m_base + ms * 16 + (lane & 15);
         const bool compute_row = row >= t.m_begin && row < t.m_end;
         const bool zero_row = row >= t.zero_from && row < t.zero_to;
@@ -1211,9 +1219,8 @@ template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> t
 // natural order (=> 8-byte instead of 16-byte BF16 stores).  See load_fragment_tr.
 // SPLITK (persistent launch only): tail balancing for tile counts just above a multiple of the CU count.  The first
 // p.sk_first_tile tiles are walked as usual; the remaining p.sk_tiles tiles (the partial last round) are cut along K into
-// p.sk_factor pieces, one per otherwise idle CU.  Every piece writes its FP32 partial tile to the workspace, publishes it
-// (agent-scope release, then a relaxed counter increment -- MI355X_MICROARCH.md, "Workgroup dispatch ... visibility") and the
-// LAST arriver of a tile (no spinning: no residency assumption) sums all pieces in fixed order, resets the counter and stores.
+// p.sk_factor pieces, one per otherwise idle CU.  Every piece writes its FP32 partial tile to the workspace; the sum (in piece order:
+// bit-repeatable) and the output stores are done by dg_split_k_reduce_kernel, launched right behind on the same stream.
 // A_MN: operand A is MN-major ([K][M], unit stride along m, row pitch a_sk): the tn / tt layouts without the re-majoring pass.
 // Same piece / transpose-read geometry as B_MN; A rows keep their natural order (subtile ms of a wave = rows 16 ms .. 16 ms + 15),
 // so a lane's row scales come as MS dword loads (ScaleLandingN) and the epilogue runs with INTERLEAVED_ROWS = false.
@@ -1719,11 +1726,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             if (piece.split && !(t.m_end > t.m0)) {
                 store = piece.index == 0;               // an all-padding tile: its zero rows are written once
             } else if (piece.split) {
-                // FP32 partial tile of this K piece: lane-linear 16-byte stores, [subtile][wave][lane].  The partials cross XCDs
-                // (every XCD has its own L2): they are written through (sc0 sc1) and read back past the caches (sc0 sc1), the way
-                // agent-scope atomics travel, so neither side needs an L2 write-back / invalidate -- a release fence here would
-                // also flush the D tiles of the earlier rounds that are still dirty in the L2 (measured: ~20 us per launch).
-                constexpr int kCoherent = 17;               // aux bits of the gfx950 buffer instructions: sc0 | sc1
+                // FP32 partial tile of this K piece: lane-linear 16-byte stores, [subtile][wave][lane], ordinary (write-back) stores.
+                // The sum over the pieces and the output stores belong to dg_split_k_reduce_kernel, launched behind this kernel on
+                // the same stream: the kernel boundary is the only synchronisation (no counters, no spinning, nothing written
+                // through), and the reduction runs on every CU instead of on the last arriver of each tile alone.
                 uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 +
                                       static_cast<int64_t>(piece.tail) * p.sk_factor * (BM * BN * 4);
                 const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, p.sk_factor * (BM * BN * 4), 0x00020000);
@@ -1733,54 +1739,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out[ms][ns]), slab,
-                                                               lane_off, piece.index * (BM * BN * 4) + (ms * NS + ns) * (NW * 1024), kCoherent);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // written through: acknowledged = visible to the other XCDs
-                __syncthreads();
-                int* counters = static_cast<int*>(p.sk_workspace);
-                int* flag = reinterpret_cast<int*>(lds);            // the rings are idle: a tail piece has no successor to prefetch
-                if (threadIdx.x == 0) {
-                    const int arrived = __hip_atomic_fetch_add(counters + piece.tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int last = arrived == p.sk_factor - 1;
-                    if (last)
-                        __hip_atomic_store(counters + piece.tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                    *flag = last;
-                }
-                __syncthreads();
-                store = *flag != 0;
-                if (store) {
-                    // all pieces, mine included, in piece order: the sum does not depend on who arrived last.  The loads of up to
-                    // two pieces (of one half of the subtile rows: 2 x 32 registers) are issued back to back and added when
-                    // they have all arrived: the partials come from the far side of the fabric (~2 us per dependent round trip),
-                    // so a load -> add chain per piece costs pieces + 1 round trips per half (measured: 17 us + 1.3 us per
-                    // piece for the whole exchange), this form one per two pieces (four at once spill: 77 registers).
-                    constexpr int HM = MS / 2, CHUNK = 2;
-                    #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        for (int s0 = 0; s0 < p.sk_factor; s0 += CHUNK) {
-                            v4f buf[CHUNK][HM][NS];
-                            #pragma unroll
-                            for (int c = 0; c < CHUNK; ++c) {
-                                const int s = imin(s0 + c, p.sk_factor - 1);      // past the end: the last piece again (not added)
-                                #pragma unroll
-                                for (int ms = 0; ms < HM; ++ms)
-                                    #pragma unroll
-                                    for (int ns = 0; ns < NS; ++ns)
-                                        buf[c][ms][ns] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(
-                                            slab, lane_off, s * (BM * BN * 4) + ((half * HM + ms) * NS + ns) * (NW * 1024), kCoherent));
-                            }
-                            #pragma unroll
-                            for (int c = 0; c < CHUNK; ++c) {
-                                if (s0 + c < p.sk_factor) {
-                                    #pragma unroll
-                                    for (int ms = 0; ms < HM; ++ms)
-                                        #pragma unroll
-                                        for (int ns = 0; ns < NS; ++ns)
-                                            out[half * HM + ms][ns] = (s0 + c == 0) ? buf[c][ms][ns] : out[half * HM + ms][ns] + buf[c][ms][ns];
-                                }
-                            }
-                        }
-                    }
-                }
+                                                               lane_off, piece.index * (BM * BN * 4) + (ms * NS + ns) * (NW * 1024), 0);
+                store = false;
             }
         }
         if (store)
@@ -1804,6 +1764,60 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
     duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED>(p);
+}
+
+
+// Second phase of the K split: one workgroup per (split tile, M-subtile row) -- sk_tiles x MS workgroups, the thread geometry of the
+// duo kernel that wrote the partials -- sums the tile's sk_factor partial subtiles in piece order and stores them through the
+// shared epilogue (padding rows, accumulation, FP32 / BF16, column maps as for an unsplit tile).  A piece-count-sized read per
+// workgroup instead of sk_factor whole tiles on the last arriver of each tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_split_k_reduce_kernel(const GemmParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tail = blockIdx.x / MS, ms_mine = blockIdx.x % MS;
+    MaskedWalk walk;
+    const Tile t = get_tile<BM, BN>(p, p.sk_first_tile + tail, walk, 0);
+    if (!t.valid || !(t.m_end > t.m0))
+        return;                                 // (an all-padding tile: its zero rows were written by the first phase)
+    uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 + static_cast<int64_t>(tail) * p.sk_factor * (BM * BN * 4);
+    const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, p.sk_factor * (BM * BN * 4), 0x00020000);
+    const int lane_off = (wave * 64 + lane) * 16;
+    v4f sum[NS], nxt[NS];
+    auto load_piece = [&](v4f (&dst)[NS], int s) {
+        #pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+            dst[ns] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(
+                slab, lane_off, s * (BM * BN * 4) + (ms_mine * NS + ns) * (NW * 1024), 0));
+    };
+    load_piece(sum, 0);
+    for (int s = 1; s < p.sk_factor; ++s) {     // piece order: the sum does not depend on which piece finished when
+        load_piece(nxt, s);
+        #pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+            sum[ns] += nxt[ns];
+    }
+    auto store_row = [&](auto ms_c) {
+        constexpr int ROW = decltype(ms_c)::value;
+        v4f out[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                out[ms][ns] = ms == ROW ? sum[ns] : v4f{0.f, 0.f, 0.f, 0.f};
+        store_tile<MS, NS, true, false, B_MN>(p, t, 0, out, t.m0 + wm * WM, t.n0 + wn * WN, ROW);
+    };
+    static_assert(MS == 4, "one case per M-subtile row of the 64-row wave tile");
+    switch (ms_mine) {
+        case 0: store_row(std::integral_constant<int, 0>{}); break;
+        case 1: store_row(std::integral_constant<int, 1>{}); break;
+        case 2: store_row(std::integral_constant<int, 2>{}); break;
+        default: store_row(std::integral_constant<int, 3>{}); break;
+    }
 }
 
 

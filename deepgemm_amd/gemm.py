@@ -207,7 +207,7 @@ _SPLIT_K_WORKSPACES = {}
 
 def _split_k_workspace(device: torch.device, stream: int) -> Optional[torch.Tensor]:
     """Scratch buffer of the K-split tail (dg_m_grouped_fp8_gemm_nt_contiguous_ws): one zero-filled buffer per device and
-    stream, created on first use and kept (the kernel leaves its arrival counters zero; launches of one stream are ordered, so
+    stream, created on first use and kept (its contents never matter between launches; launches of one stream are ordered, so
     they can share it).  The C ABI itself never allocates.  ``None`` (= no K split) on a stream that is being captured and
     has no buffer yet: an allocation made during capture belongs to the graph's private pool and must not outlive it."""
     key = (device.index, stream)
@@ -232,7 +232,7 @@ def _dense_split_k_workspace(m: int, n: int, k: int, gran_n: int, device: torch.
         return None
     num_kb = k // 128
     pieces = min(8, cus // tail, num_kb)
-    if pieces < 2 or num_kb * (pieces - 1) * 100 <= (1700 + 130 * pieces) * pieces:
+    if pieces < 2 or num_kb * (pieces - 1) * 100 <= (1100 + 100 * pieces) * pieces:
         return None
     return _split_k_workspace(device, current_stream_ptr())
 

@@ -139,10 +139,10 @@ int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
                                         int64_t d_stride_m, int use_psum, int m_alignment, void* stream);
 
 /* The same with a caller-owned scratch buffer for tail balancing: when the tile count is just above a multiple of the CU count
- * (BASELINE config 4: 576 tiles of 128 x 256 on 256 CUs = 2.25 rounds) the partial last round is cut along K over the idle CUs,
- * FP32 partial tiles go through `workspace` and the last arriver of a tile reduces them in a fixed order (deterministic).
- * workspace: device memory, 16-byte aligned, at least dg_split_k_workspace_bytes() bytes, ZERO-filled once before its first use
- * (the kernel leaves its counters zero), used by one stream at a time; workspace == NULL gives the entry point above.
+ * (BASELINE config 4: 576 tiles of 128 x 256 on 256 CUs = 2.25 rounds) the partial last round is cut along K over the idle CUs:
+ * FP32 partial tiles go through `workspace` and a second kernel, launched behind the first on the same stream, sums them in a fixed
+ * order (deterministic) and stores the tiles.  workspace: device memory, 16-byte aligned, at least dg_split_k_workspace_bytes()
+ * bytes, contents irrelevant, used by one stream at a time; workspace == NULL gives the entry point above.
  * (The reference's persistent scheduler has no such step: its tiles are not split; the library never allocates, hence the
  * caller-owned buffer -- the host layer keeps one per device and stream.) */
 int dg_m_grouped_fp8_gemm_nt_contiguous_ws(const void* a, const float* sfa, const void* b, const float* sfb, void* d,

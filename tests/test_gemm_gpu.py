@@ -397,8 +397,8 @@ def _split_k_case(actual_ms, n, k, use_psum, alignment):
 ])
 def test_m_grouped_contiguous_split_k_tail(use_psum, actual_ms, n, k, alignment):
     """The K-split tail of the persistent 128 x 256 duo kernel (the partial last round cut along K over the idle CUs, FP32
-    partials through the caller's workspace, last arriver reduces in piece order): every row against the oracle, padding rows
-    zero, nothing outside D, bit-repeatable, arrival counters left at zero."""
+    partials through the caller's workspace, summed in piece order by the reduction kernel behind it): every row against the oracle,
+    padding rows zero, nothing outside D, bit-repeatable."""
     from deepgemm_amd import gemm as gemm_mod
     gen.reset_seed(11)
     case, tiles, cus = _split_k_case(actual_ms, n, k, use_psum, alignment)
@@ -426,7 +426,7 @@ def test_m_grouped_contiguous_split_k_tail(use_psum, actual_ms, n, k, alignment)
             assert bool((outs[0][start + actual:start + aligned] == 0).all()), f'{cfg}: padding rows must be zeros'
             start += aligned
     for ws in gemm_mod._SPLIT_K_WORKSPACES.values():
-        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'arrival counters must be left at zero'
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'the workspace header stays untouched'
     # the plain persistent walk of the same kernel (no workspace: dense entry) and the non-split kernel agree with it to rounding
     dg.set_forced_config('duo_128x256')
     plain = torch.empty_like(case.d)
@@ -489,7 +489,7 @@ def test_dense_split_k_under_filled_launch(m, n, k, b_k_major, out_dtype, accumu
     else:
         assert_close_to_oracle(outs[0], want, 'dense split K')
     for ws in gemm_mod._SPLIT_K_WORKSPACES.values():
-        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'arrival counters must be left at zero'
+        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'the workspace header stays untouched'
     dg.set_forced_config('duo_128x256' if b_k_major or m <= 256 else 'duo_bmn_128x256')
     plain = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
     dg.fp8_gemm_nt(case.a, case.b, plain, c=plain if accumulate else None)
