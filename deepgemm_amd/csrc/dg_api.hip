@@ -361,7 +361,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // ... unless the K loop is long and the caller lent a workspace: cutting every 128 x 256 tile along K over the idle CUs
         // beats one deep-ring tile per CU (tools/sweep.py: 4096 x 512 x 32768: 88.6 us against 166.4; 1024 x 1024 x 16384: 41.3 / 79.5;
         // 1024 x 512 x 8192: 30.5 / 42.8; break-even near K = 7168 -- 512 x 4096 x 7168: 38.7 / 39.7, 4096 x 512 x 4096: 32.6 / 25.3).
-        // Model: stream = 5 us + 0.66 (64 x 128) or 0.36 (64 x 32) us per K block, split = 16 us + 1.05 us per K block of a piece
+        // Model: stream = 5 us + 0.66 (64 x 128) or 0.27 (64 x 32, four K blocks per stage) us per K block, split = 16 us + 1.05 us per K block of a piece
         // (two-phase exchange: 1024 x 512 x 8192 21.8 us, 1024 x 1024 x 16384 33.2, 512 x 4096 x 7168 31.3, 4096 x 512 x 4096 25.2 / stream 24.2).
         // Decode-sized M with MORE 64 x 128 tiles than CUs: the second round of one-tile-per-CU stream tiles is mostly idle, while the
         // 128 x 256 duo tile (two-segment schedule, 3 x 32 KiB weight ring) covers the same columns in half as many tiles and reaches
@@ -386,7 +386,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             const long num_kb = p.k / 128;
             const long pieces = split_k_pieces(tiles, num_cus(), num_kb);
             if (pieces >= 2 && tiles < num_cus()) {
-                const double t_stream = 5.0 + num_kb * (std::strcmp(pick, "stream_64x32") == 0 ? 0.36 : 0.66);
+                const double t_stream = 5.0 + num_kb * (std::strcmp(pick, "stream_64x32") == 0 ? 0.27 : 0.66);
                 const double t_split = 16.0 + static_cast<double>((num_kb + pieces - 1) / pieces) * 1.05;
                 if (t_split < t_stream)
                     pick = "duo_sk_128x256";
