@@ -315,9 +315,14 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     if (bmn_eligible(p) && m_for_tiling > 256) {
         const bool contiguous = p.gemm_type != dg::kNormal;
         const long tiles256 = static_cast<long>(ceil_div(m_for_tiling, 256)) * ceil_div(p.n, 256);
-        const char* pick = (contiguous || tiles256 < num_cus() / 2) ? "duo_bmn_128x256" : "duo_bmn_256x256";
+        // dense: rounds x tile work of the two tile shapes, with the weights of the K-major table (duo_256x256 1.10, duo_128x256 0.78):
+        // e.g. 4096 x 2048 x 7168 = 128 / 256 tiles: one round either way, 76.1 us on 256-row tiles, 60.6 on 128-row tiles
+        const long tiles128r = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
+        const double cost256 = static_cast<double>((tiles256 + num_cus() - 1) / num_cus()) * (256.0 * 256.0 / 1.10 + 4096.0);
+        const double cost128 = static_cast<double>((tiles128r + num_cus() - 1) / num_cus()) * (128.0 * 256.0 / 0.78 + 4096.0);
+        const char* pick = (contiguous || cost128 < cost256) ? "duo_bmn_128x256" : "duo_bmn_256x256";
         if (p.k % 128 != 0)             // (dense only, see bmn_eligible) the forms with the K-tail stage
-            pick = tiles256 < num_cus() / 2 ? "duo_bmn_kt_128x256" : "duo_bmn_kt_256x256";
+            pick = cost128 < cost256 ? "duo_bmn_kt_128x256" : "duo_bmn_kt_256x256";
         else if (std::strcmp(pick, "duo_bmn_128x256") == 0 && p.sk_workspace != nullptr &&
                  (!contiguous || bm_must_divide % 128 == 0)) {
             // a partial last round (or an under-filled launch) of 128 x 256 tiles: cut it along K over the idle CUs
@@ -337,7 +342,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     const bool tail_ok = fast_eligible(p, false);       // k % 128 != 0: only the kernels with a tail stage
     if (!fast_ok && tail_ok && p.sfb_gran_n == 128 && p.sfa_sm == 1 && p.gemm_type == dg::kNormal) {
         const long tiles256 = static_cast<long>(ceil_div(m_for_tiling, 256)) * ceil_div(p.n, 256);
-        const char* pick = tiles256 < num_cus() / 2 ? "duo_kt_128x256" : "duo_kt_256x256";
+        const char* pick = tiles256 <= num_cus() / 2 ? "duo_kt_128x256" : "duo_kt_256x256";
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, pick) == 0)
                 return &kConfigs[i];
