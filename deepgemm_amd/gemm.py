@@ -85,11 +85,11 @@ def _b_ok_beside_mn_major_a(b: torch.Tensor, n: int, k: int) -> bool:
 
 
 def _few_tiles_long_k(m: int, n: int, k: int) -> bool:
-    """The MN-major-A kernels exist for 256 x 256 tiles only and are never K-split: a problem whose 256 x 256 tiles cover less than
+    """The MN-major-A kernels exist for 256 x 256 tiles only and are never K-split: a problem whose 256 x 256 tiles cover at most
     half the chip while the K loop is long (wgrad of a narrow layer: 576 x 4096 x 7168 = 48 tiles) is better served by re-majoring A
     (a few microseconds) and the 128 x 256 tiles of the K-major-A kernels, which the K split can spread over the idle CUs."""
     cus = int(lib.dg_get_num_cus())
-    return -(-m // 256) * -(-n // 256) * 2 < cus and k >= 4096
+    return -(-m // 256) * -(-n // 256) * 2 <= cus and k >= 2048
 
 
 def _dense_operands(a_data: torch.Tensor, b_data: torch.Tensor, sfa: torch.Tensor, gran_n: int, m: int, n: int, k: int):
