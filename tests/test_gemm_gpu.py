@@ -1005,20 +1005,28 @@ def test_hip_graph_capture_and_replay():
     dense.a = (dense.a[0], dg.get_mn_major_tma_aligned_tensor(dense.a[1]))
     masked = gen.generate_m_grouped_masked(4, 128, 48, 512, 512)
     masked_a = (masked.a[0], dg.get_mn_major_tma_aligned_tensor(masked.a[1]))
-    # eager results (also warms every lazily initialised piece of host state)
+    skinny = gen.generate_normal(1024, 512, 8192)          # K split: two kernels per call and the per-stream workspace
+    skinny.a = (skinny.a[0], dg.get_mn_major_tma_aligned_tensor(skinny.a[1]))
+    # eager results (also warms every lazily initialised piece of host state, the K-split workspace of this stream included)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dg.fp8_gemm_nt(skinny.a, skinny.b, skinny.d)
+        assert dg.last_config() == 'duo_sk_128x256'
+    side.synchronize()
     dg.fp8_gemm_nt(dense.a, dense.b, dense.d)
     dg.m_grouped_fp8_gemm_nt_masked(masked_a, masked.b, masked.d, masked.masked_m, 48)
     torch.cuda.synchronize()
-    want_dense, want_masked = dense.d.clone(), masked.d.clone()
+    want_dense, want_masked, want_skinny = dense.d.clone(), masked.d.clone(), skinny.d.clone()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):
         dg.fp8_gemm_nt(dense.a, dense.b, dense.d)
         dg.m_grouped_fp8_gemm_nt_masked(masked_a, masked.b, masked.d, masked.masked_m, 48)
+        dg.fp8_gemm_nt(skinny.a, skinny.b, skinny.d)
     for _ in range(3):
-        dense.d.zero_(), masked.d.zero_()
+        dense.d.zero_(), masked.d.zero_(), skinny.d.zero_()
         graph.replay()
         torch.cuda.synchronize()
-        assert torch.equal(dense.d, want_dense)
+        assert torch.equal(dense.d, want_dense) and torch.equal(skinny.d, want_skinny)
         for g in range(4):
             rows = int(masked.masked_m[g])
             assert torch.equal(masked.d[g, :rows], want_masked[g, :rows])
