@@ -205,6 +205,7 @@ const E8Config kE8Configs[] = {
     // decode-sized M (masked / dense, M <= 64 per group): the deep-ring stream tile with the quad's words riding in every stage
     {"e8_stream_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, true>, 64, 128, 256, false, true, true},
     {"e8_stream_nt_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, true>, 64, 128, 256, false, true, true},
+    {"e8_stream_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true>, 64, 32, 256, false, true, true},
 #ifdef DG_EXPERIMENTS
     {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
@@ -591,16 +592,26 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
         // decode-sized M with a round of 64 x 128 tiles to fill the chip (the rule of the FP32-scale stream kernel): weights stream
         // once, five K blocks in flight per CU; non-temporal weight policy when the launch's weights exceed the Infinity Cache
         const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
-        if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && m_hint <= 64 && tiles128 >= 96 && p.sfa_sm == 1 && p.sfb_sn == 1) {
-            bool stream = true;
-            if (tiles128 > num_cus()) {         // more stream tiles than CUs: the round model of select_config (128 x 256 tile = the quad form)
+        if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && p.sfa_sm == 1 && p.sfb_sn == 1) {
+            // the tile rules of the FP32-scale stream kernels (select_config): 64 x 128 when a round of them covers the chip, 64 x 32 below
+            const E8Config* pick = nullptr;
+            if (m_hint <= 64)
+                pick = tiles128 >= 96 ? &kE8Configs[3] : &kE8Configs[5];
+            else if (m_hint <= 256 && tiles128 < 96)
+                pick = &kE8Configs[5];
+            else if (m_hint <= 256 && tiles128 < 256)
+                pick = &kE8Configs[3];
+            if (pick == &kE8Configs[3] && tiles128 > num_cus()) {   // more stream tiles than CUs: the round model of select_config (128 x 256 tile = the quad form)
                 const long slots = num_cus(), num_kb = p.k / 128;
                 const long rounds_s = (tiles128 + slots - 1) / slots, rounds_d = (groups * ceil_div(p.n, 256) + slots - 1) / slots;
                 const double floor_us = static_cast<double>(groups) * p.n * p.k / 5.8e6;
-                stream = !(std::max(floor_us, 6.0 + rounds_d * num_kb * 0.80) < 0.9 * std::max(floor_us, 5.0 + rounds_s * num_kb * 0.62));
+                if (std::max(floor_us, 6.0 + rounds_d * num_kb * 0.80) < 0.9 * std::max(floor_us, 5.0 + rounds_s * num_kb * 0.62))
+                    pick = nullptr;
             }
-            if (stream)
-                cfg = static_cast<double>(groups) * p.n * p.k >= 200e6 ? &kE8Configs[4] : &kE8Configs[3];
+            if (pick == &kE8Configs[3] && static_cast<double>(groups) * p.n * p.k >= 200e6)
+                pick = &kE8Configs[4];
+            if (pick != nullptr)
+                cfg = pick;
         }
     }
     if (cfg->stream && (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum)) {

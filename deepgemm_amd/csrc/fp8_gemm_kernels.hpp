@@ -1847,7 +1847,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
     constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + 1 + SFB_PIECES) * KBS;      // per wave per stage, scale pieces included
-    static_assert(!E8 || (MS == 4 && KBS == 1), "packed-scale form: 64-row tiles, one K block per stage");
+    static_assert(!E8 || MS == 4 || MS == 1, "packed-scale form: a lane reads its MS row words with one LDS read");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA piece and one SFB value per tile");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
@@ -1969,11 +1969,15 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 const uint8_t* stage = lds + cur + u * BLOCK_BYTES;
                 if constexpr (E8) {
                     const int shift = ((sb * KBS + u) & 3) * 8;         // this block's byte of the quad's words
-                    const v4i qa = *reinterpret_cast<const v4i*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
                     int ea[MS], eb[NS];
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
-                        ea[ms] = static_cast<int>(static_cast<unsigned>(qa[ms]) >> shift);
+                    if constexpr (MS == 4) {
+                        const v4i qa = *reinterpret_cast<const v4i*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                        #pragma unroll
+                        for (int ms = 0; ms < MS; ++ms)
+                            ea[ms] = static_cast<int>(static_cast<unsigned>(qa[ms]) >> shift);
+                    } else {
+                        ea[0] = static_cast<int>(*reinterpret_cast<const unsigned*>(stage + SFA_OFF + (wm * WM + (lane & 15)) * 4) >> shift);
+                    }
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns) {
                         // the weight row in MFMA row slot i = lane & 15 of N-subtile ns (see b_row_perm)

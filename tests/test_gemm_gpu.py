@@ -811,7 +811,7 @@ def test_packed_ue8m0_scales_hw_path(m, n, k):
     assert_close_fp32(d32, want32, 'packed ue8m0 fp32 accumulate')
 
 
-E8_DENSE_CONFIGS = ['auto', 'e8_quad_256x256', 'e8_quad_128x256', 'e8_duo_256x256']
+E8_DENSE_CONFIGS = ['auto', 'e8_quad_256x256', 'e8_quad_128x256', 'e8_duo_256x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32']
 
 
 @pytest.mark.parametrize('m,n,k', [(512, 768, 1024), (300, 520, 896), (4096, 4096, 1536), (129, 4096, 384)])
@@ -904,7 +904,7 @@ def test_packed_ue8m0_m_grouped_masked(masked_ms, max_m, n, k):
     oracle.m_grouped_fp8_gemm_nt_masked(*cpu_pair(case.a), *cpu_pair(case.b), want, case.masked_m.cpu())
     a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
     expected_m = max(1, int(sum(masked_ms) / len(masked_ms)))
-    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128'] + (['e8_quad_256x256'] if k % 512 == 0 else []):
+    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32'] + (['e8_quad_256x256'] if k % 512 == 0 else []):
         dg.set_forced_config(cfg)
         case.d.fill_(float('nan'))
         dg.m_grouped_fp8_gemm_nt_masked(a, b, case.d, case.masked_m, expected_m)
