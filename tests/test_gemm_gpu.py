@@ -619,6 +619,38 @@ def test_set_num_sms_limits_the_persistent_kernels(num_sms):
     assert calc_diff(got[0][0], dense.ref_d) < gen.FP8_MAX_DIFF and calc_diff(got[1][0], skinny.ref_d) < gen.FP8_MAX_DIFF
 
 
+@pytest.mark.parametrize('seed', [101, 202, 303])
+def test_dense_random_shapes_and_layouts_vs_oracle(seed):
+    """Randomised dense problems through the automatic selection -- every majorness, K tails (multiples of 16), odd M / N, BF16 and
+    accumulating FP32 outputs, shapes that reach the stream, duo, K-tail, K-split and layout-agnostic kernels -- each against the
+    oracle.  (Fixed seeds: a failure reproduces.)"""
+    rng = random.Random(seed)
+    picked = set()
+    for _ in range(14):
+        m = rng.choice([1, 7, 64, 100, 129, 256, 300, 520, 777, 1024, 1536])
+        n = rng.choice([16, 136, 256, 384, 520, 1024, 2048])
+        k = rng.choice([128, 144, 256, 320, 512, 1088, 2112, 4096])
+        a_k, b_k = rng.random() < 0.6, rng.random() < 0.6
+        accumulate = rng.random() < 0.3
+        out_dtype = torch.float if accumulate or rng.random() < 0.2 else torch.bfloat16
+        if not a_k and m % 16:
+            m = (m + 15) // 16 * 16          # an MN-major view needs a 16-byte row pitch to be a legal operand of the fast kernels
+        gen.reset_seed(seed + m + n + k)
+        case = gen.generate_normal(m, n, k, a_k, b_k, accumulate=accumulate, out_dtype=out_dtype)
+        c_cpu = case.c.cpu().clone() if accumulate else None
+        want = oracle_dense(case, c_cpu=c_cpu)
+        dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None)
+        label = f'm={m} n={n} k={k} a_k={a_k} b_k={b_k} acc={accumulate} {out_dtype} [{dg.last_config()}]'
+        picked.add(dg.last_config())
+        if out_dtype == torch.float:
+            assert_close_fp32(case.d, want, label)
+        else:
+            assert_close_to_oracle(case.d, want, label, addend=c_cpu)
+        if m * n >= 16384:              # (the reference's gate is statistical: a handful of outputs is FP8 quantisation noise)
+            assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF, label
+    assert len(picked) >= 3, picked
+
+
 def test_import_is_fork_safe_and_bench_runs():
     """(i) importing the package must not initialise the GPU runtime: a forked child can still pick its device (reference
     tests/test_lazy_init.py:7-20); (ii) bench.py prints one well-formed JSON line carrying roofline and cpu_baseline."""
