@@ -290,3 +290,53 @@ def test_every_reference_keyword_by_name():
                                         mk.d, mk.masked_m, 32)
     with pytest.raises(RuntimeError, match='gran_n == 128'):           # per-column FP32 SFB is a dense-only recipe
         dg.m_grouped_fp8_gemm_nt_masked(mk.a, (mk.b[0], torch.ones(2, 128, 2)), mk.d, mk.masked_m, 32, recipe=(1, 1, 128))
+
+
+def test_operand_majorness_decisions_on_the_host():
+    """Which FP8 operands the dense operator hands over as they are (deepgemm_amd/gemm.py:_dense_operands; the C-side twins are
+    amn_eligible / bmn_eligible in dg_api.hip): decided from shapes, strides and alignment alone -- CPU tensors suffice, the
+    re-majoring kernel itself is never reached here (REMAJOR_MIN_MACS keeps small problems in place)."""
+    from deepgemm_amd import gemm
+    k_major = torch.empty((1024, 2048), dtype=torch.uint8).view(torch.float8_e4m3fn)
+    mn_major = torch.empty((2048, 1024), dtype=torch.uint8).view(torch.float8_e4m3fn).t()          # [1024, 2048] view, unit stride along m
+    assert gemm._a_mn_major_self_ok(mn_major, 1024, 2048) and not gemm._a_mn_major_self_ok(k_major, 1024, 2048)
+    assert not gemm._a_mn_major_self_ok(mn_major[:256], 256, 2048)                                 # M <= 256: not a 256-row-tile problem
+    assert not gemm._a_mn_major_self_ok(mn_major, 1024, 2040)                                      # K not in whole 16-byte chunks
+    odd_pitch = torch.empty((2048, 1032), dtype=torch.uint8).view(torch.float8_e4m3fn).t()[:1024]
+    assert not gemm._a_mn_major_self_ok(odd_pitch, 1024, 2048)                                     # row pitch 1032: not a multiple of 16
+    assert gemm._b_ok_beside_mn_major_a(k_major, 1024, 2048) and gemm._b_ok_beside_mn_major_a(mn_major, 1024, 2048)
+    assert not gemm._b_ok_beside_mn_major_a(mn_major[:1000], 1000, 2048)                           # N % 16 != 0 with an MN-major B
+    # few 256 x 256 tiles and a long K loop: A is re-majored so that the K split can use the idle CUs (rule, not alignment)
+    assert gemm._few_tiles_long_k(576, 4096, 7168) and gemm._few_tiles_long_k(2048, 4096, 7168)
+    assert not gemm._few_tiles_long_k(2048, 7168, 2048) and not gemm._few_tiles_long_k(576, 4096, 1024)
+    sfa = torch.empty((16, 1024), dtype=torch.float).t()                                           # MN-major SFA
+    saved, gemm.REMAJOR_MIN_MACS = gemm.REMAJOR_MIN_MACS, 1 << 62
+    try:
+        a, b = gemm._dense_operands(mn_major, k_major, sfa, 128, 1024, 1024, 2048)
+        assert a is mn_major and b is k_major                                                      # tt: both as they are
+        a, b = gemm._dense_operands(k_major, mn_major, sfa, 128, 1024, 1024, 2048)
+        assert a is k_major and b is mn_major                                                      # nn
+    finally:
+        gemm.REMAJOR_MIN_MACS = saved
+
+
+def test_split_k_workspace_is_only_requested_when_the_model_says_so():
+    """deepgemm_amd/gemm.py:_dense_split_k_workspace mirrors dg_api.hip's split_k_pieces / split_k_pays: ordinary calls must neither
+    create nor pass a buffer (creating one needs a device: not reached for these shapes)."""
+    from deepgemm_amd import gemm
+    cpu = torch.device('cpu')
+    for m, n, k in ((4096, 4096, 7168), (2048, 7168, 2048), (64, 4096, 7168), (4096, 4096, 128), (4096, 7168, 2112)):
+        assert gemm._dense_split_k_workspace(m, n, k, 128, cpu) is None, (m, n, k)
+    assert gemm._dense_split_k_workspace(4096, 512, 32768, 1, cpu) is None                        # recipe (1, 1, 128): another kernel family
+
+
+def test_packed_ue8m0_words_expand_to_exact_powers_of_two():
+    from deepgemm_amd import gemm
+    from deepgemm_amd.utils.math import pack_ue8m0_to_int
+    k = 2112                                                                                       # 17 K blocks: a partial last word
+    exps = torch.randint(100, 150, (37, 20), dtype=torch.int32)                                    # 5 whole words per row
+    sf = (exps << 23).view(torch.float)
+    packed = pack_ue8m0_to_int(sf)
+    assert packed.dtype == torch.int and packed.shape == (37, 5)
+    back = gemm._unpack_ue8m0(packed, k)
+    assert back.shape == (37, 17) and torch.equal(back, sf[:, :17])
