@@ -35,6 +35,7 @@ SIGNATURES = {
     'dg_set_debug_buffer': (_i32, [_vp]),
     'dg_list_configs': (_cp, []),
     'dg_last_config': (_cp, []),
+    'dg_select_config': (_cp, [_i32] * 12),
     'dg_last_error': (_cp, []),
     'dg_version': (_cp, []),
 }

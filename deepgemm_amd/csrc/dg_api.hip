@@ -292,8 +292,8 @@ bool split_k_pays(long pieces, long num_kb) {
 }
 
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
-const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expected_m, int bm_must_divide) {
-    const std::string forced = forced_config();
+const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expected_m, int bm_must_divide, bool ignore_forced = false) {
+    const std::string forced = ignore_forced ? std::string("auto") : forced_config();
     if (forced != "auto") {
         for (int i = 0; i < kNumConfigs; ++i)
             if (forced == kConfigs[i].name)
@@ -568,18 +568,10 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
 // Launch of a packed-UE8M0 problem (GemmParams filled by the entry point, scale pointers = packed words).  Kernel choice:
 // the 4-wave in-place-accumulating quad kernels -- 256 x 256 tiles for dense problems of whole K quads that fill the chip and
 // for contiguous layouts with several rounds of two-pass tiles, 128 x 256 tiles otherwise; the 8-wave forms only by name.
-int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
-    if (!fast_eligible(p)) {
-        g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0";
-        return 3;
-    }
-    const bool grouped = p.gemm_type != dg::kNormal;
-    const std::string forced = forced_config();
+// Automatic choice among the packed-UE8M0 kernels (forced names are resolved by the caller).
+const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
     const E8Config* cfg = nullptr;
-    for (const E8Config& c : kE8Configs)
-        if (forced == c.name)
-            cfg = &c;
-    if (cfg == nullptr) {
+    {
         const int m_hint = expected_m > 0 ? expected_m : p.m;
         const long groups = p.gemm_type == dg::kMasked ? p.num_groups : 1;
         const long tiles256 = groups * ceil_div(m_hint, 256) * ceil_div(p.n, 256);
@@ -614,6 +606,22 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
                 cfg = pick;
         }
     }
+    return cfg;
+}
+
+int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
+    if (!fast_eligible(p)) {
+        g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0";
+        return 3;
+    }
+    const bool grouped = p.gemm_type != dg::kNormal;
+    const std::string forced = forced_config();
+    const E8Config* cfg = nullptr;
+    for (const E8Config& c : kE8Configs)
+        if (forced == c.name)
+            cfg = &c;
+    if (cfg == nullptr)
+        cfg = select_e8_config(p, expected_m);
     if (cfg->stream && (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum)) {
         g_last_error = std::string("config '") + cfg->name + "' does not implement the contiguous layouts";
         return 3;
@@ -1156,6 +1164,33 @@ const char* dg_get_forced_config(void) {
     thread_local std::string copy;
     copy = forced_config();
     return copy.c_str();
+}
+
+const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups, int expected_m, int a_mn_major, int b_mn_major,
+                             int sfb_gran_n, int m_alignment, int has_workspace, int packed_ue8m0) {
+    // the kernel the automatic selection would launch for a problem of this shape with 16-byte aligned, densely packed operands and
+    // MN-major SFA; nothing is launched and no device is needed (256 CUs are assumed when none is visible)
+    static thread_local std::string name;
+    dg::GemmParams p{};
+    p.a = p.b = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(1) << 20);
+    p.sfa = p.sfb = reinterpret_cast<const float*>(static_cast<uintptr_t>(1) << 21);
+    p.d = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 22);
+    p.m = m; p.n = n; p.k = k; p.num_groups = num_groups > 0 ? num_groups : 1;
+    p.a_sm = a_mn_major ? 1 : k; p.a_sk = a_mn_major ? m : 1; p.a_sg = static_cast<int64_t>(m) * k;
+    p.b_sn = b_mn_major ? 1 : k; p.b_sk = b_mn_major ? n : 1; p.b_sg = static_cast<int64_t>(n) * k;
+    p.sfa_sm = 1; p.sfa_sk = (m + 3) / 4 * 4; p.sfb_sn = packed_ue8m0 || sfb_gran_n == 1 ? 1 : (k + 127) / 128;
+    p.sfb_sk = packed_ue8m0 || sfb_gran_n == 1 ? (n + 3) / 4 * 4 : 1;
+    p.d_sm = n; p.sfb_gran_n = sfb_gran_n; p.d_dtype = DG_BF16; p.gemm_type = gemm_type; p.m_alignment = m_alignment;
+    p.sk_workspace = has_workspace ? reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23) : nullptr;
+    if (packed_ue8m0) {
+        p.sfb_gran_n = 128;
+        name = fast_eligible(p) ? select_e8_config(p, expected_m)->name : "";
+    } else {
+        const int bm_must_divide = (gemm_type == dg::kContiguous || gemm_type == dg::kContiguousPsum) ? m_alignment : 0;
+        const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide, true);
+        name = cfg != nullptr ? cfg->name : "";
+    }
+    return name.c_str();
 }
 
 const char* dg_last_config(void) { return g_last_config.c_str(); }

@@ -226,6 +226,12 @@ const char* dg_list_configs(void);
 int dg_set_debug_buffer(void* device_buffer);
 /* Name of the configuration the last GEMM call on this thread selected (for DG_PRINT_CONFIGS-style logging). */
 const char* dg_last_config(void);
+/* The kernel configuration the automatic selection picks for a problem of this shape (16-byte aligned, densely packed operands of
+ * the given majorness, MN-major SFA; gemm_type: 0 dense, 1 contiguous, 2 contiguous psum, 3 masked; m = rows of the dense / contiguous
+ * problem or rows per group of the masked one).  Nothing is launched and no device is needed: the analogue of inspecting
+ * get_best_config (csrc/jit_kernels/heuristics/common.hpp:14-52) -- the host tests pin the choices with it. */
+const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups, int expected_m, int a_mn_major, int b_mn_major,
+                             int sfb_gran_n, int m_alignment, int has_workspace, int packed_ue8m0);
 
 const char* dg_last_error(void);
 const char* dg_version(void);

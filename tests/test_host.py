@@ -340,3 +340,46 @@ def test_packed_ue8m0_words_expand_to_exact_powers_of_two():
     assert packed.dtype == torch.int and packed.shape == (37, 5)
     back = gemm._unpack_ue8m0(packed, k)
     assert back.shape == (37, 17) and torch.equal(back, sf[:, :17])
+
+
+def test_automatic_kernel_selection_is_pinned():
+    """The tile-selection heuristics (dg_api.hip: select_config / select_e8_config, the analogue of get_best_config,
+    csrc/jit_kernels/heuristics/common.hpp:14-52) on BASELINE's configurations and on the entries of the reference's sweeps that each
+    rule exists for -- through dg_select_config, which launches nothing.  A changed choice must be a decision, not an accident."""
+    from deepgemm_amd._lib import lib
+
+    def pick(gemm_type, m, n, k, groups=1, expected_m=0, a_mn=0, b_mn=0, gran_n=128, alignment=0, workspace=1, packed=0):
+        return lib.dg_select_config(gemm_type, m, n, k, groups, expected_m, a_mn, b_mn, gran_n, alignment, workspace, packed).decode()
+    dense, contiguous, masked = 0, 1, 3
+    # BASELINE configs[1..4]
+    assert pick(dense, 4096, 4096, 7168) == 'duo_p_256x256'
+    assert [pick(dense, 2048, 7168, 2048, a_mn=a, b_mn=b) for a, b in ((0, 0), (0, 1), (1, 1), (1, 0))] == \
+        ['duo_p_256x256', 'duo_bmn_256x256', 'duo_abmn_256x256', 'duo_amn_256x256']
+    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128) == 'duo_sk_128x256'              # 576 tiles = 2.25 rounds: K-split tail
+    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128, workspace=0) == 'duo_128x256'
+    assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48) == 'stream_nt_64x128'                  # 235 MB of weights: non-temporal stream
+    # packed UE8M0 scales
+    assert pick(dense, 4096, 4096, 7168, packed=1) == 'e8_quad_256x256'
+    assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48, packed=1) == 'e8_stream_nt_64x128'
+    assert pick(dense, 128, 4096, 7168, packed=1) == 'e8_stream_64x32'
+    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128, packed=1) == 'e8_quad_128x256'
+    # recipe (1, 1, 128)
+    assert pick(dense, 4096, 4096, 7168, gran_n=1) == 'pipe_pc_256x256'
+    assert pick(dense, 4096, 4096, 7168, gran_n=1, a_mn=1, b_mn=1) == 'pipe_pc_mn_256x256'
+    # the reference's dense sweep: small M, K tails, few tiles with long K loops, tile-count quantisation
+    assert pick(dense, 1, 7168, 16384) == 'stream_64x32' and pick(dense, 128, 4096, 7168) == 'stream_64x32'
+    assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_64x128'
+    assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256'                                            # K split beats one stream tile per CU
+    assert pick(dense, 4096, 7168, 2112, b_mn=1) == 'duo_bmn_kt_256x256' and pick(dense, 4096, 7168, 2112) == 'duo_kt_256x256'
+    assert pick(dense, 4096, 512, 32768, b_mn=1) == 'duo_sk_bmn_128x256' and pick(dense, 4096, 576, 7168) == 'duo_sk_128x256'
+    assert pick(dense, 4096, 576, 7168, workspace=0) == 'duo_128x256'
+    assert pick(dense, 4096, 2048, 7168, b_mn=1) == 'duo_bmn_128x256'                                   # 128 / 256 tiles: one round either way
+    assert pick(dense, 4096, 2112, 7168) == 'duo_p_256x256'                                             # 144 tiles: one round of 256-row tiles
+    assert pick(dense, 70, 136, 200) == 'generic_128x128'                                               # K not in whole 16-byte chunks
+    # the reference's grouped sweeps
+    assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128) == 'duo_p_256x256'              # many rounds: persistent two-pass walk
+    assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128, b_mn=1) == 'duo_bmn_256x256'
+    assert pick(masked, 4096, 4096, 4096, groups=32, expected_m=192) == 'duo_p_256x256'
+    assert pick(masked, 4096, 6144, 7168, groups=6, expected_m=20) == 'duo_128x256'                     # 288 stream tiles > 256 CUs
+    assert pick(masked, 4096, 4096, 4096, groups=6, expected_m=20) == 'stream_64x128'
+    assert pick(masked, 4096, 6144, 7168, groups=32, expected_m=20) == 'stream_nt_64x128'
