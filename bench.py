@@ -59,10 +59,12 @@ def parse_args():
     ap.add_argument('--no-secondary', action='store_true', help='skip the shortened runs of the other configurations')
     ap.add_argument('--clock-warmup-s', type=float, default=1.0, help='untimed load before the warm-up steps (seconds)')
     ap.add_argument('--sets', type=int, default=4, help='rotating input sets (defeats Infinity-Cache residency)')
+    ap.add_argument('--ep-capacity', type=int, default=0,
+                    help='masked workload with --gpus > 1: rows per (rank, expert) block of the fixed-shape exchange (0 = exact split sizes)')
     return ap.parse_args()
 
 
-def make_ep_workload(sets: int, world: int, rank: int, phase_events: list):
+def make_ep_workload(sets: int, world: int, rank: int, phase_events: list, capacity: int = 0):
     """BASELINE configs[4] across ranks: 8 experts per rank (8 * world in total, weights resident on their owner), 48
     token rows per rank routed to top-8 experts => about 48 rows per expert; one step = all-to-all dispatch + local masked
     grouped GEMM + all-to-all combine + top-k weighted reduce on the token's owner (deepgemm_amd/ep.py)."""
@@ -81,7 +83,8 @@ def make_ep_workload(sets: int, world: int, rank: int, phase_events: list):
         ids = torch.stack([torch.randperm(num_experts, device='cuda')[:top_k] for _ in range(tokens)])
         weights = torch.softmax(torch.randn((tokens, top_k), device='cuda'), dim=-1)
         calls.append(lambda x=x, ids=ids, weights=weights: ep.ep_m_grouped_fp8_gemm_nt_masked(
-            x, ids, b_local, num_experts, max_m, expected_m=48, topk_weights=weights, phase_events=phase_events))
+            x, ids, b_local, num_experts, max_m, expected_m=48, topk_weights=weights, phase_events=phase_events,
+            capacity=capacity if capacity > 0 else None))
     flops = 2.0 * tokens * top_k * n * k
     nbytes = float(b_local[0].numel() + 4 * b_local[1].numel() + tokens * top_k * (k + 4 * k // 128 + 2 * n))
     desc = {'workload': f'EP m_grouped_fp8_gemm_nt_masked: {num_experts} experts / {world} GPUs ({per_rank} per rank), about 48 rows per expert, '
@@ -91,12 +94,12 @@ def make_ep_workload(sets: int, world: int, rank: int, phase_events: list):
     return calls, flops, nbytes, desc, lambda: float('nan'), 'hbm'
 
 
-def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_events=None):
+def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_events=None, ep_capacity: int = 0):
     """Returns (zero-arg callables, flops per step, algorithmic bytes per step, description, checker, roofline bound)."""
     calls, cases = [], []
     bound = 'mfma'
     if name == 'masked' and world > 1:
-        return make_ep_workload(sets, world, rank, phase_events)
+        return make_ep_workload(sets, world, rank, phase_events, ep_capacity)
     if name in ('dense', 'dense_ue8m0'):
         m, n, k = 4096, 4096, 7168
         packed = name == 'dense_ue8m0'
@@ -294,7 +297,7 @@ def run(rank: int, world: int, local_rank: int, args):
 
     dg.set_forced_config(args.config)
     phase_events = []
-    calls, flops, nbytes, desc, check, bound = make_workload(args.workload, args.sets, world, rank, phase_events)
+    calls, flops, nbytes, desc, check, bound = make_workload(args.workload, args.sets, world, rank, phase_events, args.ep_capacity)
 
     calls[0]()
     torch.cuda.synchronize()

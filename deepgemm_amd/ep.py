@@ -18,9 +18,10 @@ xGMI is a point-to-point mesh, so an all-to-all puts only each pair's own traffi
 sizes (<= 64 rows per expert) the messages are a few MB per GPU and latency dominated.
 
 The collective layer is ``torch.distributed`` (backend ``nccl`` = RCCL on ROCm; ``gloo`` in the CPU tests, where the
-local GEMM is replaced by the test's checker through the ``local_gemm`` argument).  Nothing here allocates inside a
-captured region or synchronises with the host except for the split sizes, which ``all_to_all_single`` needs as Python
-ints (one small device-to-host copy per step, as in any unfused EP dispatch).
+local GEMM is replaced by the test's checker through the ``local_gemm`` argument).  The exact-size exchange (``dispatch`` /
+``combine``) needs the split sizes as Python ints -- one small device-to-host copy per step, as in any unfused EP dispatch; the
+fixed-capacity exchange (``dispatch_fixed`` / ``combine_fixed``) pads every (rank, expert) block to ``capacity`` rows instead
+and never touches the host: the form for latency-bound, graph-captured decode steps.
 """
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
@@ -133,6 +134,99 @@ def combine(d: torch.Tensor, plan: DispatchPlan, tokens: int, top_k: int, group=
     return (out.float() * topk_weights.to(torch.float).unsqueeze(-1)).sum(dim=1).to(d.dtype)
 
 
+@dataclass
+class FixedPlan:
+    """Bookkeeping of one fixed-capacity dispatch (device tensors only: nothing here ever reached the host)."""
+    send_order: torch.Tensor          # [P] permutation that sorts this rank's (row, expert) pairs by destination expert
+    pair_rank: torch.Tensor           # [P] destination rank of every sorted pair
+    pair_expert: torch.Tensor         # [P] local expert index on that rank
+    pair_pos: torch.Tensor            # [P] slot inside the (this rank -> expert) block, clamped to capacity - 1
+    recv_expert: torch.Tensor         # [world * per_rank * capacity] local expert of every received slot
+    recv_slot: torch.Tensor           # same shape: row inside that expert's masked block (invalid slots: clamped, never read back)
+    masked_m: torch.Tensor            # [G_local] int32 rows per local expert
+    overflow: torch.Tensor            # 0-dim bool: a block or an expert was over capacity (rows were dropped)
+
+
+def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, max_m: int, capacity: int,
+                   group=None) -> Tuple[TensorPair, FixedPlan]:
+    """The dispatch without any host synchronisation (a decode step that is captured into a hipGraph cannot read split sizes back):
+    every rank sends every peer a block of fixed shape ``[experts per rank, capacity, K + K / 32 bytes]`` plus the row counts of its
+    blocks -- two equal-split all-to-alls -- and the receiver compacts the valid rows into the masked layout with index arithmetic
+    on the device.  ``capacity`` = the most rows one rank may send to one expert (``tokens`` is always enough: a token names an
+    expert at most once); the price is the padding on the wire, ``world * experts_per_rank * capacity`` rows per rank instead of
+    ``tokens * top_k``.  Rows over capacity (or over ``max_m`` on the receiver) are dropped and ``plan.overflow`` is set -- check it
+    where a synchronisation is affordable.  Returns the local masked operand and the plan for :func:`combine_fixed`."""
+    x_fp8, x_sf = x
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    first, last = expert_range(num_experts, rank, world)
+    per_rank = last - first
+    tokens, top_k = expert_ids.shape
+    device = x_fp8.device
+    k, sf_bytes = x_fp8.size(1), 4 * x_sf.size(1)
+
+    flat_expert = expert_ids.reshape(-1).to(torch.int64)
+    flat_row = torch.arange(tokens, device=device).repeat_interleave(top_k)
+    order = torch.argsort(flat_expert, stable=True)
+    sorted_expert = flat_expert[order]
+    per_expert = torch.bincount(sorted_expert, minlength=num_experts)
+    run_begin = torch.cumsum(per_expert, dim=0) - per_expert
+    pos = torch.arange(sorted_expert.numel(), device=device) - run_begin[sorted_expert]
+    overflow = (per_expert > capacity).any()
+    pair_rank, pair_expert = sorted_expert // per_rank, sorted_expert % per_rank
+    pair_pos = pos.clamp(max=capacity - 1)                 # (over capacity: collides with the last slot; overflow says so)
+
+    rows = flat_row[order]
+    send = torch.zeros((world, per_rank, capacity, k + sf_bytes), dtype=torch.uint8, device=device)
+    packed = torch.empty((rows.numel(), k + sf_bytes), dtype=torch.uint8, device=device)
+    packed[:, :k] = x_fp8.view(torch.uint8)[rows]
+    packed[:, k:] = x_sf.contiguous().view(torch.uint8).view(tokens, sf_bytes)[rows]
+    send[pair_rank, pair_expert, pair_pos] = packed
+    send_counts = per_expert.clamp(max=capacity).view(world, per_rank).to(torch.int32)
+
+    recv = torch.empty_like(send)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts.contiguous(), group=group)
+    dist.all_to_all_single(recv, send, group=group)
+
+    # slot of entry (source s, expert g, c): rows of earlier sources first; invalid entries go to the dump row max_m
+    offsets = torch.cumsum(recv_counts, dim=0) - recv_counts                        # [world, per_rank]
+    c = torch.arange(capacity, device=device).view(1, 1, capacity)
+    slot = offsets.unsqueeze(-1) + c
+    valid = (c < recv_counts.unsqueeze(-1)) & (slot < max_m)
+    overflow = overflow | (recv_counts.sum(dim=0) > max_m).any()
+    recv_expert = torch.arange(per_rank, device=device).view(1, per_rank, 1).expand(world, per_rank, capacity).reshape(-1)
+    recv_slot = slot.clamp(max=max_m - 1).reshape(-1).to(torch.int64)
+    # row of the flat [per_rank * max_m (+ 1 dump row)] stores: invalid entries all land in the dump row behind the last block
+    flat_row = torch.where(valid.reshape(-1), recv_expert * max_m + recv_slot, torch.full_like(recv_slot, per_rank * max_m))
+    masked_m = recv_counts.sum(dim=0).clamp(max=max_m).to(torch.int32)
+
+    a_store = torch.zeros((per_rank * max_m + 1, k), dtype=torch.uint8, device=device)
+    sf_store = torch.zeros((per_rank * max_m + 1, x_sf.size(1)), dtype=torch.float, device=device)
+    flat = recv.view(-1, k + sf_bytes)
+    a_store[flat_row] = flat[:, :k]
+    sf_store[flat_row] = flat[:, k:].contiguous().view(torch.float)
+    plan = FixedPlan(order, pair_rank, pair_expert, pair_pos, recv_expert, recv_slot, masked_m, overflow)
+    a = a_store[:per_rank * max_m].view(torch.float8_e4m3fn).view(per_rank, max_m, k)
+    return (a, sf_store[:per_rank * max_m].view(per_rank, max_m, x_sf.size(1))), plan
+
+
+def combine_fixed(d: torch.Tensor, plan: FixedPlan, tokens: int, top_k: int, world: int, capacity: int, group=None,
+                  topk_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The return path of :func:`dispatch_fixed`: result rows travel back in the same fixed-shape blocks (one equal-split all-to-all),
+    every rank picks its pairs' rows out of the blocks it gets back.  Same outputs as :func:`combine`."""
+    per_rank, max_m, n = d.size(0), d.size(1), d.size(2)
+    # (invalid entries read some valid row: those slots of the blocks are never picked by their source rank)
+    blocks = d[plan.recv_expert, plan.recv_slot].view(world, per_rank, capacity, n).contiguous()
+    back = torch.empty_like(blocks)
+    dist.all_to_all_single(back, blocks, group=group)
+    out = torch.empty((tokens * top_k, n), dtype=d.dtype, device=d.device)
+    out[plan.send_order] = back[plan.pair_rank, plan.pair_expert, plan.pair_pos]
+    out = out.view(tokens, top_k, n)
+    if topk_weights is None:
+        return out
+    return (out.float() * topk_weights.to(torch.float).unsqueeze(-1)).sum(dim=1).to(d.dtype)
+
+
 def _default_local_gemm(a: TensorPair, b: TensorPair, d: torch.Tensor, masked_m: torch.Tensor, expected_m: int) -> None:
     from .gemm import m_grouped_fp8_gemm_nt_masked          # the HIP path; there is no CPU fallback
     m_grouped_fp8_gemm_nt_masked(a, b, d, masked_m, expected_m)
@@ -142,13 +236,15 @@ def ep_m_grouped_fp8_gemm_nt_masked(x: TensorPair, expert_ids: torch.Tensor, b_l
                                     max_m: int, expected_m: Optional[int] = None, group=None,
                                     local_gemm: Callable = _default_local_gemm,
                                     topk_weights: Optional[torch.Tensor] = None,
-                                    phase_events: Optional[list] = None) -> torch.Tensor:
+                                    phase_events: Optional[list] = None, capacity: Optional[int] = None) -> torch.Tensor:
     """One expert-parallel step: dispatch -> local masked grouped GEMM -> combine (-> top-k weighted reduce).
 
     ``b_local = (B [G_local, N, K] fp8, SFB [G_local, N / 128, K / 128])`` are this rank's resident expert weights.
     Returns ``[T, top_k, N]`` BF16 (row ``(t, j)`` is ``x[t] @ B[expert_ids[t, j]]^T``) or, with ``topk_weights``, ``[T, N]``.
     ``phase_events``: a list that receives one ``(e0, e1, e2, e3)`` tuple of recorded CUDA events per call -- dispatch is
     ``e0..e1``, the local GEMM ``e1..e2``, combine ``e2..e3`` (bench.py's time split; only on CUDA tensors).
+    ``capacity``: rows one rank may send to one expert -- selects the fixed-shape exchange (:func:`dispatch_fixed`), which never
+    synchronises with the host (capturable); ``None`` = exact split sizes (one small device-to-host copy per step).
     """
     tokens, top_k = expert_ids.shape
     marks = []
@@ -159,13 +255,19 @@ def ep_m_grouped_fp8_gemm_nt_masked(x: TensorPair, expert_ids: torch.Tensor, b_l
             ev.record()
             marks.append(ev)
     mark()
-    (a, sfa), plan = dispatch(x, expert_ids, num_experts, max_m, group)
+    if capacity is None:
+        (a, sfa), plan = dispatch(x, expert_ids, num_experts, max_m, group)
+    else:
+        (a, sfa), plan = dispatch_fixed(x, expert_ids, num_experts, max_m, capacity, group)
     mark()
     groups, n = b_local[0].size(0), b_local[0].size(1)
     d = torch.empty((groups, max_m, n), dtype=torch.bfloat16, device=a.device)
     local_gemm((a, sfa), b_local, d, plan.masked_m, expected_m if expected_m is not None else max(1, max_m // 2))
     mark()
-    out = combine(d, plan, tokens, top_k, group, topk_weights)
+    if capacity is None:
+        out = combine(d, plan, tokens, top_k, group, topk_weights)
+    else:
+        out = combine_fixed(d, plan, tokens, top_k, dist.get_world_size(group), capacity, group, topk_weights)
     mark()
     if phase_events is not None:
         phase_events.append(tuple(marks))

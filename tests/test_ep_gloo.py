@@ -57,6 +57,19 @@ def _worker(rank: int, world: int, port: int, num_experts: int, tokens: int, top
         assert reduced.shape == (x.size(0), n) and reduced.dtype == torch.bfloat16
         assert torch.equal(reduced, (out.float() * weights.unsqueeze(-1)).sum(dim=1).to(torch.bfloat16))
 
+        # the fixed-capacity exchange (no host synchronisation): same rows, same bits
+        fixed = ep.ep_m_grouped_fp8_gemm_nt_masked(xq, expert_ids, b_local, num_experts, max_m, local_gemm=_oracle_local_gemm,
+                                                   capacity=tokens + world)      # (the same on every rank)
+        assert torch.equal(fixed, out)
+        fixed_reduced = ep.ep_m_grouped_fp8_gemm_nt_masked(xq, expert_ids, b_local, num_experts, max_m, local_gemm=_oracle_local_gemm,
+                                                           topk_weights=weights, capacity=tokens + world)
+        assert torch.equal(fixed_reduced, reduced)
+        (a_fixed, _), plan_fixed = ep.dispatch_fixed(xq, expert_ids, num_experts, max_m, 2)      # capacity 2: rows may be dropped
+        assert a_fixed.shape[1] == max_m and a_fixed.is_contiguous()
+        busiest = int(torch.bincount(expert_ids.reshape(-1), minlength=num_experts).max())
+        flag_local = torch.tensor([int(busiest > 2)])
+        assert bool(plan_fixed.overflow) or int(flag_local) == 0                 # my own over-full blocks are always reported
+
         # capacity overflow is an error, not silent truncation
         if rank == 0:
             pass

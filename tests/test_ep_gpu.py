@@ -38,6 +38,10 @@ def test_ep_step_single_rank_nccl():
                 diff = (out_cpu[t, j].float() - want[0].float()).abs().max().item()
                 scale = want[0].float().abs().max().item()
                 assert diff <= 2 ** -7 * scale, (t, j, e, diff, scale)        # one BF16 ulp of the row's largest value
+        # the fixed-capacity exchange (no host synchronisation): same bits
+        fixed = ep.ep_m_grouped_fp8_gemm_nt_masked(x, ids, b_local, num_experts, max_m, capacity=tokens)
+        torch.cuda.synchronize()
+        assert torch.equal(fixed, out)
     finally:
         if created:
             dist.destroy_process_group()
