@@ -1193,6 +1193,49 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
     return name.c_str();
 }
 
+int dg_operand_plan(int gemm_type, const void* a, const void* b, int m, int n, int k, int64_t a_sm, int64_t a_sk, int64_t b_sn,
+                    int64_t b_sk, int64_t b_sg, int64_t sfa_sm, int sfb_gran_n, int m_alignment) {
+    // Which MN-major FP8 operands the caller should re-major into K-major scratch before the launch (bit 0: A, bit 1: B), decided
+    // with the very predicates select_config() / launch_gemm() apply, so that an operand left as it is always finds its kernel.
+    const bool a_mn = a_sk != 1, b_mn = b_sk != 1;
+    const int all = (a_mn ? 1 : 0) | (b_mn ? 2 : 0);
+    if (all == 0)
+        return 0;
+    const uint8_t* scratch = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(1) << 20);    // (a fresh allocation: aligned, dense)
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b);
+    p.sfa = p.sfb = reinterpret_cast<const float*>(static_cast<uintptr_t>(1) << 21);
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = a_sm; p.a_sk = a_sk; p.b_sn = b_sn; p.b_sk = b_sk; p.b_sg = b_sg;
+    p.sfa_sm = sfa_sm; p.sfa_sk = (m + 3) / 4 * 4; p.sfb_sn = 1; p.sfb_sk = (n + 3) / 4 * 4;
+    p.sfb_gran_n = sfb_gran_n; p.gemm_type = gemm_type; p.m_alignment = m_alignment;
+    if (gemm_type != dg::kNormal)       // contiguous layouts: A is K-major by contract; B as it is when the B_MN kernels take it
+        return (b_mn && bmn_eligible(p) && m > 256 && m_alignment % 128 == 0) ? 0 : all;
+    if (sfb_gran_n == 1)                // recipe (1, 1, 128): the transpose-read kernel wants BOTH operands MN-major
+        return (a_mn && b_mn && per_col_mn_eligible(p) && m > 64) ? 0 : all;
+    if (sfb_gran_n != 128 || sfa_sm != 1)
+        return all;
+    if (a_mn && m > 256) {
+        // The MN-major-A kernels exist for 256 x 256 tiles only and are never K-split: a problem whose 256 x 256 tiles cover at most
+        // half the chip while the K loop is long (wgrad of a narrow layer: 576 x 4096 x 7168 = 48 tiles) is better served by
+        // re-majoring A (a few microseconds) and the 128 x 256 tiles of the K-major-A kernels, which the K split spreads out.
+        const bool few_tiles_long_k = static_cast<long>(ceil_div(m, 256)) * ceil_div(n, 256) * 2 <= num_cus() && k >= 2048;
+        if (!few_tiles_long_k) {
+            if (amn_eligible(p))
+                return 0;
+            dg::GemmParams q = p;       // B re-majored
+            q.b = scratch; q.b_sn = k; q.b_sk = 1;
+            if (b_mn && amn_eligible(q))
+                return 2;
+        }
+    }
+    dg::GemmParams q = p;               // A K-major (as given, or re-majored)
+    if (a_mn) { q.a = scratch; q.a_sm = k; q.a_sk = 1; }
+    if (b_mn && bmn_eligible(q) && m > 256)
+        return a_mn ? 1 : 0;
+    return all;
+}
+
 const char* dg_last_config(void) { return g_last_config.c_str(); }
 const char* dg_last_error(void) { return g_last_error.c_str(); }
 const char* dg_version(void) { return "deepgemm_amd 0.1.0 (gfx950)"; }

@@ -40,22 +40,6 @@ def _as_k_major(t: torch.Tensor, macs: int) -> torch.Tensor:
     return _remajor(t)
 
 
-def _both_mn_major_aligned(a: torch.Tensor, b: torch.Tensor, m: int, n: int) -> bool:
-    return (a.stride(-2) == 1 and b.stride(-2) == 1 and m > 64 and m % 16 == 0 and n % 16 == 0 and
-            a.stride(-1) % 16 == 0 and b.stride(-1) % 16 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
-
-
-def _b_mn_major_native(b: torch.Tensor, m: int, n: int, k: int, a: torch.Tensor, m_alignment: int = 128) -> bool:
-    """MN-major B ([.., N, K] view with unit stride along N) that the B_MN kernels take as it is.  Mirrors dg_api.hip's
-    bmn_eligible() and the tile rule of select_config() -- K-major 16-byte aligned A, whole 16-byte K chunks, 32-bit piece offsets, a
-    contiguous-layout alignment the 128-row tiles divide -- so that whatever passes here finds a kernel there; anything else is
-    re-majored into K-major scratch by the caller."""
-    return (b.stride(-2) == 1 and b.stride(-1) != 1 and m > 256 and n % 16 == 0 and k % 16 == 0 and k > 128 and m_alignment % 128 == 0 and
-            b.stride(-1) % 16 == 0 and b.data_ptr() % 16 == 0 and (b.dim() == 2 or b.stride(0) % 16 == 0) and
-            b.stride(-1) <= (1 << 22) and k * b.stride(-1) < (1 << 31) and
-            a.stride(-1) == 1 and a.stride(-2) % 16 == 0 and a.data_ptr() % 16 == 0 and a.stride(-2) <= (1 << 22))
-
-
 def _remajor(t: torch.Tensor) -> torch.Tensor:
     """An MN-major FP8 operand view ``[.., mn, k]`` (stride 1 along mn) as a fresh K-major tensor (dg_transpose_fp8)."""
     require_device(t)
@@ -67,51 +51,21 @@ def _remajor(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _a_mn_major_self_ok(a: torch.Tensor, m: int, k: int) -> bool:
-    """A's half of dg_api.hip's amn_eligible() + the m > 256 rule of select_config(): a dense MN-major A ([M, K] view with unit
-    stride along M) that the A_MN kernels take as it is."""
-    return (a.dim() == 2 and a.stride(0) == 1 and a.stride(1) != 1 and m > 256 and k % 16 == 0 and k > 128 and a.stride(1) % 16 == 0 and
-            a.data_ptr() % 16 == 0 and a.stride(1) <= (1 << 22) and k * a.stride(1) < (1 << 31))
-
-
-def _b_ok_beside_mn_major_a(b: torch.Tensor, n: int, k: int) -> bool:
-    """B's half of amn_eligible(): K-major, or MN-major with whole 16-byte chunks along N."""
-    if b.data_ptr() % 16 != 0:
-        return False
-    if b.stride(1) == 1:
-        return b.stride(0) % 16 == 0 and b.stride(0) <= (1 << 22)
-    return (b.stride(0) == 1 and n % 16 == 0 and b.stride(1) % 16 == 0 and b.stride(1) <= (1 << 22) and
-            k * b.stride(1) < (1 << 31))
-
-
-def _few_tiles_long_k(m: int, n: int, k: int) -> bool:
-    """The MN-major-A kernels exist for 256 x 256 tiles only and are never K-split: a problem whose 256 x 256 tiles cover at most
-    half the chip while the K loop is long (wgrad of a narrow layer: 576 x 4096 x 7168 = 48 tiles) is better served by re-majoring A
-    (a few microseconds) and the 128 x 256 tiles of the K-major-A kernels, which the K split can spread over the idle CUs."""
-    cus = int(lib.dg_get_num_cus())
-    return -(-m // 256) * -(-n // 256) * 2 <= cus and k >= 2048
+def _operand_plan(gemm_type: int, a: torch.Tensor, b: torch.Tensor, sfa: torch.Tensor, gran_n: int, m: int, n: int, k: int,
+                  m_alignment: int = 128) -> int:
+    """dg_operand_plan (include/deepgemm_amd.h): which MN-major operands no kernel reads in place (bit 0: A, bit 1: B).  The C side
+    decides with the predicates its own launch applies -- there is no Python copy of the alignment / tile rules to drift."""
+    return int(lib.dg_operand_plan(gemm_type, a.data_ptr(), b.data_ptr(), m, n, k, a.stride(-2), a.stride(-1), b.stride(-2), b.stride(-1),
+                                   b.stride(0) if b.dim() == 3 else 0, sfa.stride(-2), gran_n, m_alignment))
 
 
 def _dense_operands(a_data: torch.Tensor, b_data: torch.Tensor, sfa: torch.Tensor, gran_n: int, m: int, n: int, k: int):
     """The FP8 operands as the C entry will read them: as they are wherever a kernel takes that majorness natively, re-majored
     into K-major scratch (dg_transpose_fp8) otherwise.  One place for the cached and the uncached path of fp8_gemm_nt."""
-    macs = m * n * k
-    if gran_n == 1 and _both_mn_major_aligned(a_data, b_data, m, n):
-        return a_data, b_data       # recipe (1, 1, 128) with both operands MN-major: the kernel reads them as they are
-    if gran_n == 128 and sfa.stride(0) == 1:
-        if a_data.stride(-1) != 1 and _a_mn_major_self_ok(a_data, m, k) and not _few_tiles_long_k(m, n, k):
-            # large MN-major A: transpose reads (duo_amn / duo_abmn); B as it is when that kernel can take it, else re-majored
-            if _b_ok_beside_mn_major_a(b_data, n, k):
-                return a_data, b_data
-            b_k = _as_k_major(b_data, macs)
-            if _b_ok_beside_mn_major_a(b_k, n, k):
-                return a_data, b_k
-            return _as_k_major(a_data, macs), b_k
-        a_k = _as_k_major(a_data, macs)
-        if _b_mn_major_native(b_data, m, n, k, a_k):
-            return a_k, b_data      # large MN-major B: read natively through transpose reads (duo_bmn)
-        return a_k, _as_k_major(b_data, macs)
-    return _as_k_major(a_data, macs), _as_k_major(b_data, macs)
+    if a_data.stride(-1) == 1 and b_data.stride(-1) == 1:
+        return a_data, b_data
+    plan, macs = _operand_plan(0, a_data, b_data, sfa, gran_n, m, n, k), m * n * k
+    return (_as_k_major(a_data, macs) if plan & 1 else a_data), (_as_k_major(b_data, macs) if plan & 2 else b_data)
 
 
 # Host-overhead diet for decode-sized calls: the reference's checks cost ~20 us of Python per call, more than the kernel of
@@ -379,7 +333,8 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
                                                               None, num_groups, disable_ue8m0_cast)
     host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
-    if not (sfa.stride(0) == 1 and _b_mn_major_native(b_data, m, n, k, a_data, runtime.get_mk_alignment_for_contiguous_layout())):
+    if b_data.stride(-1) != 1 and _operand_plan(2 if use_psum_layout else 1, a_data, b_data, sfa, gran_n, m, n, k,
+                                                runtime.get_mk_alignment_for_contiguous_layout()) & 2:
         b_data = _as_k_major(b_data, m * n * k)
     stream = current_stream_ptr()
     workspace = _split_k_workspace(d.device, stream)

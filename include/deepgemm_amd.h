@@ -233,6 +233,16 @@ const char* dg_last_config(void);
 const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups, int expected_m, int a_mn_major, int b_mn_major,
                              int sfb_gran_n, int m_alignment, int has_workspace, int packed_ue8m0);
 
+/* Which MN-major FP8 operands the host side should re-major into K-major scratch (dg_transpose_fp8) before calling
+ * dg_fp8_gemm_nt_ws / dg_m_grouped_fp8_gemm_nt_contiguous_ws: bit 0 = A, bit 1 = B; 0 = every operand is read where it lies.
+ * Decided with the predicates the launch itself applies (pointer and pitch alignment, 32-bit offset range, tile rules), so an
+ * operand left in place always finds its native kernel.  The reference reads the majorness off the strides (csrc/apis/gemm.hpp:83-88)
+ * and hands it to the TMA descriptors (SM100: csrc/jit_kernels/impls/sm100_fp8_fp4_gemm_1d1d.hpp; SM90 asserts K-major,
+ * csrc/jit_kernels/impls/sm90_fp8_gemm_1d2d.hpp:90); here the kernels that read MN-major operands natively have alignment rules.
+ * gemm_type as in dg_select_config; b_sg = group pitch of B (0 for dense); sfa_sm = element stride of SFA along m. */
+int dg_operand_plan(int gemm_type, const void* a, const void* b, int m, int n, int k, int64_t a_sm, int64_t a_sk, int64_t b_sn,
+                    int64_t b_sk, int64_t b_sg, int64_t sfa_sm, int sfb_gran_n, int m_alignment);
+
 const char* dg_last_error(void);
 const char* dg_version(void);
 

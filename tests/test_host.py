@@ -293,29 +293,57 @@ def test_every_reference_keyword_by_name():
 
 
 def test_operand_majorness_decisions_on_the_host():
-    """Which FP8 operands the dense operator hands over as they are (deepgemm_amd/gemm.py:_dense_operands; the C-side twins are
-    amn_eligible / bmn_eligible in dg_api.hip): decided from shapes, strides and alignment alone -- CPU tensors suffice, the
-    re-majoring kernel itself is never reached here (REMAJOR_MIN_MACS keeps small problems in place)."""
+    """Which FP8 operands the operators hand over as they are: dg_operand_plan (include/deepgemm_amd.h), the one owner of the alignment
+    and tile rules (amn_eligible / bmn_eligible / per_col_mn_eligible in dg_api.hip) -- decided from shapes, strides and pointers
+    alone, so CPU tensors suffice; the re-majoring kernel itself is never reached here (REMAJOR_MIN_MACS keeps the operands in place)."""
     from deepgemm_amd import gemm
-    k_major = torch.empty((1024, 2048), dtype=torch.uint8).view(torch.float8_e4m3fn)
-    mn_major = torch.empty((2048, 1024), dtype=torch.uint8).view(torch.float8_e4m3fn).t()          # [1024, 2048] view, unit stride along m
-    assert gemm._a_mn_major_self_ok(mn_major, 1024, 2048) and not gemm._a_mn_major_self_ok(k_major, 1024, 2048)
-    assert not gemm._a_mn_major_self_ok(mn_major[:256], 256, 2048)                                 # M <= 256: not a 256-row-tile problem
-    assert not gemm._a_mn_major_self_ok(mn_major, 1024, 2040)                                      # K not in whole 16-byte chunks
-    odd_pitch = torch.empty((2048, 1032), dtype=torch.uint8).view(torch.float8_e4m3fn).t()[:1024]
-    assert not gemm._a_mn_major_self_ok(odd_pitch, 1024, 2048)                                     # row pitch 1032: not a multiple of 16
-    assert gemm._b_ok_beside_mn_major_a(k_major, 1024, 2048) and gemm._b_ok_beside_mn_major_a(mn_major, 1024, 2048)
-    assert not gemm._b_ok_beside_mn_major_a(mn_major[:1000], 1000, 2048)                           # N % 16 != 0 with an MN-major B
-    # few 256 x 256 tiles and a long K loop: A is re-majored so that the K split can use the idle CUs (rule, not alignment)
-    assert gemm._few_tiles_long_k(576, 4096, 7168) and gemm._few_tiles_long_k(2048, 4096, 7168)
-    assert not gemm._few_tiles_long_k(2048, 7168, 2048) and not gemm._few_tiles_long_k(576, 4096, 1024)
-    sfa = torch.empty((16, 1024), dtype=torch.float).t()                                           # MN-major SFA
+    a_bit, b_bit = 1, 2
+
+    def fp8(rows, cols):
+        return torch.empty((rows, cols), dtype=torch.uint8).view(torch.float8_e4m3fn)
+    k_major = fp8(1024, 1024)
+    mn_major = fp8(1024, 1024).t()                                                  # [1024, 1024] view, unit stride along m / n
+    sfa = torch.empty((8, 1024), dtype=torch.float).t()                           # MN-major SFA
+
+    def plan(a, b, m=1024, n=1024, k=1024, gran_n=128, sf=sfa, gemm_type=0, alignment=128):
+        return gemm._operand_plan(gemm_type, a, b, sf, gran_n, m, n, k, alignment)
+    assert plan(k_major, k_major) == 0
+    assert plan(mn_major, k_major) == 0 and plan(mn_major, mn_major) == 0          # tn / tt: transpose reads of A (duo_amn / duo_abmn)
+    assert plan(k_major, mn_major) == 0                                            # nn: duo_bmn
+    # M <= 256 is not a 256-row-tile problem: nothing reads MN-major operands in place
+    assert plan(mn_major[:256], k_major, m=256) == a_bit and plan(k_major[:256], mn_major, m=256) == b_bit
+    # A's pitch not a multiple of 16 bytes: A is re-majored, B still read in place by the B_MN kernels
+    odd_pitch = fp8(1024, 1032).t()[:1024]
+    assert plan(odd_pitch, k_major) == a_bit and plan(odd_pitch, mn_major) == a_bit
+    # N % 16 != 0 with an MN-major B: re-major B, keep the MN-major A
+    assert plan(mn_major, mn_major[:1000], n=1000) == b_bit and plan(k_major, mn_major[:1000], n=1000) == b_bit
+    # a partial last K block (K = 1040 = 16 x 65): the MN-major-A kernels have no tail stage, the B_MN ones do
+    a_t, b_t = fp8(1040, 1024).t(), fp8(1040, 1024).t()
+    sf_t = torch.empty((9, 1024)).t()
+    assert plan(a_t, b_t, k=1040, sf=sf_t) == a_bit and plan(a_t, fp8(1024, 1040), k=1040, sf=sf_t) == a_bit
+    assert plan(fp8(1024, 1040), b_t, k=1040, sf=sf_t) == 0
+    assert plan(fp8(1024, 1016), fp8(1016, 1024).t(), k=1016) == b_bit                # K not in whole 16-byte chunks: generic kernel, K-major
+    # few 256 x 256 tiles and a long K loop: A is re-majored so that the K split can use the idle CUs (a rule, not alignment)
+    for (m, n, k), want in (((576, 4096, 7168), a_bit), ((2048, 4096, 7168), a_bit), ((2048, 7168, 2048), 0), ((576, 4096, 1024), 0)):
+        assert plan(fp8(k, m).t(), fp8(n, k), m, n, k, sf=torch.empty((k // 128, m)).t()) == want, (m, n, k)
+    # MN-major SFA is what the fast kernels read: a K-major SFA sends everything to the K-major generic path
+    assert plan(mn_major, mn_major, sf=torch.empty((1024, 8))) == a_bit | b_bit
+    # recipe (1, 1, 128): only BOTH operands MN-major are read in place (pipe_pc_mn)
+    assert plan(mn_major, mn_major, gran_n=1) == 0 and plan(mn_major, k_major, gran_n=1) == a_bit and plan(k_major, mn_major, gran_n=1) == b_bit
+    # contiguous layout (A K-major by contract): B in place for alignments the 128-row tiles divide
+    b3 = torch.empty((4, 1024, 1024), dtype=torch.uint8).view(torch.float8_e4m3fn).transpose(1, 2)       # [4, 1024, 1024], unit stride along n
+    a_c = fp8(4096, 1024)
+    sf_c = torch.empty((8, 4096)).t()
+    assert plan(a_c, b3, m=4096, sf=sf_c, gemm_type=1) == 0 and plan(a_c, b3, m=4096, sf=sf_c, gemm_type=2) == 0
+    assert plan(a_c, b3, m=4096, sf=sf_c, gemm_type=1, alignment=64) == b_bit
     saved, gemm.REMAJOR_MIN_MACS = gemm.REMAJOR_MIN_MACS, 1 << 62
     try:
-        a, b = gemm._dense_operands(mn_major, k_major, sfa, 128, 1024, 1024, 2048)
-        assert a is mn_major and b is k_major                                                      # tt: both as they are
-        a, b = gemm._dense_operands(k_major, mn_major, sfa, 128, 1024, 1024, 2048)
-        assert a is k_major and b is mn_major                                                      # nn
+        a, b = gemm._dense_operands(mn_major, k_major, sfa, 128, 1024, 1024, 1024)
+        assert a is mn_major and b is k_major
+        a, b = gemm._dense_operands(k_major, mn_major, sfa, 128, 1024, 1024, 1024)
+        assert a is k_major and b is mn_major
+        a, b = gemm._dense_operands(odd_pitch, mn_major, sfa, 128, 1024, 1024, 1024)   # (would be re-majored above the size threshold)
+        assert a is odd_pitch and b is mn_major
     finally:
         gemm.REMAJOR_MIN_MACS = saved
 
