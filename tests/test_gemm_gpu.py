@@ -242,6 +242,25 @@ def test_mn_major_a_native_path(m, n, k, b_k_major, out_dtype, accumulate):
     assert dg.last_config().startswith('duo_a') and torch.equal(d3, case.d)
 
 
+@pytest.mark.parametrize('b_k_major', [True, False])
+def test_mn_major_a_with_k_tail_is_re_majored_onto_a_tail_kernel(b_k_major):
+    """The MN-major-A kernels have no K-tail stage: dg_operand_plan sends A (and only A) through dg_transpose_fp8 so that the call lands
+    on duo_kt / duo_bmn_kt instead of the layout-agnostic kernel (what the former Python-side predicate let happen)."""
+    m, n, k = 512, 768, 2112
+    gen.reset_seed(7)
+    case = gen.generate_normal(m, n, k, a_k_major=False, b_k_major=b_k_major)
+    assert case.a[0].stride(0) == 1
+    want = oracle_dense(case)
+    dg.fp8_gemm_nt(case.a, case.b, case.d)
+    assert dg.last_config().startswith('duo_kt_' if b_k_major else 'duo_bmn_kt_'), dg.last_config()
+    assert_close_to_oracle(case.d, want, 'mn-major a, k tail')
+    d2 = torch.empty_like(case.d)
+    dg.set_forced_config('generic_128x128')
+    dg.fp8_gemm_nt(case.a, case.b, d2)
+    dg.set_forced_config('auto')
+    assert torch.equal(d2, case.d)
+
+
 @pytest.mark.parametrize('m,n,k', [(512, 512, 576), (1040, 784, 2112), (4096, 1024, 320), (130, 4096, 1088)])
 @pytest.mark.parametrize('b_k_major', [True, False])
 def test_k_tail_fast_path(m, n, k, b_k_major):
