@@ -432,14 +432,22 @@ def _k_grouped_sf(sf: torch.Tensor, mn: int, sum_k: int) -> torch.Tensor:
     return get_mn_major_tma_aligned_tensor(sf)
 
 
-def _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, layout, a_ld, b_ld) -> None:
+_NO_NATIVE_KERNEL = 3       # dg_k_grouped_fp8_gemm_nt_contiguous(DG_KGROUPED_ROWS): conditions not met, nothing was launched
+
+
+def _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, layout, a_ld, b_ld, may_decline: bool = False) -> bool:
+    """False (only with ``may_decline``) = the library has no kernel for this operand form and launched nothing."""
     import ctypes
     require_device(a_data, b_data, sfa, sfb, d)
     ks_arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
-    check(lib.dg_k_grouped_fp8_gemm_nt_contiguous(
+    rc = lib.dg_k_grouped_fp8_gemm_nt_contiguous(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n,
         ctypes.cast(ks_arr, ctypes.c_void_p), len(ks), layout, a_ld, b_ld,
-        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr()))
+        sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr())
+    if may_decline and rc == _NO_NATIVE_KERNEL:
+        return False
+    check(rc)
+    return True
 
 
 def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks_cpu, grouped_layout: torch.Tensor,
@@ -498,15 +506,9 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
         return
     host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
     sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
-    from . import runtime as _rt
-    # (mirrors the DG_KGROUPED_ROWS conditions of dg_k_grouped_fp8_gemm_nt_contiguous: anything else is re-majored below)
-    native = (m > 64 and m % 16 == 0 and n % 16 == 0 and num_groups <= 64 and a_data.data_ptr() % 16 == 0 and
-              b_data.data_ptr() % 16 == 0 and sum_k * max(m, n) < 2 ** 31 and max(m, n) <= (1 << 22) and
-              sfa.stride(0) == 1 and sfb.stride(0) == 1 and sfa.data_ptr() % 16 == 0 and sfb.data_ptr() % 16 == 0 and
-              sfa.stride(1) % 4 == 0 and sfb.stride(1) % 4 == 0 and _rt.last_forced_config() == 'auto')
-    if native:
-        # MN-major operands straight into the kernel: LDS-DMA of [k][m] rows, hardware transpose reads for the fragments
-        _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0))
+    # MN-major operands straight into the kernel (LDS-DMA of [k][m] rows, hardware transpose reads for the fragments) wherever the
+    # library's own DG_KGROUPED_ROWS conditions hold -- it declines without launching otherwise, and the operands are re-majored
+    if _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0), may_decline=True):
         return
     a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))       # [M, sum_k], [N, sum_k]: K-major
     _k_grouped_launch(a_km, sfa, b_km, sfb, d, m, n, ks, _KGROUPED_COLUMNS, a_km.stride(0), b_km.stride(0))

@@ -108,8 +108,9 @@ int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_
  *     and group g is a column range: what an MN-major [sum_k, m] operand (TN form) becomes after dg_transpose_fp8.
  *   ab_layout DG_KGROUPED_ROWS: the MN-major operands themselves, a [sum_k, m] with row pitch a_stride_m (b: [sum_k, n],
  *     b_stride_n), group g = a row range: the TN form without a re-majoring pass (hardware transpose reads out of LDS).
- *     Needs 16-byte aligned rows, MN-major scales, m > 64, at most 64 groups; otherwise returns non-zero and the caller
- *     re-majors (dg_transpose_fp8) and uses DG_KGROUPED_COLUMNS.
+ *     Needs 16-byte aligned rows, MN-major 16-byte aligned scales, m > 64, at most 64 groups; otherwise returns 3 WITHOUT
+ *     launching anything and the caller re-majors (dg_transpose_fp8) and uses DG_KGROUPED_COLUMNS -- the host layer tries
+ *     this form first and keeps no copy of the conditions.
  *   sfa element (row, kb) at sfa[row * sfa_stride_m + kb * sfa_stride_k], kb counted over the whole K axis; same for sfb
  *   (one scale per row of B per 128-K block: recipe (1, 1, 128)).
  *   d [num_groups, m, n] FP32, dense; the result is accumulated onto it (the caller copies C into D first). */
