@@ -329,13 +329,59 @@ __device__ __forceinline__ void store_rows_full_line_natural(const GemmParams& p
     store_rows_full_line_packed<MS, INTERLEAVED_ROWS>(p, t, d_group_off, w0, w1, ms, m_base, n_base);
 }
 
+// FP32 reduce-add of a whole wave tile (recipe (1, 1, 128) wgrad / K-grouped GEMMs: D += A B^T): the old values of FOUR subtile rows
+// are fetched before the first add, so a wave makes MS / 4 memory round trips instead of MS -- the tail of these kernels is the latency
+// of those trips (a 256 x 256 FP32 tile: 8 trips of ~2 us against a K loop of 80-120 us), not bytes.  Loads are unconditional from a
+// row clamped into the tile's computed range (always inside D); only the stores are predicated.  COL(ns) = first of the lane's four
+// consecutive columns of N-subtile ns.
+template <int MS, int NS, bool INTERLEAVED_ROWS, typename ColFn>
+__device__ __forceinline__ void reduce_add_tile_fp32(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
+                                                     int m_base, ColFn col_of) {
+    static_assert(MS % 4 == 0, "four subtile rows per round trip");
+    const int lane = threadIdx.x & 63;
+    float* dbase = reinterpret_cast<float*>(p.d) + d_group_off;
+    int coff[NS];
+    #pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+        coff[ns] = d_col(p, col_of(ns));
+    #pragma unroll
+    for (int mb = 0; mb < MS; mb += 4) {
+        v4f old[4][NS];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + mb + u : m_base + (mb + u) * 16 + (lane & 15);
+            const float* src = dbase + static_cast<int64_t>(imin(imax(row, t.m_begin), t.m_end - 1)) * p.d_sm;
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                old[u][ns] = *reinterpret_cast<const v4f*>(src + coff[ns]);
+        }
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + mb + u : m_base + (mb + u) * 16 + (lane & 15);
+            const bool compute_row = row >= t.m_begin && row < t.m_end;
+            const bool zero_row = row >= t.zero_from && row < t.zero_to;
+            float* dst = dbase + static_cast<int64_t>(row) * p.d_sm;
+            if (zero_row) {
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    *reinterpret_cast<v4f*>(dst + coff[ns]) = v4f{0.f, 0.f, 0.f, 0.f};
+            } else if (compute_row) {
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    *reinterpret_cast<v4f*>(dst + coff[ns]) = acc[mb + u][ns] + old[u][ns];
+            }
+        }
+    }
+}
+
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
 // NATURAL_COLS: acc[ms][ns][r] belongs to column n_base + ns*16 + lg*4 + r (B rows in their natural order in the LDS
 // image: the MN-major operand path); only the FP32 vector path and the element-wise paths exist for it.
 // ms_only >= 0: only that M-subtile is stored (the K-split reduction kernel works on one subtile row per workgroup).
-template <int MS, int NS, bool INTERLEAVED_ROWS = false, bool NT_STORE = false, bool NATURAL_COLS = false>
+// BATCH_RMW: FP32 reduce-add through reduce_add_tile_fp32 (the kernels whose every call accumulates; costs 64 live registers).
+template <int MS, int NS, bool INTERLEAVED_ROWS = false, bool NT_STORE = false, bool NATURAL_COLS = false, bool BATCH_RMW = false>
 __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
                                            int m_base, int n_base, int ms_only = -1) {
     const int lane = threadIdx.x & 63, lg = lane >> 4;
@@ -350,6 +396,13 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
             }
         }
         const bool full = n_base + NS * 16 <= p.n;
+        if constexpr (BATCH_RMW && MS % 4 == 0) {
+            if (p.d_dtype != 0 && p.accumulate && full && p.d_vec_ok && ms_only < 0 && t.m_end > t.m_begin) {
+                reduce_add_tile_fp32<MS, NS, INTERLEAVED_ROWS>(p, t, d_group_off, acc, m_base,
+                                                               [&](int ns) { return n_base + ns * 16 + lg * 4; });
+                return;
+            }
+        }
         #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
             if (ms_only >= 0 && ms != ms_only)
@@ -429,6 +482,13 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
             for (int ms = 0; ms < MS; ++ms)
                 if (ms_only < 0 || ms == ms_only)
                     store_rows_full_line<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
+            return;
+        }
+    }
+    if constexpr (BATCH_RMW && MS % 4 == 0 && NS % 2 == 0) {
+        if (p.d_dtype != 0 && p.accumulate && n_base + NS * 16 <= p.n && p.d_vec_ok && ms_only < 0 && t.m_end > t.m_begin) {
+            reduce_add_tile_fp32<MS, NS, INTERLEAVED_ROWS>(p, t, d_group_off, acc, m_base,
+                                                           [&](int ns) { return n_lane + (ns >> 1) * 32 + (ns & 1) * 4; });
             return;
         }
     }
@@ -1086,7 +1146,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
                 out[ms][ns] = v4f{accs[ms][ns][0], accs[ms][ns][1], accs[ms][ns][2], accs[ms][ns][3]};
-        store_tile<MS, NS, false, false, MN>(p, t, (p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg, out, t.m0 + wm * WM,
+        store_tile<MS, NS, false, false, MN, true>(p, t, (p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg, out, t.m0 + wm * WM,
                                              t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
