@@ -374,6 +374,61 @@ __device__ __forceinline__ void reduce_add_tile_fp32(const GemmParams& p, const 
     }
 }
 
+// BF16 reduce-add of a whole wave tile (D = bf16(D + bf16(A B^T)), the reference's BF16 accumulation, tests/generators.py:138-140): the old
+// values of TWO subtile rows per memory round trip (MS / 2 trips per wave tile instead of one per 16-byte vector, 2 MS); loads from
+// a row clamped into the tile's computed range, stores predicated.  n_lane: the lane's first column (+ h * 32 for pair h of N-subtiles).
+template <int MS, int NS, bool INTERLEAVED_ROWS>
+__device__ __forceinline__ void reduce_add_tile_bf16(const GemmParams& p, const Tile& t, int64_t d_group_off, v4f (&acc)[MS][NS],
+                                                     int m_base, int n_lane) {
+    static_assert(MS % 2 == 0 && NS % 2 == 0, "two subtile rows per round trip, 8 columns per lane and pair of N-subtiles");
+    const int lane = threadIdx.x & 63;
+    uint16_t* dbase = reinterpret_cast<uint16_t*>(p.d) + d_group_off;
+    int coff[NS / 2];
+    #pragma unroll
+    for (int h = 0; h < NS / 2; ++h)
+        coff[h] = d_col(p, n_lane + h * 32);
+    #pragma unroll
+    for (int mb = 0; mb < MS; mb += 2) {
+        uint4 old[2][NS / 2];
+        #pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + mb + u : m_base + (mb + u) * 16 + (lane & 15);
+            const uint16_t* src = dbase + static_cast<int64_t>(imin(imax(row, t.m_begin), t.m_end - 1)) * p.d_sm;
+            #pragma unroll
+            for (int h = 0; h < NS / 2; ++h)
+                old[u][h] = *reinterpret_cast<const uint4*>(src + coff[h]);
+        }
+        #pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = INTERLEAVED_ROWS ? m_base + (lane & 15) * MS + mb + u : m_base + (mb + u) * 16 + (lane & 15);
+            const bool compute_row = row >= t.m_begin && row < t.m_end;
+            const bool zero_row = row >= t.zero_from && row < t.zero_to;
+            uint16_t* dst = dbase + static_cast<int64_t>(row) * p.d_sm;
+            if (zero_row) {
+                #pragma unroll
+                for (int h = 0; h < NS / 2; ++h)
+                    *reinterpret_cast<uint4*>(dst + coff[h]) = make_uint4(0u, 0u, 0u, 0u);
+            } else if (compute_row) {
+                #pragma unroll
+                for (int h = 0; h < NS / 2; ++h) {
+                    const uint32_t o[4] = {old[u][h].x, old[u][h].y, old[u][h].z, old[u][h].w};
+                    uint32_t w[4];
+                    #pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const v4f v = acc[mb + u][2 * h + j];
+                        w[2 * j] = pack_bf16(v[0], v[1]);
+                        w[2 * j + 1] = pack_bf16(v[2], v[3]);
+                    }
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        w[j] = pack_bf16(bf16_lo(o[j]) + bf16_lo(w[j]), bf16_hi(o[j]) + bf16_hi(w[j]));
+                    *reinterpret_cast<uint4*>(dst + coff[h]) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+    }
+}
+
 // Epilogue.  acc[ms][ns][r] = D[m = m_base + ms*16 + (lane & 15)][n = n_base + lg*4*NS + ns*4 + r].
 // accumulate => reduce-add in D's dtype (reference: epilogue/sm100_store_cd.cuh:121-129).
 // INTERLEAVED_ROWS: acc[ms] belongs to row m_base + (lane & 15) * MS + ms instead (the duo kernel's A-row permutation).
@@ -482,6 +537,12 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
             for (int ms = 0; ms < MS; ++ms)
                 if (ms_only < 0 || ms == ms_only)
                     store_rows_full_line<MS, INTERLEAVED_ROWS>(p, t, d_group_off, acc[ms], ms, m_base, n_base);
+            return;
+        }
+    }
+    if constexpr (!NT_STORE && MS % 2 == 0 && NS % 2 == 0) {
+        if (p.d_dtype == 0 && p.accumulate && n_base + NS * 16 <= p.n && p.d_vec_ok && ms_only < 0 && t.m_end > t.m_begin) {
+            reduce_add_tile_bf16<MS, NS, INTERLEAVED_ROWS>(p, t, d_group_off, acc, m_base, n_lane);
             return;
         }
     }
