@@ -19,18 +19,24 @@ ap.add_argument('--shape', default='2048x7168x2048')
 ap.add_argument('--layouts', default='nt,nn,tn,tt')
 ap.add_argument('--configs', default='auto')
 ap.add_argument('--iters', type=int, default=30)
+ap.add_argument('--wgrad', action='store_true', help='recipe (1, 1, 128), FP32 accumulation into D (the wgrad form)')
 args = ap.parse_args()
 m, n, k = (int(x) for x in args.shape.split('x'))
 dbg = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device='cuda')
 for layout in args.layouts.split(','):
     gen.reset_seed(0)
-    case = gen.generate_normal(m, n, k, layout[0] == 'n', layout[1] == 't')
+    if args.wgrad:
+        case = gen.generate_normal(m, n, k, layout[0] == 'n', layout[1] == 't', accumulate=True, out_dtype=torch.float, per_token_b=True)
+        case.b = (case.b[0], dg.get_mn_major_tma_aligned_tensor(case.b[1]))
+    else:
+        case = gen.generate_normal(m, n, k, layout[0] == 'n', layout[1] == 't')
     a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+    kwargs = {'c': case.d, 'recipe': (1, 1, 128)} if args.wgrad else {}
     for cfg in args.configs.split(','):
         dg.set_forced_config(cfg)
         try:
             for _ in range(5):
-                dg.fp8_gemm_nt(a, case.b, case.d)
+                dg.fp8_gemm_nt(a, case.b, case.d, **kwargs)
         except RuntimeError as e:
             print(json.dumps({'layout': layout, 'config': cfg, 'error': str(e)[:120]}), flush=True)
             continue
@@ -39,14 +45,14 @@ for layout in args.layouts.split(','):
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         for _ in range(args.iters):
-            dg.fp8_gemm_nt(a, case.b, case.d)
+            dg.fp8_gemm_nt(a, case.b, case.d, **kwargs)
         end.record()
         torch.cuda.synchronize()
         us = start.elapsed_time(end) / args.iters * 1e3
         dbg.zero_()
         lib.dg_set_debug_buffer(dbg.data_ptr())
         for _ in range(3):
-            dg.fp8_gemm_nt(a, case.b, case.d)
+            dg.fp8_gemm_nt(a, case.b, case.d, **kwargs)
         torch.cuda.synchronize()
         lib.dg_set_debug_buffer(None)
         t = dbg.view(-1, 4).cpu().double()
