@@ -1027,6 +1027,63 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
     return 0;
 }
 
+int dg_k_grouped_fp8_gemm_tn_psum(const void* a, const float* sfa, const void* b, const float* sfb, float* d, int m, int n, int total_k,
+                                  const int32_t* psum_layout, int num_groups, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
+                                  int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k, void* stream) {
+    DG_CHECK(m >= 0 && n >= 0 && num_groups >= 0 && total_k >= 0);
+    if (m == 0 || n == 0 || num_groups == 0 || total_k == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr && psum_layout != nullptr);
+    DG_CHECK(ab_layout == DG_KGROUPED_COLUMNS || ab_layout == DG_KGROUPED_ROWS);
+    DG_CHECK(total_k % 128 == 0);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.sfa = sfa; p.sfb = sfb; p.d = d;
+    p.layout = psum_layout;
+    p.m = m; p.n = n; p.k = total_k; p.num_groups = num_groups;
+    p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+    p.d_sm = n; p.d_sg = static_cast<int64_t>(m) * n;
+    p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1; p.m_alignment = 0;
+    p.kg_blocks = 0; p.kg_psum = 1;
+    const bool mn_major = ab_layout == DG_KGROUPED_ROWS;
+    bool ok = m > 64;
+    if (mn_major) {
+        ok = ok && aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= m && b_stride_n >= n &&
+             a_stride_m <= (1 << 22) && b_stride_n <= (1 << 22) && static_cast<int64_t>(total_k) * a_stride_m < (1LL << 31) &&
+             static_cast<int64_t>(total_k) * b_stride_n < (1LL << 31) && sfa_stride_m == 1 && sfb_stride_n == 1 && aligned16(sfa) &&
+             aligned16(sfb) && sfa_stride_k % 4 == 0 && sfb_stride_k % 4 == 0;
+        p.a_sm = 1; p.a_sk = a_stride_m; p.b_sn = 1; p.b_sk = b_stride_n;
+    } else {
+        p.a_sm = a_stride_m; p.a_sk = 1; p.b_sn = b_stride_n; p.b_sk = 1;
+        p.gemm_type = dg::kNormal;
+        ok = ok && per_col_eligible(p);
+    }
+    if (!ok) {
+        g_last_error = "the psum form of the K-grouped GEMM needs m > 64, 16-byte aligned operand rows and MN-major, 16-byte aligned "
+                       "scales (nothing was launched; DG_KGROUPED_ROWS callers re-major the operands and retry with DG_KGROUPED_COLUMNS)";
+        return 3;
+    }
+    p.gemm_type = dg::kKGrouped;
+    p.num_m_tiles = ceil_div(m, 256);
+    p.num_n_tiles = ceil_div(n, 256);
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    p.d_vec_ok = aligned16(p.d) && (p.d_sm * 4) % 16 == 0 && (p.d_sg * 4) % 16 == 0;
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * num_groups;
+    if (grid > 0x7fffffffL)
+        return fail(__FILE__, __LINE__, "grid too large");
+    if (mn_major) {
+        g_last_config = "pipe_pc_mn_256x256";
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    } else {
+        g_last_config = "pipe_pc_256x256";
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    }
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream) {
     DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
     if (batches == 0 || mn == 0 || sf_k == 0)

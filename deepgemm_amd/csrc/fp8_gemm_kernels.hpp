@@ -50,6 +50,10 @@ struct GemmParams {
     // another (row stride k_g); 0: column ranges of one K-major matrix (row strides a_sm / b_sn).
     int kg_blocks;
     int kg_prefix[kMaxKGroups + 1];
+    // kg_psum != 0: the K ranges are read on the device instead -- `layout[g]` is group g's END along K (the reference's psum layout,
+    // scheduler/gemm.cuh:74-85), the group starts at the previous end rounded up to 128 and whole 128-blocks are computed (the rows
+    // between an end and the next multiple of 128 hold zeros by the layout's contract); k = rows of the operands (a multiple of 128)
+    int kg_psum;
     int head_lr, head_mid, head_right;  // epilogue column map of fp8_gemm_nt_skip_head_mid: D column of GEMM column n is
                                     // n + (n + head_right) / head_lr * head_mid (head_lr = left + right; 0 = identity)
     int d_dtype;                    // 0 bf16, 1 fp32
@@ -1025,9 +1029,17 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
         int64_t kg_a_off = 0, kg_b_off = 0, kg_sf_blocks = 0;      // K-grouped launch: where the group's operands start
         int k_extent = p.k;
         if (p.gemm_type == kKGrouped) {
-            const int k_begin = p.kg_prefix[t.group];
-            k_extent = p.kg_prefix[t.group + 1] - k_begin;
-            if (k_extent == 0)
+            int k_begin, k_stop;
+            if (p.kg_psum) {
+                const int prev_end = t.group > 0 ? p.layout[t.group - 1] : 0;
+                k_begin = __builtin_amdgcn_readfirstlane((prev_end + 127) & ~127);
+                k_stop = __builtin_amdgcn_readfirstlane(imin((p.layout[t.group] + 127) & ~127, p.k));
+            } else {
+                k_begin = p.kg_prefix[t.group];
+                k_stop = p.kg_prefix[t.group + 1];
+            }
+            k_extent = k_stop - k_begin;
+            if (k_extent <= 0)
                 continue;                                         // empty group: D[g] stays as it is
             num_kb = k_extent / 128;
             kg_sf_blocks = k_begin / 128;

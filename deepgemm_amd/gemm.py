@@ -405,23 +405,20 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
 _KGROUPED_BLOCKS, _KGROUPED_COLUMNS, _KGROUPED_ROWS = 0, 1, 2
 
 
-def _check_k_grouped_args(ks_cpu, grouped_layout: torch.Tensor, num_groups: int, use_psum_layout: bool, k_alignment: int) -> int:
-    """csrc/apis/gemm.hpp:48-69, same order and condition text.  The psum form (K ranges read from the device tensor, groups
-    starting at multiples of the K alignment, ``ks_cpu`` optional) exists only in the reference's SM100 driver
-    (``sm100_k_grouped_fp8_gemm_1d1d``); asking for it here ends where the reference ends on an architecture without it."""
+def _check_k_grouped_args(ks_cpu, grouped_layout: torch.Tensor, num_groups: int, use_psum_layout: bool, k_alignment: int,
+                          sum_k_if_ks_cpu_missing: int = 0) -> int:
+    """csrc/apis/gemm.hpp:48-69, same order and condition text: the sum of the host-side K extents, or -- psum layout with ``ks_cpu``
+    missing or empty, the K ranges then live on the device only -- the operands' own extent."""
     host_assert(grouped_layout.is_contiguous(), 'grouped_layout.is_contiguous()')
     host_assert(grouped_layout.dtype == torch.int, 'grouped_layout.scalar_type() == torch::kInt')
     host_assert(grouped_layout.numel() == num_groups, 'static_cast<int>(grouped_layout.numel()) == num_groups')
-    if ks_cpu is None or len(ks_cpu) == 0:
-        host_assert(use_psum_layout, 'use_psum_layout')
-    else:
+    if ks_cpu is not None and len(ks_cpu) > 0:
         host_assert(len(ks_cpu) == num_groups, 'static_cast<int>(ks_cpu.value().size()) == num_groups')
         for k in ks_cpu:
             host_assert(k % k_alignment == 0, 'k % k_alignment == 0')
-    if use_psum_layout:
-        raise RuntimeError('Assertion error (gemm.py): Unsupported architecture '
-                           '(the psum layout of the K-grouped GEMM is implemented by the reference for SM100 only)')
-    return int(sum(ks_cpu))
+        return int(sum(ks_cpu))
+    host_assert(use_psum_layout, 'use_psum_layout')
+    return sum_k_if_ks_cpu_missing
 
 
 def _k_grouped_sf(sf: torch.Tensor, mn: int, sum_k: int) -> torch.Tensor:
@@ -445,6 +442,18 @@ def _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, layout, a_ld, b_ld,
         ctypes.cast(ks_arr, ctypes.c_void_p), len(ks), layout, a_ld, b_ld,
         sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr())
     if may_decline and rc == _NO_NATIVE_KERNEL:
+        return False
+    check(rc)
+    return True
+
+
+def _k_grouped_psum_launch(a_data, sfa, b_data, sfb, d, m, n, total_k, psum_layout, layout, a_ld, b_ld) -> bool:
+    """dg_k_grouped_fp8_gemm_tn_psum; False = the library has no kernel for this operand form and launched nothing."""
+    require_device(a_data, b_data, sfa, sfb, d, psum_layout)
+    rc = lib.dg_k_grouped_fp8_gemm_tn_psum(
+        a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, total_k, psum_layout.data_ptr(),
+        psum_layout.numel(), layout, a_ld, b_ld, sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr())
+    if rc == _NO_NATIVE_KERNEL:
         return False
     check(rc)
     return True
@@ -483,17 +492,29 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
                                      c: Optional[torch.Tensor] = None, recipe: Tuple[int, int, int] = (1, 1, 128),
                                      compiled_dims: str = 'mn', use_psum_layout: bool = False) -> None:
     """MN-major operands: ``a[0] [sum_k, M]``, ``a[1] [sum_k / 128, M]`` (per-channel scales), ``b`` likewise with N;
-    ``d [G, M, N]`` FP32 ``= c + A_g^T @ B_g`` (csrc/apis/gemm.hpp:299-346).  The FP8 operands are re-majored once by
-    ``dg_transpose_fp8`` (HBM-bound, 2 bytes per element) and every group then is a column range of a K-major matrix."""
+    ``d [G, M, N]`` FP32 ``= c + A_g^T @ B_g`` (csrc/apis/gemm.hpp:299-346).  The operands go into the kernel as they are wherever the
+    library takes them (hardware transpose reads), else they are re-majored once by ``dg_transpose_fp8``.
+
+    ``use_psum_layout``: ``grouped_layout[g]`` is group g's END along K, groups start at the previous end rounded up to the K alignment,
+    the rows in between hold zeros (tests/generators.py:480-530) and ``ks_cpu`` may be missing -- the K ranges are then read on the
+    device, no host copy of the group sizes exists.  Implemented for FP32 per-channel scales with ``gran_k`` = K alignment = 128 (the
+    reference: SM100 only, packed UE8M0 scales, also ``gran_k`` 32 and alignments that are not the scale granularity -- those end
+    where the reference ends on an architecture without them)."""
     (a_data, a_sf), (b_data, b_sf) = a, b
     ks = ks_cpu
     recipe = tuple(recipe)
     host_assert(recipe[0] == 1 and recipe[1] == 1, 'std::get<0>(recipe) == 1 and std::get<1>(recipe) == 1')
     host_assert(recipe[2] == 128, 'gran_k == 128 (gran_k == 32 needs the packed UE8M0 scale format)')
+    k_alignment = runtime.get_mk_alignment_for_contiguous_layout()
+    host_assert(k_alignment % 32 == 0, 'k_alignment % 32 == 0')
     host_assert(d.dim() == 3, 'd.dim() == 3')
     num_groups, m, n = (int(x) for x in d.shape)
-    sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, 128)
     host_assert(a_data.dim() == 2 and b_data.dim() == 2, 'a.first.dim() == 2 and b.first.dim() == 2')
+    # (K extents in whole scale blocks: the reference's `k % k_alignment == 0` with this path's one supported alignment)
+    sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, 128, int(a_data.size(0)))
+    if use_psum_layout and k_alignment != 128:
+        raise RuntimeError('Assertion error (gemm.py): Unsupported architecture (the psum layout of the K-grouped GEMM with a K '
+                           f'alignment of {k_alignment} != gran_k is implemented by the reference for SM100 packed UE8M0 scales only)')
     host_assert(a_data.dtype == torch.float8_e4m3fn and b_data.dtype == torch.float8_e4m3fn,
                 'ab.scalar_type() == torch::kFloat8_e4m3fn')
     host_assert(tuple(a_data.shape) == (sum_k, m) and tuple(b_data.shape) == (sum_k, n),
@@ -505,7 +526,20 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     if _early_return(m, n, sum_k, d, c):
         return
     host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
+    host_assert(sum_k % 128 == 0, 'sum_k % 128 == 0 (the operands end on a scale-block boundary)')
     sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
+    if use_psum_layout:
+        # K ranges from the device tensor (with or without ks_cpu: what the reference's kernel does, scheduler/gemm.cuh:74-85)
+        require_device(grouped_layout)
+        if _k_grouped_psum_launch(a_data, sfa, b_data, sfb, d, m, n, sum_k, grouped_layout, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0)):
+            return
+        a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))
+        if _k_grouped_psum_launch(a_km, sfa, b_km, sfb, d, m, n, sum_k, grouped_layout, _KGROUPED_COLUMNS, a_km.stride(0), b_km.stride(0)):
+            return
+        # no single-launch kernel for this problem (m <= 64 ...): one launch per group needs the extents on the host
+        host_assert(ks is not None and len(ks) > 0, 'ks_cpu.has_value() (this problem size has no device-side K-range kernel)')
+        _k_grouped_launch(a_km, sfa, b_km, sfb, d, m, n, ks, _KGROUPED_COLUMNS, a_km.stride(0), b_km.stride(0))
+        return
     # MN-major operands straight into the kernel (LDS-DMA of [k][m] rows, hardware transpose reads for the fragments) wherever the
     # library's own DG_KGROUPED_ROWS conditions hold -- it declines without launching otherwise, and the operands are re-majored
     if _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0), may_decline=True):

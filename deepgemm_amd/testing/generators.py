@@ -199,6 +199,49 @@ class KGroupedCase:
     grouped_layout: torch.Tensor
 
 
+def build_psum_layout_from_ks(real_ks: List[int], k_alignment: int) -> List[int]:
+    """tests/generators.py:480-487: per-group END offsets along K; every group starts at the previous end rounded up."""
+    ends, prev_end = [], 0
+    for k in real_ks:
+        prev_end = align(prev_end, k_alignment) + k
+        ends.append(prev_end)
+    return ends
+
+
+def generate_k_grouped_contiguous_psum(num_groups: int, m: int, n: int, real_ks: List[int], k_alignment: int = 128,
+                                       device: str = 'cuda') -> KGroupedCase:
+    """tests/generators.py:490-530 with FP32 scales and gran_k = 128: MN-major ``a [total_k, m]``, ``b [total_k, n]`` whose rows between
+    a group's end and the next multiple of ``k_alignment`` are zeros, each group cast on its own padded copy (compact scale rows:
+    ceil(k / 128) per group); ``grouped_layout`` = the ends; ``ks`` = the aligned extents (what a caller may pass as ``ks_cpu``)."""
+    assert len(real_ks) == num_groups and k_alignment == 128
+    from ..utils.math import per_channel_cast_to_fp8
+    ends = build_psum_layout_from_ks(real_ks, k_alignment)
+    total_k = align(ends[-1] if ends else 0, k_alignment)
+    a_q = torch.zeros((total_k, m), device=device, dtype=torch.float8_e4m3fn)
+    b_q = torch.zeros((total_k, n), device=device, dtype=torch.float8_e4m3fn)
+    sfa = torch.ones((total_k // 128, m), device=device, dtype=torch.float)
+    sfb = torch.ones((total_k // 128, n), device=device, dtype=torch.float)
+    c = torch.randn((num_groups, m, n), device=device, dtype=torch.float) * 32
+    ref_d = torch.empty_like(c)
+    a_groups, b_groups = [], []
+    for g, (k, end) in enumerate(zip(real_ks, ends)):
+        if k == 0:
+            ref_d[g] = c[g]
+            a_groups.append(None), b_groups.append(None)
+            continue
+        start, k_pad = end - k, align(k, 128)
+        a_g = torch.zeros((k_pad, m), device=device, dtype=torch.bfloat16)
+        b_g = torch.zeros((k_pad, n), device=device, dtype=torch.bfloat16)
+        a_g[:k], b_g[:k] = torch.randn((k, m), device=device, dtype=torch.bfloat16), torch.randn((k, n), device=device, dtype=torch.bfloat16)
+        ref_d[g] = c[g] + a_g.float().t() @ b_g.float()
+        a_q[start:start + k_pad], sfa[start // 128:(start + k_pad) // 128] = per_channel_cast_to_fp8(a_g, use_ue8m0=False)
+        b_q[start:start + k_pad], sfb[start // 128:(start + k_pad) // 128] = per_channel_cast_to_fp8(b_g, use_ue8m0=False)
+        a_groups.append((a_q[start:start + k_pad].t().contiguous(), sfa[start // 128:(start + k_pad) // 128].t().contiguous()))
+        b_groups.append((b_q[start:start + k_pad].t().contiguous(), sfb[start // 128:(start + k_pad) // 128].t().contiguous()))
+    layout = torch.tensor(ends, device=device, dtype=torch.int32)
+    return KGroupedCase((a_q, sfa), (b_q, sfb), a_groups, b_groups, c, c.clone(), ref_d, [align(k, k_alignment) for k in real_ks], layout)
+
+
 def generate_k_grouped_contiguous(num_groups: int, m: int, n: int, ks: List[int], k_major: bool,
                                   device: str = 'cuda') -> KGroupedCase:
     """tests/generators.py:436-477: ``a [sum_k, m]``, ``b [sum_k, n]`` BF16, per group ``ref_d[g] = c[g] + a_g^T @ b_g``;

@@ -123,6 +123,21 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
                                         int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
                                         void* stream);
 
+/* The TN form with the reference's psum layout, K ranges read ON THE DEVICE (no host copy of the group sizes): replaces
+ * sm100_k_grouped_fp8_gemm_1d1d(..., use_psum_layout = true) as called from k_grouped_fp8_gemm_tn_contiguous with ks_cpu missing
+ * (csrc/apis/gemm.hpp:48-69,299-346; scheduler: deep_gemm/include/deep_gemm/scheduler/gemm.cuh:74-85,238-261) for FP32 per-channel
+ * scales with gran_k = K alignment = 128.
+ *   psum_layout (device, int32[num_groups]): group g ends at row psum_layout[g] of the K axis and starts at the previous end rounded up
+ *     to 128; rows between an end and the next multiple of 128 hold zeros (the layout's contract: whole 128-row blocks are computed);
+ *     an end equal to its start = empty group, D[g] stays as it is.  total_k = rows of a / b, a multiple of 128.
+ *   ab_layout DG_KGROUPED_ROWS: a [total_k, m], b [total_k, n] MN-major as they are; DG_KGROUPED_COLUMNS: K-major [m, total_k] /
+ *     [n, total_k] (after dg_transpose_fp8).  Needs m > 64, 16-byte aligned rows and MN-major, 16-byte aligned scales: otherwise
+ *     returns 3 WITHOUT launching (ROWS callers re-major and retry with COLUMNS; there is no per-group fallback -- the host does not
+ *     know the ranges).  Scales and d as in dg_k_grouped_fp8_gemm_nt_contiguous. */
+int dg_k_grouped_fp8_gemm_tn_psum(const void* a, const float* sfa, const void* b, const float* sfb, float* d, int m, int n, int total_k,
+                                  const int32_t* psum_layout, int num_groups, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
+                                  int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k, void* stream);
+
 /* M-grouped contiguous GEMM.  Replaces sm90_m_grouped_fp8_gemm_contiguous_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:147) /
  * sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:161) as called from
  * m_grouped_fp8_fp4_gemm_nt_contiguous (csrc/apis/gemm.hpp:166-232).

@@ -997,6 +997,51 @@ def test_k_grouped_contiguous(k_major, num_groups, m, n, ks):
     assert torch.equal(d2, case.d)
 
 
+@pytest.mark.parametrize('num_groups,m,n,real_ks', [(4, 256, 384, [300, 0, 129, 512]), (2, 304, 272, [1000, 77]), (3, 512, 1024, [128, 1, 640]),
+                                                    (2, 64, 128, [200, 256]),
+                                                    (72, 128, 256, [(37 * i) % 300 for i in range(72)])])      # more groups than fit in kernel arguments
+def test_k_grouped_tn_psum_layout(num_groups, m, n, real_ks):
+    """k_grouped_fp8_gemm_tn_contiguous(use_psum_layout=True) (csrc/apis/gemm.hpp:299-346, scheduler/gemm.cuh:74-85; reference test:
+    tests/test_fp8_fp4.py:198-225): K ranges read from the device tensor of group ENDS -- with ``ks_cpu`` given, missing or empty
+    ("unsynced" calls) -- groups of any real K inside zero-padded 128-row blocks, empty groups, in-place accumulation."""
+    gen.reset_seed(sum(real_ks) + m)
+    case = gen.generate_k_grouped_contiguous_psum(num_groups, m, n, real_ks)
+    results = []
+    for ks_cpu in (case.ks, None, []):
+        if m <= 64 and not ks_cpu:
+            with pytest.raises(RuntimeError, match='ks_cpu.has_value'):       # no single-launch kernel at this size: the host must know the extents
+                dg.k_grouped_fp8_gemm_tn_contiguous(case.a, case.b, case.c.clone(), ks_cpu, case.grouped_layout, c=case.c, use_psum_layout=True)
+            continue
+        d = case.c.clone()
+        dg.k_grouped_fp8_gemm_tn_contiguous(case.a, case.b, d, ks_cpu, case.grouped_layout, c=d, use_psum_layout=True)
+        if m > 64 and m % 16 == 0 and n % 16 == 0:
+            assert dg.last_config() == 'pipe_pc_mn_256x256', dg.last_config()     # operands in place, ranges from the device
+        results.append(d)
+    for other in results[1:]:
+        assert torch.equal(other, results[0])
+    d = results[0]
+    for g, k in enumerate(real_ks):
+        if k == 0:
+            assert torch.equal(d[g], case.c[g])
+            continue
+        (a_g, sfa_g), (b_g, sfb_g) = case.a_groups[g], case.b_groups[g]
+        want = torch.empty((m, n), dtype=torch.float)
+        oracle.fp8_gemm_nt(a_g.cpu(), sfa_g.cpu(), b_g.cpu(), sfb_g.cpu(), want, c=case.c[g].cpu(), gran_n=1)
+        assert_close_fp32(d[g], want, f'k-grouped psum group {g}')
+    assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+    # the same problem through the non-psum operator (host extents = the aligned sizes): same bits
+    d2 = case.c.clone()
+    dg.k_grouped_fp8_gemm_tn_contiguous(case.a, case.b, d2, case.ks, torch.tensor(case.ks, device='cuda', dtype=torch.int32), c=d2)
+    assert torch.equal(d2, d)
+    # operands the in-place form does not take (rows off 16 bytes): re-majored, still device-side ranges
+    if m > 64:
+        a_off = torch.empty((case.a[0].numel() + 1,), dtype=torch.uint8, device='cuda')[1:].view(torch.float8_e4m3fn).view(case.a[0].shape)
+        a_off.copy_(case.a[0])
+        d3 = case.c.clone()
+        dg.k_grouped_fp8_gemm_tn_contiguous((a_off, case.a[1]), case.b, d3, None, case.grouped_layout, c=d3, use_psum_layout=True)
+        assert dg.last_config() == 'pipe_pc_256x256' and torch.equal(d3, d)
+
+
 def test_k_grouped_argument_checks():
     gen.reset_seed(1)
     case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)

@@ -266,13 +266,21 @@ def test_every_reference_keyword_by_name():
     with pytest.raises(RuntimeError, match='no CPU path'):
         dg.k_grouped_fp8_gemm_tn_contiguous(a=kt.a, b=kt.b, d=kt.d, ks_cpu=kt.ks, grouped_layout=kt.grouped_layout, c=kt.c,
                                             recipe=(1, 1, 128), compiled_dims='mn', use_psum_layout=False)
-    # ks_cpu missing: legal only together with the psum layout (csrc/apis/gemm.hpp:66-68), which the reference implements for
-    # SM100 alone -- the call ends where the reference ends on an architecture without that driver
+    # ks_cpu missing: legal only together with the psum layout (csrc/apis/gemm.hpp:66-68) -- the K ranges then come from the device
+    # tensor; implemented for a K alignment of 128 (= gran_k), other alignments end where the reference ends off SM100
     for missing in (None, []):
         with pytest.raises(RuntimeError, match=r'\): use_psum_layout'):
             dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c)
-        with pytest.raises(RuntimeError, match='Unsupported architecture'):
+        with pytest.raises(RuntimeError, match='no CPU path'):
             dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c, use_psum_layout=True)
+        dg.set_mk_alignment_for_contiguous_layout(64)
+        try:
+            with pytest.raises(RuntimeError, match='Unsupported architecture'):
+                dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c, use_psum_layout=True)
+        finally:
+            dg.set_mk_alignment_for_contiguous_layout(128)
+    with pytest.raises(RuntimeError, match='sum_k == sum_k_'):     # host extents that disagree with the operands
+        dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, [128, 128], kt.grouped_layout, c=kt.c, use_psum_layout=True)
     with pytest.raises(RuntimeError, match='no CPU path'):
         dg.fp8_gemm_nt_skip_head_mid(a=c.a, b=c.b, d=torch.empty(128, 256 + 2 * 32, dtype=torch.bfloat16), head_splits=(64, 32, 64),
                                      recipe=None, compiled_dims='nk', disable_ue8m0_cast=False)
