@@ -1126,3 +1126,23 @@ def test_hip_graph_capture_and_replay():
         for g in range(4):
             rows = int(masked.masked_m[g])
             assert torch.equal(masked.d[g, :rows], want_masked[g, :rows])
+    # the K-grouped GEMM with device-side K ranges: captured once, replayed with different group ends in the device tensor
+    kg = gen.generate_k_grouped_contiguous_psum(3, 256, 384, [300, 129, 512])
+    layouts = [kg.grouped_layout.clone(), kg.grouped_layout.clone()]
+    layouts[1][2] -= 256                                        # the last group ends two scale blocks earlier
+    wants = []
+    for layout in layouts:
+        d = kg.c.clone()
+        dg.k_grouped_fp8_gemm_tn_contiguous(kg.a, kg.b, d, None, layout, c=d, use_psum_layout=True)
+        wants.append(d)
+    assert not torch.equal(wants[0][2], wants[1][2]) and torch.equal(wants[0][:2], wants[1][:2])
+    live_layout, live_d = layouts[0].clone(), kg.c.clone()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=side):
+        dg.k_grouped_fp8_gemm_tn_contiguous(kg.a, kg.b, live_d, [], live_layout, c=live_d, use_psum_layout=True)
+    for which in (0, 1, 0):
+        live_layout.copy_(layouts[which])
+        live_d.copy_(kg.c)
+        graph2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(live_d, wants[which])
