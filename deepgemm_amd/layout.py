@@ -116,6 +116,47 @@ def get_mn_major_tma_aligned_packed_ue8m0_tensor(sf: torch.Tensor, psum_layout: 
     return out.squeeze(0) if sf.dim() == 2 else out
 
 
+def get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor(sf: torch.Tensor, grouped_layout: torch.Tensor, ks_cpu, gran_k: int,
+                                                           k_alignment: int, use_psum_layout: bool = False) -> torch.Tensor:
+    """Per-channel FP32 power-of-two scales of a K-grouped operand, ``[sum_g ceil(k_g / gran_k), mn]`` (compact rows per group) ->
+    packed UE8M0 words ``[sum_g ceil(k_g / (4 gran_k)), mn]`` int32: four consecutive scale rows OF ONE GROUP per word (byte j = row
+    4 q + j, a group's last word zero-padded), MN-major.  Reference: csrc/jit_kernels/impls/smxx_layout.hpp:255-316 (kernel
+    ``pack_fp32_into_ue8m0``, impls/smxx_layout.cuh:148); checks in its order.  The group extents are taken from ``ks_cpu`` (the reference
+    reads the same numbers from ``grouped_layout`` on the device); one gather, works on any device.  The psum form packs from
+    device-side ends and exists for SM100 only in the reference (tests/test_layout.py:108-111): it ends here as it ends there."""
+    host_assert(gran_k in (32, 128), 'gran_k == 32 or gran_k == 128')
+    host_assert(k_alignment % 32 == 0, 'k_alignment % 32 == 0')
+    host_assert(sf.dim() == 2, 'sf.dim() == 2')
+    sf_k, mn = (int(x) for x in sf.shape)
+    num_groups = grouped_layout.numel()
+    host_assert(sf.is_contiguous(), 'sf.is_contiguous()')
+    host_assert(num_groups <= 128 and mn % 4 == 0, 'num_groups <= 128 and mn % 4 == 0')
+    host_assert(grouped_layout.is_contiguous() and grouped_layout.dtype == torch.int,
+                'grouped_layout.is_contiguous() and grouped_layout.scalar_type() == torch::kInt')
+    has_synced_ks = ks_cpu is not None and len(ks_cpu) > 0
+    if has_synced_ks:
+        host_assert(len(ks_cpu) == num_groups, 'static_cast<int>(ks_cpu.value().size()) == num_groups')
+    else:
+        host_assert(use_psum_layout, 'use_psum_layout')
+    if use_psum_layout:
+        raise RuntimeError('Assertion error (layout.py): Unsupported architecture (the psum form of the K-grouped scale packing is '
+                           'implemented by the reference for SM100 only)')
+    host_assert(sf.dtype == torch.float, 'sf.scalar_type() == torch::kFloat')
+    rows = [ceil_div(int(k), gran_k) for k in ks_cpu]
+    host_assert(sum(rows) == sf_k, 'use_psum_layout or ref_sf_k == sf_k')
+    index, first = [], 0
+    for r in rows:
+        for q in range(ceil_div(r, 4)):
+            index.append([first + 4 * q + j if 4 * q + j < r else sf_k for j in range(4)])      # sf_k = the appended zero row
+        first += r
+    if not index:
+        return torch.empty((0, mn), dtype=torch.int, device=sf.device)
+    exps = ((sf.view(torch.int) >> 23) & 0xff).to(torch.uint8)
+    exps = torch.cat([exps, torch.zeros((1, mn), dtype=torch.uint8, device=sf.device)])
+    picked = exps[torch.tensor(index, dtype=torch.long, device=sf.device)]              # [packed rows, 4, mn]
+    return picked.permute(0, 2, 1).contiguous().view(torch.int).squeeze(-1)
+
+
 Recipe = Union[Tuple[int, int, int], Tuple[int, int]]
 
 

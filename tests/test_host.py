@@ -419,3 +419,46 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(masked, 4096, 6144, 7168, groups=6, expected_m=20) == 'duo_128x256'                     # 288 stream tiles > 256 CUs
     assert pick(masked, 4096, 4096, 4096, groups=6, expected_m=20) == 'stream_64x128'
     assert pick(masked, 4096, 6144, 7168, groups=32, expected_m=20) == 'stream_nt_64x128'
+
+
+def test_k_grouped_packed_ue8m0_scale_layout():
+    """get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor against the reference's own check (tests/test_layout.py:82-98: every group's
+    rows equal the reference's torch statement of the packing, :20-42, applied to that group alone), incl. an empty group and both scale
+    granularities; argument checks in the reference's order (csrc/jit_kernels/impls/smxx_layout.hpp:261-287)."""
+    import random
+    from deepgemm_amd.utils.math import align, ceil_div, per_channel_cast_to_fp8
+
+    def torch_statement(x):                       # [mn, k] FP32 -> [mn, ceil(k / 4)] int32, byte j of word q = exponent of column 4 q + j
+        mn, k = x.shape
+        padded = torch.zeros((mn, align(k, 4)), dtype=torch.uint8)
+        padded[:, :k] = (x.view(torch.int) >> 23).to(torch.uint8)
+        return padded.view(torch.int)
+    random.seed(0)
+    for mn in (64, 260):
+        for groups, avg_k in ((16, 2048), (3, 384), (128, 256)):
+            for gran_k in (32, 128):
+                ks = [align(int(random.uniform(0.7, 1.3) * avg_k), gran_k) for _ in range(groups)]
+                ks[1] = 0
+                x = torch.randn((sum(ks), mn), dtype=torch.bfloat16)
+                _, sf = per_channel_cast_to_fp8(x, use_ue8m0=True, gran_k=gran_k)
+                layout = torch.tensor(ks, dtype=torch.int)
+                packed = dg.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor(sf, layout, ks, gran_k, gran_k)
+                sf_ks, packed_ks = [k // gran_k for k in ks], [ceil_div(k, gran_k * 4) for k in ks]
+                assert packed.shape == (sum(packed_ks), mn) and packed.dtype == torch.int and packed.is_contiguous()
+                for got, part in zip(packed.split(packed_ks), sf.split(sf_ks)):
+                    if part.size(0):
+                        assert torch.equal(got, torch_statement(part.T.contiguous()).T), (mn, groups, gran_k)
+    sf, layout = torch.ones((6, 8)), torch.tensor([256, 512], dtype=torch.int)
+    assert dg.utils.layout.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor is dg.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor
+    assert dg.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor(sf, layout, [256, 512], 128, 128).shape == (2, 8)
+    for args, message in (((sf, layout, [256, 512], 64, 128), 'gran_k == 32 or gran_k == 128'),
+                          ((sf, layout, [256, 512], 128, 48), 'k_alignment % 32 == 0'),
+                          ((sf[:, :6].contiguous(), layout, [256, 512], 128, 128), 'mn % 4 == 0'),
+                          ((sf, layout, [256], 128, 128), r'ks_cpu.value\(\).size\(\)\) == num_groups'),
+                          ((sf, layout, None, 128, 128), 'use_psum_layout'),
+                          ((sf, layout, [256, 384], 128, 128), 'ref_sf_k == sf_k')):
+        with pytest.raises(RuntimeError, match=message):
+            dg.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor(*args)
+    with pytest.raises(RuntimeError, match='Unsupported architecture'):
+        dg.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor(sf, layout, None, 128, 128, use_psum_layout=True)
+
