@@ -455,7 +455,70 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     return best;
 }
 
+// Under-filled recipe-(1, 1, 128) launches (wgrad of a narrow layer: 576 x 4096 x 7168 = 48 tiles of 256 x 256 for 256 CUs, 56 K blocks at
+// ~2.2 us each): the K axis is cut into `pieces` ranges that run as the groups of ONE K-grouped launch of the same kernel, each writing
+// an FP32 partial matrix into the caller's workspace; dg_sum_partials_kernel then adds them in piece order and performs the operator's
+// output step.  Returns the number of pieces (0 = one ordinary launch).  Model (us): one launch 15 + 2.2 per K block; split 30 + 2.2 per
+// K block of a piece + the partials' write and read at ~4 TB/s.  workspace_bytes = 0: "as large as needed" (the host layer's query).
+int per_col_split_pieces(const dg::GemmParams& p, size_t workspace_bytes) {
+    if (p.sfb_gran_n != 1 || p.gemm_type != dg::kNormal || p.head_lr > 0 || p.m <= 64 || p.k % 128 != 0 || forced_config() != "auto")
+        return 0;
+    if (!per_col_eligible(p) && !per_col_mn_eligible(p))
+        return 0;
+    const long tiles = static_cast<long>(ceil_div(p.m, 256)) * ceil_div(p.n, 256), num_kb = p.k / 128;
+    const size_t per_piece = static_cast<size_t>(p.m) * p.n * sizeof(float);
+    long pieces = std::min<long>(std::min<long>(8, num_cus() / tiles), num_kb / 4);
+    if (workspace_bytes > 0)
+        pieces = std::min<long>(pieces, workspace_bytes > 4096 ? static_cast<long>((workspace_bytes - 4096) / per_piece) : 0);
+    if (pieces < 2 || num_kb < 24)
+        return 0;
+    const double t_one = 15.0 + 2.2 * num_kb;
+    const double t_split = 30.0 + 2.2 * ((num_kb + pieces - 1) / pieces) + static_cast<double>(pieces) * per_piece / 4.0e6;
+    return t_split < 0.75 * t_one ? static_cast<int>(pieces) : 0;
+}
+
+int launch_per_col_split(const dg::GemmParams& dense, int pieces, void* stream) {
+    dg::GemmParams p = dense;
+    const bool mn_major = !per_col_eligible(dense);
+    float* parts = reinterpret_cast<float*>(static_cast<uint8_t*>(dense.sk_workspace) + 4096);
+    p.d = parts; p.d_sm = dense.n; p.d_sg = static_cast<int64_t>(dense.m) * dense.n; p.d_dtype = DG_FP32; p.accumulate = 0;
+    p.gemm_type = dg::kKGrouped; p.num_groups = pieces; p.kg_blocks = 0; p.kg_psum = 0;
+    p.sk_workspace = nullptr; p.sk_first_tile = 0; p.sk_tiles = 0; p.sk_factor = 1;
+    const int num_kb = dense.k / 128;
+    for (int i = 0; i <= pieces; ++i)
+        p.kg_prefix[i] = 128 * static_cast<int>(static_cast<long>(i) * num_kb / pieces);
+    p.num_m_tiles = ceil_div(p.m, 256);
+    p.num_n_tiles = ceil_div(p.n, 256);
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    p.d_vec_ok = dense.n % 4 == 0;
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * pieces;
+    g_last_config = mn_major ? "pipe_pc_mn_ks_256x256" : "pipe_pc_ks_256x256";
+    if (mn_major)
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    else
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    DG_HIP_CHECK(hipGetLastError());
+    const size_t elem = dense.d_dtype == DG_BF16 ? 2 : 4;
+    const int vec_ok = dense.n % 4 == 0 && (dense.d_dtype == DG_BF16 || (aligned16(dense.d) && (dense.d_sm * elem) % 16 == 0));
+    const long quads = static_cast<long>(dense.m) * ((dense.n + 3) / 4);
+    const long blocks = std::min<long>((quads + 255) / 256, static_cast<long>(num_cus()) * 8);
+    hipLaunchKernelGGL(dg::dg_sum_partials_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       parts, pieces, static_cast<int64_t>(dense.m) * dense.n, dense.d, dense.m, dense.n, dense.d_sm, dense.d_dtype,
+                       dense.accumulate, vec_ok);
+    DG_HIP_CHECK(hipGetLastError());
+    if (getenv("DG_PRINT_CONFIGS") != nullptr)
+        fprintf(stderr, "[deepgemm_amd] type=%d m=%d n=%d k=%d -> %s pieces=%d grid=%ld\n", dense.gemm_type, dense.m, dense.n, dense.k,
+                g_last_config.c_str(), pieces, grid);
+    return 0;
+}
+
 int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
+    if (p.sk_workspace != nullptr)
+        if (const int pieces = per_col_split_pieces(p, g_workspace_bytes); pieces >= 2)
+            return launch_per_col_split(p, pieces, stream);
     const int bm_must_divide =
         (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) ? p.m_alignment : 0;
     const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide);
@@ -870,9 +933,9 @@ int dg_m_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
 }
 
 int64_t dg_split_k_workspace_bytes(void) {
-    // counters (4 KiB) + the largest tail a launch can have: at most half a round of tiles (128 on 256 CUs), each CU of the round
-    // holding one FP32 partial tile of 128 x 256
-    return 4096 + static_cast<int64_t>(device_cu_count()) * 128 * 256 * static_cast<int64_t>(sizeof(float));
+    // 4 KiB header + one FP32 partial tile of 256 x 256 per CU: the K split of the duo kernels needs half of it (at most half a round
+    // of 128 x 256 tiles, one partial tile per CU of the round), the recipe-(1, 1, 128) split all of it (pieces x tiles <= CUs)
+    return 4096 + static_cast<int64_t>(device_cu_count()) * 256 * 256 * static_cast<int64_t>(sizeof(float));
 }
 
 int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void* b, const float* sfb, void* d,
@@ -1248,6 +1311,27 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
         name = cfg != nullptr ? cfg->name : "";
     }
     return name.c_str();
+}
+
+int dg_dense_wants_workspace(int m, int n, int k, int a_mn_major, int b_mn_major, int sfb_gran_n) {
+    // would the automatic selection cut this dense problem (16-byte aligned, densely packed operands, MN-major scales) along K if the
+    // caller lent it a workspace?  The host layer asks before it creates / passes one; no model is kept on that side.
+    if (m <= 0 || n <= 0 || k <= 0)
+        return 0;
+    dg::GemmParams p{};
+    p.a = p.b = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(1) << 20);
+    p.sfa = p.sfb = reinterpret_cast<const float*>(static_cast<uintptr_t>(1) << 21);
+    p.d = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 22);
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = a_mn_major ? 1 : k; p.a_sk = a_mn_major ? m : 1;
+    p.b_sn = b_mn_major ? 1 : k; p.b_sk = b_mn_major ? n : 1;
+    p.sfa_sm = 1; p.sfa_sk = (m + 3) / 4 * 4; p.sfb_sn = sfb_gran_n == 1 ? 1 : (k + 127) / 128; p.sfb_sk = sfb_gran_n == 1 ? (n + 3) / 4 * 4 : 1;
+    p.d_sm = n; p.sfb_gran_n = sfb_gran_n; p.d_dtype = DG_BF16; p.gemm_type = dg::kNormal;
+    p.sk_workspace = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23);
+    if (per_col_split_pieces(p, 0) >= 2)
+        return 1;
+    const Config* cfg = select_config(p, p.m, 0, 0, true);
+    return cfg != nullptr && cfg->split_k ? 1 : 0;
 }
 
 int dg_operand_plan(int gemm_type, const void* a, const void* b, int m, int n, int k, int64_t a_sm, int64_t a_sk, int64_t b_sn,

@@ -2430,6 +2430,52 @@ void dg_fp8_gemm_duo_e8_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Second phase of the K split of an under-filled recipe-(1, 1, 128) launch (dg_api.hip: launch_per_col_split): D (+)= the sum of
+// `pieces` FP32 partial matrices [m][n] (dense, piece_stride floats apart), added in piece order (bit-repeatable), then the
+// operator's own output step -- FP32 or BF16, plain or reduce-add in D's dtype.  Four columns per thread, grid-stride.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void dg_sum_partials_kernel(const float* __restrict__ parts, int pieces, int64_t piece_stride, void* d, int m, int n, int64_t d_sm,
+                            int d_dtype, int accumulate, int vec_ok) {
+    const int64_t quads = (n + 3) / 4, total = static_cast<int64_t>(m) * quads;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t row = i / quads;
+        const int col = static_cast<int>(i - row * quads) * 4;
+        const int cnt = n - col < 4 ? n - col : 4;
+        const float* src = parts + row * n + col;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec_ok && cnt == 4) {
+            for (int q = 0; q < pieces; ++q) {
+                const v4f t = *reinterpret_cast<const v4f*>(src + q * piece_stride);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            }
+        } else {
+            for (int q = 0; q < pieces; ++q)
+                for (int e = 0; e < cnt; ++e)
+                    v[e] += src[q * piece_stride + e];
+        }
+        if (d_dtype != 0) {
+            float* dst = reinterpret_cast<float*>(d) + row * d_sm + col;
+            if (vec_ok && cnt == 4) {
+                v4f out = {v[0], v[1], v[2], v[3]};
+                if (accumulate) out += *reinterpret_cast<const v4f*>(dst);
+                *reinterpret_cast<v4f*>(dst) = out;
+            } else {
+                for (int e = 0; e < cnt; ++e)
+                    dst[e] = accumulate ? dst[e] + v[e] : v[e];
+            }
+        } else {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(d) + row * d_sm + col;
+            for (int e = 0; e < cnt; ++e) {
+                float w = round_bf16(v[e]);
+                if (accumulate) w = w + bf16_lo(static_cast<uint32_t>(dst[e]));
+                dst[e] = static_cast<uint16_t>(pack_bf16(w, 0.f) & 0xffffu);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Generic path: any operand majorness / alignment / K tail, both SFB granularities.  128 x 128 tile, 4 waves,
 // register-staged loads written into the same swizzled LDS image.  Correctness first.
 // ---------------------------------------------------------------------------------------------------------------

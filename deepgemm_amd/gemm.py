@@ -174,25 +174,18 @@ def _split_k_workspace(device: torch.device, stream: int) -> Optional[torch.Tens
     return ws
 
 
-def _dense_split_k_workspace(m: int, n: int, k: int, gran_n: int, device: torch.device) -> Optional[torch.Tensor]:
-    """The K-split scratch buffer for a dense call whose 128 x 256 tiles leave most of the chip idle in their (only or last) round
-    while the K loop is long (dg_api.hip: split_k_pieces / split_k_pays, mirrored here so that ordinary calls neither create nor
-    pass a buffer); None otherwise.  The C side decides for itself whether it splits."""
-    if gran_n != 128 or k % 128 != 0 or m <= 64:
-        return None
-    cus = int(lib.dg_get_num_cus())
-    tail = (-(-m // 128) * -(-n // 256)) % cus
-    if tail == 0:
-        return None
-    num_kb = k // 128
-    pieces = min(8, cus // tail, num_kb)
-    if pieces < 2 or num_kb * (pieces - 1) * 100 <= (1100 + 100 * pieces) * pieces:
+def _dense_split_k_workspace(m: int, n: int, k: int, gran_n: int, device: torch.device, a_mn_major: bool = False,
+                             b_mn_major: bool = False) -> Optional[torch.Tensor]:
+    """The K-split scratch buffer for a dense call the library would cut along K (dg_dense_wants_workspace: under-filled launches and
+    partial last rounds of 128 x 256 tiles with long K loops, under-filled recipe (1, 1, 128) launches); None otherwise, so that ordinary
+    calls neither create nor pass a buffer.  The C side owns the model and decides again, with the real pointers, at launch."""
+    if not lib.dg_dense_wants_workspace(m, n, k, int(a_mn_major), int(b_mn_major), gran_n):
         return None
     return _split_k_workspace(device, current_stream_ptr())
 
 
 def _call_dense(a_data, sfa, b_data, sfb, d, c, m, n, k, gran_n) -> None:
-    ws = _dense_split_k_workspace(m, n, k, gran_n, d.device)
+    ws = _dense_split_k_workspace(m, n, k, gran_n, d.device, a_data.stride(-1) != 1, b_data.stride(-1) != 1)
     check(lib.dg_fp8_gemm_nt_ws(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),

@@ -249,6 +249,11 @@ const char* dg_last_config(void);
 const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups, int expected_m, int a_mn_major, int b_mn_major,
                              int sfb_gran_n, int m_alignment, int has_workspace, int packed_ue8m0);
 
+/* 1 if the automatic selection would cut this dense problem along K given a workspace (dg_fp8_gemm_nt_ws): under-filled launches
+ * with long K loops, partial last rounds of 128 x 256 tiles, under-filled recipe-(1, 1, 128) launches.  The host layer asks before it
+ * creates and passes its per-stream buffer (dg_split_k_workspace_bytes()); operands assumed 16-byte aligned and densely packed. */
+int dg_dense_wants_workspace(int m, int n, int k, int a_mn_major, int b_mn_major, int sfb_gran_n);
+
 /* Which MN-major FP8 operands the host side should re-major into K-major scratch (dg_transpose_fp8) before calling
  * dg_fp8_gemm_nt_ws / dg_m_grouped_fp8_gemm_nt_contiguous_ws: bit 0 = A, bit 1 = B; 0 = every operand is read where it lies.
  * Decided with the predicates the launch itself applies (pointer and pitch alignment, 32-bit offset range, tile rules), so an

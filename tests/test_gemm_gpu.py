@@ -190,6 +190,38 @@ def test_per_column_sfb_mn_major_operands(m, n, k):
     assert torch.equal(d2, case.d)
 
 
+@pytest.mark.parametrize('m,n,k,mn_major', [(576, 4096, 7168, False), (576, 4096, 7168, True), (320, 1032, 4096, False),
+                                             (320, 1040, 4096, True), (200, 518, 3072, False)])
+@pytest.mark.parametrize('out_dtype,accumulate', [(torch.float, True), (torch.bfloat16, False), (torch.bfloat16, True), (torch.float, False)])
+def test_per_column_sfb_k_split(m, n, k, mn_major, out_dtype, accumulate):
+    """Under-filled recipe (1, 1, 128) launches with long K loops (the wgrad entries of the reference sweep with M = 576,
+    tests/generators.py:150-153): the K axis runs as the groups of one K-grouped launch into FP32 partial matrices, a second kernel adds
+    them in piece order and performs the output step (FP32 / BF16, plain / reduce-add).  Against the oracle, and against the one-launch
+    kernel (same arithmetic, the K blocks summed in a different association: equal up to FP32 rounding)."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k, not mn_major, not mn_major, accumulate=accumulate, out_dtype=out_dtype, per_token_b=True)
+    c_cpu = case.c.cpu().clone() if accumulate else None
+    want = oracle_dense(case, gran_n=1, c_cpu=c_cpu)
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None, recipe=(1, 1, 128))
+    assert dg.last_config() == ('pipe_pc_mn_ks_256x256' if mn_major else 'pipe_pc_ks_256x256'), dg.last_config()
+    if out_dtype == torch.float:
+        assert_close_fp32(case.d, want, 'per-column SFB, K split')
+    else:
+        assert_close_to_oracle(case.d, want, 'per-column SFB, K split', addend=c_cpu)
+    assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    first = case.d.clone()
+    # bit-repeatable, and next to the one-launch kernel
+    d2 = c_cpu.cuda() if accumulate else torch.full_like(case.d, float('nan'))
+    dg.fp8_gemm_nt(case.a, case.b, d2, c=d2 if accumulate else None, recipe=(1, 1, 128))
+    assert torch.equal(d2, first)
+    dg.set_forced_config('pipe_pc_mn_256x256' if mn_major else 'pipe_pc_256x256')
+    d3 = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
+    dg.fp8_gemm_nt(case.a, case.b, d3, c=d3 if accumulate else None, recipe=(1, 1, 128))
+    dg.set_forced_config('auto')
+    assert dg.last_config() == ('pipe_pc_mn_256x256' if mn_major else 'pipe_pc_256x256')
+    assert calc_diff(d3, first) < (1e-6 if out_dtype == torch.bfloat16 else 1e-9)      # (BF16: a rounding flips now and then)
+
+
 @pytest.mark.parametrize('m,n,k', [(512, 512, 512), (1040, 784, 896), (4096, 2048, 1024)])
 @pytest.mark.parametrize('out_dtype,accumulate', [(torch.bfloat16, False), (torch.float, True)])
 def test_mn_major_b_native_path(m, n, k, out_dtype, accumulate):

@@ -357,13 +357,23 @@ def test_operand_majorness_decisions_on_the_host():
 
 
 def test_split_k_workspace_is_only_requested_when_the_model_says_so():
-    """deepgemm_amd/gemm.py:_dense_split_k_workspace mirrors dg_api.hip's split_k_pieces / split_k_pays: ordinary calls must neither
-    create nor pass a buffer (creating one needs a device: not reached for these shapes)."""
+    """deepgemm_amd/gemm.py:_dense_split_k_workspace asks the library (dg_dense_wants_workspace: split_k_pieces / split_k_pays / the
+    stream-vs-split model / per_col_split_pieces in dg_api.hip): ordinary calls must neither create nor pass a buffer (creating one
+    needs a device: not reached for these shapes)."""
     from deepgemm_amd import gemm
+    from deepgemm_amd._lib import lib
     cpu = torch.device('cpu')
     for m, n, k in ((4096, 4096, 7168), (2048, 7168, 2048), (64, 4096, 7168), (4096, 4096, 128), (4096, 7168, 2112)):
         assert gemm._dense_split_k_workspace(m, n, k, 128, cpu) is None, (m, n, k)
-    assert gemm._dense_split_k_workspace(4096, 512, 32768, 1, cpu) is None                        # recipe (1, 1, 128): another kernel family
+    # recipe (1, 1, 128): only under-filled launches with long K loops (wgrad of a narrow layer)
+    for m, n, k in ((4096, 4096, 7168), (2112, 4096, 7168), (576, 4096, 1024), (64, 4096, 7168)):
+        assert gemm._dense_split_k_workspace(m, n, k, 1, cpu) is None, (m, n, k)
+    wants = lambda m, n, k, gran_n=128, a_mn=0, b_mn=0: lib.dg_dense_wants_workspace(m, n, k, a_mn, b_mn, gran_n)      # noqa: E731
+    assert wants(4096, 512, 32768) == 1 and wants(4096, 512, 32768, b_mn=1) == 1          # 64 tiles of 128 x 256, 256 K blocks
+    assert wants(1024, 1024, 16384) == 1 and wants(512, 4096, 7168) == 1
+    assert wants(576, 4096, 7168, 1) == 1 and wants(576, 4096, 7168, 1, 1, 1) == 1        # 48 tiles of 256 x 256, 56 K blocks: K pieces as groups
+    assert wants(4096, 512, 32768, 1) == 1
+    assert wants(576, 4096, 7168, 1, 1, 0) == 0                                            # mixed majorness: the layout-agnostic kernel, no split
 
 
 def test_packed_ue8m0_words_expand_to_exact_powers_of_two():
