@@ -31,8 +31,9 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
-WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0']
-SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0']
+WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit']
+SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0',
+             'wgrad_ksplit']
 
 
 def measured_traffic(kernel: str):
@@ -153,8 +154,9 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
                             + ('K tail on the fast path' if name == 'dgrad_ktail' else 'under-filled launch: K split') + ')',
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
-    elif name == 'wgrad':
-        m, n, k = 4096, 4096, 7168
+    elif name in ('wgrad', 'wgrad_ksplit'):
+        # (wgrad_ksplit: the sweep's wgrad entry of a 576-wide layer -- 48 tiles for 256 CUs: the K pieces run as groups of one launch)
+        m, n, k = (4096, 4096, 7168) if name == 'wgrad' else (576, 4096, 7168)
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float, per_token_b=True)
