@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|kgrouped|dense_ue8m0]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|masked_ue8m0|dgrad_ktail|dgrad_ksplit]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
