@@ -140,14 +140,17 @@ const Config kConfigs[] = {
     {"stream_nt_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4>, true},
-    {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>, true, false,
+    {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>, true, false,
      false, true},
-    {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>, true,
+    {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
      false, false, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
 #ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
     {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
+    {"pipe_pc_s2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>, true, false, false, true},
+    {"pipe_pc_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 3, false>, true, false, false, true},
+    {"pipe_pc_s4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 4, false>, true, false, false, true},
     {"pipe_s0_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
     {"pipe_s1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 1>},
     {"pipe_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 3>},
@@ -495,10 +498,10 @@ int launch_per_col_split(const dg::GemmParams& dense, int pieces, void* stream) 
     const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * pieces;
     g_last_config = mn_major ? "pipe_pc_mn_ks_256x256" : "pipe_pc_ks_256x256";
     if (mn_major)
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p);
     else
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p);
     DG_HIP_CHECK(hipGetLastError());
     const size_t elem = dense.d_dtype == DG_BF16 ? 2 : 4;
@@ -1023,7 +1026,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
             if (grid > 0x7fffffffL)
                 return fail(__FILE__, __LINE__, "grid too large");
             g_last_config = "pipe_pc_mn_256x256";
-            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>),
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>),
                                dim3(static_cast<unsigned>(grid)), dim3(512), 0, static_cast<hipStream_t>(stream), p);
             DG_HIP_CHECK(hipGetLastError());
             return 0;
@@ -1053,7 +1056,7 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
             if (grid > 0x7fffffffL)
                 return fail(__FILE__, __LINE__, "grid too large");
             g_last_config = "pipe_pc_256x256";
-            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>), dim3(static_cast<unsigned>(grid)),
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>), dim3(static_cast<unsigned>(grid)),
                                dim3(512), 0, static_cast<hipStream_t>(stream), p);
             DG_HIP_CHECK(hipGetLastError());
             return 0;
@@ -1136,11 +1139,11 @@ int dg_k_grouped_fp8_gemm_tn_psum(const void* a, const float* sfa, const void* b
         return fail(__FILE__, __LINE__, "grid too large");
     if (mn_major) {
         g_last_config = "pipe_pc_mn_256x256";
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p);
     } else {
         g_last_config = "pipe_pc_256x256";
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p);
     }
     DG_HIP_CHECK(hipGetLastError());
