@@ -463,8 +463,9 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
 // an FP32 partial matrix into the caller's workspace; dg_sum_partials_kernel then adds them in piece order and performs the operator's
 // output step.  Returns the number of pieces (0 = one ordinary launch).  Model (us): one launch 15 + 2.2 per K block; split 30 + 2.2 per
 // K block of a piece + the partials' write and read at ~4 TB/s.  workspace_bytes = 0: "as large as needed" (the host layer's query).
-int per_col_split_pieces(const dg::GemmParams& p, size_t workspace_bytes) {
-    if (p.sfb_gran_n != 1 || p.gemm_type != dg::kNormal || p.head_lr > 0 || p.m <= 64 || p.k % 128 != 0 || forced_config() != "auto")
+int per_col_split_pieces(const dg::GemmParams& p, size_t workspace_bytes, bool ignore_forced = false) {
+    if (p.sfb_gran_n != 1 || p.gemm_type != dg::kNormal || p.head_lr > 0 || p.m <= 64 || p.k % 128 != 0 ||
+        (!ignore_forced && forced_config() != "auto"))
         return 0;
     if (!per_col_eligible(p) && !per_col_mn_eligible(p))
         return 0;
@@ -1308,6 +1309,8 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
     if (packed_ue8m0) {
         p.sfb_gran_n = 128;
         name = fast_eligible(p) ? select_e8_config(p, expected_m)->name : "";
+    } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
+        name = per_col_eligible(p) ? "pipe_pc_ks_256x256" : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)
     } else {
         const int bm_must_divide = (gemm_type == dg::kContiguous || gemm_type == dg::kContiguousPsum) ? m_alignment : 0;
         const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide, true);
@@ -1331,7 +1334,7 @@ int dg_dense_wants_workspace(int m, int n, int k, int a_mn_major, int b_mn_major
     p.sfa_sm = 1; p.sfa_sk = (m + 3) / 4 * 4; p.sfb_sn = sfb_gran_n == 1 ? 1 : (k + 127) / 128; p.sfb_sk = sfb_gran_n == 1 ? (n + 3) / 4 * 4 : 1;
     p.d_sm = n; p.sfb_gran_n = sfb_gran_n; p.d_dtype = DG_BF16; p.gemm_type = dg::kNormal;
     p.sk_workspace = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23);
-    if (per_col_split_pieces(p, 0) >= 2)
+    if (per_col_split_pieces(p, 0, true) >= 2)
         return 1;
     const Config* cfg = select_config(p, p.m, 0, 0, true);
     return cfg != nullptr && cfg->split_k ? 1 : 0;
