@@ -476,3 +476,16 @@ def test_k_grouped_packed_ue8m0_scale_layout():
     with pytest.raises(RuntimeError, match='Unsupported architecture'):
         dg.get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor(sf, layout, None, 128, 128, use_psum_layout=True)
 
+
+def test_bench_workload_tables_are_consistent():
+    """bench.py: every secondary workload is a selectable workload, the headline is not among them, and the argument parser accepts the
+    driver's flags with defaults that finish in minutes (the timed numbers themselves are the GPU tests' and the driver's business)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.SECONDARY) <= set(bench.WORKLOADS) and 'dense' in bench.WORKLOADS and 'dense' not in bench.SECONDARY
+    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 13
+    assert bench.PEAK_FP8_TFLOPS == 5000.0
+
