@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|masked_ue8m0|dgrad_ktail|dgrad_ksplit]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -31,9 +31,10 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
-WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit']
-SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0',
-             'wgrad_ksplit']
+WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
+             'dense_sm100']
+SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
+             'masked_ue8m0', 'wgrad_ksplit']
 
 
 def measured_traffic(kernel: str):
@@ -101,7 +102,29 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
     bound = 'mfma'
     if name == 'masked' and world > 1:
         return make_ep_workload(sets, world, rank, phase_events, ep_capacity)
-    if name in ('dense', 'dense_ue8m0'):
+    if name == 'dense_sm100':
+        # C2 as an SM100-style caller sends it: FP32 power-of-two scales (per_token / per_block casts with use_ue8m0=True, row-major
+        # SFA as the cast returns it), scaling-factor mode 'sm100' -- the WHOLE call: the cast branch's pack launches (SFA; SFB with the
+        # per-128-row broadcast fused in) + the hardware-scaled GEMM (reference default on SM100, csrc/apis/layout.hpp:48-54)
+        m, n, k = 4096, 4096, 7168
+        for i in range(sets):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k, use_ue8m0=True)
+            cases.append(case)
+
+            def call(c=case):
+                dg.set_sf_cast_mode('sm100')
+                try:
+                    dg.fp8_gemm_nt(c.a, c.b, c.d)
+                finally:
+                    dg.set_sf_cast_mode('sm90')
+            calls.append(call)
+        flops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k}, FP32 power-of-two scales, sf cast mode sm100: whole call (cast branch + GEMM)',
+                'm': m, 'n': n, 'k': k, 'sfa_layout': 'FP32 row-major (as per_token_cast_to_fp8 returns it); cast to packed UE8M0 inside the call'}
+        check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+    elif name in ('dense', 'dense_ue8m0'):
         m, n, k = 4096, 4096, 7168
         packed = name == 'dense_ue8m0'
         for i in range(sets):

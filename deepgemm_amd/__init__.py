@@ -7,7 +7,7 @@ from . import _lib                                    # loads the HIP extension;
 from .runtime import (                                # noqa: F401
     set_num_sms, get_num_sms, set_tc_util, get_tc_util, set_pdl, get_pdl,
     set_ignore_compile_dims, set_block_size_multiple_of,
-    set_forced_config, list_configs, last_config,
+    set_forced_config, list_configs, last_config, set_sf_cast_mode, get_sf_cast_mode,
 )
 from .gemm import (                                   # noqa: F401
     fp8_gemm_nt, fp8_gemm_nn, fp8_gemm_tn, fp8_gemm_tt,

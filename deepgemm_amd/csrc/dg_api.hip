@@ -1167,15 +1167,24 @@ int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int s
 
 int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_k,
                      int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, void* stream) {
+    return dg_pack_sf_ue8m0_ex(sf, out, batches, mn, sf_k, sf_stride_b, sf_stride_mn, sf_stride_k, 1, nullptr, 0, 0, stream);
+}
+
+int dg_pack_sf_ue8m0_ex(const float* sf, int32_t* out, int batches, int mn, int sf_k,
+                        int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, int gran_mn,
+                        const int32_t* psum_layout, int num_psum_groups, int m_alignment, void* stream) {
     DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
     if (batches == 0 || mn == 0 || sf_k == 0)
         return 0;
     DG_CHECK(sf != nullptr && out != nullptr);
+    DG_CHECK(gran_mn >= 1);
     DG_CHECK(batches <= 65535 && (sf_k + 63) / 64 <= 65535);
+    DG_CHECK(psum_layout == nullptr || (batches == 1 && num_psum_groups > 0 && m_alignment > 0));      // smxx_layout.hpp:190-194
     const int aligned_mn = (mn + 3) / 4 * 4;
     const dim3 grid((mn + 63) / 64, (sf_k + 63) / 64, batches);
     hipLaunchKernelGGL(dg::dg_pack_sf_ue8m0_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
-                       sf, out, mn, sf_k, aligned_mn, sf_stride_b, sf_stride_mn, sf_stride_k);
+                       sf, out, mn, sf_k, aligned_mn, sf_stride_b, sf_stride_mn, sf_stride_k, gran_mn, psum_layout,
+                       psum_layout != nullptr ? num_psum_groups : 0, m_alignment);
     DG_HIP_CHECK(hipGetLastError());
     return 0;
 }

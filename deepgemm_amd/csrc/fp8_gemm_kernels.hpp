@@ -2676,15 +2676,19 @@ void dg_transpose_sf_fp32_kernel(const float* __restrict__ sf, float* __restrict
     }
 }
 
-// SF packing kernel: FP32 power-of-two scales [batches, mn, sf_k] (any strides) -> packed UE8M0 words, MN-major:
-// word (row, kq) = exponent bytes of K blocks 4 kq .. 4 kq + 3 of that row (byte j = bits 30..23 of sf[row][4 kq + j],
-// blocks past sf_k are zero bytes), stored at out[batch * packed_k * aligned_mn + kq * aligned_mn + row].  Semantics of
-// the reference's transpose_and_pack_fp32_into_ue8m0 / pack_fp32_into_ue8m0 (impls/smxx_layout.cuh:56,148) and of its
-// torch twin (jit_kernels/impls/smxx_layout.hpp:156-179).  A block packs a 64 (mn) x 64 (sf_k) patch through LDS: the
-// read runs along whichever input axis has unit stride, the write along mn.
+// SF packing kernel: FP32 power-of-two scales [batches, ceil(mn / gran_mn), sf_k] (any strides) -> packed UE8M0 words, MN-major:
+// word (row, kq) = exponent bytes of K blocks 4 kq .. 4 kq + 3 of source row `row / gran_mn` (byte j = bits 30..23 of
+// sf[row / gran_mn][4 kq + j], blocks past sf_k are zero bytes), stored at out[batch * packed_k * aligned_mn + kq * aligned_mn + row].
+// Semantics of the reference's transpose_and_pack_fp32_into_ue8m0 / pack_fp32_into_ue8m0 (impls/smxx_layout.cuh:56,148) and of its
+// torch twin (jit_kernels/impls/smxx_layout.hpp:156-179).  gran_mn > 1 fuses the row broadcast the reference performs with
+// index_select in front of the pack (csrc/apis/layout.hpp:52-54: per-128-row scales -> one word per row) -- no temporary.
+// psum_layout != nullptr (smxx_layout.cuh:76-94): rows outside every group's range [align(end[g-1], m_alignment), end[g]) -- the
+// uninitialised gap rows of the psum contiguous layout -- get zero words (a finite scale code; 0xff would be NaN).
+// A block packs a 64 (mn) x 64 (sf_k) patch through LDS: the read runs along whichever input axis has unit stride, the write along mn.
 __global__ __launch_bounds__(256)
 void dg_pack_sf_ue8m0_kernel(const float* __restrict__ sf, int32_t* __restrict__ out, int mn, int sf_k, int aligned_mn,
-                             int64_t stride_b, int64_t stride_mn, int64_t stride_k) {
+                             int64_t stride_b, int64_t stride_mn, int64_t stride_k, int gran_mn,
+                             const int32_t* __restrict__ psum_layout, int num_psum_groups, int m_alignment) {
     __shared__ uint8_t patch[64][68];            // [row][k], exponent bytes; 68: 4-byte aligned rows, 17-word pitch
     const int batch = blockIdx.z;
     const int mn0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
@@ -2692,20 +2696,31 @@ void dg_pack_sf_ue8m0_kernel(const float* __restrict__ sf, int32_t* __restrict__
     const float* src = sf + static_cast<int64_t>(batch) * stride_b;
     int32_t* dst = out + static_cast<int64_t>(batch) * aligned_mn * packed_k;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const bool k_fast = stride_k == 1;
+    const bool k_fast = stride_k == 1 || gran_mn > 1;                // (broadcast rows: neighbouring lanes would read the same word)
     for (int i = ty; i < 64; i += 4) {
         const int r = k_fast ? i : tx, c = k_fast ? tx : i;          // patch coordinates of this thread's element
         const int row = mn0 + r, col = k0 + c;
         uint32_t bits = 0;
         if (row < mn && col < sf_k)
-            bits = __float_as_uint(src[static_cast<int64_t>(row) * stride_mn + static_cast<int64_t>(col) * stride_k]);
+            bits = __float_as_uint(src[static_cast<int64_t>(row / gran_mn) * stride_mn + static_cast<int64_t>(col) * stride_k]);
         patch[r][c] = static_cast<uint8_t>(bits >> 23);
+    }
+    const int out_row = mn0 + tx;
+    bool valid = true;
+    if (psum_layout != nullptr) {
+        valid = false;
+        int start = 0;
+        for (int g = 0; g < num_psum_groups; ++g) {
+            const int end = psum_layout[g];
+            valid = valid || (out_row >= start && out_row < end);
+            start = (end + m_alignment - 1) / m_alignment * m_alignment;
+        }
     }
     __syncthreads();
     for (int q = ty; q < 16; q += 4) {
-        const int row = mn0 + tx, kq = k0 / 4 + q;
-        if (row < mn && kq < packed_k)
-            dst[static_cast<int64_t>(kq) * aligned_mn + row] = *reinterpret_cast<const int32_t*>(&patch[tx][q * 4]);
+        const int kq = k0 / 4 + q;
+        if (out_row < mn && kq < packed_k)
+            dst[static_cast<int64_t>(kq) * aligned_mn + out_row] = valid ? *reinterpret_cast<const int32_t*>(&patch[tx][q * 4]) : 0;
     }
 }
 

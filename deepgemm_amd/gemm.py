@@ -4,8 +4,10 @@ Signatures, keyword names/defaults, assertion order and in-place semantics follo
 (``csrc/apis/gemm.hpp:19-297`` and the ``m.def`` table at ``:645-717``).  Differences, all supersets:
   * MN-major FP8 operands, ``c`` accumulation and FP32 outputs are accepted for every dense layout (the reference only
     accepts them on SM100; SURVEY appendix A3/A4);
-  * ``compiled_dims`` and ``disable_ue8m0_cast`` are accepted and do not affect results (there is no JIT and scales are
-    consumed as FP32).
+  * ``compiled_dims`` is accepted and does not affect results (there is no JIT);
+  * ``disable_ue8m0_cast`` is the reference's keyword (csrc/apis/layout.hpp:40-50): it matters in the ``'sm100'`` scaling-factor
+    mode (``runtime.set_sf_cast_mode``), where FP32 scales are cast to packed UE8M0 words and the hardware-scaled MFMA kernels run
+    unless a call disables the cast; in the default ``'sm90'`` mode FP32 scales are always consumed as FP32.
 Every call is asynchronous on the current torch stream and never synchronises.
 """
 from typing import Optional, Tuple
@@ -121,12 +123,27 @@ def _unpack_ue8m0(sf_packed: torch.Tensor, k: int) -> torch.Tensor:
     return (exps << 23).view(torch.float).contiguous()
 
 
+def _casts_to_ue8m0(a_sf: torch.Tensor, b_sf: torch.Tensor, disable_ue8m0_cast: bool) -> bool:
+    """FP32 scale tensors that the layout step will cast to packed UE8M0 words: the reference's default on SM100
+    (csrc/apis/layout.hpp:48-54), here the ``'sm100'`` mode of ``runtime.set_sf_cast_mode``."""
+    return (not disable_ue8m0_cast and a_sf.dtype == torch.float and b_sf.dtype == torch.float and
+            runtime.get_sf_cast_mode() == 'sm100')
+
+
+def _truncate_to_ue8m0(sf: torch.Tensor) -> torch.Tensor:
+    """FP32 scales with everything but the exponent byte dropped: the value the cast branch's ``>> 23`` keeps (exactly 2^(e - 127))."""
+    return (sf.view(torch.int) & 0x7f800000).view(torch.float)
+
+
 def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a, recipe_b) -> None:
-    """Power-of-two scales handed over as packed exponent bytes (the reference's SM100 format, recipe (1, 1, 128)):
-    hardware-scaled MFMA path, no FP32 promotion."""
-    host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
-    host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
-    host_assert(recipe_a is None and recipe_b is None, 'not recipe_a.has_value() and not recipe_b.has_value()')
+    """Power-of-two scales handed over as packed exponent bytes (the reference's SM100 format, recipe (1, 1, 128)) -- or FP32 scales in
+    the ``'sm100'`` mode, which the layout step casts to that format (csrc/apis/layout.hpp:48-54): hardware-scaled MFMA path, no FP32
+    promotion."""
+    fp32_in = a_sf.dtype == torch.float and b_sf.dtype == torch.float
+    if not fp32_in:
+        host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
+        host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
+        host_assert(recipe_a is None and recipe_b is None, 'not recipe_a.has_value() and not recipe_b.has_value()')
     major_check(a_data), major_check(b_data)
     check_major_type_cd(d)
     m, k = _check_ab_fp8(a_data, 2)
@@ -137,15 +154,22 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
         return
     if k % 128 != 0:
         # A partial last K block (the reference's SM100 kernels take any K: TMA zero-fills): the hardware-scaled kernels need whole
-        # blocks, so the exponents are expanded to FP32 scales -- exactly, they are powers of two -- and the recipe (1, 1, 128) path
+        # blocks, so the exponents are expanded to FP32 scales -- exactly, they are powers of two -- and the FP32-scale path
         # computes the same sums (layout-agnostic kernel: correct, not fast).  `c` has been folded into `d` by _early_return.
+        if fp32_in:
+            fp8_gemm_nt((a_data, _truncate_to_ue8m0(a_sf)), (b_data, _truncate_to_ue8m0(b_sf)), d, d if c is not None else None,
+                        recipe, recipe_a, recipe_b, disable_ue8m0_cast=True)
+            return
         host_assert(a_sf.dim() == 2 and b_sf.dim() == 2 and a_sf.size(0) == m and b_sf.size(0) == n and
                     a_sf.size(1) == -(-k // 512) and b_sf.size(1) == -(-k // 512),
                     'sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4)')
         fp8_gemm_nt((a_data, _unpack_ue8m0(a_sf, k)), (b_data, _unpack_ue8m0(b_sf, k)), d, d if c is not None else None,
-                    recipe=(1, 1, 128))
+                    recipe=(1, 1, 128), disable_ue8m0_cast=True)
         return
-    sfa, sfb = _packed_sf_mn_major(a_sf, m, k), _packed_sf_mn_major(b_sf, n, k)
+    if fp32_in:
+        sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, None, False)
+    else:
+        sfa, sfb = _packed_sf_mn_major(a_sf, m, k), _packed_sf_mn_major(b_sf, n, k)
     require_device(a_data, b_data, sfa, sfb, d)
     a_data = a_data if a_data.stride(-1) == 1 else _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
     b_data = b_data if b_data.stride(-1) == 1 else _as_k_major(b_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
@@ -194,15 +218,20 @@ def _call_dense(a_data, sfa, b_data, sfb, d, c, m, n, k, gran_n) -> None:
         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, current_stream_ptr()))
 
 
-def _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b):
-    """Both scale tensors as packed UE8M0 words in the MN-major layout (csrc/apis/layout.hpp:58-60: the (INT, 1, gran_k) branch of
-    transform_sf_into_required_layout; default recipe for int scales is (1, 1, 128), csrc/utils/layout.hpp:64-77)."""
+def _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b, psum_layout=None):
+    """Both scale tensors as packed UE8M0 words in the MN-major layout (csrc/apis/layout.hpp:56-58: the (INT, 1, gran_k) branch of
+    transform_sf_into_required_layout; default recipe for int scales is (1, 1, 128), csrc/utils/layout.hpp:64-77) -- or, for FP32
+    scales in the 'sm100' mode, the cast branch (:48-54; ``psum_layout`` lets the SFA pack zero the psum layout's gap rows)."""
+    host_assert(k % 128 == 0, 'k % 128 == 0')
+    if a_sf.dtype == torch.float and b_sf.dtype == torch.float:
+        sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b,
+                                                             False, psum_layout)
+        return sfa, sfb
     host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
     host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
     host_assert((recipe_a is None) == (recipe_b is None), 'recipe_a.has_value() == recipe_b.has_value()')
     host_assert(recipe_a is None or (tuple(recipe_a) == (1, 128) and tuple(recipe_b) == (1, 128)),
                 'recipe_a == (1, 128) and recipe_b == (1, 128) for packed UE8M0 scaling factors')
-    host_assert(k % 128 == 0, 'k % 128 == 0')
     return (transform_sf_into_required_layout(a_sf, m, k, (1, 128), num_groups_a),
             transform_sf_into_required_layout(b_sf, n, k, (1, 128), num_groups_b))
 
@@ -238,12 +267,12 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
                 disable_ue8m0_cast: bool = False) -> None:
     """D = C + A @ B^T with per-128-block FP32 scales; ``a = (A_fp8 [M,K], SFA)``, ``b = (B_fp8 [N,K], SFB)``."""
     (a_data, a_sf), (b_data, b_sf) = a, b
-    if a_sf.dtype == torch.int or b_sf.dtype == torch.int:
+    if a_sf.dtype == torch.int or b_sf.dtype == torch.int or _casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast):
         return _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a, recipe_b)
     same_cd = c is not None and c.data_ptr() == d.data_ptr()
     key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(c), same_cd,
            recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),
-           recipe_b if recipe_b is None else tuple(recipe_b))
+           recipe_b if recipe_b is None else tuple(recipe_b))         # (FP32 scales consumed as FP32: the mode / keyword took the other exit)
     plan = _VALIDATED_DENSE.get(key)
     if plan is not None:
         m, n, k, gran_n, sfa_ready = plan
@@ -263,7 +292,7 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     if _early_return(m, n, k, d, c):
         return
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                              None, None, disable_ue8m0_cast)
+                                                              None, None, True)     # (FP32 scales stay FP32 on this exit)
     require_device(a_data, b_data, sfa, sfb, d)
     if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
         _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf)
@@ -311,9 +340,11 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     check_major_type_cd(d)
     if m == 0:
         return
-    if a_sf.dtype == torch.int or b_sf.dtype == torch.int:
-        # packed UE8M0 scales (SM100 format, recipe (1, 1, 128)): hardware-scaled MFMA kernels
-        sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, num_groups)
+    if a_sf.dtype == torch.int or b_sf.dtype == torch.int or (_casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast) and k % 128 == 0):
+        # packed UE8M0 scales (SM100 format, recipe (1, 1, 128)) or FP32 scales cast to them ('sm100' mode): hardware-scaled MFMA kernels
+        # (csrc/apis/gemm.hpp:213-216: the psum layout goes to the SFA pack so that it skips the gap rows)
+        sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, num_groups,
+                                   grouped_layout if use_psum_layout and a_sf.dtype == torch.float else None)
         require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
         b_km = b_data if b_data.stride(-1) == 1 else _remajor(b_data)
         check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(
@@ -323,7 +354,7 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
             runtime.get_mk_alignment_for_contiguous_layout(), current_stream_ptr()))
         return
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                              None, num_groups, disable_ue8m0_cast)
+                                                              None, num_groups, True)
     host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
     require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
     if b_data.stride(-1) != 1 and _operand_plan(2 if use_psum_layout else 1, a_data, b_data, sfa, gran_n, m, n, k,
@@ -354,7 +385,7 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
     """``a [G,M,K]``, ``b [G,N,K]``, ``d [G,M,N]``; only ``d[g, :masked_m[g]]`` is written; ``masked_m`` stays on
     the device, ``expected_m`` is a tuning hint."""
     (a_data, a_sf), (b_data, b_sf) = a, b
-    if a_sf.dtype == torch.int or b_sf.dtype == torch.int:
+    if a_sf.dtype == torch.int or b_sf.dtype == torch.int or (_casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast) and a_data.size(-1) % 128 == 0):
         return _m_grouped_masked_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, masked_m, expected_m, recipe, recipe_a, recipe_b)
     key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(masked_m), expected_m > 0,
            recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),
@@ -378,7 +409,7 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
         host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
         check_major_type_cd(d)
         sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                                  num_groups, num_groups, disable_ue8m0_cast)
+                                                                  num_groups, num_groups, True)
         host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
         require_device(a_data, b_data, sfa, sfb, d, masked_m)
         if sfb is b_sf and len(_VALIDATED_MASKED) < 4096:
@@ -560,8 +591,8 @@ def fp8_gemm_nt_skip_head_mid(a: TensorPair, b: TensorPair, d: torch.Tensor, hea
                 'n % (left + right) == 0 and n_ == n + n / (left + right) * mid')
     if m == 0:
         return
-    sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, None, None, None, None,
-                                                              disable_ue8m0_cast)
+    # (the head-split epilogue lives on the FP32-scale kernels: FP32 scales are consumed as FP32 in either scaling-factor mode)
+    sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, None, None, None, None, True)
     require_device(a_data, b_data, sfa, sfb, d)
     check(lib.dg_fp8_gemm_nt_skip_head_mid(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,

@@ -98,21 +98,39 @@ def get_mn_major_tma_aligned_tensor(sf: torch.Tensor) -> torch.Tensor:
     return out.squeeze(0) if sf.dim() == 2 else out
 
 
-def get_mn_major_tma_aligned_packed_ue8m0_tensor(sf: torch.Tensor, psum_layout: Optional[torch.Tensor] = None) -> torch.Tensor:
+def get_mn_major_tma_aligned_packed_ue8m0_tensor(sf: torch.Tensor, psum_layout: Optional[torch.Tensor] = None,
+                                                 _gran_mn: int = 1, _mn: Optional[int] = None) -> torch.Tensor:
     """[..., mn, sf_k] FP32 power-of-two scales -> packed UE8M0 words ``[..., mn, ceil(sf_k / 4)]`` int32 with strides
     ``(packed_k * aligned_mn, 1, aligned_mn)``: four exponent bytes per word, MN-major (the layout the scaled-MFMA kernels
-    read).  Reference: csrc/jit_kernels/impls/smxx_layout.hpp:181-246; mantissa bits are dropped as there (``>> 23``)."""
+    read).  Reference: csrc/jit_kernels/impls/smxx_layout.hpp:181-246; mantissa bits are dropped as in its torch twin (``>> 23``).
+
+    ``psum_layout`` (the cumulative row ends of the psum contiguous layout, int32 on the device): rows in the gaps between a group's
+    end and the next group's aligned start hold uninitialised scales -- they are packed as zero words (smxx_layout.cuh:76-94).
+    ``_gran_mn`` / ``_mn`` (host-layer internal): ``sf`` has one row per ``_gran_mn`` of the ``_mn`` output rows; the broadcast the
+    reference materialises with ``index_select`` (csrc/apis/layout.hpp:52-53) happens inside the pack kernel."""
     host_assert(sf.dim() in (2, 3), 'dim == 2 or dim == 3')
     host_assert(sf.dtype == torch.float, 'sf.scalar_type() == torch::kFloat')
-    host_assert(psum_layout is None, 'not psum_layout.has_value() (psum gaps are not skipped on gfx950: pack the whole tensor)')
-    require_device(sf)
     batched = sf.unsqueeze(0) if sf.dim() == 2 else sf
-    nb, mn, sf_k = batched.shape
+    nb, src_rows, sf_k = batched.shape
+    mn = src_rows if _mn is None else _mn
+    host_assert(ceil_div(mn, _gran_mn) == src_rows, 'sf.size(-2) == ceil_div(mn, gran_mn)')
+    require_device(sf)
     aligned_mn, packed_k = get_tma_aligned_size(mn, 4), ceil_div(sf_k, 4)
+    layout_ptr, num_psum_groups, m_alignment = None, 0, 0
+    if psum_layout is not None:
+        from . import runtime
+        host_assert(nb == 1 and batched.is_contiguous(), 'num_sf_batches == 1 and batched_sf.is_contiguous()')
+        host_assert(psum_layout.dtype == torch.int and psum_layout.is_contiguous(),
+                    'psum_layout->scalar_type() == torch::kInt and psum_layout->is_contiguous()')
+        host_assert(psum_layout.numel() > 0, 'psum_layout->numel() > 0')
+        require_device(psum_layout)
+        layout_ptr, num_psum_groups = psum_layout.data_ptr(), psum_layout.numel()
+        m_alignment = runtime.get_mk_alignment_for_contiguous_layout()
     out = torch.empty_strided((nb, mn, packed_k), (packed_k * aligned_mn, 1, aligned_mn), dtype=torch.int, device=sf.device)
     host_assert(nb <= 65535, 'num_sf_batches <= 65535')
-    check(lib.dg_pack_sf_ue8m0(batched.data_ptr(), out.data_ptr(), nb, mn, sf_k,
-                               batched.stride(0), batched.stride(1), batched.stride(2), current_stream_ptr()))
+    check(lib.dg_pack_sf_ue8m0_ex(batched.data_ptr(), out.data_ptr(), nb, mn, sf_k,
+                                  batched.stride(0), batched.stride(1), batched.stride(2), _gran_mn,
+                                  layout_ptr, num_psum_groups, m_alignment, current_stream_ptr()))
     return out.squeeze(0) if sf.dim() == 2 else out
 
 
@@ -174,14 +192,21 @@ def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe:
     else:
         raise RuntimeError('Assertion error (layout.py): Invalid recipe')
     check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups)
+    from . import runtime
+    fp32_as_is = runtime.get_sf_cast_mode() == 'sm90' or disable_ue8m0_cast     # reference: arch_major == 9 or disable_ue8m0_cast
 
-    # (FP32, 1, 128): MN-major, padded -- csrc/apis/layout.hpp:40-42
-    if sf.dtype == torch.float and gran_mn == 1 and gran_k == 128:
+    # (FP32, 1, 128) consumed as FP32: MN-major, padded -- csrc/apis/layout.hpp:40-42
+    if sf.dtype == torch.float and gran_mn == 1 and gran_k == 128 and fp32_as_is:
         return get_mn_major_tma_aligned_tensor(sf)
-    # (FP32, 128, 128): only checked -- csrc/apis/layout.hpp:44-46
-    if sf.dtype == torch.float and gran_mn == 128 and gran_k == 128:
+    # (FP32, 128, 128) consumed as FP32: only checked -- csrc/apis/layout.hpp:44-46
+    if sf.dtype == torch.float and gran_mn == 128 and gran_k == 128 and fp32_as_is:
         return check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups, False, True, torch.float)
-    # (INT, 1, 128): packed UE8M0 words, only checked and brought to the MN-major layout -- csrc/apis/layout.hpp:60-62
+    # (FP32, x, 128) in 'sm100' mode: cast to (INT, 1, 128) -- broadcast to rows, packed, MN-major -- csrc/apis/layout.hpp:48-54.
+    # One fused kernel (dg_pack_sf_ue8m0_ex): no index_select temporary.
+    if sf.dtype == torch.float and gran_k == 128 and runtime.get_sf_cast_mode() == 'sm100':
+        host_assert(not disable_ue8m0_cast, 'not disable_ue8m0_cast')
+        return get_mn_major_tma_aligned_packed_ue8m0_tensor(sf, psum_layout, _gran_mn=gran_mn, _mn=mn)
+    # (INT, 1, 128): packed UE8M0 words, only checked and brought to the MN-major layout -- csrc/apis/layout.hpp:56-58
     if sf.dtype == torch.int and gran_mn == 1 and gran_k == 128:
         host_assert(sf.dim() == (2 if num_groups is None else 3), 'sf.dim() == static_cast<int>(num_groups.has_value()) + 2')
         host_assert(sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4),

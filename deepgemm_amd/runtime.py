@@ -9,7 +9,26 @@ from ._lib import lib, check
 
 _LEGACY_MK_ALIGNMENT = 128      # reference csrc/jit_kernels/heuristics/runtime.hpp:10
 _state = {'tc_util': 100, 'pdl': False, 'ignore_compile_dims': False, 'block_size_multiple_of': (1, 1),
-          'mk_alignment': _LEGACY_MK_ALIGNMENT}
+          'mk_alignment': _LEGACY_MK_ALIGNMENT, 'sf_cast_mode': 'sm90'}
+
+
+def set_sf_cast_mode(mode: str) -> None:
+    """Which architecture's scaling-factor convention FP32 scale tensors follow in ``transform_sf_into_required_layout`` -- the role
+    ``device_runtime->get_arch_major()`` plays in the reference (csrc/apis/layout.hpp:22,40-58).  Process-wide, like the knobs below.
+
+    ``'sm90'`` (default): FP32 scales are consumed as FP32 -- (1, 128) MN-major, (128, 128) checked only; results are the reference's
+    SM90 results for ANY positive scales (BASELINE's headline semantics).
+    ``'sm100'``: unless a call passes ``disable_ue8m0_cast=True`` (the reference's keyword, default False), FP32 scales are cast to
+    UE8M0 -- per-128-row scales broadcast to rows, exponent bytes packed four to a word (mantissa bits dropped, as the reference's
+    ``>> 23``; its producers hand over powers of two) -- and the GEMM runs on the hardware-scaled MFMA kernels, the path the reference
+    takes by default on SM100."""
+    if mode not in ('sm90', 'sm100'):
+        raise ValueError(f"sf cast mode must be 'sm90' or 'sm100', got {mode!r}")
+    _state['sf_cast_mode'] = mode
+
+
+def get_sf_cast_mode() -> str:
+    return _state['sf_cast_mode']
 
 
 def set_num_sms(new_num_sms: int) -> None:

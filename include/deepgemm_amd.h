@@ -98,6 +98,18 @@ int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_pack
 int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_k,
                      int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, void* stream);
 
+/* The same packing with the two steps the reference's FP32 -> UE8M0 cast branch puts around it (transform_sf_into_required_layout,
+ * csrc/apis/layout.hpp:48-54, the default of its SM100 path) fused in:
+ *   gran_mn > 1: `sf` holds one row of scales per `gran_mn` rows ([batches, ceil(mn / gran_mn), sf_k]); output row r takes source row
+ *     r / gran_mn -- the reference materialises this broadcast with index_select first (layout.hpp:52-53), here there is no temporary;
+ *   psum_layout != NULL (device pointer to num_psum_groups cumulative row ends of the psum contiguous layout, batches == 1): rows that
+ *     lie in no group's range [align(end[g-1], m_alignment), end[g]) get zero words, as transpose_and_pack_fp32_into_ue8m0 does for
+ *     the layout's uninitialised gap rows (deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:76-94,139-141).
+ * `mn` counts OUTPUT rows. */
+int dg_pack_sf_ue8m0_ex(const float* sf, int32_t* out, int batches, int mn, int sf_k,
+                        int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, int gran_mn,
+                        const int32_t* psum_layout, int num_psum_groups, int m_alignment, void* stream);
+
 /* K-grouped contiguous GEMM (MoE weight gradients): D[g] += A_g * B_g^T for every group g, where group g owns the K range
  * [sum(ks[:g]), sum(ks[:g+1])) of both operands.  Replaces sm90_k_grouped_fp8_gemm_1d1d / sm100_k_grouped_fp8_gemm_1d1d as
  * called from k_grouped_fp8_gemm_nt_contiguous / k_grouped_fp8_gemm_tn_contiguous (csrc/apis/gemm.hpp:299-400).

@@ -64,6 +64,38 @@ def test_knobs_round_trip():
         dg.set_forced_config('bogus')
     dg.set_forced_config('generic_128x128'), dg.set_forced_config('auto')
     assert 'pipe_256x256' in dg.list_configs()
+    # scaling-factor mode (the role of the reference's arch_major in csrc/apis/layout.hpp:22,40-58): FP32 scales stay FP32 by default
+    assert dg.get_sf_cast_mode() == 'sm90'
+    dg.set_sf_cast_mode('sm100')
+    assert dg.get_sf_cast_mode() == 'sm100'
+    with pytest.raises(ValueError, match='sm90'):
+        dg.set_sf_cast_mode('sm80')
+    assert dg.get_sf_cast_mode() == 'sm100'
+    dg.set_sf_cast_mode('sm90')
+
+
+def test_sf_cast_mode_on_the_host():
+    """The cast branch's host logic without a device: which calls take it, what it asserts (csrc/apis/layout.hpp:40-54)."""
+    from deepgemm_amd.gemm import _casts_to_ue8m0, _truncate_to_ue8m0
+    from deepgemm_amd.layout import get_mn_major_tma_aligned_packed_ue8m0_tensor, transform_sf_into_required_layout
+    f, i = torch.ones((4, 2)), torch.ones((4, 1), dtype=torch.int)
+    assert not _casts_to_ue8m0(f, f, False)
+    dg.set_sf_cast_mode('sm100')
+    try:
+        assert _casts_to_ue8m0(f, f, False) and not _casts_to_ue8m0(f, f, True) and not _casts_to_ue8m0(i, i, False)
+        # the keyword and the default mode keep FP32 scales FP32 (no device needed: zero-copy / check-only branches)
+        sfb = torch.ones((1, 2))
+        assert transform_sf_into_required_layout(sfb, 128, 256, (128, 128), None, None, True) is sfb
+        # the cast itself runs on the device only
+        with pytest.raises(RuntimeError, match='must live on the GPU'):
+            transform_sf_into_required_layout(sfb, 128, 256, (128, 128))
+        with pytest.raises(RuntimeError, match='sf.size\\(-2\\) == ceil_div\\(mn, gran_mn\\)'):
+            get_mn_major_tma_aligned_packed_ue8m0_tensor(torch.ones((3, 2)), None, _gran_mn=128, _mn=128)
+    finally:
+        dg.set_sf_cast_mode('sm90')
+    assert transform_sf_into_required_layout(torch.ones((1, 2)), 128, 256, (128, 128)).dtype == torch.float
+    x = torch.tensor([1.0, 1.5, 3.999, 0.3, 448.0 / 3])
+    assert torch.equal(_truncate_to_ue8m0(x), torch.tensor([1.0, 1.0, 2.0, 0.25, 128.0]))
 
 
 def test_c_abi_reports_errors_without_launching():
@@ -486,6 +518,6 @@ def test_bench_workload_tables_are_consistent():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert set(bench.SECONDARY) <= set(bench.WORKLOADS) and 'dense' in bench.WORKLOADS and 'dense' not in bench.SECONDARY
-    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 13
+    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 14
     assert bench.PEAK_FP8_TFLOPS == 5000.0
 

@@ -7,11 +7,17 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof'
+
+
+def is_gemm(name: str) -> bool:
+    return 'gemm' in name.lower() or 'Cijk_' in name      # (this library's kernels; hipBLASLt's Tensile kernels of the comparator runs)
+
+
 for path in sorted(glob.glob(os.path.join(root, '**', '*kernel_stats.csv'), recursive=True)):
     print('==', path)
     with open(path) as f:
         for i, row in enumerate(csv.reader(f)):
-            if i == 0 or i < 6 or 'gemm' in row[0]:
+            if i == 0 or i < 6 or is_gemm(row[0]):
                 print(','.join(row)[:240])
 for path in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True)):
     print('==', path)
@@ -19,7 +25,7 @@ for path in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv')
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get('Kernel_Name', '')
-            if 'gemm' not in name:
+            if not is_gemm(name):
                 continue
             key = (name[:60], row.get('Counter_Name'))
             sums[key] += float(row.get('Counter_Value', 0))
@@ -31,7 +37,7 @@ for path in sorted(glob.glob(os.path.join(root, '**', '*counter_collection.csv')
         durs = defaultdict(list)
         with open(trace) as f:
             for row in csv.DictReader(f):
-                if 'gemm' in row['Kernel_Name']:
+                if is_gemm(row['Kernel_Name']):
                     durs[row['Kernel_Name'][:60]].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
         for name, d in durs.items():
             print(f'{name:60s} kernel-trace duration us: mean={sum(d) / len(d):.2f} min={min(d):.2f} max={max(d):.2f} (n={len(d)})')

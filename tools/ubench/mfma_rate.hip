@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     v2f_ acc2[16];
     for (int i = 0; i < 16; ++i) acc2[i] = v2f_{0.f, 0.f};
     __syncthreads();
+    const long long r0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz counter: shader clock = memtime ticks / real time
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         #pragma unroll
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     }
     if constexpr (MODE == 5) { if (threadIdx.x < 256) __builtin_amdgcn_s_barrier(); }   // balance the stagger barrier
     const long long t1 = __builtin_amdgcn_s_memtime();
+    const long long r1 = __builtin_amdgcn_s_memrealtime();
     float r = 0.f;
     for (int i = 0; i < 32; ++i) r += acc[i];
     for (int i = 0; i < 4; ++i) r += part[i][0] + part[i][1] + part[i][2] + part[i][3];
@@ -160,8 +163,10 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(const int* __restrict__ 
     for (int i = 0; i < 8; ++i) r += fill[i];
     for (int i = 0; i < 16; ++i) r += acc2[i][0] + acc2[i][1];
     out[tid] = r;
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
         cycles[tid >> 6] = t1 - t0;
+        cycles[4096 + (tid >> 6)] = r1 - r0;
+    }
 }
 
 template <int MODE, int PAD = 0, bool BAR = false>
@@ -178,18 +183,67 @@ void run(const char* name, int threads, const int* src, float* out, long long* c
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const int waves = blocks * threads / 64;
-    std::vector<long long> h(waves);
+    std::vector<long long> h(waves), hr(waves);
     hipMemcpy(h.data(), cyc, waves * sizeof(long long), hipMemcpyDeviceToHost);
-    double mean = 0, mx = 0, mn = 1e30;
+    hipMemcpy(hr.data(), cyc + 4096, waves * sizeof(long long), hipMemcpyDeviceToHost);
+    double mean = 0, mx = 0, mn = 1e30, clk = 0;
     for (auto c : h) { mean += c; mx = c > mx ? c : mx; mn = c < mn ? c : mn; }
+    for (int w = 0; w < waves; ++w) clk += static_cast<double>(h[w]) / static_cast<double>(hr[w]) * 100.0;     // MHz per wave
+    clk /= waves;
     mean /= waves;
     const double mfma_per_simd = 32.0 * iters * (threads / 256);
     const double flops = 2.0 * 16 * 16 * 128 * 32.0 * iters * waves;
-    printf("%-34s waves/SIMD=%d  wall=%8.1f us  ticks/wave min %9.0f mean %9.0f max %9.0f  max-ticks per MFMA per SIMD=%6.2f  clock~%6.1f MHz  %7.1f TFLOPS\n",
-           name, threads / 256, ms * 1e3, mn, mean, mx, mx / mfma_per_simd, mx / (ms * 1e3), flops / (ms * 1e-3) / 1e12);
+    printf("%-46s waves/SIMD=%d  wall=%8.1f us  ticks/wave min %9.0f mean %9.0f max %9.0f  max-ticks per MFMA per SIMD=%6.2f  clock~%6.1f MHz (ticks/wall) %6.1f MHz (s_memtime/s_memrealtime)  %7.1f TFLOPS\n",
+           name, threads / 256, ms * 1e3, mn, mean, mx, mx / mfma_per_simd, mx / (ms * 1e3), clk, flops / (ms * 1e-3) / 1e12);
+    fflush(stdout);
 }
 
-int main() {
+// `mfma_rate ceiling [file]`: the table behind the "what can this part sustain" question (profiles/r03_ceiling): register-resident
+// MFMA streams with zero / uniform-random / reference-quantised operand bytes (file = 256 KiB of per_token_cast_to_fp8 output,
+// tools/ceiling.py writes it), 1 and 2 waves per SIMD, long enough (iters) that launch overhead does not matter.
+int ceiling_table(const char* data_file) {
+    const int n = 1 << 16;
+    std::vector<int> rnd(n), zer(n, 0), quant;
+    srand(1);
+    for (auto& x : rnd) {
+        unsigned v = 0;
+        for (int b = 0; b < 4; ++b) { unsigned byte = rand() & 0xff; if ((byte & 0x7f) == 0x7f) byte ^= 1; v |= byte << (8 * b); }
+        x = (int)v;
+    }
+    if (data_file != nullptr) {
+        FILE* f = fopen(data_file, "rb");
+        if (f != nullptr) {
+            quant.resize(n);
+            if (fread(quant.data(), 4, n, f) != (size_t)n) quant.clear();
+            fclose(f);
+        }
+        if (quant.empty()) printf("(could not read %d bytes from %s: the reference-quantised rows are skipped)\n", n * 4, data_file);
+    }
+    int *d_rnd, *d_zer, *d_q = nullptr; float* out; long long* cyc;
+    hipMalloc(&d_rnd, n * 4); hipMalloc(&d_zer, n * 4); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 2 * 4096 * 8);
+    hipMemcpy(d_rnd, rnd.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_zer, zer.data(), n * 4, hipMemcpyHostToDevice);
+    if (!quant.empty()) { hipMalloc(&d_q, n * 4); hipMemcpy(d_q, quant.data(), n * 4, hipMemcpyHostToDevice); }
+    const int iters = 8000;          // 256 k MFMAs per wave: 3.5 - 5 ms per launch
+    run<3>("warm-up", 512, d_rnd, out, cyc, iters);
+    run<3>("warm-up", 512, d_rnd, out, cyc, iters);
+    struct Fill { const char* name; const int* ptr; } fills[3] = {{"zeros", d_zer}, {"uniform random bytes", d_rnd}, {"reference-quantised bytes", d_q}};
+    for (const Fill& f : fills) {
+        if (f.ptr == nullptr) continue;
+        printf("--- operand fill: %s\n", f.name);
+        for (int threads : {256, 512}) {
+            run<2>("unscaled MFMA, accumulate in place", threads, f.ptr, out, cyc, iters);
+            run<10>("scaled MFMA (UE8M0), accumulate in place", threads, f.ptr, out, cyc, iters);
+            run<3>("zero-C MFMA ring, no VALU", threads, f.ptr, out, cyc, iters);
+            run<1>("zero-C MFMA + 4 promotion FMAs per MFMA", threads, f.ptr, out, cyc, iters);
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "ceiling")
+        return ceiling_table(argc > 2 ? argv[2] : nullptr);
     const int n = 1 << 16;
     std::vector<int> rnd(n), zer(n, 0);
     srand(1);
@@ -200,7 +254,7 @@ int main() {
         x = (int)v;
     }
     int *d_rnd, *d_zer; float* out; long long* cyc;
-    hipMalloc(&d_rnd, n * 4); hipMalloc(&d_zer, n * 4); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 4096 * 8);
+    hipMalloc(&d_rnd, n * 4); hipMalloc(&d_zer, n * 4); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 2 * 4096 * 8);
     hipMemcpy(d_rnd, rnd.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_zer, zer.data(), n * 4, hipMemcpyHostToDevice);
     const int iters = 2000;
