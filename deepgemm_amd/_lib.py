@@ -27,6 +27,8 @@ SIGNATURES = {
     'dg_transpose_sf_fp32': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     'dg_pack_sf_ue8m0': (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     'dg_pack_sf_ue8m0_ex': (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i32, _i32, _vp]),
+    'dg_pack_sf_pair_ue8m0': (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _i32, _i32,
+                              _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp]),
     'dg_per_token_cast_to_fp8': (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _vp]),
     'dg_block_cast_to_fp8': (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     'dg_transpose_fp8': (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _vp]),

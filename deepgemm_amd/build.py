@@ -19,6 +19,13 @@ if os.environ.get('DG_EXPERIMENTS', '') not in ('', '0'):
     FLAGS.append('-DDG_EXPERIMENTS')
 
 
+# Tuning aid (tools/ A/B runs of two builds in one GPU session): DG_VARIANT=<tag> builds csrc/libdeepgemm_amd_<tag>.so with the extra
+# compiler flags of DG_VARIANT_FLAGS (e.g. -DDG_NT_STORES) and the package loads THAT library.  Unset = the product library.
+_VARIANT = os.environ.get('DG_VARIANT', '')
+if _VARIANT:
+    LIB_PATH = os.path.join(CSRC, f'libdeepgemm_amd_{_VARIANT}.so')
+    FLAGS = FLAGS + os.environ.get('DG_VARIANT_FLAGS', '').split()
+
 STAMP_PATH = LIB_PATH + '.flags'      # the flag set the library was built with (DG_EXPERIMENTS toggles must rebuild)
 
 # The fast kernels rely on properties of hipcc's code generation that the language does not promise (registers written by inline-asm

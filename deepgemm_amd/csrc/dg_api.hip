@@ -273,6 +273,13 @@ bool per_col_mn_eligible(const dg::GemmParams& p) {
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Non-temporal output stores (GemmParams::d_nt): when one launch writes at least half of the chip's 32 MiB of L2 the output cannot stay
+// cache-resident for its consumer anyway, and streaming it out is 5-6 % of a C2 call (see store_rows_full_line_packed).
+int output_streams_past_l2(const dg::GemmParams& p) {
+    const int64_t rows = p.gemm_type == dg::kMasked ? static_cast<int64_t>(p.num_groups) * p.m : p.m;
+    return !p.accumulate && rows * p.n * (p.d_dtype == DG_BF16 ? 2 : 4) >= (16LL << 20) ? 1 : 0;
+}
+
 // K pieces per tile of the partial last round (0 = no split): as many as the idle workgroup slots allow, at most 8 and at most
 // one per K block.  A launch of fewer tiles than slots is all "last round": every tile is cut (dense problems with few tiles
 // and a long K loop, e.g. the dgrad shape 4096 x 512 x 32768: 64 tiles of 128 x 256).
@@ -577,6 +584,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
+    p.d_nt = output_streams_past_l2(p);
     if (p.head_lr > 0 && ((p.head_lr - p.head_right) % 8 != 0 || p.head_mid % 8 != 0 || p.head_right % 8 != 0))
         p.d_vec_ok = 0;                  // a 16-byte store would straddle a head split: element-wise stores
     p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
@@ -712,6 +720,7 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
+    p.d_nt = output_streams_past_l2(p);
     p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
     long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
     if (p.gemm_type == dg::kMasked)
@@ -1170,21 +1179,57 @@ int dg_pack_sf_ue8m0(const float* sf, int32_t* out, int batches, int mn, int sf_
     return dg_pack_sf_ue8m0_ex(sf, out, batches, mn, sf_k, sf_stride_b, sf_stride_mn, sf_stride_k, 1, nullptr, 0, 0, stream);
 }
 
-int dg_pack_sf_ue8m0_ex(const float* sf, int32_t* out, int batches, int mn, int sf_k,
-                        int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, int gran_mn,
-                        const int32_t* psum_layout, int num_psum_groups, int m_alignment, void* stream) {
+namespace {
+int64_t pack_items(const dg::PackSfArgs& a) { return static_cast<int64_t>(a.blocks_mn) * ((a.sf_k + 3) / 4) * a.batches; }
+
+int fill_pack_args(dg::PackSfArgs& a, const float* sf, int32_t* out, int batches, int mn, int sf_k, int64_t sf_stride_b,
+                   int64_t sf_stride_mn, int64_t sf_stride_k, int gran_mn, const int32_t* psum_layout, int num_psum_groups,
+                   int m_alignment) {
     DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
+    a = dg::PackSfArgs{};
     if (batches == 0 || mn == 0 || sf_k == 0)
         return 0;
     DG_CHECK(sf != nullptr && out != nullptr);
     DG_CHECK(gran_mn >= 1);
-    DG_CHECK(batches <= 65535 && (sf_k + 63) / 64 <= 65535);
     DG_CHECK(psum_layout == nullptr || (batches == 1 && num_psum_groups > 0 && m_alignment > 0));      // smxx_layout.hpp:190-194
-    const int aligned_mn = (mn + 3) / 4 * 4;
-    const dim3 grid((mn + 63) / 64, (sf_k + 63) / 64, batches);
-    hipLaunchKernelGGL(dg::dg_pack_sf_ue8m0_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
-                       sf, out, mn, sf_k, aligned_mn, sf_stride_b, sf_stride_mn, sf_stride_k, gran_mn, psum_layout,
-                       psum_layout != nullptr ? num_psum_groups : 0, m_alignment);
+    a.sf = sf; a.out = out; a.mn = mn; a.sf_k = sf_k; a.aligned_mn = (mn + 3) / 4 * 4;
+    a.stride_b = sf_stride_b; a.stride_mn = sf_stride_mn; a.stride_k = sf_stride_k; a.gran_mn = gran_mn;
+    a.psum_layout = psum_layout; a.num_psum_groups = psum_layout != nullptr ? num_psum_groups : 0; a.m_alignment = m_alignment;
+    a.blocks_mn = (mn + 255) / 256; a.batches = batches;
+    DG_CHECK(pack_items(a) < (1LL << 30));
+    return 0;
+}
+}  // namespace
+
+int dg_pack_sf_ue8m0_ex(const float* sf, int32_t* out, int batches, int mn, int sf_k,
+                        int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, int gran_mn,
+                        const int32_t* psum_layout, int num_psum_groups, int m_alignment, void* stream) {
+    dg::PackSfArgs a, none{};
+    if (const int rc = fill_pack_args(a, sf, out, batches, mn, sf_k, sf_stride_b, sf_stride_mn, sf_stride_k, gran_mn, psum_layout,
+                                      num_psum_groups, m_alignment); rc != 0)
+        return rc;
+    const int64_t grid = pack_items(a);
+    if (grid == 0)
+        return 0;
+    hipLaunchKernelGGL(dg::dg_pack_sf_ue8m0_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), a, none);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int dg_pack_sf_pair_ue8m0(const float* sfa, int32_t* out_a, int batches_a, int m, int64_t sfa_stride_b, int64_t sfa_stride_m,
+                          int64_t sfa_stride_k, int gran_m, const int32_t* psum_layout, int num_psum_groups, int m_alignment,
+                          const float* sfb, int32_t* out_b, int batches_b, int n, int64_t sfb_stride_b, int64_t sfb_stride_n,
+                          int64_t sfb_stride_k, int gran_n, int sf_k, void* stream) {
+    dg::PackSfArgs a, b;
+    if (const int rc = fill_pack_args(a, sfa, out_a, batches_a, m, sf_k, sfa_stride_b, sfa_stride_m, sfa_stride_k, gran_m, psum_layout,
+                                      num_psum_groups, m_alignment); rc != 0)
+        return rc;
+    if (const int rc = fill_pack_args(b, sfb, out_b, batches_b, n, sf_k, sfb_stride_b, sfb_stride_n, sfb_stride_k, gran_n, nullptr, 0, 0); rc != 0)
+        return rc;
+    const int64_t grid = pack_items(a) + pack_items(b);
+    if (grid == 0)
+        return 0;
+    hipLaunchKernelGGL(dg::dg_pack_sf_ue8m0_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b);
     DG_HIP_CHECK(hipGetLastError());
     return 0;
 }

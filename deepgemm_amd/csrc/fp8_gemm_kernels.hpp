@@ -63,6 +63,7 @@ struct GemmParams {
     int num_m_tiles, num_n_tiles;   // per group
     int group_m;                    // tile-order swizzle: m-tiles per L2 group
     int d_vec_ok;                   // 16-byte aligned D rows => vector stores
+    int d_nt;                       // non-temporal policy on the full-line BF16 output stores (large outputs: set by the host)
     long long* dbg;                 // tuning aid (normally null): per wave {kernel entry, K loop begin, K loop end, after stores} s_memtime ticks
     // K-split tail of a persistent launch (duo kernels built with SPLITK): tiles [sk_first_tile, sk_first_tile + sk_tiles) are cut
     // into sk_factor K pieces; sk_workspace = int32 arrival counters [sk_tiles] (zero between launches) in its first 4 KiB, then
@@ -285,7 +286,22 @@ __device__ __forceinline__ void store_rows_full_line_packed(const GemmParams& p,
             continue;
         const uint32_t* v = half == 0 ? x : y;
         uint16_t* drow = reinterpret_cast<uint16_t*>(p.d) + d_group_off + static_cast<int64_t>(row) * p.d_sm;
-        *reinterpret_cast<uint4*>(drow + d_col(p, col)) = zero_row ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(v[0], v[1], v[2], v[3]);
+        // Large outputs leave with the non-temporal policy: a GEMM's D is written once and read by nobody in this launch; streaming it
+        // past the L2's replacement (and out of the kernel-end write-back) was worth 5-6 % of the whole C2 call on BOTH kernel families
+        // (97.2 -> 92.2 us, 86.2 -> 80.9 us; sc1 write-through alone: nothing) -- what hipBLASLt's kernels do ("NTD").  Small outputs
+        // (the consumer kernel finds them in the L2) keep the default policy: GemmParams::d_nt is set by the host from the output size.
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 data = zero_row ? u4{0u, 0u, 0u, 0u} : u4{v[0], v[1], v[2], v[3]};
+        u4* addr = reinterpret_cast<u4*>(drow + d_col(p, col));
+#ifdef DG_NO_NT
+        if (false)
+#else
+        if (p.d_nt)     // (inline asm: hipcc merges a __builtin_nontemporal_store with the plain store of the other branch and drops the hint;
+                        //  s_nop 1: an asm dwordx4 store's data registers must not be rewritten by the next instruction)
+#endif
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(addr), "v"(data) : "memory");
+        else
+            *addr = data;
     }
 }
 
@@ -1271,6 +1287,7 @@ __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const 
     static_assert(MS == 8 || MS == 4, "unrolled by hand");
     if constexpr (MS == 8)
         asm volatile(
+            "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
             "buffer_load_dwordx4 %0, %3, %4, 0 offen\n\t"
             "buffer_load_dwordx4 %1, %3, %4, 0 offen offset:16\n\t"
             "buffer_load_dword %2, %5, %6, 0 offen"
@@ -1311,6 +1328,7 @@ __device__ __forceinline__ void issue_scale_loads_n(ScaleLandingN<MS>& l, const 
                                                     const v4i& sfb_rsrc, int sfb_voff) {
     static_assert(MS == 8, "unrolled by hand");
     asm volatile(
+        "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
         "buffer_load_dword %0, %9, %10, 0 offen\n\t"
         "buffer_load_dword %1, %9, %10, 0 offen offset:64\n\t"
         "buffer_load_dword %2, %9, %10, 0 offen offset:128\n\t"
@@ -2190,6 +2208,7 @@ struct E8Landing { v4i sa[2]; int sb[4]; };
 __device__ __forceinline__ void issue_e8_scale_loads(E8Landing& l, const v4i& sfa_rsrc, int sfa_voff, const v4i& sfb_rsrc,
                                                      int sfb_voff0, int sfb_voff1, int sfb_voff2, int sfb_voff3) {
     asm volatile(
+        "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
         "buffer_load_dwordx4 %0, %6, %7, 0 offen\n\t"
         "buffer_load_dwordx4 %1, %6, %7, 0 offen offset:16\n\t"
         "buffer_load_dword %2, %8, %12, 0 offen\n\t"
@@ -2685,43 +2704,56 @@ void dg_transpose_sf_fp32_kernel(const float* __restrict__ sf, float* __restrict
 // psum_layout != nullptr (smxx_layout.cuh:76-94): rows outside every group's range [align(end[g-1], m_alignment), end[g]) -- the
 // uninitialised gap rows of the psum contiguous layout -- get zero words (a finite scale code; 0xff would be NaN).
 // A block packs a 64 (mn) x 64 (sf_k) patch through LDS: the read runs along whichever input axis has unit stride, the write along mn.
-__global__ __launch_bounds__(256)
-void dg_pack_sf_ue8m0_kernel(const float* __restrict__ sf, int32_t* __restrict__ out, int mn, int sf_k, int aligned_mn,
-                             int64_t stride_b, int64_t stride_mn, int64_t stride_k, int gran_mn,
-                             const int32_t* __restrict__ psum_layout, int num_psum_groups, int m_alignment) {
-    __shared__ uint8_t patch[64][68];            // [row][k], exponent bytes; 68: 4-byte aligned rows, 17-word pitch
-    const int batch = blockIdx.z;
-    const int mn0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-    const int packed_k = (sf_k + 3) / 4;
-    const float* src = sf + static_cast<int64_t>(batch) * stride_b;
-    int32_t* dst = out + static_cast<int64_t>(batch) * aligned_mn * packed_k;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const bool k_fast = stride_k == 1 || gran_mn > 1;                // (broadcast rows: neighbouring lanes would read the same word)
-    for (int i = ty; i < 64; i += 4) {
-        const int r = k_fast ? i : tx, c = k_fast ? tx : i;          // patch coordinates of this thread's element
-        const int row = mn0 + r, col = k0 + c;
-        uint32_t bits = 0;
-        if (row < mn && col < sf_k)
-            bits = __float_as_uint(src[static_cast<int64_t>(row / gran_mn) * stride_mn + static_cast<int64_t>(col) * stride_k]);
-        patch[r][c] = static_cast<uint8_t>(bits >> 23);
+struct PackSfArgs {
+    const float* sf; int32_t* out;
+    int mn, sf_k, aligned_mn;
+    int64_t stride_b, stride_mn, stride_k;
+    int gran_mn;
+    const int32_t* psum_layout; int num_psum_groups, m_alignment;
+    int blocks_mn, batches;                     // work items of this tensor: blocks_mn (256 rows each) x packed_k x batches
+};
+
+// One output word per thread, 256 consecutive rows per block (the write runs along mn: coalesced; the four reads of a word are four
+// independent loads -- this kernel sits in front of a GEMM on the same stream and its cost is latency: the first version, a 64 x 64 patch
+// through LDS with one dependent load per loop iteration, took 8 us for 0.9 MB).
+__device__ __forceinline__ void pack_sf_ue8m0_words(const PackSfArgs& a, int block_mn, int kq, int batch) {
+    const int row = block_mn * 256 + static_cast<int>(threadIdx.x);
+    if (row >= a.mn)
+        return;
+    const int packed_k = (a.sf_k + 3) / 4;
+    const float* src = a.sf + static_cast<int64_t>(batch) * a.stride_b + static_cast<int64_t>(row / a.gran_mn) * a.stride_mn;
+    uint32_t bits[4];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = 4 * kq + j;
+        bits[j] = col < a.sf_k ? __float_as_uint(src[static_cast<int64_t>(col) * a.stride_k]) : 0u;
     }
-    const int out_row = mn0 + tx;
     bool valid = true;
-    if (psum_layout != nullptr) {
+    if (a.psum_layout != nullptr) {
         valid = false;
         int start = 0;
-        for (int g = 0; g < num_psum_groups; ++g) {
-            const int end = psum_layout[g];
-            valid = valid || (out_row >= start && out_row < end);
-            start = (end + m_alignment - 1) / m_alignment * m_alignment;
+        for (int g = 0; g < a.num_psum_groups; ++g) {
+            const int end = a.psum_layout[g];
+            valid = valid || (row >= start && row < end);
+            start = (end + a.m_alignment - 1) / a.m_alignment * a.m_alignment;
         }
     }
-    __syncthreads();
-    for (int q = ty; q < 16; q += 4) {
-        const int kq = k0 / 4 + q;
-        if (out_row < mn && kq < packed_k)
-            dst[static_cast<int64_t>(kq) * aligned_mn + out_row] = valid ? *reinterpret_cast<const int32_t*>(&patch[tx][q * 4]) : 0;
-    }
+    const uint32_t word = ((bits[0] >> 23) & 0xffu) | (((bits[1] >> 23) & 0xffu) << 8) | (((bits[2] >> 23) & 0xffu) << 16) | ((bits[3] >> 23) << 24);
+    a.out[(static_cast<int64_t>(batch) * packed_k + kq) * a.aligned_mn + row] = valid ? static_cast<int32_t>(word) : 0;
+}
+
+// One launch packs up to two scale tensors (the SFA / SFB pair of a GEMM call in the 'sm100' scaling-factor mode: one kernel boundary in
+// front of the GEMM instead of two): block ids [0, work items of a) belong to `a`, the rest to `b`.
+__global__ __launch_bounds__(256)
+void dg_pack_sf_ue8m0_kernel(const PackSfArgs a, const PackSfArgs b) {
+    const int items_a = a.blocks_mn * ((a.sf_k + 3) / 4) * a.batches;
+    const bool second = static_cast<int>(blockIdx.x) >= items_a;
+    const PackSfArgs& t = second ? b : a;
+    int id = static_cast<int>(blockIdx.x) - (second ? items_a : 0);
+    const int bx = id % t.blocks_mn;
+    id /= t.blocks_mn;
+    const int packed_k = (t.sf_k + 3) / 4;
+    pack_sf_ue8m0_words(t, bx, id % packed_k, id / packed_k);
 }
 
 // Fused per-token quantiser (the producer side of operand A): BF16 [m, n] -> e4m3fn [m, n] + one FP32 scale per

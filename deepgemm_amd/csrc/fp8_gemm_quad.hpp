@@ -41,6 +41,7 @@ __device__ __forceinline__ void issue_e8q_scale_loads(E8LandingQ& l, const v4i& 
     static_assert(MS == 8 || MS == 4, "unrolled by hand");
     if constexpr (MS == 8)
         asm volatile(
+            "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
             "buffer_load_dwordx4 %0, %10, %11, %12 offen\n\t"
             "buffer_load_dwordx4 %1, %10, %11, %12 offen offset:16\n\t"
             "buffer_load_dword %2, %13, %14, %15 offen\n\t"
@@ -57,6 +58,7 @@ __device__ __forceinline__ void issue_e8q_scale_loads(E8LandingQ& l, const v4i& 
             : "memory");
     else
         asm volatile(
+            "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
             "buffer_load_dwordx4 %0, %9, %10, %11 offen\n\t"
             "buffer_load_dword %1, %12, %13, %14 offen\n\t"
             "buffer_load_dword %2, %12, %13, %14 offen offset:16\n\t"

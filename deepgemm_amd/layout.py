@@ -216,6 +216,34 @@ def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe:
                        '(gran_k = 32 scales are not supported on gfx950)')
 
 
+def _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, gran_m, gran_n, num_groups_a, num_groups_b, psum_layout):
+    """The cast branch (csrc/apis/layout.hpp:48-54) for BOTH scale tensors of a call in one launch (dg_pack_sf_pair_ue8m0): checks as
+    transform_sf_into_required_layout makes them for each tensor, one kernel boundary in front of the GEMM instead of two."""
+    check_sf_layout(sfa, m, k, gran_m, 128, num_groups_a)
+    check_sf_layout(sfb, n, k, gran_n, 128, num_groups_b)
+    require_device(sfa, sfb)
+    ba, bb = (sfa.unsqueeze(0) if sfa.dim() == 2 else sfa), (sfb.unsqueeze(0) if sfb.dim() == 2 else sfb)
+    sf_k, packed_k = ceil_div(k, 128), ceil_div(ceil_div(k, 128), 4)
+    host_assert(ba.size(0) <= 65535 and bb.size(0) <= 65535, 'num_sf_batches <= 65535')
+    layout_ptr, num_psum_groups, m_alignment = None, 0, 0
+    if psum_layout is not None:
+        from . import runtime
+        host_assert(ba.size(0) == 1 and ba.is_contiguous(), 'num_sf_batches == 1 and batched_sf.is_contiguous()')
+        host_assert(psum_layout.dtype == torch.int and psum_layout.is_contiguous(),
+                    'psum_layout->scalar_type() == torch::kInt and psum_layout->is_contiguous()')
+        host_assert(psum_layout.numel() > 0, 'psum_layout->numel() > 0')
+        require_device(psum_layout)
+        layout_ptr, num_psum_groups, m_alignment = psum_layout.data_ptr(), psum_layout.numel(), runtime.get_mk_alignment_for_contiguous_layout()
+    am, an = get_tma_aligned_size(m, 4), get_tma_aligned_size(n, 4)
+    out_a = torch.empty_strided((ba.size(0), m, packed_k), (packed_k * am, 1, am), dtype=torch.int, device=sfa.device)
+    out_b = torch.empty_strided((bb.size(0), n, packed_k), (packed_k * an, 1, an), dtype=torch.int, device=sfb.device)
+    check(lib.dg_pack_sf_pair_ue8m0(ba.data_ptr(), out_a.data_ptr(), ba.size(0), m, ba.stride(0), ba.stride(1), ba.stride(2), gran_m,
+                                    layout_ptr, num_psum_groups, m_alignment,
+                                    bb.data_ptr(), out_b.data_ptr(), bb.size(0), n, bb.stride(0), bb.stride(1), bb.stride(2), gran_n,
+                                    sf_k, current_stream_ptr()))
+    return (out_a.squeeze(0) if sfa.dim() == 2 else out_a), (out_b.squeeze(0) if sfb.dim() == 2 else out_b)
+
+
 def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, recipe_b,
                                            num_groups_a, num_groups_b, disable_ue8m0_cast=False, psum_layout=None):
     """Returns (sfa', sfb', gran_n_of_sfb).  Recipe selection: csrc/apis/layout.hpp:74-80."""
@@ -228,6 +256,9 @@ def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, 
         host_assert(len(recipe) == 3, 'recipe must be (gran_m, gran_n, gran_k)')
         host_assert(recipe[0] == 1 and recipe[2] == 128 and recipe[1] in (1, 128),
                     'supported recipes: (1, 128, 128) and (1, 1, 128)')
+        from . import runtime
+        if (sfa.dtype == torch.float and sfb.dtype == torch.float and not disable_ue8m0_cast and runtime.get_sf_cast_mode() == 'sm100'):
+            return _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, recipe[0], recipe[1], num_groups_a, num_groups_b, psum_layout) + (recipe[1],)
         t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe, num_groups_a, True, disable_ue8m0_cast, psum_layout)
         t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe, num_groups_b, False, disable_ue8m0_cast)
         gran_n = recipe[1]

@@ -110,6 +110,15 @@ int dg_pack_sf_ue8m0_ex(const float* sf, int32_t* out, int batches, int mn, int 
                         int64_t sf_stride_b, int64_t sf_stride_mn, int64_t sf_stride_k, int gran_mn,
                         const int32_t* psum_layout, int num_psum_groups, int m_alignment, void* stream);
 
+/* Both scale tensors of one GEMM call in ONE launch (one kernel boundary in front of the GEMM instead of two): the SFA half takes the
+ * arguments of dg_pack_sf_ue8m0_ex (psum_layout applies to SFA only, csrc/apis/layout.hpp:63-66), the SFB half has no psum layout;
+ * both have sf_k = ceil(k / 128) K blocks.  What transform_sf_pair_into_required_layout (csrc/apis/layout.hpp:61-90) does for FP32
+ * scales on the reference's SM100 path, as one kernel. */
+int dg_pack_sf_pair_ue8m0(const float* sfa, int32_t* out_a, int batches_a, int m, int64_t sfa_stride_b, int64_t sfa_stride_m,
+                          int64_t sfa_stride_k, int gran_m, const int32_t* psum_layout, int num_psum_groups, int m_alignment,
+                          const float* sfb, int32_t* out_b, int batches_b, int n, int64_t sfb_stride_b, int64_t sfb_stride_n,
+                          int64_t sfb_stride_k, int gran_n, int sf_k, void* stream);
+
 /* K-grouped contiguous GEMM (MoE weight gradients): D[g] += A_g * B_g^T for every group g, where group g owns the K range
  * [sum(ks[:g]), sum(ks[:g+1])) of both operands.  Replaces sm90_k_grouped_fp8_gemm_1d1d / sm100_k_grouped_fp8_gemm_1d1d as
  * called from k_grouped_fp8_gemm_nt_contiguous / k_grouped_fp8_gemm_tn_contiguous (csrc/apis/gemm.hpp:299-400).

@@ -50,6 +50,20 @@ def test_landing_hazard_checker_on_synthetic_streams():
     assert check([load, 's_waitcnt lgkmcnt(0)', 'v_add_f32_e32 v1, v2, v3', 's_waitcnt vmcnt(0)', 'v_mov_b32_e32 v20, v8']) == []
 
 
+def test_sgpr_vmem_hazard_checker_on_synthetic_streams():
+    """VALU-written SGPR -> vector-memory read needs 5 wait states; nothing pads an inline-asm string (the round-3 wrong-tile bug)."""
+    check = _report_module().sgpr_vmem_hazards
+    load = 'buffer_load_dwordx4 v[108:111], v151, s[68:71], s6 offen'
+    assert [h[1] for h in check(['v_readlane_b32 s6, v213, 37', load])] == ['v_readlane_b32 s6, v213, 37']
+    assert check(['v_readlane_b32 s6, v213, 37', 's_nop 4', load]) == []
+    assert check(['v_readlane_b32 s6, v213, 37', 's_nop 3', load]) != []
+    assert check(['v_readlane_b32 s7, v213, 37', load]) == []                                   # another register
+    assert check(['v_readfirstlane_b32 s70, v3', 's_mov_b32 s1, s2', 's_nop 1', load]) != []    # descriptor word, 3 states only
+    assert check(['v_readfirstlane_b32 s70, v3', 's_mov_b32 s1, s2', 's_nop 3', load]) == []
+    assert check(['v_cmp_lt_u32_e64 s[6:7], v1, v2', 'global_load_dword v1, v2, s[6:7]']) != []
+    assert check(['s_mov_b32 s6, s9', load]) == []                                               # SALU writer: no hazard
+
+
 @pytest.mark.skipif(not os.path.exists(LLVM_OBJDUMP), reason='llvm-objdump of the ROCm toolchain not available')
 def test_no_spill_traffic_inside_the_k_loop_of_production_kernels():
     mod = _report_module()
@@ -65,3 +79,5 @@ def test_no_spill_traffic_inside_the_k_loop_of_production_kernels():
         # covers it, anywhere in the kernel; inside the K loop no branch is taken while such a load is in flight
         assert not r['landing_touches'], f'{name}: landing registers touched before their wait: {r["landing_touches"][:3]}'
         assert not r['landing_branches_in_mfma_range'], f'{name}: branch with VGPR-landing loads in flight: {r["landing_branches_in_mfma_range"][:3]}'
+        # a VALU-written SGPR (spill reload, readfirstlane) must not feed a vector-memory instruction within 5 wait states
+        assert not r['sgpr_vmem_hazards'], f'{name}: VALU-written SGPR read by a VMEM instruction too early: {r["sgpr_vmem_hazards"][:3]}'

@@ -71,6 +71,52 @@ def landing_hazards(body):
     return bad
 
 
+_SREG = re.compile(r'\bs(\d+)\b|\bs\[(\d+):(\d+)\]')
+
+
+def _sregs(text):
+    regs = set()
+    for m in _SREG.finditer(text):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+def sgpr_vmem_hazards(body, need=5):
+    """gfx950 data hazard "VALU writes an SGPR -> a vector-memory instruction reads it (descriptor or scalar offset)": 5 wait states.
+    hipcc pads its own code, but NOTHING pads an inline-asm string: round 3 found `v_readlane_b32 s6, v213, 37` (an SGPR reloaded from a
+    spill lane) directly in front of an asm `buffer_load_dwordx4 ..., s6 offen` -- the load went out with the stale offset and whole wave
+    tiles came out wrong, run-dependent.  The asm scale-load blocks now open with `s_nop 4`; this check keeps it that way.  Returns
+    (index, writer instruction, reader instruction) for every VMEM instruction with fewer than `need` wait states behind a VALU write of
+    one of its SGPRs (v_readlane / v_readfirstlane / any v_* with an SGPR destination) in the linear stream."""
+    bad = []
+    for idx, ins in enumerate(body):
+        op = ins.split()[0] if ins.split() else ''
+        if not op.startswith(('buffer_', 'global_', 'flat_', 'scratch_')):
+            continue
+        used = _sregs(ins[len(op):])
+        if not used:
+            continue
+        states = 0
+        for back in range(idx - 1, max(idx - 1 - need, -1), -1):
+            prev = body[back]
+            pop = prev.split()[0] if prev.split() else ''
+            if pop.startswith('v_'):
+                first = prev[len(pop):].split(',')[0]
+                if pop.startswith(('v_readlane', 'v_readfirstlane')) or re.match(r'\s*s(\d+|\[)', first):
+                    if used & _sregs(first):
+                        bad.append((idx, prev, ins))
+                        break
+            if pop.startswith(('s_cbranch', 's_branch', 's_setpc', 's_endpgm')):
+                break                                   # (another block: not a linear predecessor)
+            states += 1 + (int(prev.split()[1]) if pop == 's_nop' and len(prev.split()) > 1 and prev.split()[1].isdigit() else 0)
+            if states >= need:
+                break
+    return bad
+
+
 def report():
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, 'lib.so')
@@ -127,6 +173,7 @@ def report():
                     'scratch_in_mfma_range': sum(1 for ins in loop if ins.startswith('scratch_')),
                     'lane_ops_in_mfma_range': sum(1 for ins in loop if ins.startswith(('v_readlane', 'v_writelane'))),
                     'landing_touches': [h for h in landing_hazards(body) if h[1] == 'touch'],
+                    'sgpr_vmem_hazards': sgpr_vmem_hazards(body),
                     'landing_branches_in_mfma_range': [h for h in landing_hazards(loop) if h[1] == 'branch']})
     return out
 
@@ -139,4 +186,4 @@ if __name__ == '__main__':
         for r in sorted(rows, key=lambda r: r['kernel']):
             print(f"{r['kernel'][:78]:78s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} "
                   f"range {r['mfma_range_instructions']:5d} scratch-in-range {r['scratch_in_mfma_range']:3d} "
-                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d} landing-touches {len(r['landing_touches']):2d} branches-in-range-with-loads-in-flight {len(r['landing_branches_in_mfma_range']):2d}")
+                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d} landing-touches {len(r['landing_touches']):2d} sgpr->vmem hazards {len(r['sgpr_vmem_hazards']):2d} branches-in-range-with-loads-in-flight {len(r['landing_branches_in_mfma_range']):2d}")
