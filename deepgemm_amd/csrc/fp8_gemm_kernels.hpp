@@ -66,8 +66,9 @@ struct GemmParams {
     int d_nt;                       // non-temporal policy on the full-line BF16 output stores (large outputs: set by the host)
     long long* dbg;                 // tuning aid (normally null): per wave {kernel entry, K loop begin, K loop end, after stores} s_memtime ticks
     // K-split tail of a persistent launch (duo kernels built with SPLITK): tiles [sk_first_tile, sk_first_tile + sk_tiles) are cut
-    // into sk_factor K pieces; sk_workspace = int32 arrival counters [sk_tiles] (zero between launches) in its first 4 KiB, then
-    // FP32 partial tiles [sk_tiles][sk_factor][BM * BN]
+    // into sk_factor K pieces, each written as an FP32 partial tile to sk_workspace + 4 KiB: [sk_tiles][sk_factor][BM * BN]; a second
+    // kernel (dg_split_k_reduce_kernel, same stream) sums them in piece order.  The first 4 KiB of the workspace are RESERVED and
+    // unused (they held the arrival counters of the one-kernel form); nothing depends on their contents.
     void* sk_workspace;
     int sk_first_tile, sk_tiles, sk_factor;
 };
@@ -1386,11 +1387,19 @@ template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> t
 // the 128-row tile 1.43 k cycles per K block against 1.02 k of matrix work; 16-step segments halve the barriers.  Waits: at the
 // end of L "everything but this segment's own loads has landed" (my pieces of block kb+1, certified to the others by the next
 // barrier), at the end of M the scales of block kb+1 (straight-line from their loads, in front of the loop's back edge).
+// STREAM_A (256-row tiles, K-major operands): TWO segments per K block like MERGED, for a wave tile whose fragments do not all fit in
+// registers: L reads the B fragments and the first two A fragments, M runs ALL MS * NS steps and streams the remaining A
+// fragments through a 4-deep register ring (one fragment = two ds_read_b128 per row of NS steps).  Half the barrier round trips of
+// the four-segment schedule (2 per K block and wave instead of 4: each costs ~70 cycles of matrix pipe).  The LDS-DMA work is split
+// by role so that the 3-slot A ring / 2-slot B ring still suffice with the halves one segment apart: the LOWER half issues all pieces
+// of B(kb+1) in its L(kb) (B(kb-1)'s slot: everybody's L(kb-1) reads are done), the UPPER half all pieces of A(kb+2) in its L(kb)
+// (A(kb-1)'s slot: the upper half itself finished M(kb-1) last).  Prologue: A(0) B(0) A(1).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false>
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MERGED ? MS : MS / 2;
+    static_assert(!STREAM_A || (BM == 256 && !MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK), "STREAM_A: dense 256-row tiles, K-major operands");
     constexpr int TOTAL = MS * NS, SEG = HS * NS, DEPTH = 3;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = MERGED ? 3 : 2;
     constexpr int SCALE_LOADS = A_MN ? MS + 1 : MS / 4 + 1;    // vector-memory operations of one issue_scale_loads_any
@@ -1448,6 +1457,16 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     #pragma unroll
     for (int q = 0; q < B_ITERS; ++q)
         b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+    // STREAM_A: the 2 * A_ITERS pieces this wave issues per K block in its role (upper half: A units, lower half: B units)
+    [[maybe_unused]] int role_piece_voff[STREAM_A ? 2 * A_ITERS : 1];
+    if constexpr (STREAM_A) {
+        #pragma unroll
+        for (int q = 0; q < 2 * A_ITERS; ++q) {
+            const int unit = (upper_half ? wave - NW / 2 : wave) + (NW / 2) * q;
+            role_piece_voff[q] = upper_half ? a_voff + a_unit_row(unit) * lda
+                                            : b_row_perm<WN>(unit * 8 + piece_row) * ldb + src_chunk * 16;
+        }
+    }
     // MN-major B: lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k); u = wave + 8q => f lane-constant
     const int ldb_mn = static_cast<int>(p.b_sk), lda_mn = static_cast<int>(p.a_sk);
     const int mn_chunk = ((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3))) << 4;
@@ -1512,8 +1531,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, 0, 0, q);
         #pragma unroll
         for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, A_BYTES, 1, q);
-        #pragma unroll
-        for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, B_BYTES, 1, q);
+        if constexpr (!STREAM_A) {          // (STREAM_A: B(1) belongs to the lower half's first load segment)
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, B_BYTES, 1, q);
+        }
     };
 
     // Tile iteration state: (tile_id, pass); contiguous layout with BM = 2 x alignment: a tile whose halves belong to two
@@ -1611,7 +1632,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // scale loads to their wait: hipcc may copy the landing registers at any control-flow join in between.)
                 issue_scales(land, 0);
                 issue_prologue(t);
-                wait_landing_any<A_ITERS + B_ITERS, MS>(land);
+                wait_landing_any<STREAM_A ? A_ITERS : A_ITERS + B_ITERS, MS>(land);
             }
             raw_barrier();
             if (upper_half)
@@ -1622,11 +1643,94 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             v8i bf[NS], af[HS];
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
 
+            if constexpr (STREAM_A) {
+                // One copy of the K loop per wave half, chosen once: the halves differ in which pieces they issue and in two wait
+                // counts (immediates), and no branch may sit between an asm scale load and its wait (the landing-register rule).
+                auto k_loop = [&](auto upper_tag) {
+                    constexpr bool UPPER = decltype(upper_tag)::value;
+                    for (int kb = 0; kb < nkb; ++kb) {
+                        const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                        const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
+                        // ---------------- L ----------------
+                        raw_barrier();
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                        #pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                        scale_tail = scale[MS - 1];
+                        #pragma unroll
+                        for (int ms = 0; ms < MS; ++ms) {
+                            scale[ms] = landed_sfa<MS>(land, ms) * land.sb;
+                            pin_vgpr(scale[ms]);
+                        }
+                        issue_scales(land, kb + 1);
+                        // role split of the refills, 2 * A_ITERS = 2 * B_ITERS pieces per wave either way (see the STREAM_A note above)
+                        if constexpr (UPPER) {
+                            #pragma unroll
+                            for (int q = 0; q < 2 * A_ITERS; ++q) {
+                                const int unit = (wave - NW / 2) + (NW / 2) * q;          // 32 units over the 4 upper waves
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                    __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.a_base), 0, tm.a_bytes, 0x00020000),
+                                    (__attribute__((address_space(3))) void*)(lds + a_fill + unit * 1024), 16,
+                                    role_piece_voff[q], (kb0 + imin(kb + 2, nkb - 1)) * 128, 0, 0);
+                            }
+                        } else {
+                            #pragma unroll
+                            for (int q = 0; q < 2 * B_ITERS; ++q) {
+                                const int unit = wave + (NW / 2) * q;                     // 32 units over the 4 lower waves
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                    __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.b_base), 0, tm.b_bytes, 0x00020000),
+                                    (__attribute__((address_space(3))) void*)(lds + B_BASE + (b_cur ^ B_BYTES) + unit * 1024), 16,
+                                    role_piece_voff[q], (kb0 + imin(kb + 1, nkb - 1)) * 128, 0, 0);
+                            }
+                        }
+                        // upper half: my pieces of A(kb+1) -- issued one K block ago, read by the lower half from its next L on -- have
+                        // landed (this segment's scale loads and pieces stay in flight); lower half: nothing to certify here
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_s_waitcnt(waitcnt_imm(UPPER ? 2 * A_ITERS + SCALE_LOADS : 63, 0));
+                        asm volatile("" ::: "memory");
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            asm volatile("" : "+v"(bf[ns]) :: "memory");
+                        #pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            asm volatile("" : "+v"(af[h]) :: "memory");
+
+                        // ---------------- M ----------------
+                        raw_barrier();
+                        #pragma unroll
+                        for (int i = 0; i < TOTAL; ++i) {
+                            const int ns = i % NS, h = i / NS;
+                            // the fragment of row h + 2 replaces the one row h - 2 used (its MFMAs were issued >= NS steps ago)
+                            if (ns == 0 && h + 2 < MS)
+                                af[(h + 2) & 3] = load_fragment(a_tile + (h + 2) * 2048, frag_off);
+                            const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
+                            const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
+                            mfma_promote_step(part[i & DEPTH], bf[ns], af[h & 3], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                        }
+                        // in front of the back edge: the scales of block kb+1 (both halves), and for the lower half its pieces of B(kb+1),
+                        // which everybody reads from the next L on (issued a whole matrix segment ago)
+                        wait_landing_any<UPPER ? 2 * A_ITERS : 0, MS>(land);
+                        b_cur ^= B_BYTES;
+                        const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
+                        a_fill = a_cur;
+                        a_cur = a_next;
+                    }
+                };
+                if (upper_half)
+                    k_loop(std::true_type{});
+                else
+                    k_loop(std::false_type{});
+            } else
             for (int kb = 0; kb < nkb; ++kb) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
 
-                if constexpr (MERGED) {
+                if constexpr (STREAM_A) {
+                    // (own loop below: one copy per wave half)
+                } else if constexpr (MERGED) {
                     // ---------------- L ----------------
                     raw_barrier();
                     [[maybe_unused]] FragTr bfq[NS];
@@ -1911,10 +2015,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false>
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A>(p);
 }
 
 

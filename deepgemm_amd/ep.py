@@ -168,7 +168,8 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
     flat_row = torch.arange(tokens, device=device).repeat_interleave(top_k)
     order = torch.argsort(flat_expert, stable=True)
     sorted_expert = flat_expert[order]
-    per_expert = torch.bincount(sorted_expert, minlength=num_experts)
+    # (not torch.bincount: it reads the maximum back to size its output -- a device-to-host synchronisation, illegal under stream capture)
+    per_expert = torch.zeros(num_experts, dtype=torch.int64, device=device).scatter_add_(0, flat_expert, torch.ones_like(flat_expert))
     run_begin = torch.cumsum(per_expert, dim=0) - per_expert
     pos = torch.arange(sorted_expert.numel(), device=device) - run_begin[sorted_expert]
     overflow = (per_expert > capacity).any()

@@ -187,7 +187,10 @@ def _split_k_workspace(device: torch.device, stream: int) -> Optional[torch.Tens
     """Scratch buffer of the K-split tail (dg_m_grouped_fp8_gemm_nt_contiguous_ws): one zero-filled buffer per device and
     stream, created on first use and kept (its contents never matter between launches; launches of one stream are ordered, so
     they can share it).  The C ABI itself never allocates.  ``None`` (= no K split) on a stream that is being captured and
-    has no buffer yet: an allocation made during capture belongs to the graph's private pool and must not outlive it."""
+    has no buffer yet: an allocation made during capture belongs to the graph's private pool and must not outlive it.
+    The buffer is keyed by the stream the call was ISSUED on: a graph captured on stream S keeps using S's buffer when it is replayed on
+    another stream T -- replay such a graph concurrently with eager K-split calls on S and the two share scratch memory; keep them on one
+    stream (or capture after warming the replay stream up) if that matters."""
     key = (device.index, stream)
     ws = _SPLIT_K_WORKSPACES.get(key)
     if ws is None:
@@ -361,7 +364,11 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
                                                 runtime.get_mk_alignment_for_contiguous_layout()) & 2:
         b_data = _as_k_major(b_data, m * n * k)
     stream = current_stream_ptr()
-    workspace = _split_k_workspace(d.device, stream)
+    # the K-split scratch buffer only where the library's own selection would cut this problem along K (it answers without launching:
+    # dg_select_config with has_workspace = 1) -- ordinary grouped calls neither create nor pass the 64 MiB buffer
+    picked = lib.dg_select_config(2 if use_psum_layout else 1, m, n, k, num_groups, 0, 0, int(b_data.stride(-1) != 1), 128,
+                                  runtime.get_mk_alignment_for_contiguous_layout(), 1, 0)
+    workspace = _split_k_workspace(d.device, stream) if b'_sk_' in picked else None
     check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ws(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
         num_groups, m, n, k, a_data.stride(0), a_data.stride(1),

@@ -171,20 +171,25 @@ def pack_sf_ue8m0(sf: torch.Tensor) -> torch.Tensor:
     return out.squeeze(0) if squeeze else out
 
 
-def fp8_gemm_nt_blockwise_torch(a, sfa, b, sfb, gran_n: int = 128, out_dtype=torch.bfloat16) -> torch.Tensor:
-    """Same arithmetic as ``dgo_rows`` expressed with torch CPU ops (float64 block products are exact),
-    used where the C loop nest would take too long (full BASELINE.json sizes, row subsets)."""
+def fp8_gemm_nt_blockwise_torch(a, sfa, b, sfb, gran_n: int = 128, out_dtype=torch.bfloat16, c=None) -> torch.Tensor:
+    """Same arithmetic as ``dgo_rows`` expressed with torch ops on the operands' own device (float64 block products of FP8 values are
+    exact, so the block sum is the correctly rounded one whatever order the GEMM behind ``@`` uses), used where the C loop nest would
+    take too long: full BASELINE.json sizes on the CPU for row subsets, and -- on the GPU box -- EVERY row of every BASELINE config
+    (tests/test_full_output_parity_gpu.py; MI355X runs FP64 GEMMs at tens of TFLOPS).  ``c``: the accumulation operand (added in the
+    output dtype's memory arithmetic: FP32 add for FP32 outputs, BF16 round-then-add for BF16, as the reduce-add epilogue does)."""
     m, k = a.shape
     n = b.shape[0]
-    total = torch.zeros((m, n), dtype=torch.float32)
-    a64, b64 = a.to(torch.float64), b.to(torch.float64)
-    col_block = torch.arange(n) // gran_n
+    dev = a.device
+    total = torch.zeros((m, n), dtype=torch.float32, device=dev)
+    col_block = torch.arange(n, device=dev) // gran_n
     for kb in range((k + 127) // 128):
         ks = slice(kb * 128, min(k, kb * 128 + 128))
-        block = (a64[:, ks] @ b64[:, ks].t()).to(torch.float32)
+        block = (a[:, ks].to(torch.float64) @ b[:, ks].to(torch.float64).t()).to(torch.float32)
         scale = sfa[:, kb].unsqueeze(1) * sfb[col_block, kb].unsqueeze(0)
         total += scale * block
-    return total.to(out_dtype)
+    if c is None:
+        return total.to(out_dtype)
+    return (total + c.float()) if out_dtype == torch.float else (total.to(out_dtype).float() + c.float()).to(out_dtype)
 
 
 def dequant_matmul_f64(a, sfa, b, sfb, gran_n: int = 128) -> torch.Tensor:

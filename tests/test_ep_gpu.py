@@ -42,6 +42,21 @@ def test_ep_step_single_rank_nccl():
         fixed = ep.ep_m_grouped_fp8_gemm_nt_masked(x, ids, b_local, num_experts, max_m, capacity=tokens)
         torch.cuda.synchronize()
         assert torch.equal(fixed, out)
+        # ... and it really is free of host synchronisation: torch's sync debug mode turns every implicit device-to-host wait
+        # (an .item(), a nonzero(), torch.bincount sizing its output ...) into an error for the duration of the step -- the property a
+        # hipGraph capture of a decode step needs.  (Capturing the RCCL exchange itself at world size 1 is not attempted here.)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode('error')
+        try:
+            (a_fix, sfa_fix), plan = ep.dispatch_fixed(x, ids, num_experts, max_m, tokens)
+            d_fix = torch.empty((num_experts, max_m, n), dtype=torch.bfloat16, device='cuda')
+            import deepgemm_amd as dg
+            dg.m_grouped_fp8_gemm_nt_masked((a_fix, sfa_fix), b_local, d_fix, plan.masked_m, max(1, tokens * top_k // num_experts))
+            again = ep.combine_fixed(d_fix, plan, tokens, top_k, 1, tokens)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        torch.cuda.synchronize()
+        assert torch.equal(again, out)
     finally:
         if created:
             dist.destroy_process_group()
