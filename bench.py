@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -32,9 +32,10 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
-             'dense_sm100']
+             'dense_sm100', 'decode_m1', 'decode_m1_long']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
-             'masked_ue8m0', 'wgrad_ksplit']
+             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long']
+GRAPHED = {'decode_m1', 'decode_m1_long'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
 def measured_traffic(kernel: str):
@@ -160,6 +161,21 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         desc = {'workload': f'fp8_gemm_{layout} M={m} N={n} K={k} (BASELINE configs[2]; whole operator call, majorness from strides)',
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+    elif name in ('decode_m1', 'decode_m1_long'):
+        # batch-1 decode entries of the reference's dense sweep (tests/generators.py:119-121, m = 1): a weight stream, HBM-bound
+        bound = 'hbm'
+        m, n, k = (1, 4096, 7168) if name == 'decode_m1' else (1, 7168, 16384)
+        for i in range(sets):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            cases.append(case)
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        flops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (decode entry of the reference sweep; timed as a hipGraph replay of 20 calls, '
+                            'the eager per-call time -- host-bound -- beside it)', 'm': m, 'n': n, 'k': k}
+        check = lambda: calc_diff(cases[0].d.float(), cases[0].ref_d.float()) if m * n >= 4096 else float('nan')    # noqa: E731
     elif name in ('dgrad_ktail', 'dgrad_ksplit'):
         # two dgrad entries of the reference's dense sweep (tests/generators.py:139-145: fp8_gemm_nn with m = 4096 and the (n, k) pairs
         # swapped): K = 2112 is not a multiple of 128 (K-tail stage), n = 512 with K = 32768 fills a quarter of the chip (K split)
@@ -256,6 +272,32 @@ def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, ke
     return rec
 
 
+def graph_replay_seconds(calls, per_graph: int) -> float:
+    """Seconds per call of `per_graph` calls captured into one hipGraph and replayed (every operator call is stream-ordered and
+    capturable): what a decode loop that replays its step as a graph pays -- kernel plus kernel boundary, no host path."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):
+            calls[i % len(calls)]()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(per_graph):
+            calls[i % len(calls)]()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(10):
+        graph.replay()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / 1e3 / (10 * per_graph)
+
+
 def run_secondary(sets: int):
     """The other configurations, shortened (about 0.3 s of launches each after a short warm-up): HIP-event time per operator
     call and its roofline fraction (MN-major operands are read as they are: one kernel per call)."""
@@ -281,8 +323,12 @@ def run_secondary(sets: int):
             end.record()
             torch.cuda.synchronize()
             call_s = start.elapsed_time(end) / 1e3 / steps
+            extra = {}
+            if name in GRAPHED:
+                extra['eager_call_us'] = call_s * 1e6
+                call_s = graph_replay_seconds(calls, 20)
             rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
-                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config())}
+                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config()), **extra}
             out.append(rec)
         except Exception as e:                                       # noqa: BLE001  (a secondary line must not take the headline down)
             out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'[:200]})

@@ -67,7 +67,14 @@ def check(rc: int) -> None:
         raise RuntimeError(lib.dg_last_error().decode() or f'deepgemm_amd call failed with code {rc}')
 
 
-def current_stream_ptr() -> int:
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def current_stream_ptr(device_index: int = -1) -> int:
+    """hipStream_t of torch's current stream.  The raw getter costs ~0.3 us; torch.cuda.current_stream() builds a Stream object through
+    several Python layers (~3 us -- a quarter of the whole host path of a decode-sized call)."""
+    if _raw_stream is not None:
+        return _raw_stream(device_index if device_index >= 0 else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

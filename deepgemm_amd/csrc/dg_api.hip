@@ -140,6 +140,9 @@ const Config kConfigs[] = {
     {"stream_nt_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4>, true},
+    // M <= 16 / 32 (decode batches): 16 output columns per workgroup over the whole K, the 8 waves split K; weights straight into registers
+    {"skinny_16", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1>},
+    {"skinny_32", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2>},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>, true, false,
      false, true},
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
@@ -362,6 +365,23 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             if (std::strcmp(kConfigs[i].name, pick) == 0)
                 return &kConfigs[i];
     }
+    // Decode batches (M <= 32), dense: the skinny weight-stream kernel (every CU streams its own 16 columns with 128 KiB in flight;
+    // tools/survey.py m = 1 rows: 19-21 us on the stream tiles -> see DESIGN.md)
+    // (tools/skinny_bench.py, whole eager call / hipGraph replay: m = 1, 4096 x 7168: 18.4 -> 12.1 / 7.4 us; 7168 x 16384: 36.0 -> 27.8 us;
+    // short K loops -- k = 512, 1536: 4 and 12 K blocks for 8 waves -- and wide N stay on the stream tiles (12.4 us against 18-23);
+    // 17..32 rows re-read A twice as often as they read B: only the k = 7168, n <= 4608 class gains, 18.4 -> 15 us)
+    if (fast_ok && p.gemm_type == dg::kNormal && p.sfb_gran_n == 128 && p.head_lr == 0 && p.n % 16 == 0) {
+        const int num_kb = p.k / 128;
+        const char* pick = nullptr;
+        if (m_for_tiling <= 16 && num_kb >= 16)
+            pick = "skinny_16";
+        else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608)
+            pick = "skinny_32";
+        if (pick != nullptr)
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (std::strcmp(kConfigs[i].name, pick) == 0)
+                    return &kConfigs[i];
+    }
     // HBM-bound shapes (M up to a few 64-row tiles: every weight byte is streamed once or twice): the deep-ring stream
     // kernels.  A CU sustains only ~25 GB/s of HBM stream (bytes in flight / latency), so the tile count has to cover
     // the chip: 64 x 128 tiles when there are enough of them, 64 x 32 otherwise (measured: tools/ref_shapes.py).
@@ -550,6 +570,10 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     const bool bmn_form = std::strstr(cfg->name, "_bmn") != nullptr;       // duo_bmn_*, duo_sk_bmn_*
     if (bmn_form && !bmn_eligible(p)) {
         g_last_error = std::string("forced config '") + cfg->name + "' needs K-major A, MN-major 16-byte aligned B and MN-major SFA";
+        return 3;
+    }
+    if (std::strncmp(cfg->name, "skinny", 6) == 0 && (p.m > cfg->bm || p.gemm_type != dg::kNormal || p.head_lr != 0)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' implements dense problems with m <= its row count";
         return 3;
     }
     if (p.k % 128 != 0 && cfg->fast && !cfg->k_tail) {

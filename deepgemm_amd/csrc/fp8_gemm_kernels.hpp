@@ -2775,6 +2775,103 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny kernel: dense GEMMs with M <= 16 * MS rows (batch-1 ... batch-32 decode: the m = 1 rows of the reference's dense sweep,
+// tests/generators.py:119-121).  The tile kernels cannot win here: a 64-row tile wastes the matrix core, and with n / 32 ... n / 128
+// workgroups of ONE latency chain each (0.27 - 0.66 us per K block) a CU has far too few weight bytes in flight.  This kernel is a
+// weight stream: one workgroup owns 16 output columns over the WHOLE K, its 8 waves split K into 8 contiguous ranges, and every
+// wave pulls its B fragments (16 weight rows x 128 K bytes = 2 KiB per K block) straight from HBM into registers -- no LDS ring, no
+// barriers in the loop, eight K blocks of loads in flight per wave (128 KiB per CU).  A (<= 32 rows, L2-resident) is read the same
+// way.  Operand roles as everywhere: weight rows feed the MFMA's row slot, so a lane owns ONE m and four n; promotion in K-block
+// order inside a wave's range, the eight partial 16 x 16 tiles are summed in wave order through 8 KiB of LDS (bit-repeatable), and the
+// result leaves through the shared epilogue (natural column order).  K permutation inside a block: lane group g supplies the
+// 16-byte chunks g and g + 4 of both operands (the same bijection on both sides leaves the contraction unchanged), so each of the
+// two loads of a fragment covers 64 contiguous bytes per row.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MS>
+__global__ __launch_bounds__(512)
+void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
+    constexpr int NW = 8, CH = 4;                               // K blocks per software-pipeline chunk (two chunks in flight)
+    __shared__ float red[NW][MS][256];
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int num_kb = p.k / 128;
+    const int kb_begin = wave * num_kb / NW, kb_end = (wave + 1) * num_kb / NW;
+    const uint8_t* b_ptr = p.b + static_cast<int64_t>(imin(n0 + r, p.n - 1)) * p.b_sn + g * 16;
+    const uint8_t* a_ptr[MS];
+    const float* sfa_ptr[MS];
+    #pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        const int row = imin(ms * 16 + r, p.m - 1);             // rows past m: a valid row's bytes, the result is never stored
+        a_ptr[ms] = p.a + static_cast<int64_t>(row) * p.a_sm + g * 16;
+        sfa_ptr[ms] = p.sfa + static_cast<int64_t>(row) * p.sfa_sm;
+    }
+    const float* sfb_ptr = p.sfb + static_cast<int64_t>(n0 / 128) * p.sfb_sn;
+
+    struct Chunk { v4i b[CH][2]; v4i a[MS][CH][2]; float sa[MS][CH]; float sb[CH]; };
+    auto load_chunk = [&](Chunk& c, int kb0) {
+        #pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int kb = imin(kb0 + j, num_kb - 1);          // past the range: re-read the last block (never used)
+            const int64_t off = static_cast<int64_t>(kb) * 128;
+            c.b[j][0] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr + off));
+            c.b[j][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr + off + 64));
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+                c.a[ms][j][0] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off);
+                c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off + 64);
+                c.sa[ms][j] = sfa_ptr[ms][static_cast<int64_t>(kb) * p.sfa_sk];
+            }
+            c.sb[j] = sfb_ptr[static_cast<int64_t>(kb) * p.sfb_sk];
+        }
+    };
+    v4f acc[MS];
+    #pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+        acc[ms] = v4f{0.f, 0.f, 0.f, 0.f};
+    auto compute_chunk = [&](const Chunk& c, int kb0) {
+        #pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (kb0 + j < kb_end) {                             // wave-uniform
+                const v8i bf = __builtin_shufflevector(c.b[j][0], c.b[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const v8i af = __builtin_shufflevector(c.a[ms][j][0], c.a[ms][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const v4f part = mfma_fp8_k128(bf, af);
+                    const float scale = c.sa[ms][j] * c.sb[j];
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[ms][e] = __builtin_fmaf(scale, part[e], acc[ms][e]);
+                }
+            }
+        }
+    };
+    Chunk c0, c1;
+    if (kb_begin < kb_end)
+        load_chunk(c0, kb_begin);
+    for (int kb = kb_begin; kb < kb_end; kb += 2 * CH) {
+        if (kb + CH < kb_end) load_chunk(c1, kb + CH);
+        compute_chunk(c0, kb);
+        if (kb + 2 * CH < kb_end) load_chunk(c0, kb + 2 * CH);
+        if (kb + CH < kb_end) compute_chunk(c1, kb + CH);
+    }
+    #pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+        *reinterpret_cast<v4f*>(&red[wave][ms][lane * 4]) = acc[ms];
+    __syncthreads();
+    if (wave < MS) {
+        v4f sum = *reinterpret_cast<const v4f*>(&red[0][wave][lane * 4]);
+        #pragma unroll
+        for (int w = 1; w < NW; ++w)
+            sum += *reinterpret_cast<const v4f*>(&red[w][wave][lane * 4]);
+        Tile t;
+        t.m0 = 0; t.n0 = n0; t.group = 0; t.m_begin = 0; t.m_end = p.m; t.zero_from = t.zero_to = p.m; t.valid = true; t.second_pass = false;
+        v4f out[1][1] = {{sum}};
+        store_tile<1, 1, false, false, true>(p, t, 0, out, wave * 16, n0);
+    }
+}
+
 // SF layout kernel: [batches, mn, sf_k] row-major FP32 -> MN-major with mn padded to a multiple of 4 floats
 // (semantics of transpose_fp32, deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:12-50).  One block moves a
 // 64 (mn) x 64 (sf_k) patch through LDS so that both the read (along sf_k) and the write (along mn) are coalesced.

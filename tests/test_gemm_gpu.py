@@ -51,6 +51,38 @@ def test_golden_fixtures(golden_gemm):
             assert calc_diff(d.cpu(), ref_d) < gen.FP8_MAX_DIFF
 
 
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 7168), (7, 576, 2048), (16, 2112, 7168), (17, 4096, 4096), (32, 1024, 8192), (1, 16, 128), (3, 64, 640)])
+def test_skinny_decode_kernel(m, n, k):
+    """Decode batches (M <= 32) on the skinny weight-stream kernel (16 columns per workgroup, the 8 waves split K, the partial tiles are
+    summed in wave order): oracle parity for BF16, FP32 and accumulating outputs, bit-repeatable, wider D rows, row-major SFA."""
+    gen.reset_seed(m + n)
+    cfg = 'skinny_16' if m <= 16 else 'skinny_32'
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    dg.fp8_gemm_nt(case.a, case.b, case.d)                        # automatic pick first (short K loops stay on the stream tiles)
+    assert_close_to_oracle(case.d, want, f'auto: {dg.last_config()}')
+    if k >= 2048 and (m <= 16 or (4096 <= k <= 8192 and n <= 4608)):
+        assert dg.last_config() == cfg, dg.last_config()
+    dg.set_forced_config(cfg)
+    wide = torch.full((m, n + 24), float('nan'), device='cuda', dtype=torch.bfloat16)
+    d = wide[:, :n]
+    dg.fp8_gemm_nt(case.a, case.b, d)
+    assert dg.last_config() == cfg
+    assert_close_to_oracle(d, want, cfg)
+    assert bool(torch.isnan(wide[:, n:]).all())
+    assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF or m * n < 4096     # (tiny outputs: the reference gate is noise-limited)
+    again = torch.empty_like(case.d)
+    dg.fp8_gemm_nt((case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1])), case.b, again)
+    assert torch.equal(again, d.contiguous())                     # MN-major SFA, repeat: same bits
+    acc_case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float)
+    c_cpu = acc_case.c.cpu().clone()
+    dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
+    assert_close_fp32(acc_case.d, oracle_dense(acc_case, c_cpu=c_cpu), f'{cfg} fp32 accumulate')
+    with pytest.raises(RuntimeError, match='m <= its row count'):
+        big = gen.generate_normal(40, n, k)
+        dg.fp8_gemm_nt(big.a, big.b, big.d)
+
+
 DENSE_SHAPES = [(1, 128, 128), (7, 136, 256), (128, 2112, 512), (129, 576, 384), (256, 256, 1024), (300, 520, 384),
                 (16, 4096, 512), (64, 256, 7168), (384, 768, 256)]
 
@@ -734,7 +766,7 @@ def test_import_is_fork_safe_and_bench_runs():
     assert 'zero-copy' in line['config']['sfa_layout']
     # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0 (C2, C5), two dgrad entries
     secondary = line['secondary']
-    assert len(secondary) == 14 and not [s for s in secondary if 'error' in s], secondary
+    assert len(secondary) == 16 and not [s for s in secondary if 'error' in s], secondary
     for rec in secondary:
         assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
     assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
