@@ -52,7 +52,9 @@ def landing_hazards(body):
         if op.startswith(_VMEM):
             operands = ins[len(op):]
             first = operands.split(',')[0]
-            is_load = 'load' in op and not ins.rstrip().endswith(' lds')
+            # (scratch reloads are the compiler's own, waited for by its own counters: hipcc does emit back-to-back reloads into
+            #  one register, e.g. `scratch_load_dwordx2 v[56:57]` + `scratch_load_dword v56`; the rule is about INLINE-ASM loads)
+            is_load = 'load' in op and not ins.rstrip().endswith(' lds') and not op.startswith('scratch_')
             dst = _vregs(first) if is_load else set()
             rest = _vregs(operands) - dst if is_load else _vregs(operands)
             if in_flight & rest or (in_flight & dst):
