@@ -433,7 +433,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 4096, 4096, 7168) == 'duo_p_256x256'
     assert [pick(dense, 2048, 7168, 2048, a_mn=a, b_mn=b) for a, b in ((0, 0), (0, 1), (1, 1), (1, 0))] == \
         ['duo_p_256x256', 'duo_bmn_256x256', 'duo_abmn_256x256', 'duo_amn_256x256']
-    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128) == 'duo_sk_128x256'              # 576 tiles = 2.25 rounds: K-split tail
+    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128) == 'duo_tab_256x256'             # group-relative 256-row tiles + K-split remainders
     assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128, workspace=0) == 'duo_128x256'
     assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48) == 'stream_nt_64x128'                  # 235 MB of weights: non-temporal stream
     # packed UE8M0 scales
@@ -463,7 +463,8 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 4096, 2112, 7168) == 'duo_p_256x256'                                             # 144 tiles: one round of 256-row tiles
     assert pick(dense, 70, 136, 200) == 'generic_128x128'                                               # K not in whole 16-byte chunks
     # the reference's grouped sweeps
-    assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128) == 'duo_p_256x256'              # many rounds: persistent two-pass walk
+    assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128) == 'duo_tab_256x256'            # many rounds: group-relative tiles too
+    assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128, workspace=0) == 'duo_p_256x256'  # no workspace: persistent two-pass walk
     assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128, b_mn=1) == 'duo_bmn_256x256'
     assert pick(masked, 4096, 4096, 4096, groups=32, expected_m=192) == 'duo_p_256x256'
     assert pick(masked, 4096, 6144, 7168, groups=6, expected_m=20) == 'duo_128x256'                     # 288 stream tiles > 256 CUs
