@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -32,10 +32,10 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
-             'dense_sm100', 'decode_m1', 'decode_m1_long']
+             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
-             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long']
-GRAPHED = {'decode_m1', 'decode_m1_long'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
+             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp']
+GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
 def measured_traffic(kernel: str):
@@ -176,6 +176,57 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (decode entry of the reference sweep; timed as a hipGraph replay of 20 calls, '
                             'the eager per-call time -- host-bound -- beside it)', 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d.float(), cases[0].ref_d.float()) if m * n >= 4096 else float('nan')    # noqa: E731
+    elif name in ('expert_mlp', 'expert_mlp_unfused'):
+        # decode-size expert MLP of one EP rank (the single-GPU half of the reference's Mega-MoE, deep_gemm/mega/__init__.py:155): 8 local
+        # experts x <= 64 tokens, hidden 7168 -> 2 x 2048 (SwiGLU) -> 7168.  'expert_mlp' = GEMM1 with SwiGLU + per-token FP8 re-quantisation
+        # fused into its epilogue + masked GEMM2 (2 launches); '_unfused' = masked GEMM1 -> BF16 -> torch SwiGLU -> the reference's
+        # per_token_cast_to_fp8 -> masked GEMM2 (bit-identical result, tests/test_mega_gpu.py).  Weight streams: HBM-bound.
+        from deepgemm_amd.utils.math import per_block_cast_to_fp8, per_token_cast_to_fp8
+        bound = 'hbm'
+        groups, m_max, hidden, inter, expected = 8, 64, 7168, 2048, 48
+        cast = lambda w: tuple(torch.stack(t) for t in zip(*[per_block_cast_to_fp8(w[g], use_ue8m0=False) for g in range(groups)]))   # noqa: E731
+        rows_total = 0
+        for i in range(sets):               # every set has its own weights (352 MB a set: two sets do not fit the 256 MB last-level cache)
+            gen.reset_seed(i)
+            w1 = cast(torch.randn((groups, 2 * inter, hidden), device='cuda', dtype=torch.bfloat16) / hidden ** 0.5)
+            w2 = cast(torch.randn((groups, hidden, inter), device='cuda', dtype=torch.bfloat16) / inter ** 0.5)
+            x_bf16 = torch.randn((groups, m_max, hidden), device='cuda', dtype=torch.bfloat16)
+            xq = [per_token_cast_to_fp8(x_bf16[g], use_ue8m0=False) for g in range(groups)]
+            x = (torch.stack([q[0] for q in xq]), dg.get_mn_major_tma_aligned_tensor(torch.stack([q[1] for q in xq])))
+            masked = torch.randint(expected - 16, m_max + 1, (groups,), device='cuda', dtype=torch.int)
+            rows_total = int(masked.sum().item()) if i == 0 else rows_total
+            y = torch.zeros((groups, m_max, hidden), device='cuda', dtype=torch.bfloat16)
+            cases.append((x, y, masked, w1, w2))
+            if name == 'expert_mlp':
+                w1_t, w2_t = dg.transform_weights_for_mega_moe(w1, w2)
+                mid = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+                calls.append(lambda x=x, y=y, masked=masked, mid=mid, w1_t=w1_t, w2_t=w2_t:
+                             dg.fp8_mega_moe_local(x, w1_t, w2_t, y, masked, expected, intermediate=mid))
+            else:
+                h = torch.zeros((groups, m_max, 2 * inter), device='cuda', dtype=torch.bfloat16)
+
+                def call(x=x, y=y, masked=masked, h=h, w1=w1, w2=w2):
+                    dg.m_grouped_fp8_gemm_nt_masked(x, w1, h, masked, expected)
+                    act = (torch.nn.functional.silu(h[..., :inter].float()) * h[..., inter:].float()).to(torch.bfloat16)
+                    q, sf = per_token_cast_to_fp8(act.view(groups * m_max, inter), use_ue8m0=False)
+                    dg.m_grouped_fp8_gemm_nt_masked((q.view(groups, m_max, inter), sf.view(groups, m_max, inter // 128)), w2, y, masked, expected)
+                calls.append(call)
+        flops = 2.0 * rows_total * hidden * inter * 3
+        nbytes = groups * 3 * inter * hidden + rows_total * (hidden + 2 * inter + 2 * hidden)       # both weight streams + x, the FP8 intermediate (written, read), y
+        desc = {'workload': f'expert MLP, {groups} local experts x <= {m_max} tokens ({rows_total} valid), {hidden} -> 2 x {inter} -> {hidden}: '
+                            + ('GEMM1 with fused SwiGLU + per-token FP8 re-quantisation, then masked GEMM2' if name == 'expert_mlp' else
+                               'unfused: masked GEMM1 -> torch SwiGLU -> per_token_cast_to_fp8 -> masked GEMM2')
+                            + ' (hipGraph replay of 20 steps; eager beside it)', 'experts': groups, 'hidden': hidden, 'intermediate': inter}
+
+        def check():
+            x_, y, masked, w1, w2 = cases[0]
+            want = torch.zeros_like(y)
+            h = torch.zeros((groups, m_max, 2 * inter), device='cuda', dtype=torch.bfloat16)
+            dg.m_grouped_fp8_gemm_nt_masked(x_, w1, h, masked, expected)
+            act = (torch.nn.functional.silu(h[..., :inter].float()) * h[..., inter:].float()).to(torch.bfloat16)
+            q, sf = per_token_cast_to_fp8(act.view(groups * m_max, inter), use_ue8m0=False)
+            dg.m_grouped_fp8_gemm_nt_masked((q.view(groups, m_max, inter), sf.view(groups, m_max, inter // 128)), w2, want, masked, expected)
+            return calc_diff(y.float(), want.float())
     elif name in ('dgrad_ktail', 'dgrad_ksplit'):
         # two dgrad entries of the reference's dense sweep (tests/generators.py:139-145: fp8_gemm_nn with m = 4096 and the (n, k) pairs
         # swapped): K = 2112 is not a multiple of 128 (K-tail stage), n = 512 with K = 32768 fills a quarter of the chip (K split)
@@ -327,6 +378,12 @@ def run_secondary(sets: int):
             if name in GRAPHED:
                 extra['eager_call_us'] = call_s * 1e6
                 call_s = graph_replay_seconds(calls, 20)
+            if name == 'expert_mlp':
+                other = make_workload('expert_mlp_unfused', 2)[0]
+                other[0]()
+                extra['unfused_us'] = graph_replay_seconds(other, 20) * 1e6
+                extra['fused_us'] = call_s * 1e6
+                other = None
             rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
                    'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config()), **extra}
             out.append(rec)

@@ -10,7 +10,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libdeepgemm_amd.so')
 SOURCES = ['dg_api.hip']
-HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_experiments.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
+HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_moe.hpp', 'fp8_gemm_experiments.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
 # DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that DESIGN.md section 5 quotes (tools/cycles.py,

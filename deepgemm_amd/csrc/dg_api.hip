@@ -14,6 +14,7 @@
 #include "../../include/deepgemm_amd.h"
 #include "fp8_gemm_kernels.hpp"
 #include "fp8_gemm_quad.hpp"
+#include "fp8_gemm_moe.hpp"
 #ifdef DG_EXPERIMENTS
 #include "fp8_gemm_experiments.hpp"
 #endif
@@ -1082,6 +1083,60 @@ int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void*
     p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
     p.gemm_type = dg::kMasked; p.m_alignment = 0;
     return launch_gemm(p, expected_m < m_max ? expected_m : m_max, stream);
+}
+
+int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n) {
+    return static_cast<int64_t>(num_groups) * ceil_div(m_max, 64) * (n / 128) * 64 * 4;
+}
+
+int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
+                                           float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
+                                           int64_t a_stride_g, int64_t a_stride_m, int64_t b_stride_g, int64_t b_stride_n,
+                                           int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t sfb_stride_g, int64_t sfb_stride_n,
+                                           int64_t sfb_stride_k, int64_t out_stride_g, int64_t out_stride_m, int64_t out_sf_stride_g,
+                                           int64_t out_sf_stride_k, float activation_clamp, int use_ue8m0, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
+    DG_CHECK(expected_m > 0 && m_max > 0 && n > 0 && k > 0 && num_groups > 0);
+    DG_CHECK(a != nullptr && b_interleaved != nullptr && sfa != nullptr && sfb != nullptr && out_fp8 != nullptr && out_sf != nullptr &&
+             masked_m != nullptr);
+    DG_CHECK(n % 256 == 0);                             // whole pairs of [64 gate | 64 up] column tiles = whole 128-wide blocks of the intermediate
+    DG_CHECK(k % 128 == 0);
+    DG_CHECK(out_stride_m >= n / 2 && out_stride_m % 8 == 0 && (reinterpret_cast<uintptr_t>(out_fp8) & 7) == 0);
+    DG_CHECK(out_sf_stride_k >= m_max);
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.sfa = sfa; p.b = static_cast<const uint8_t*>(b_interleaved); p.sfb = sfb; p.d = nullptr;
+    p.layout = masked_m;
+    p.m = m_max; p.n = n; p.k = k; p.num_groups = num_groups;
+    p.a_sg = a_stride_g; p.a_sm = a_stride_m; p.a_sk = 1;
+    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = 1;
+    p.sfa_sg = sfa_stride_g; p.sfa_sm = 1; p.sfa_sk = sfa_stride_k;
+    p.sfb_sg = sfb_stride_g; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
+    p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
+    p.gemm_type = dg::kMasked; p.m_alignment = 0;
+    if (!fast_eligible(p) || !aligned16(sfa) || (sfa_stride_k * 4) % 16 != 0 || (sfa_stride_g * 4) % 16 != 0) {
+        g_last_error = "dg_m_grouped_fp8_gemm_nt_masked_swiglu needs K-major 16-byte aligned FP8 operands and MN-major 16-byte aligned SFA rows";
+        return 3;
+    }
+    p.num_m_tiles = ceil_div(m_max, 64);
+    p.num_n_tiles = n / 128;
+    p.group_m = 1;
+    p.dbg = nullptr;
+    const long max_tiles = static_cast<long>(num_groups) * p.num_m_tiles * p.num_n_tiles;
+    if (workspace == nullptr || workspace_bytes < dg_swiglu_workspace_bytes(num_groups, m_max, n) || (reinterpret_cast<uintptr_t>(workspace) & 3) != 0) {
+        g_last_error = "dg_m_grouped_fp8_gemm_nt_masked_swiglu needs a zero-initialised workspace of dg_swiglu_workspace_bytes(num_groups, m_max, n) bytes";
+        return 3;
+    }
+    dg::SwigluOut o{};
+    o.amax_ws = static_cast<uint32_t*>(workspace);
+    o.q = static_cast<uint8_t*>(out_fp8); o.sf = out_sf;
+    o.q_sg = out_stride_g; o.q_sm = out_stride_m; o.sf_sg = out_sf_stride_g; o.sf_sk = out_sf_stride_k;
+    o.clamp = activation_clamp; o.use_ue8m0 = use_ue8m0 ? 1 : 0;
+    const long grid = std::min<long>(max_tiles, num_cus() & ~1);             // even: tile t and its partner t ^ 1 run in the same iteration
+    g_last_config = "stream_swiglu_64x128";
+    hipLaunchKernelGGL(dg::dg_fp8_gemm_stream_swiglu_kernel<6>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), p, o);
+    DG_HIP_CHECK(hipGetLastError());
+    (void)expected_m;
+    return 0;
 }
 
 int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, float* d,

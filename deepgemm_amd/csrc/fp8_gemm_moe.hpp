@@ -1,0 +1,289 @@
+// Fused expert MLP hand-off (the single-GPU half of the reference's Mega-MoE kernel): the first grouped GEMM of an expert MLP with the
+// SwiGLU activation and the per-token FP8 re-quantisation for the SECOND GEMM in its epilogue -- the BF16 intermediate [rows, 2 I] never
+// goes to memory; what leaves the kernel is GEMM2's operand pair (A_fp8 [G, M, I], SFA [G, I / 128, M] FP32, MN-major).
+//
+// Reference: the L1 -> L2 hand-off inside deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh (GEMM1 epilogue: SwiGLU on the
+// gate / up halves, amax, re-quantisation, L2 operand written for the second UMMA pipeline), weight layout
+// deep_gemm/mega/__init__.py:115-151 (`transform_weights_for_mega_moe`: gate and up rows interleaved so that one output tile holds
+// both halves of the same intermediate columns).  The dispatch / combine over NVLink of that kernel is NOT here (it needs a multi-GPU
+// node: deepgemm_amd/ep.py does the exchange with RCCL all-to-alls around this operator).
+//
+// MI355X form.  At decode sizes this operator is a WEIGHT STREAM (8 experts x 4096 x 7168 bytes for <= 512 tokens): what matters is
+// HBM bytes in flight on ALL 256 CUs -- one CU sustains about 30 GB/s from HBM whatever the kernel (a 64 x 256 tile version of this
+// kernel with 128 workgroups ran at 3.0 TB/s, the plain 64 x 128 stream kernel with 256 workgroups and a 6-deep ring at 5.0 TB/s;
+// profiles/r03_mlp/NOTES.md).  So the tile is the plain stream kernel's 64 x 128 with its 6-stage ring, and the weight layout
+// (deepgemm_amd/mega.py) interleaves gate and up rows in BLOCKS OF 64: tile columns [0, 64) = gate rows 64 j .. 64 j + 63, [64, 128) =
+// the up rows of the same j.  A 1 x 128 quantisation block of the intermediate then spans TWO tiles (j = 2 i and 2 i + 1), computed
+// by two workgroups on two CUs: they exchange their per-row amax through a small global workspace (one 32-bit slot per row and tile:
+// bit 31 = valid, the reader clears the slot again, so the workspace is zeroed once and then serves every launch and every hipGraph
+// replay).  The partner of tile t is tile t ^ 1 -- adjacent in launch order, handled by the neighbouring workgroup in the same
+// iteration of the persistent loop; hardware dispatches a kernel's workgroups in order, so a waiting workgroup's partner is already
+// resident or is the next one to be placed: no deadlock, whatever else runs on the device.  The FP32 weight scales stay the 128 x 128
+// blocks the weights were quantised with: gate rows 64 j .. belong to scale block j / 2 of the gate half, likewise up -- two SFB
+// values per tile, as laid out by mega.py (scale rows interleaved [gate 0, up 0, gate 1, up 1, ...]).
+// Kernel: 4 waves, wave tile 64 x 32 (waves 0, 1 hold gate columns, waves 2, 3 the matching up columns), K loop of
+// stream_kernel_body (fp8_gemm_kernels.hpp): promotion by FMA in K-block order, bit-identical to the plain masked kernel.  Epilogue,
+// after the K loop has released the LDS:
+//   1. every accumulator is rounded to BF16 (the value the unfused pipeline stores and reloads);
+//   2. the up waves park their values in LDS, the gate waves read them at the same (lane, register) position: y = silu(g) * u in FP32
+//      (optionally clamped: g <= c, |u| <= c), rounded to BF16;
+//   3. amax over the row's 64 values of this tile: 8 in a lane, 4 lanes of a row (lane bits 4, 5), 2 gate waves (LDS); then the
+//      exchange with the partner tile (wave 0, one lane per row): amax over the 128-wide block;
+//   4. scale = max(amax, 1e-4) * (1 / 448) (optionally rounded up to a power of two), q = e4m3(y * (1 / scale)) -- the arithmetic of
+//      per_token_cast_to_fp8 (deep_gemm/utils/math.py:26-38) as torch executes it on a device;
+//   5. one 8-byte store per lane and M-subtile (8 consecutive intermediate columns), one scale per row and PAIR of tiles.
+// Bit-exact against "masked GEMM -> BF16 -> torch SwiGLU -> reference per_token_cast_to_fp8" (tests/test_mega_gpu.py).
+#pragma once
+#include "fp8_gemm_kernels.hpp"
+
+#ifndef DG_SWIGLU_B_AUX
+#define DG_SWIGLU_B_AUX 2
+#endif
+
+namespace dg {
+
+struct SwigluOut {
+    uint8_t* q;             // [G, m_max, I] e4m3
+    float* sf;              // [G, I / 128, sf_sk] FP32: element (g, kb, m) at sf[g * sf_sg + kb * sf_sk + m]
+    int64_t q_sg, q_sm, sf_sg, sf_sk;
+    float clamp;            // <= 0: none
+    int use_ue8m0;
+    uint32_t* amax_ws;      // [tiles][64] exchange slots, all zero between launches
+};
+
+template <int STAGES>
+__device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, const SwigluOut& o) {
+    constexpr int BM = 64, BN = 128, NW = 4, WM = 64, WN = 32, MS = 4, NS = 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256;
+    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, STAGE_BYTES = SFB_OFF + SFB_BYTES;
+    constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int PIECES = A_ITERS + B_ITERS + 2;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert((STAGES - 1) * PIECES < 64 && LDS_BYTES <= 160 * 1024 && STAGES >= 3, "ring geometry");
+    static_assert(2 * (MS * NS * 4) * 64 * 4 + 3 * 64 * 4 <= LDS_BYTES, "the epilogue exchange fits in the ring's LDS");
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
+    const int a_voff = piece_row * MS * lda + src_chunk * 16;
+    const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
+
+    // Persistent walk over the groups (masked_m lives on the device).  Order inside a group: the two tiles of a quantisation block
+    // adjacent (tile_id ^ 1 is the partner; every group holds an even number of tiles), then M tiles, then blocks.
+    struct { int m0, n0, m_end; } t;
+    int walk_group = 0, walk_base = 0;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        int nmt;
+        while (true) {
+            if (walk_group >= p.num_groups)
+                return;
+            t.m_end = imin(p.layout[walk_group], p.m);
+            nmt = (t.m_end + BM - 1) / BM;
+            if (tile_id < walk_base + nmt * p.num_n_tiles)
+                break;
+            walk_base += nmt * p.num_n_tiles;
+            ++walk_group;
+        }
+        {
+            const int local = tile_id - walk_base, rest = local >> 1;
+            t.m0 = (rest % nmt) * BM;
+            t.n0 = (2 * (rest / nmt) + (local & 1)) * BN;
+        }
+        const int64_t group = walk_group;
+
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = p.a + group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
+            const uint8_t* b_base = p.b + group * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
+            const int a_rows = imin(t.m_end - t.m0, BM);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0, (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0, (BN - 1) * ldb + p.k, 0x00020000);
+            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+            float* sfa_tile = const_cast<float*>(p.sfa) + group * p.sfa_sg + t.m0;
+            const int sfa_rows = imin(p.m - t.m0, BM);
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_kb - 1) * sfa_kb_stride + sfa_rows * 4, 0x00020000);
+            // two SFB values per tile: the 128 x 128 scale blocks its 64 gate rows and its 64 up rows were quantised in
+            float* sfb_tile = const_cast<float*>(p.sfb) + group * p.sfb_sg + static_cast<int64_t>(t.n0 / 256) * 2 * p.sfb_sn;
+            const int sfb_sn_bytes = static_cast<int>(p.sfb_sn) * 4;
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_kb - 1) * sfb_kb_stride + sfb_sn_bytes + 4, 0x00020000);
+
+            auto issue_block = [&](int slot_off, int j) {
+                const unsigned oob = j < num_kb ? 0u : OOB;
+                uint8_t* stage = lds + slot_off;
+                #pragma unroll
+                for (int q = 0; q < A_ITERS; ++q) {
+                    const int unit = wave + NW * q;
+                    const int voff = static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        a_rsrc, (__attribute__((address_space(3))) void*)(stage + unit * 1024), 16, voff, j * 128, 0, 0);
+                }
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q) {
+                    const int unit = wave + NW * q;
+                    const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
+                                                      (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | oob));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, DG_SWIGLU_B_AUX);   // nt: weights stream once
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    sfa_rsrc, (__attribute__((address_space(3))) void*)(stage + SFA_OFF), 4,
+                    static_cast<int>(static_cast<unsigned>(lane * 4 + j * sfa_kb_stride) | oob), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                   // lanes 0..31: the gate block's scale, lanes 32..63: the up block's
+                    sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF), 4,
+                    static_cast<int>(static_cast<unsigned>((lane >> 5) * sfb_sn_bytes + j * sfb_kb_stride) | oob), 0, 0, 0);
+            };
+            #pragma unroll
+            for (int j = 0; j < STAGES - 1; ++j)
+                issue_block(j * STAGE_BYTES, j);
+
+            int cur = 0, fill = (STAGES - 1) * STAGE_BYTES;
+            for (int kb = 0; kb < num_kb; ++kb) {
+                asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((STAGES - 2) * PIECES) : "memory");
+                raw_barrier();
+                issue_block(fill, kb + STAGES - 1);
+                const uint8_t* stage = lds + cur;
+                const v4f q = *reinterpret_cast<const v4f*>(stage + SFA_OFF + ((lane & 15) * MS) * 4);
+                const float sa[MS] = {q[0], q[1], q[2], q[3]};
+                const float sb = *reinterpret_cast<const float*>(stage + SFB_OFF + (wn >> 1) * 128);
+                const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;
+                v8i bf[NS];
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const v8i af = load_fragment(stage + ms * 2048, frag_off);
+                    const float scale = sa[ms] * sb;
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        const v4f part = mfma_fp8_k128(bf[ns], af);
+                        #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[ms][ns][e] = __builtin_fmaf(scale, part[e], acc[ms][ns][e]);      // the promotion of every other kernel: fused multiply-add
+                    }
+                }
+                fill = cur;
+                cur = (cur == (STAGES - 1) * STAGE_BYTES) ? 0 : cur + STAGE_BYTES;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                        // the ring is free: the epilogue exchange lives in its first 17 KiB
+
+            // ---- 1. BF16 rounding; 2. up waves -> LDS ----
+            float* xch = reinterpret_cast<float*>(lds);                 // [2 up waves][MS * NS * 4 registers][64 lanes]
+            float* row_max = reinterpret_cast<float*>(lds + 2 * (MS * NS * 4) * 64 * 4);    // [2 gate waves][64 rows], then [64] block amax
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[ms][ns][e] = round_bf16(acc[ms][ns][e]);
+            if (wn >= 2) {
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            xch[((wn - 2) * (MS * NS * 4) + (ms * NS + ns) * 4 + e) * 64 + lane] = acc[ms][ns][e];
+            }
+            __syncthreads();
+            float amax[MS] = {0.f, 0.f, 0.f, 0.f};
+            if (wn < 2) {
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float g = acc[ms][ns][e];
+                            float u = xch[(wn * (MS * NS * 4) + (ms * NS + ns) * 4 + e) * 64 + lane];
+                            if (o.clamp > 0.f) {
+                                g = fminf(g, o.clamp);
+                                u = fminf(fmaxf(u, -o.clamp), o.clamp);
+                            }
+                            const float y = round_bf16((g / (1.0f + expf(-g))) * u);     // torch: silu(g.float()) * u.float() -> bf16
+                            acc[ms][ns][e] = y;
+                            amax[ms] = fmaxf(amax[ms], fabsf(y));
+                        }
+                // 3. the row's 4 lanes (lane bits 4, 5), then the two gate waves
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    amax[ms] = fmaxf(amax[ms], __shfl_xor(amax[ms], 16, 64));
+                    amax[ms] = fmaxf(amax[ms], __shfl_xor(amax[ms], 32, 64));
+                    if (lg == 0)
+                        row_max[wn * 64 + (lane & 15) * MS + ms] = amax[ms];         // tile row of (lane, ms): interleaved rows
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // 3b. the other half of the 128-wide block lives in tile_id ^ 1: publish this tile's row amax, take the partner's, clear its slot
+                const float mine = fmaxf(row_max[lane], row_max[64 + lane]);
+                __hip_atomic_store(o.amax_ws + static_cast<int64_t>(tile_id) * 64 + lane, 0x80000000u | __float_as_uint(mine),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t* theirs = o.amax_ws + static_cast<int64_t>(tile_id ^ 1) * 64 + lane;
+                uint32_t v;
+                do {
+                    v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(v & 0x80000000u))
+                        __builtin_amdgcn_s_sleep(1);
+                } while (!(v & 0x80000000u));
+                __hip_atomic_store(theirs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                row_max[128 + lane] = fmaxf(mine, __uint_as_float(v & 0x7fffffffu));
+            }
+            __syncthreads();
+            if (wn < 2) {
+                const int kb2 = t.n0 / (2 * BN);                         // the intermediate's 128-block = GEMM2's K block
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const int row_in_tile = (lane & 15) * MS + ms;
+                    const int row = t.m0 + row_in_tile;
+                    float scale = fmaxf(row_max[128 + row_in_tile], 1e-4f) * (1.0f / 448.0f);     // the reference kernel (math.cuh:93) and torch's `/ 448.0` on a device both multiply
+                    if (o.use_ue8m0) {
+                        const uint32_t bits = __float_as_uint(scale);
+                        uint32_t e = ((bits >> 23) & 0xffu) + ((bits & 0x7fffffu) != 0 ? 1u : 0u);
+                        e = e < 1u ? 1u : (e > 254u ? 254u : e);
+                        scale = __uint_as_float(e << 23);
+                    }
+                    const float inv = 1.0f / scale;
+                    if (row >= t.m_end)
+                        continue;
+                    uint8_t* qrow = o.q + group * o.q_sg + static_cast<int64_t>(row) * o.q_sm + (t.n0 / BN) * 64 + wn * 32 + lg * 8;
+                    int w0 = 0, w1 = 0;                                  // N-subtiles 0 and 1: 8 consecutive intermediate columns
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][0][0] * inv, acc[ms][0][1] * inv, w0, false);
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][0][2] * inv, acc[ms][0][3] * inv, w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][1][0] * inv, acc[ms][1][1] * inv, w1, false);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][1][2] * inv, acc[ms][1][3] * inv, w1, true);
+                    *reinterpret_cast<uint2*>(qrow) = make_uint2(static_cast<uint32_t>(w0), static_cast<uint32_t>(w1));
+                    if (wn == 0 && lg == 0 && (tile_id & 1) == 0)
+                        o.sf[group * o.sf_sg + static_cast<int64_t>(kb2) * o.sf_sk + row] = scale;
+                }
+            }
+            __syncthreads();                        // the next tile's prologue refills the LDS
+        }
+    }
+}
+
+template <int STAGES>
+__global__ __launch_bounds__(256)
+void dg_fp8_gemm_stream_swiglu_kernel(const GemmParams p, const SwigluOut o) {
+    stream_swiglu_kernel_body<STAGES>(p, o);
+}
+
+}  // namespace dg

@@ -119,6 +119,34 @@ int dg_pack_sf_pair_ue8m0(const float* sfa, int32_t* out_a, int batches_a, int m
                           const float* sfb, int32_t* out_b, int batches_b, int n, int64_t sfb_stride_b, int64_t sfb_stride_n,
                           int64_t sfb_stride_k, int gran_n, int sf_k, void* stream);
 
+/* First GEMM of an expert MLP with the SwiGLU activation and the per-token FP8 re-quantisation for the second GEMM fused into its
+ * epilogue: the single-GPU half of the reference's Mega-MoE kernel (the L1 -> L2 hand-off of
+ * deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh; host side csrc/apis/mega.hpp:30-159, deep_gemm/mega/__init__.py:155;
+ * its NVLink dispatch / combine is not part of this entry -- deepgemm_amd/ep.py exchanges tokens with RCCL around it).
+ *   a [G, m_max, k] e4m3 K-major, sfa FP32 MN-major (element (g, m, kb) at sfa[g * stride_g + kb * stride_k + m]), masked_m as in
+ *   dg_m_grouped_fp8_gemm_nt_masked.
+ *   b_interleaved [G, n, k], n = 2 I: the expert's W1 with its gate rows (first I) and up rows (last I) interleaved in blocks of 64 --
+ *   rows [128 j, 128 j + 64) = gate rows [64 j, 64 j + 64), rows [128 j + 64, 128 j + 128) = up rows [64 j, ...) -- and sfb its
+ *   128 x 128 FP32 block scales [G, n / 128, k / 128] with the scale rows interleaved [gate 0, up 0, gate 1, up 1, ...]
+ *   (deepgemm_amd.transform_weights_for_mega_moe; the reference interleaves at granularity 8 for its own kernel,
+ *   deep_gemm/mega/__init__.py:115-122).
+ *   out_fp8 [G, m_max, I] e4m3 (row stride out_stride_m) and out_sf FP32 (element (g, m, j) at out_sf[g * stride_g + j * stride_k + m],
+ *   j = 128-block of I: the MN-major layout GEMM2 reads zero-copy): rows m < masked_m[g] hold
+ *       y = bf16( silu(bf16(h[m, gate])) * bf16(h[m, up]) ),  h = A B^T with the blockwise scales (FP32 accumulation),
+ *       optional clamp g <= c, |u| <= c (activation_clamp > 0);  per_token_cast_to_fp8(y) (deep_gemm/utils/math.py:26-38), 1 x 128 blocks,
+ *   bit for bit what "dg_m_grouped_fp8_gemm_nt_masked -> BF16 -> SwiGLU -> per_token_cast_to_fp8" produces; other rows are untouched.
+ *   workspace: dg_swiglu_workspace_bytes(num_groups, m_max, n) bytes of device memory, ZEROED ONCE by the caller; the kernel leaves it
+ *   zeroed (the two workgroups that share a 1 x 128 quantisation block exchange their row amax through it), so one workspace serves every
+ *   later launch and hipGraph replay on the same stream.  One workspace per stream that runs this entry concurrently. */
+int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n);
+int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
+                                           float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
+                                           int64_t a_stride_g, int64_t a_stride_m, int64_t b_stride_g, int64_t b_stride_n,
+                                           int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t sfb_stride_g, int64_t sfb_stride_n,
+                                           int64_t sfb_stride_k, int64_t out_stride_g, int64_t out_stride_m, int64_t out_sf_stride_g,
+                                           int64_t out_sf_stride_k, float activation_clamp, int use_ue8m0, void* workspace, int64_t workspace_bytes,
+                                           void* stream);
+
 /* K-grouped contiguous GEMM (MoE weight gradients): D[g] += A_g * B_g^T for every group g, where group g owns the K range
  * [sum(ks[:g]), sum(ks[:g+1])) of both operands.  Replaces sm90_k_grouped_fp8_gemm_1d1d / sm100_k_grouped_fp8_gemm_1d1d as
  * called from k_grouped_fp8_gemm_nt_contiguous / k_grouped_fp8_gemm_tn_contiguous (csrc/apis/gemm.hpp:299-400).

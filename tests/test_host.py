@@ -523,6 +523,32 @@ def test_bench_workload_tables_are_consistent():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert set(bench.SECONDARY) <= set(bench.WORKLOADS) and 'dense' in bench.WORKLOADS and 'dense' not in bench.SECONDARY
-    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 16 and bench.GRAPHED <= set(bench.SECONDARY)
+    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 17 and bench.GRAPHED <= set(bench.WORKLOADS)
     assert bench.PEAK_FP8_TFLOPS == 5000.0
 
+
+
+def test_mega_weight_transform_and_validation_on_the_host():
+    """transform_weights_for_mega_moe is pure layout work (runs without a GPU); the fused operator validates before it needs a device."""
+    import deepgemm_amd as dg
+    groups, inter, k = 2, 256, 256
+    w = torch.arange(groups * 2 * inter, dtype=torch.int32).remainder(251).to(torch.uint8).view(groups, 2 * inter, 1).expand(-1, -1, k).contiguous()
+    sf = torch.arange(groups * 4 * 2, dtype=torch.float).view(groups, 4, 2)
+    (w_t, sf_t), l2 = dg.transform_weights_for_mega_moe((w.view(torch.float8_e4m3fn), sf), ('l2', 'unchanged'))
+    assert l2 == ('l2', 'unchanged')
+    wt = w_t.view(torch.uint8)
+    for blk in range(4):            # kernel tile blk: columns [0, 64) = gate rows 64 blk .., [64, 128) = the up rows of the same blk
+        assert torch.equal(wt[:, 128 * blk:128 * blk + 64], w[:, 64 * blk:64 * blk + 64])
+        assert torch.equal(wt[:, 128 * blk + 64:128 * blk + 128], w[:, inter + 64 * blk:inter + 64 * blk + 64])
+    for blk in range(2):            # scale rows: [gate 0, up 0, gate 1, up 1]
+        assert torch.equal(sf_t[:, 2 * blk], sf[:, blk]) and torch.equal(sf_t[:, 2 * blk + 1], sf[:, 2 + blk])
+    q, q_sf = dg.empty_intermediate(3, 70, 512, 'cpu')
+    assert q.shape == (3, 70, 512) and q_sf.shape == (3, 70, 4) and q_sf.stride() == (4 * 72, 1, 72)
+    x = (torch.zeros((groups, 8, k), dtype=torch.float8_e4m3fn), torch.ones((groups, 8, 2)))
+    masked = torch.zeros(groups, dtype=torch.int)
+    with pytest.raises(RuntimeError, match='Assertion error'):        # out must be [G, m, n / 2]
+        dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, (w_t, sf_t), dg.empty_intermediate(groups, 8, 2 * inter, 'cpu'), masked, 1)
+    with pytest.raises(RuntimeError, match='Assertion error'):        # expected_m > 0
+        dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, (w_t, sf_t), dg.empty_intermediate(groups, 8, inter, 'cpu'), masked, 0)
+    with pytest.raises(RuntimeError, match='no CPU path'):   # valid arguments: fails loudly for want of a GPU, no CPU path
+        dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, (w_t, sf_t), dg.empty_intermediate(groups, 8, inter, 'cpu'), masked, 1)
