@@ -705,8 +705,12 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
 // s_nop padding).  The ring runs across K blocks: the last three steps of block kb are promoted during the first
 // three MFMAs of block kb+1 with block kb's scales.  hipcc, left alone, emits mfma / s_nop 11 / fma per step.
 // ---------------------------------------------------------------------------------------------------------------
+// (Negative result, round 3: the four promotion FMAs as TWO v_pk_fma_f32 -- half the VALU issue slots -- run C2 at 110 us instead of
+// 91.5 us, C3 36.2 instead of 30.0: packed FP32 FMAs issue at half rate behind a matrix instruction on this part.  -DDG_PK_FMA builds it.)
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mfma_promote_step(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
                                                   float (&c)[4], float scale, const v4f& part_old) {
+#ifndef DG_PK_FMA
     asm volatile(
         "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
         "v_fmac_f32 %1, %7, %8\n\t"
@@ -717,6 +721,18 @@ __device__ __forceinline__ void mfma_promote_step(v4f& part_new, const v8i& rows
         : "v"(rows_operand), "v"(cols_operand), "v"(scale), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]),
           "v"(part_old[3])
         : "memory");
+#else
+    v2f c01 = {c[0], c[1]}, c23 = {c[2], c[3]};
+    const v2f s2 = {scale, scale}, p01 = {part_old[0], part_old[1]}, p23 = {part_old[2], part_old[3]};
+    asm volatile(
+        "v_mfma_f32_16x16x128_f8f6f4 %0, %3, %4, 0\n\t"
+        "v_pk_fma_f32 %1, %5, %6, %1\n\t"
+        "v_pk_fma_f32 %2, %5, %7, %2"
+        : "=&v"(part_new), "+v"(c01), "+v"(c23)
+        : "v"(rows_operand), "v"(cols_operand), "v"(s2), "v"(p01), "v"(p23)
+        : "memory");
+    c[0] = c01[0]; c[1] = c01[1]; c[2] = c23[0]; c[3] = c23[1];
+#endif
 }
 
 // Forces `x` to be materialised in a VGPR at this point of the instruction stream (scheduling fence for one value).
@@ -725,6 +741,7 @@ __device__ __forceinline__ void pin_vgpr(float& x) { asm volatile("" : "+v"(x));
 __device__ __forceinline__ void promote_only(float (&c)[4], float scale, const v4f& part_old) {
     // Drain step.  s_nop 3 keeps >= 12 wait states between the last MFMA and the first read of its result even if
     // every intervening instruction issues back to back.
+#ifndef DG_PK_FMA
     asm volatile(
         "s_nop 3\n\t"
         "v_fmac_f32 %0, %4, %5\n\t"
@@ -734,6 +751,18 @@ __device__ __forceinline__ void promote_only(float (&c)[4], float scale, const v
         : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
         : "v"(scale), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]), "v"(part_old[3])
         : "memory");
+#else
+    v2f c01 = {c[0], c[1]}, c23 = {c[2], c[3]};
+    const v2f s2 = {scale, scale}, p01 = {part_old[0], part_old[1]}, p23 = {part_old[2], part_old[3]};
+    asm volatile(
+        "s_nop 3\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0\n\t"
+        "v_pk_fma_f32 %1, %2, %4, %1"
+        : "+v"(c01), "+v"(c23)
+        : "v"(s2), "v"(p01), "v"(p23)
+        : "memory");
+    c[0] = c01[0]; c[1] = c01[1]; c[2] = c23[0]; c[3] = c23[1];
+#endif
 }
 
 // SPREAD: LDS-DMA piece placement: 0 = the whole next stage at the head of the K block, n = one piece every n MFMA steps.
