@@ -110,10 +110,19 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 
 // QV (timing experiments, DG_EXPERIMENTS builds only; results are garbage):
 //   0 production; 1 no LDS-DMA in the loop; 2 no fragment reads in the loop; 3 neither (matrix stream + barrier);
-//   5 no barrier in the loop.
+//   5 no barrier in the loop; 6 (STAGED) every staged load re-reads K block 0 (cache hits: what does memory latency cost?).
 // BM = 256: wave tile 128 x 128 (MS = 8), the dense / large contiguous form; BM = 128: wave tile 64 x 128 (MS = 4) for the
 // grouped layouts whose M alignment is 128 rows (contiguous, psum, masked) and for small dense problems.
-template <int BM, int BN, int QV = 0>
+// STAGED: the operand bytes go global -> VGPR -> ds_write_b128 instead of through LDS-DMA.  Why: a buffer_load ... lds of 1 KiB costs
+// its wave ~83 ns of LDS-DMA throughput whatever the source (tools/ubench/fill_rate.hip: 4 waves per CU fill at 50 GB/s from L2 through
+// LDS-DMA, 80 GB/s through registers; 8 waves 80 / 103), and this kernel's 16 pieces per wave and K block at 83 ns are 1.33 us --
+// MORE than the 1.1 us its 64 MFMAs take: with the LDS-DMA pieces the loop is fill-bound (81.7 us for C2; 66.3 us with the pieces
+// compiled out, profiles/r03_fill/NOTES.md; hipBLASLt's 4-wave kernel sits on the same 16 x 86 ns = 1.38 us per K block).
+// Schedule: the same piece positions and LDS slots as the LDS-DMA form; position i of the piece stream WRITES the piece that form
+// would have issued there (loaded half a K block earlier into one of POS / 2 staging registers of 16 bytes per lane) and
+// then LOADS the piece of position i + POS / 2 into the freed register -- so every piece is in LDS no later than before, and its global
+// load is in flight half a K block longer.
+template <int BM, int BN, int QV = 0, bool STAGED = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int NW = 4, WAVES_N = 2;
     constexpr int WM = BM / 2, WN = BN / 2, MS = WM / 16, NS = WN / 16;
@@ -122,7 +131,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
-    constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5);
+    constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5), HOT_LOADS = (QV == 6);
     static_assert(NS == 8 && (MS == 8 || MS == 4), "wave tiles 128 x 128 or 64 x 128");
     constexpr int PRE_STRIDE = PRE / N_PRE, POST_STRIDE = POST / N_POST;
     static_assert(B_ITERS % 2 == 0 && PRE % N_PRE == 0 && POST % N_POST == 0 && PRE_STRIDE >= 2 && POST_STRIDE >= 2,
@@ -144,13 +153,26 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
     const int a_voff = piece_row * MS * lda + src_chunk * 16;
     const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
-    int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
-    #pragma unroll
-    for (int q = 0; q < A_ITERS; ++q)
-        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
-    #pragma unroll
-    for (int q = 0; q < B_ITERS; ++q)
-        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+    int a_piece_voff[STAGED ? 1 : A_ITERS], b_piece_voff[STAGED ? 1 : B_ITERS];
+    int a_piece_soff[STAGED ? A_ITERS : 1], b_piece_soff[STAGED ? B_ITERS : 1];     // STAGED: the (wave-uniform) row part in the soffset
+    if constexpr (STAGED) {
+        #pragma unroll
+        for (int q = 0; q < A_ITERS; ++q)
+            a_piece_soff[q] = __builtin_amdgcn_readfirstlane(a_unit_row(wave + NW * q) * lda);
+        #pragma unroll
+        for (int q = 0; q < B_ITERS; ++q)
+            b_piece_soff[q] = __builtin_amdgcn_readfirstlane(b_row_perm<WN>(q * (NW * 8)) * ldb);
+    } else {
+        #pragma unroll
+        for (int q = 0; q < A_ITERS; ++q)
+            a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
+        #pragma unroll
+        for (int q = 0; q < B_ITERS; ++q)
+            b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+    }
+    constexpr int POS = N_PRE + N_POST, DEPTH = POS / 2;            // piece positions per K block; staging registers (each serves two positions)
+    static_assert(POS % 2 == 0, "a staging register serves two positions per K block");
+    const int lane16 = lane * 16;
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;   // bytes per K quad
 
     const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
@@ -224,15 +246,44 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
 
             auto issue_a_piece = [&](int slot_off, int j, int q) {
                 if (NO_DMA) return;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_piece_voff[q],
-                    imin(j, num_kb - 1) * 128, 0, 0);
+                if constexpr (STAGED)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_voff,
+                        a_piece_soff[q] + imin(j, num_kb - 1) * 128, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_piece_voff[q],
+                        imin(j, num_kb - 1) * 128, 0, 0);
             };
             auto issue_b_piece = [&](int slot_off, int j, int q) {
                 if (NO_DMA) return;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
-                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+                if constexpr (STAGED)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
+                        b_voff, b_piece_soff[q] + imin(j, num_kb - 1) * 128, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
+                        b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+            };
+            // STAGED: position `pos` (0 .. POS - 1: N_PRE in rows 0 .. MS-3, N_POST in the last two rows; >= POS: the next block's) of
+            // block kb is: second half of B(kb+1) | A(kb+2) | first half of B(kb+2)
+            v4i stage[STAGED ? DEPTH : 1];
+            auto stage_load = [&](int r, int pos, int kb) {
+                if (pos >= POS) { pos -= POS; ++kb; }
+                if (HOT_LOADS) kb = -2;
+                if (pos < B_ITERS / 2)
+                    stage[r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(
+                        b_rsrc, b_voff, b_piece_soff[B_ITERS / 2 + pos] + imax(imin(kb + 1, num_kb - 1), 0) * 128, 0));
+                else if (pos < N_PRE)
+                    stage[r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(
+                        a_rsrc, a_voff, a_piece_soff[pos - B_ITERS / 2] + imax(imin(kb + 2, num_kb - 1), 0) * 128, 0));
+                else
+                    stage[r] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(
+                        b_rsrc, b_voff, b_piece_soff[pos - N_PRE] + imax(imin(kb + 2, num_kb - 1), 0) * 128, 0));
+            };
+            auto stage_write = [&](int r, int lds_off) {
+                *reinterpret_cast<v4i*>(lds + lds_off + lane16) = stage[r];
             };
             E8LandingQ cur, nxt;
             auto issue_scales = [&](E8LandingQ& l, int kq) {
@@ -254,6 +305,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
             tie_e8q_landing<MS>(cur);
             raw_barrier();
+            if constexpr (STAGED) {
+                #pragma unroll
+                for (int r = 0; r < DEPTH; ++r)
+                    stage_load(r, r, 0);                        // the first DEPTH positions of block 0
+            }
 
             // slots (byte offsets): A(kb), A(kb+1), A(kb+2) [= where A(kb+2) is filled]; B(kb), B(kb+1)
             int a_cur = 0, a_nxt = A_BYTES, a_fill = 2 * A_BYTES, b_cur = 0;
@@ -284,16 +340,30 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     // pieces: one per PRE_STRIDE steps: second half of B(kb+1), then A(kb+2)
                     if (step % PRE_STRIDE == 1) {
                         const int q = step / PRE_STRIDE;
-                        if (q < B_ITERS / 2)
+                        if constexpr (STAGED) {
+                            if (q < B_ITERS / 2)
+                                stage_write(q % DEPTH, B_BASE + (b_cur ^ B_BYTES) + (wave + NW * (B_ITERS / 2 + q)) * 1024);
+                            else
+                                stage_write(q % DEPTH, a_fill + (wave + NW * (q - B_ITERS / 2)) * 1024);
+                            stage_load(q % DEPTH, q + DEPTH, kb);
+                        } else if (q < B_ITERS / 2) {
                             issue_b_piece(b_cur ^ B_BYTES, kb + 1, B_ITERS / 2 + q);
-                        else
+                        } else {
                             issue_a_piece(a_fill, kb + 2, q - B_ITERS / 2);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- barrier Z ----
                 asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
+                if constexpr (STAGED) {
+                    // every piece of block kb+1 has been WRITTEN (lgkmcnt 0); the next quad's words, when tied here, were issued one
+                    // block earlier with N_POST + N_PRE staged loads behind them
+                    if (TIE_NEXT) __builtin_amdgcn_s_waitcnt(waitcnt_imm(N_POST + N_PRE, 0));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
+                }
                 if (TIE_NEXT) tie_e8q_landing<MS>(nxt);         // the next K quad's words (issued one block earlier) are in
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -307,8 +377,15 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
                     if (step == 4 && !NO_READS) af[0] = load_fragment(a_next_tile, frag_off);
                     if (step == 10 && !NO_READS) af[1] = load_fragment(a_next_tile + 2048, frag_off);
-                    if (step % POST_STRIDE == 1)
-                        issue_b_piece(b_cur, kb + 2, step / POST_STRIDE);   // B(kb)'s slot: its fragments have been in registers since the last block
+                    if (step % POST_STRIDE == 1) {
+                        if constexpr (STAGED) {
+                            const int pos = N_PRE + step / POST_STRIDE;
+                            stage_write(pos % DEPTH, B_BASE + b_cur + (wave + NW * (step / POST_STRIDE)) * 1024);
+                            stage_load(pos % DEPTH, pos + DEPTH, kb);
+                        } else {
+                            issue_b_piece(b_cur, kb + 2, step / POST_STRIDE);   // B(kb)'s slot: its fragments have been in registers since the last block
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int a_free = a_cur;
@@ -395,10 +472,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0>
+template <int BM, int BN, int QV = 0, bool STAGED = false>
 __global__ __launch_bounds__(256)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED>(p);
 }
 
 }  // namespace dg
