@@ -35,11 +35,23 @@ struct E8LandingQ { v4i sa[2]; int sb[8]; };
 
 // Packed scale words of one K quad: MS consecutive words of the lane's MS interleaved A rows (one or two dwordx4) and one
 // word per N-subtile for its B rows.  K quad in the soffset, the N-subtile in the immediate offset.  NOT valid until the wait.
-template <int MS>
+template <int MS, int NS = 8>
 __device__ __forceinline__ void issue_e8q_scale_loads(E8LandingQ& l, const v4i& sfa_rsrc, int sfa_voff, int sfa_soff,
                                                       const v4i& sfb_rsrc, int sfb_voff, int sfb_soff) {
-    static_assert(MS == 8 || MS == 4, "unrolled by hand");
-    if constexpr (MS == 8)
+    static_assert((MS == 8 || MS == 4) && (NS == 8 || (NS == 4 && MS == 8)), "unrolled by hand");
+    if constexpr (NS == 4)
+        asm volatile(
+            "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
+            "buffer_load_dwordx4 %0, %6, %7, %8 offen\n\t"
+            "buffer_load_dwordx4 %1, %6, %7, %8 offen offset:16\n\t"
+            "buffer_load_dword %2, %9, %10, %11 offen\n\t"
+            "buffer_load_dword %3, %9, %10, %11 offen offset:16\n\t"
+            "buffer_load_dword %4, %9, %10, %11 offen offset:128\n\t"
+            "buffer_load_dword %5, %9, %10, %11 offen offset:144"
+            : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3])
+            : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff), "v"(sfb_voff), "s"(sfb_rsrc), "s"(sfb_soff)
+            : "memory");
+    else if constexpr (MS == 8)
         asm volatile(
             "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
             "buffer_load_dwordx4 %0, %10, %11, %12 offen\n\t"
@@ -74,9 +86,11 @@ __device__ __forceinline__ void issue_e8q_scale_loads(E8LandingQ& l, const v4i& 
             : "memory");
 }
 
-template <int MS>
+template <int MS, int NS = 8>
 __device__ __forceinline__ void tie_e8q_landing(E8LandingQ& l) {
-    if constexpr (MS == 8)
+    if constexpr (NS == 4)
+        asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]) :: "memory");
+    else if constexpr (MS == 8)
         asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]), "+v"(l.sb[4]),
                           "+v"(l.sb[5]), "+v"(l.sb[6]), "+v"(l.sb[7]) :: "memory");
     else
@@ -122,17 +136,20 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // would have issued there (loaded half a K block earlier into one of POS / 2 staging registers of 16 bytes per lane) and
 // then LOADS the piece of position i + POS / 2 into the freed register -- so every piece is in LDS no later than before, and its global
 // load is in flight half a K block longer.
-template <int BM, int BN, int QV = 0, bool STAGED = false>
+// WAVES_N = 4 ("octo"): the same single-barrier schedule on EIGHT waves (2 x 4, wave tile 128 x 64, 128 accumulators in AGPRs: two
+// waves per SIMD fit the 512-entry register file).  Twice the waves issue the LDS-DMA pieces (8 per wave and K block: 0.82 us of fill
+// instead of 1.31), at the price of 192 instead of 128 KiB of fragment reads and two waves sharing each matrix pipe.
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
-    constexpr int NW = 4, WAVES_N = 2;
-    constexpr int WM = BM / 2, WN = BN / 2, MS = WM / 16, NS = WN / 16;
+    constexpr int NW = 2 * WAVES_N;
+    constexpr int WM = BM / 2, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int PRE = (MS - 2) * NS, POST = 2 * NS;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
     constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5), HOT_LOADS = (QV == 6);
-    static_assert(NS == 8 && (MS == 8 || MS == 4), "wave tiles 128 x 128 or 64 x 128");
+    static_assert((NS == 8 && (MS == 8 || MS == 4)) || (NS == 4 && MS == 8), "wave tiles 128 x 128, 64 x 128 or (eight waves) 128 x 64");
     constexpr int PRE_STRIDE = PRE / N_PRE, POST_STRIDE = POST / N_POST;
     static_assert(B_ITERS % 2 == 0 && PRE % N_PRE == 0 && POST % N_POST == 0 && PRE_STRIDE >= 2 && POST_STRIDE >= 2,
                   "one piece per PRE_STRIDE / POST_STRIDE steps");
@@ -217,7 +234,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 for (int j = 0; j < 4; ++j)
                     zero[ms][j] = v4f{0.f, 0.f, 0.f, 0.f};
             store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base);
-            store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base + 64);
+            if constexpr (NS == 8)
+                store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base + 64);
             advance();
             continue;
         }
@@ -288,7 +306,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             E8LandingQ cur, nxt;
             auto issue_scales = [&](E8LandingQ& l, int kq) {
                 const int q = imin(kq, num_kq - 1);
-                issue_e8q_scale_loads<MS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
+                issue_e8q_scale_loads<MS, NS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
             };
 
             // ---- prologue: A(0) B(0) words(0) | A(1) B(1)[first half]; wait for the first group only ----
@@ -303,7 +321,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             for (int q = 0; q < B_ITERS / 2; ++q) issue_b_piece(B_BYTES, 1, q);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
-            tie_e8q_landing<MS>(cur);
+            tie_e8q_landing<MS, NS>(cur);
             raw_barrier();
             if constexpr (STAGED) {
                 #pragma unroll
@@ -364,7 +382,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 } else {
                     __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
                 }
-                if (TIE_NEXT) tie_e8q_landing<MS>(nxt);         // the next K quad's words (issued one block earlier) are in
+                if (TIE_NEXT) tie_e8q_landing<MS, NS>(nxt);         // the next K quad's words (issued one block earlier) are in
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
@@ -375,8 +393,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
                     if ((step & 1) && !NO_READS)
                         bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
-                    if (step == 4 && !NO_READS) af[0] = load_fragment(a_next_tile, frag_off);
-                    if (step == 10 && !NO_READS) af[1] = load_fragment(a_next_tile + 2048, frag_off);
+                    if (step == POST / 4 && !NO_READS) af[0] = load_fragment(a_next_tile, frag_off);
+                    if (step == (POST * 5) / 8 && !NO_READS) af[1] = load_fragment(a_next_tile + 2048, frag_off);
                     if (step % POST_STRIDE == 1) {
                         if constexpr (STAGED) {
                             const int pos = N_PRE + step / POST_STRIDE;
@@ -459,7 +477,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, out, m_base, n_base + 64 * G);
             };
             store_half(std::integral_constant<int, 0>{});
-            store_half(std::integral_constant<int, 1>{});
+            if constexpr (NS == 8)
+                store_half(std::integral_constant<int, 1>{});
         }
         if (p.dbg != nullptr && tile_id == static_cast<int>(blockIdx.x) && pass == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -472,10 +491,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false>
-__global__ __launch_bounds__(256)
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2>
+__global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N>(p);
 }
 
 }  // namespace dg
