@@ -585,6 +585,12 @@ def test_split_k_tail_full_size_and_small_workspace(monkeypatch):
     gen.reset_seed(12)
     case, tiles, cus = _split_k_case([520, 500, 640, 400, 512, 700, 384, 512], 4096, 7168, False, 128)
     assert tiles % cus != 0
+    # (round 3: the automatic selection takes the group-relative tile table for this shape -- test_m_grouped_contiguous_group_relative_tiles;
+    # the K-split tail of the 128-row walk is what is under test here, by name)
+    dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
+    assert dg.last_config() == 'duo_tab_256x256' and calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+    dg.set_forced_config('duo_sk_128x256')
+    case.d.fill_(float('nan'))
     dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, case.d, case.grouped_layout)
     assert dg.last_config() == 'duo_sk_128x256'
     assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
