@@ -2863,10 +2863,13 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
 // 16-byte chunks g and g + 4 of both operands (the same bijection on both sides leaves the contraction unchanged), so each of the
 // two loads of a fragment covers 64 contiguous bytes per row.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MS>
+// (Round 3, negative: MS = 4 / 8 with CH = 2 / 1 K blocks per chunk for M <= 64 / 128 -- every workgroup re-reads the whole A through
+// L2, 16 half-used cache lines per load instruction: 64 x 4096 x 7168 22.5 us against 21.0 on the stream tiles, 128 x 4096 x 7168 41.9
+// against 21.3.  Not instantiated.)
+template <int MS, int CH = 4>
 __global__ __launch_bounds__(512)
 void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
-    constexpr int NW = 8, CH = 4;                               // K blocks per software-pipeline chunk (two chunks in flight)
+    constexpr int NW = 8;                                       // CH: K blocks per software-pipeline chunk (two chunks in flight)
     __shared__ float red[NW][MS][256];
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -44,10 +44,10 @@ for m in ms:
         dg.fp8_gemm_nt(a, case.b, case.d)
         rec['auto'] = dg.last_config()
         want = torch.empty((m, n), dtype=torch.bfloat16)
-        oracle.fp8_gemm_nt(case.a[0].cpu(), case.a[1].cpu(), case.b[0].cpu(), case.b[1].cpu(), want)
+        oracle.fp8_gemm_nt(case.a[0].cpu(), case.a[1].cpu(), case.b[0].cpu(), case.b[1].cpu(), want) if m <= 32 else want.copy_(case.ref_d)
         rec['calc_diff_vs_oracle'] = calc_diff(case.d.cpu(), want)
         rec['max_abs_err_over_rms'] = float((case.d.cpu().float() - want.float()).abs().max() / want.float().pow(2).mean().sqrt())
-        for cfg in ('auto', 'stream_64x32', 'stream_64x128'):
+        for cfg in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('auto', 'stream_64x32', 'stream_64x128')):
             dg.set_forced_config(cfg)
             try:
                 rec[f'us_{cfg}'] = round(timed(lambda: dg.fp8_gemm_nt(a, case.b, case.d)), 1)
