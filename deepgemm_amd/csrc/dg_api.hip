@@ -247,6 +247,12 @@ bool fast_eligible(const dg::GemmParams& p, bool whole_k_blocks = true) {
     return true;
 }
 
+// The stream kernels fetch the row scales of four K blocks with 16-byte requests: MN-major SFA whose K-block rows start on 16-byte
+// boundaries (what get_mn_major_tma_aligned_tensor produces: rows padded to a multiple of four floats).
+bool sfa_quads_ok(const dg::GemmParams& p) {
+    return p.sfa_sm == 1 && aligned16(p.sfa) && p.sfa_sk % 4 == 0 && p.sfa_sg % 4 == 0;
+}
+
 // A K-major, B MN-major ([K][N], unit stride along n): the B_MN forms of the duo kernels.
 bool bmn_eligible(const dg::GemmParams& p) {
     return p.sfb_gran_n == 128 && p.a_sk == 1 && p.b_sn == 1 && p.b_sk != 1 && (p.k % 128 == 0 || k_extent_ok(p.k, p.gemm_type != dg::kNormal)) &&
@@ -392,7 +398,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     // kernels.  A CU sustains only ~25 GB/s of HBM stream (bytes in flight / latency), so the tile count has to cover
     // the chip: 64 x 128 tiles when there are enough of them, 64 x 32 otherwise (measured: tools/ref_shapes.py).
     const int m_hint = expected_m > 0 ? expected_m : m_for_tiling;
-    if (fast_ok && p.sfa_sm == 1 && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum) {
+    if (fast_ok && sfa_quads_ok(p) && p.gemm_type != dg::kContiguous && p.gemm_type != dg::kContiguousPsum) {
         const int groups = (p.gemm_type == dg::kMasked) ? p.num_groups : 1;
         const long tiles128 = static_cast<long>(groups) * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
         const char* pick = nullptr;
@@ -580,6 +586,10 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     }
     if (std::strncmp(cfg->name, "skinny", 6) == 0 && (p.m > cfg->bm || p.gemm_type != dg::kNormal || p.head_lr != 0)) {
         g_last_error = std::string("forced config '") + cfg->name + "' implements dense problems with m <= its row count";
+        return 3;
+    }
+    if (std::strncmp(cfg->name, "stream", 6) == 0 && !sfa_quads_ok(p)) {
+        g_last_error = std::string("forced config '") + cfg->name + "' needs MN-major SFA with 16-byte aligned K-block rows";
         return 3;
     }
     if (p.k % 128 != 0 && cfg->fast && !cfg->k_tail) {

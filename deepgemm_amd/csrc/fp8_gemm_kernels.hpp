@@ -2171,12 +2171,23 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int SFB_PIECES = E8 ? (BN + 63) / 64 : 1;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256 * SFB_PIECES;
-    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = SFB_OFF + SFB_BYTES;
+    // FP32 scales (GSF): the scales do NOT ride in the stages.  An LDS-DMA instruction costs its wave ~57 (4 bytes per lane) to ~83 ns
+    // (16 bytes per lane) whatever it moves (profiles/r03_fill/NOTES.md), and the two scale pieces per K block that every wave used to
+    // issue were 114 of the 612 ns a wave spends per K block of a 64 x 128 tile (363 for 64 x 32).  Now ONE 16-byte-per-lane piece
+    // carries the 64 row scales of FOUR K blocks (lane l: rows 4 (l & 15) .. + 3 of block 4 g + (l >> 4): the MN-major layout makes a
+    // lane's four rows contiguous) and one 4-byte piece the four SFB values: 35 ns per K block.  They live in a ring of four group
+    // slots behind the stages and are issued in front of the data pieces of the group's first block.
+    constexpr bool GSF = !E8;
+    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = GSF ? A_BYTES + B_BYTES : SFB_OFF + SFB_BYTES;
     constexpr int STAGE_BYTES = KBS * BLOCK_BYTES;
-    constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    constexpr int SFG_OFF = STAGES * STAGE_BYTES, SFG_SLOT = 1024 + 256, SFG_SLOTS = 4;
+    constexpr int LDS_BYTES = SFG_OFF + (GSF ? SFG_SLOTS * SFG_SLOT : 0);
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
-    constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + 1 + SFB_PIECES) * KBS;      // per wave per stage, scale pieces included
+    // per wave per stage; GSF: the group pieces (two per four K blocks) are NOT counted -- the counted waits then ask for up to two
+    // more of the younger pieces than needed (stricter, never looser; the ring has STAGES - 2 stages of slack)
+    constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + (GSF ? 0 : 1 + SFB_PIECES)) * KBS;
+    static_assert(!GSF || STAGES * KBS <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
     static_assert(!E8 || MS == 4 || MS == 1, "packed-scale form: a lane reads its MS row words with one LDS read");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA piece and one SFB value per tile");
@@ -2231,17 +2242,30 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             const int num_sf_k = E8 ? (num_kb + 3) / 4 : num_kb;
             float* sfa_tile = const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0;
             const int sfa_rows = imin(p.m - t.m0, BM);
-            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_sf_k - 1) * sfa_kb_stride + sfa_rows * 4, 0x00020000);
+            // (GSF: 16-byte requests -- the MN-major layout pads the rows to a multiple of four, so a request that starts below sfa_rows is whole)
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_sf_k - 1) * sfa_kb_stride + (GSF ? (sfa_rows + 3) / 4 * 4 : sfa_rows) * 4, 0x00020000);
             float* sfb_tile = const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg +
                               (E8 ? static_cast<int64_t>(t.n0) : static_cast<int64_t>(t.n0 / 128) * p.sfb_sn);
             const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_sf_k - 1) * sfb_kb_stride + (E8 ? imin(p.n - t.n0, BN) * 4 : 4),
                                                                   0x00020000);
+            const int sfg_a_voff = (lane >> 4) * sfa_kb_stride + (lane & 15) * 16, sfg_b_voff = (lane & 3) * sfb_kb_stride;
 
             // All pieces of K block j into ring slot j % STAGES (slot_off in bytes).  Blocks past the end are issued as
             // out-of-range no-ops so that the vmcnt arithmetic stays exact.
             auto issue_block = [&](int slot_off, int j) {
                 const unsigned oob = j < num_kb ? 0u : OOB;
                 uint8_t* stage = lds + slot_off;
+                if constexpr (GSF) {
+                    if ((j & 3) == 0) {                         // the scales of K blocks j .. j + 3 (blocks past the end: out of range, zeros)
+                        uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
+                            static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), j * sfb_kb_stride, 0, 0);
+                    }
+                }
                 #pragma unroll
                 for (int q = 0; q < (NO_A ? 0 : A_ITERS); ++q) {
                     const int unit = wave + NW * q;
@@ -2257,6 +2281,8 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, B_AUX & 3);
                 }
+                if constexpr (GSF)
+                    return;
                 // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
                 const int jsf = E8 ? j >> 2 : j;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -2330,13 +2356,15 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     continue;
                 }
                 float sa[MS];
+                const int jb = sb * KBS + u;                                                       // this K block
+                const uint8_t* sfg = lds + SFG_OFF + ((jb >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;     // its group's slot: [4 blocks][64 rows], then 4 SFB values
                 if constexpr (MS == 4) {
-                    const v4f q = *reinterpret_cast<const v4f*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                    const v4f q = *reinterpret_cast<const v4f*>(sfg + (jb & 3) * 256 + (wm * WM + (lane & 15) * MS) * 4);
                     sa[0] = q[0]; sa[1] = q[1]; sa[2] = q[2]; sa[3] = q[3];
                 } else {
-                    sa[0] = *reinterpret_cast<const float*>(stage + SFA_OFF + (wm * WM + (lane & 15)) * 4);
+                    sa[0] = *reinterpret_cast<const float*>(sfg + (jb & 3) * 256 + (wm * WM + (lane & 15)) * 4);
                 }
-                const float sb = *reinterpret_cast<const float*>(stage + SFB_OFF);
+                const float sb_val = *reinterpret_cast<const float*>(sfg + 1024 + (jb & 3) * 4);
                 const uint8_t* a_tile = stage + (wm * WM) * 128;
                 const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;
                 v8i bf[NS];
@@ -2346,7 +2374,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms) {
                     const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
-                    const float scale = sa[ms] * sb;
+                    const float scale = sa[ms] * sb_val;
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns) {
                         const v4f part = mfma_fp8_k128(bf[ns], af);

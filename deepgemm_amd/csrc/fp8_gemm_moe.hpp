@@ -54,11 +54,15 @@ struct SwigluOut {
 template <int STAGES>
 __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, const SwigluOut& o) {
     constexpr int BM = 64, BN = 128, NW = 4, WM = 64, WN = 32, MS = 4, NS = 2;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256;
-    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, STAGE_BYTES = SFB_OFF + SFB_BYTES;
-    constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    // scales: one 16-byte-per-lane piece = the 64 row scales of FOUR K blocks, one 4-byte piece = their (gate, up) SFB pairs, in a ring
+    // of four group slots behind the stages (stream_kernel_body says why); not counted in PIECES (the counted waits get stricter)
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int SFG_OFF = STAGES * STAGE_BYTES, SFG_SLOT = 1024 + 256, SFG_SLOTS = 4;
+    constexpr int LDS_BYTES = SFG_OFF + SFG_SLOTS * SFG_SLOT;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    constexpr int PIECES = A_ITERS + B_ITERS + 2;
+    constexpr int PIECES = A_ITERS + B_ITERS;
+    static_assert(STAGES <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
     constexpr unsigned OOB = 0x80000000u;
     static_assert((STAGES - 1) * PIECES < 64 && LDS_BYTES <= 160 * 1024 && STAGES >= 3, "ring geometry");
     static_assert(2 * (MS * NS * 4) * 64 * 4 + 3 * 64 * 4 <= LDS_BYTES, "the epilogue exchange fits in the ring's LDS");
@@ -117,15 +121,27 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
             const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
             float* sfa_tile = const_cast<float*>(p.sfa) + group * p.sfa_sg + t.m0;
             const int sfa_rows = imin(p.m - t.m0, BM);
-            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_kb - 1) * sfa_kb_stride + sfa_rows * 4, 0x00020000);
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_kb - 1) * sfa_kb_stride + (sfa_rows + 3) / 4 * 16, 0x00020000);
+            const int sfg_a_voff = (lane >> 4) * sfa_kb_stride + (lane & 15) * 16;
             // two SFB values per tile: the 128 x 128 scale blocks its 64 gate rows and its 64 up rows were quantised in
             float* sfb_tile = const_cast<float*>(p.sfb) + group * p.sfb_sg + static_cast<int64_t>(t.n0 / 256) * 2 * p.sfb_sn;
             const int sfb_sn_bytes = static_cast<int>(p.sfb_sn) * 4;
             const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_kb - 1) * sfb_kb_stride + sfb_sn_bytes + 4, 0x00020000);
+            // SFB piece: lane l -> K block (l & 3) of the group, gate (l & 4 == 0) or up scale row: [gate x 4][up x 4] floats in the slot
+            const int sfg_b_voff = (lane & 3) * sfb_kb_stride + ((lane >> 2) & 1) * sfb_sn_bytes;
 
             auto issue_block = [&](int slot_off, int j) {
                 const unsigned oob = j < num_kb ? 0u : OOB;
                 uint8_t* stage = lds + slot_off;
+                if ((j & 3) == 0) {                             // the scales of K blocks j .. j + 3
+                    uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                        static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
+                        static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), j * sfb_kb_stride, 0, 0);
+                }
                 #pragma unroll
                 for (int q = 0; q < A_ITERS; ++q) {
                     const int unit = wave + NW * q;
@@ -141,12 +157,6 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, DG_SWIGLU_B_AUX);   // nt: weights stream once
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    sfa_rsrc, (__attribute__((address_space(3))) void*)(stage + SFA_OFF), 4,
-                    static_cast<int>(static_cast<unsigned>(lane * 4 + j * sfa_kb_stride) | oob), 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(                   // lanes 0..31: the gate block's scale, lanes 32..63: the up block's
-                    sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF), 4,
-                    static_cast<int>(static_cast<unsigned>((lane >> 5) * sfb_sn_bytes + j * sfb_kb_stride) | oob), 0, 0, 0);
             };
             #pragma unroll
             for (int j = 0; j < STAGES - 1; ++j)
@@ -158,9 +168,10 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                 raw_barrier();
                 issue_block(fill, kb + STAGES - 1);
                 const uint8_t* stage = lds + cur;
-                const v4f q = *reinterpret_cast<const v4f*>(stage + SFA_OFF + ((lane & 15) * MS) * 4);
+                const uint8_t* sfg = lds + SFG_OFF + ((kb >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;      // [4 blocks][64 rows], then [gate x 4][up x 4]
+                const v4f q = *reinterpret_cast<const v4f*>(sfg + (kb & 3) * 256 + ((lane & 15) * MS) * 4);
                 const float sa[MS] = {q[0], q[1], q[2], q[3]};
-                const float sb = *reinterpret_cast<const float*>(stage + SFB_OFF + (wn >> 1) * 128);
+                const float sb = *reinterpret_cast<const float*>(sfg + 1024 + (wn >> 1) * 16 + (kb & 3) * 4);
                 const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;
                 v8i bf[NS];
                 #pragma unroll
