@@ -224,6 +224,11 @@ const E8Config kE8Configs[] = {
     {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, 256, 256, true, false, false},
     {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, 256, 256, true, false, false},
     {"e8_octo_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 4>, 256, 256, 512, true, true, false},
+    {"e8_quad_v7", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 7>, 256, 256, 256, true, false, false},
+    {"e8_octo_v7", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 7, false, 4>, 256, 256, 512, true, false, false},
+    {"e8_octo_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1, false, 4>, 256, 256, 512, true, false, false},
+    {"e8_octo_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2, false, 4>, 256, 256, 512, true, false, false},
+    {"e8_octo_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3, false, 4>, 256, 256, 512, true, false, false},
     {"e8_quad_s_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, true>, 256, 256, 256, true, true, false},
     {"e8_quad_s_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, true>, 128, 256, 256, false, true, false},
     {"e8_quad_s_v6", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 6, true>, 256, 256, 256, true, false, false},

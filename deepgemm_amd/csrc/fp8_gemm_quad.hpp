@@ -124,7 +124,8 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 
 // QV (timing experiments, DG_EXPERIMENTS builds only; results are garbage):
 //   0 production; 1 no LDS-DMA in the loop; 2 no fragment reads in the loop; 3 neither (matrix stream + barrier);
-//   5 no barrier in the loop; 6 (STAGED) every staged load re-reads K block 0 (cache hits: what does memory latency cost?).
+//   5 no barrier in the loop; 6 (STAGED) every staged load re-reads K block 0 (cache hits: what does memory latency cost?);
+//   7 every LDS-DMA piece re-reads K block 0 (same instructions, cache hits only).
 // BM = 256: wave tile 128 x 128 (MS = 8), the dense / large contiguous form; BM = 128: wave tile 64 x 128 (MS = 4) for the
 // grouped layouts whose M alignment is 128 rows (contiguous, psum, masked) and for small dense problems.
 // STAGED: the operand bytes go global -> VGPR -> ds_write_b128 instead of through LDS-DMA.  Why: a buffer_load ... lds of 1 KiB costs
@@ -148,7 +149,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
-    constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5), HOT_LOADS = (QV == 6);
+    constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5), HOT_LOADS = (QV == 6), HOT_DMA = (QV == 7);
     static_assert((NS == 8 && (MS == 8 || MS == 4)) || (NS == 4 && MS == 8), "wave tiles 128 x 128, 64 x 128 or (eight waves) 128 x 64");
     constexpr int PRE_STRIDE = PRE / N_PRE, POST_STRIDE = POST / N_POST;
     static_assert(B_ITERS % 2 == 0 && PRE % N_PRE == 0 && POST % N_POST == 0 && PRE_STRIDE >= 2 && POST_STRIDE >= 2,
@@ -267,22 +268,22 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 if constexpr (STAGED)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_voff,
-                        a_piece_soff[q] + imin(j, num_kb - 1) * 128, 0, 0);
+                        a_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_piece_voff[q],
-                        imin(j, num_kb - 1) * 128, 0, 0);
+                        (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
             };
             auto issue_b_piece = [&](int slot_off, int j, int q) {
                 if (NO_DMA) return;
                 if constexpr (STAGED)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
-                        b_voff, b_piece_soff[q] + imin(j, num_kb - 1) * 128, 0, 0);
+                        b_voff, b_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
-                        b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+                        b_piece_voff[q], (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
             };
             // STAGED: position `pos` (0 .. POS - 1: N_PRE in rows 0 .. MS-3, N_POST in the last two rows; >= POS: the next block's) of
             // block kb is: second half of B(kb+1) | A(kb+2) | first half of B(kb+2)
