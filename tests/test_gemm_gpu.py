@@ -1250,3 +1250,34 @@ def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
     fixed = torch.empty_like(case.d)
     dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, fixed, case.grouped_layout)
     assert calc_diff(outs[0], fixed) < 2e-6           # (K pieces are summed in piece order: not the same bits as an unsplit K loop)
+
+
+def test_stream_kernels_need_aligned_scale_rows():
+    """The stream kernels fetch the row scales of four K blocks with 16-byte requests (round 3): an MN-major SFA whose K-block rows do
+    not start on 16-byte boundaries (a direct C-ABI caller: the host layer always produces the padded layout) takes another kernel --
+    same result, bit for bit -- and forcing a stream kernel onto it is refused."""
+    from deepgemm_amd._lib import lib, current_stream_ptr
+    gen.reset_seed(5)
+    m, n, k = 50, 4096, 1024
+    case = gen.generate_normal(m, n, k)
+    a, sfa = case.a
+    b, sfb = case.b
+    aligned = dg.get_mn_major_tma_aligned_tensor(sfa)                       # strides (1, 52)
+    dg.fp8_gemm_nt((a, aligned), case.b, case.d)
+    assert dg.last_config().startswith('stream_')
+    want = case.d.clone()
+    packed = torch.empty((k // 128) * m + 3, dtype=torch.float, device='cuda')[1:1 + (k // 128) * m]      # base 4 bytes off, K-block rows 200 bytes apart
+    odd = torch.as_strided(packed, (m, k // 128), (1, m))
+    odd.copy_(sfa)
+
+    def raw(d):
+        return lib.dg_fp8_gemm_nt(a.data_ptr(), odd.data_ptr(), b.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k, a.stride(0), a.stride(1),
+                                  b.stride(0), b.stride(1), odd.stride(0), odd.stride(1), sfb.stride(0), sfb.stride(1), 128, d.stride(0), 0, 0,
+                                  current_stream_ptr())
+    got = torch.full_like(want, float('nan'))
+    assert raw(got) == 0
+    assert not dg.last_config().startswith('stream_')
+    assert torch.equal(got, want)
+    dg.set_forced_config('stream_64x128')
+    assert raw(got) != 0
+    dg.set_forced_config('auto')
