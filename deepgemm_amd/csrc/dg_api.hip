@@ -709,9 +709,14 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
     int32_t* header = static_cast<int32_t*>(base.sk_workspace);
     int32_t* big = header;                   // [0] count, [1 ..] first rows: at most nb / 2 entries
     int32_t* rem = header + 512;             // at most nb entries (nb <= 500)
-    hipLaunchKernelGGL(dg::dg_build_contiguous_tile_table_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       base.layout, base.m, big, rem);
-    DG_HIP_CHECK(hipGetLastError());
+    // up to 64 blocks (M <= 8192: C4 has 36) every workgroup derives the tile list itself (GemmParams::table_mode): no table kernel and no
+    // kernel boundary in front of the GEMM (the builder cost C4 6.2 us of 141.5)
+    const bool in_kernel = nb <= 64 && getenv("DG_TABLE_KERNEL") == nullptr;
+    if (!in_kernel) {
+        hipLaunchKernelGGL(dg::dg_build_contiguous_tile_table_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           base.layout, base.m, big, rem);
+        DG_HIP_CHECK(hipGetLastError());
+    }
     const size_t elem = 2;
     auto common = [&](dg::GemmParams& q, int bm) {
         q.num_m_tiles = ceil_div(q.m, bm);      // upper bound (grouping, grid); the table holds the real count
@@ -723,7 +728,8 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
     };
     {   // the 256-row tiles
         dg::GemmParams q = base;
-        q.tile_table = big;
+        q.tile_table = in_kernel ? nullptr : big;
+        q.table_mode = in_kernel ? 1 : 0;
         q.sk_workspace = nullptr; q.sk_first_tile = 0; q.sk_tiles = 0; q.sk_factor = 1; q.sk_capacity = 0;
         common(q, 256);
         const long items = static_cast<long>(nb / 2) * n_tiles;
@@ -735,7 +741,8 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
     }
     {   // the remainders, all K-split
         dg::GemmParams r = base;
-        r.tile_table = rem;
+        r.tile_table = in_kernel ? nullptr : rem;
+        r.table_mode = in_kernel ? 2 : 0;
         common(r, 128);
         r.sk_capacity = static_cast<int>(std::min<size_t>((g_workspace_bytes - 4096) / tile_bytes, 1u << 20));
         // pieces: at most 8 and one per K block, and only where a split pays at all (split_k_pays); how many of them a launch really

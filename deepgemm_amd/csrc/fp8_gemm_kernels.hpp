@@ -77,6 +77,10 @@ struct GemmParams {
     // along K: the tile count is only known on the device, so are the pieces -- min(sk_factor, sk_capacity / tiles), see table_pieces().
     const int32_t* tile_table;
     int sk_capacity;                // FP32 partial tiles the workspace holds (table launches)
+    // table_mode 1 / 2: the same tiling WITHOUT the table kernel, for layouts of at most 64 blocks of 128 rows (M <= 8192): every
+    // workgroup derives the tile list itself from one 64-lane load of the blocks' group ids (contiguous_tile_mask: the first blocks of
+    // the 256-row tiles (1) or the 128-row remainders and padding blocks (2) as a bit mask).  tile_table stays nullptr.
+    int table_mode;
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
@@ -125,7 +129,38 @@ __device__ __forceinline__ int table_pieces(const GemmParams& p, int tiles) {
 
 // Maps a linear tile id to a tile for every GEMM type (reference scheduler semantics:
 // deep_gemm/include/deep_gemm/scheduler/gemm.cuh:156-237, :311-319).  `state` carries the masked-layout walk.
-struct MaskedWalk { int group = 0; int cum_m_tiles = 0; };
+struct MaskedWalk { int group = 0; int cum_m_tiles = 0; unsigned long long table_mask = 0; };
+
+__device__ __forceinline__ bool table_launch(const GemmParams& p) { return p.tile_table != nullptr || p.table_mode != 0; }
+
+// The tile list of dg_build_contiguous_tile_table_kernel as a bit mask over the layout's (at most 64) blocks of 128 rows, computed by a
+// whole wave: a run of blocks of one group is cut into 256-row tiles from ITS first block (mode 1: bit = first block of such a tile); an odd
+// run leaves its last block, and every block of padding rows (-1) stands alone (mode 2).  Call with all 64 lanes active.
+__device__ __forceinline__ unsigned long long contiguous_tile_mask(const int32_t* __restrict__ layout, int m, int mode) {
+    const int lane = threadIdx.x & 63, nb = (m + 127) / 128;
+    const int g = lane < nb ? layout[lane * 128] : -2;
+    const int g_prev = __shfl_up(g, 1, 64);
+    const bool starts = lane == 0 || g != g_prev || g < 0;
+    const unsigned long long start_mask = __ballot(starts);
+    const unsigned long long at_or_below = start_mask & ((2ull << lane) - 1ull);
+    const int pos = lane - (63 - __builtin_clzll(at_or_below));                           // position inside the run (lane 0 always starts one)
+    const bool next_same = g >= 0 && lane + 1 < nb && !((start_mask >> (lane + 1)) & 1ull);
+    const bool big_first = g >= 0 && (pos & 1) == 0 && next_same;
+    const bool rem = lane < nb && (g < 0 || ((pos & 1) == 0 && !next_same));
+    return __ballot(mode == 1 ? big_first : rem);
+}
+
+__device__ __forceinline__ int kth_set_bit(unsigned long long mask, int k) {
+    for (int i = 0; i < k; ++i)
+        mask &= mask - 1ull;
+    return __builtin_ctzll(mask);
+}
+__device__ __forceinline__ int table_count(const GemmParams& p, const MaskedWalk& w) {
+    return p.tile_table != nullptr ? p.tile_table[0] : __builtin_popcountll(w.table_mask);
+}
+__device__ __forceinline__ int table_first_row(const GemmParams& p, const MaskedWalk& w, int i) {
+    return p.tile_table != nullptr ? p.tile_table[1 + i] : kth_set_bit(w.table_mask, i) * 128;
+}
 
 template <int BM, int BN>
 __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, MaskedWalk& walk, int pass = 0) {
@@ -153,13 +188,13 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
         t.m_begin = t.m0;
         return t;
     }
-    if (p.tile_table != nullptr) {
+    if (table_launch(p)) {
         // contiguous layout through a tile table: group-relative M tiles (no tile straddles two groups), see GemmParams::tile_table
-        const int count = p.tile_table[0], total = count * p.num_n_tiles;
+        const int count = table_count(p, walk), total = count * p.num_n_tiles;
         if (tile_id >= total) { t.valid = false; return t; }
         int mt, nt;
         swizzled_tile(tile_id, total, count, p.num_n_tiles, p.group_m, mt, nt);
-        t.m0 = p.tile_table[1 + mt];
+        t.m0 = table_first_row(p, walk, mt);
         t.n0 = nt * BN;
         t.m_begin = t.m0;
         t.m_end = imin(t.m0 + BM, p.m);
@@ -1502,6 +1537,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     long long t_loop0 = 0, t_loop1 = 0;
 
     MaskedWalk walk;
+#ifndef DG_NO_TABLE_MASK
+    if constexpr (PERSIST && !A_MN && !B_MN && !K_TAIL)         // (the launches of launch_contiguous_tabled)
+        if (p.table_mode != 0)
+            walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
+#endif
     const int num_launched = gridDim.x;
     const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
     const int k_tail = K_TAIL ? (p.k & 127) : 0;    // a partial last K block (multiple of 16 bytes): handled after the loop, see below
@@ -1610,9 +1650,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         pc = Piece{0, num_kb, 0, 0, 1, false};
         if constexpr (SPLITK) {
             // table launch: every tile is a split tile, count and pieces come from the device-side table
-            const int sk_first = p.tile_table != nullptr ? 0 : p.sk_first_tile;
-            const int sk_tiles = p.tile_table != nullptr ? p.tile_table[0] * p.num_n_tiles : p.sk_tiles;
-            const int sk_factor = p.tile_table != nullptr ? table_pieces(p, sk_tiles) : p.sk_factor;
+            const int sk_first = table_launch(p) ? 0 : p.sk_first_tile;
+            const int sk_tiles = table_launch(p) ? table_count(p, walk) * p.num_n_tiles : p.sk_tiles;
+            const int sk_factor = table_launch(p) ? table_pieces(p, sk_tiles) : p.sk_factor;
             if (id >= sk_first && sk_factor >= 2) {
                 const int w = id - sk_first;
                 if (w >= sk_tiles * sk_factor) {
@@ -2104,8 +2144,10 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
     const int tail = blockIdx.x / MS, ms_mine = blockIdx.x % MS;
     MaskedWalk walk;
     int sk_first = p.sk_first_tile, sk_factor = p.sk_factor;
-    if (p.tile_table != nullptr) {              // table launch: the grid is an upper bound, tile count and pieces live on the device
-        const int sk_tiles = p.tile_table[0] * p.num_n_tiles;
+    if (p.table_mode != 0)
+        walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
+    if (table_launch(p)) {                      // table launch: the grid is an upper bound, tile count and pieces live on the device
+        const int sk_tiles = table_count(p, walk) * p.num_n_tiles;
         sk_first = 0;
         sk_factor = table_pieces(p, sk_tiles);
         if (tail >= sk_tiles || sk_factor < 2)
