@@ -137,6 +137,38 @@ __global__ __launch_bounds__(1024) void fill_lds_valu_kernel(const uint8_t* base
         sink[blockIdx.x] = reinterpret_cast<int*>(lds)[blockIdx.x & 1023] + static_cast<int>(t);
 }
 
+// LDS-DMA next to a matrix stream: one x4 LDS-DMA + NMFMA register-resident v_mfma_f32_16x16x128_f8f6f4 per step (and, READS > 0, that
+// many ds_read_b128 of 1 KiB each): what is left of the LDS-DMA rate when the matrix pipe and the LDS read port are busy?
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <int NMFMA, int READS>
+__global__ __launch_bounds__(1024) void fill_lds_mfma_kernel(const uint8_t* base, size_t wg_stride, unsigned region_mask, int steps, int* sink) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[128 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint8_t* mine = base + static_cast<size_t>(blockIdx.x) * wg_stride;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(mine), 0, 0x7fffffff, 0x00020000);
+    const unsigned slots = 128u / waves;
+    v8i_t a = {lane, 1, 2, 3, 4, 5, 6, 7}, b = {7, 6, 5, 4, 3, 2, 1, lane};
+    v4f_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    v4i rd = {0, 0, 0, 0};
+    for (int s = 0; s < steps; ++s) {
+        const unsigned off = (static_cast<unsigned>(s * waves + wave) * 1024u) & region_mask;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (wave * slots + (s % slots)) * 1024), 16,
+                                                 lane * 16, off, 0, 0);
+        #pragma unroll
+        for (int i = 0; i < NMFMA; ++i)
+            asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(acc[i & 3]) : "v"(a), "v"(b));
+        #pragma unroll
+        for (int i = 0; i < READS; ++i)
+            rd ^= *reinterpret_cast<const v4i*>(lds + ((wave * slots + ((s + 3 + i) % slots)) * 1024) + lane * 16);
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (sink != nullptr && threadIdx.x == 0)
+        sink[blockIdx.x] = reinterpret_cast<int*>(lds)[blockIdx.x & 1023] + static_cast<int>(acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0]) + rd[0];
+}
+
 // Half the bytes as LDS-DMA, half as global -> VGPR -> ds_write_b128: do the two paths add up?
 template <int DEPTH>
 __global__ __launch_bounds__(1024) void fill_mixed_kernel(const uint8_t* base, size_t wg_stride, unsigned region_mask, int steps, int* sink) {
@@ -202,8 +234,10 @@ int main() {
         {"dma+0fma", fill_lds_valu_kernel<0>, 8}, {"dma+16fma", fill_lds_valu_kernel<16>, 8}, {"dma+32fma", fill_lds_valu_kernel<32>, 8},
         {"dma+64fma", fill_lds_valu_kernel<64>, 8},
         {"mixed", fill_mixed_kernel<4>, 8}, {"mixed", fill_mixed_kernel<8>, 16},
+        {"dma+2mfma", fill_lds_mfma_kernel<2, 0>, 8}, {"dma+4mfma", fill_lds_mfma_kernel<4, 0>, 8}, {"dma+8mfma", fill_lds_mfma_kernel<8, 0>, 8},
+        {"dma+4mfma+2rd", fill_lds_mfma_kernel<4, 2>, 8}, {"dma+4mfma+4rd", fill_lds_mfma_kernel<4, 4>, 8}, {"dma+0mfma+2rd", fill_lds_mfma_kernel<0, 2>, 8},
     };
-    printf("%-8s %-4s %5s %5s %5s %10s %10s %12s\n", "path", "src", "wgs", "waves", "depth", "GB/s", "GB/s/CU", "KiB in flight/CU");
+    printf("%-14s %-4s %5s %5s %5s %10s %10s %12s\n", "path", "src", "wgs", "waves", "depth", "GB/s", "GB/s/CU", "KiB in flight/CU");
     for (const char* src : {"l2", "hbm"})
         for (int wgs : {256})
             for (int waves : {4, 8, 16})
@@ -215,7 +249,7 @@ int main() {
                     const unsigned mask = l2 ? (1u << 20) - 1 : static_cast<unsigned>(total / 256 - 1);
                     const int steps = l2 ? 65536 / waves : static_cast<int>(total / 256 / 1024 / waves);     // l2: 64 MiB per workgroup; hbm: its 8 MiB once
                     const double gbs = run(kr.k, wgs, waves, buf, stride, mask, steps, sink);
-                    printf("%-8s %-4s %5d %5d %5d %10.0f %10.1f %12d\n", kr.name, src, wgs, waves, kr.depth, gbs, gbs / wgs, waves * kr.depth);
+                    printf("%-14s %-4s %5d %5d %5d %10.0f %10.1f %12d\n", kr.name, src, wgs, waves, kr.depth, gbs, gbs / wgs, waves * kr.depth);
                 }
     return 0;
 }
