@@ -364,13 +364,17 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                                 stage_write(q % DEPTH, B_BASE + (b_cur ^ B_BYTES) + (wave + NW * (B_ITERS / 2 + q)) * 1024);
                             else
                                 stage_write(q % DEPTH, a_fill + (wave + NW * (q - B_ITERS / 2)) * 1024);
-                            stage_load(q % DEPTH, q + DEPTH, kb);
+                            if constexpr (PRE_STRIDE < 4)
+                                stage_load(q % DEPTH, q + DEPTH, kb);
                         } else if (q < B_ITERS / 2) {
                             issue_b_piece(b_cur ^ B_BYTES, kb + 1, B_ITERS / 2 + q);
                         } else {
                             issue_a_piece(a_fill, kb + 2, q - B_ITERS / 2);
                         }
                     }
+                    if constexpr (STAGED && PRE_STRIDE >= 4)        // the refill of the staging register two MFMA gaps behind its write:
+                        if (step % PRE_STRIDE == 3)                 // one filler per gap (both in one gap held up the next MFMA)
+                            stage_load((step / PRE_STRIDE) % DEPTH, step / PRE_STRIDE + DEPTH, kb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- barrier Z ----
@@ -400,11 +404,15 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         if constexpr (STAGED) {
                             const int pos = N_PRE + step / POST_STRIDE;
                             stage_write(pos % DEPTH, B_BASE + b_cur + (wave + NW * (step / POST_STRIDE)) * 1024);
-                            stage_load(pos % DEPTH, pos + DEPTH, kb);
+                            if constexpr (POST_STRIDE < 4)
+                                stage_load(pos % DEPTH, pos + DEPTH, kb);
                         } else {
                             issue_b_piece(b_cur, kb + 2, step / POST_STRIDE);   // B(kb)'s slot: its fragments have been in registers since the last block
                         }
                     }
+                    if constexpr (STAGED && POST_STRIDE >= 4)
+                        if (step % POST_STRIDE == 3)
+                            stage_load((N_PRE + step / POST_STRIDE) % DEPTH, N_PRE + step / POST_STRIDE + DEPTH, kb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const int a_free = a_cur;
