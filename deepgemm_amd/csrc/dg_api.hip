@@ -1158,7 +1158,7 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, cons
     o.q = static_cast<uint8_t*>(out_fp8); o.sf = out_sf;
     o.q_sg = out_stride_g; o.q_sm = out_stride_m; o.sf_sg = out_sf_stride_g; o.sf_sk = out_sf_stride_k;
     o.clamp = activation_clamp; o.use_ue8m0 = use_ue8m0 ? 1 : 0;
-    const long grid = std::min<long>(max_tiles, num_cus() & ~1);             // even: tile t and its partner t ^ 1 run in the same iteration
+    const long grid = std::min<long>(max_tiles, std::max(2, num_cus() & ~1));     // even: tile t and its partner t ^ 1 run in the same iteration
     g_last_config = "stream_swiglu_64x128";
     hipLaunchKernelGGL(dg::dg_fp8_gemm_stream_swiglu_kernel<6>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), p, o);
     DG_HIP_CHECK(hipGetLastError());

@@ -102,3 +102,28 @@ def test_expert_mlp_end_to_end():
         mlp = (torch.nn.functional.silu(hbf[:, :inter]) * hbf[:, inter:]) @ w2_bf16[g].float().t()
         assert calc_diff(y[g, :rows], mlp) < 3e-3, (g, calc_diff(y[g, :rows], mlp))      # two FP8 quantisations deep
         assert bool(torch.isnan(y[g, rows:]).all())
+
+
+def test_fused_kernel_under_a_small_cu_limit():
+    """set_num_sms(1) / (3): the persistent walk still runs its tiles in partner pairs (an even grid of at least two workgroups)."""
+    gen.reset_seed(11)
+    groups, m_max, inter, k = 3, 64, 256, 512
+    masked_ms = [64, 7, 33]
+    a = torch.randn((groups, m_max, k), device='cuda', dtype=torch.bfloat16)
+    xq = [per_token_cast_to_fp8(a[g], use_ue8m0=False) for g in range(groups)]
+    x = (torch.stack([q[0] for q in xq]), torch.stack([q[1] for q in xq]))
+    w1 = _weights(groups, 2 * inter, k)
+    w1_t, _ = dg.transform_weights_for_mega_moe(w1, w1)
+    masked = torch.tensor(masked_ms, dtype=torch.int, device='cuda')
+    want = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+    dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, want, masked, 40)
+    saved = dg.get_num_sms()
+    try:
+        for limit in (1, 3):
+            dg.set_num_sms(limit)
+            got = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+            dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, got, masked, 40)
+            for g, rows in enumerate(masked_ms):
+                assert torch.equal(got[0][g, :rows].view(torch.uint8), want[0][g, :rows].view(torch.uint8)) and torch.equal(got[1][g, :rows], want[1][g, :rows])
+    finally:
+        dg.set_num_sms(saved)
