@@ -144,6 +144,8 @@ const Config kConfigs[] = {
     // M <= 16 / 32 (decode batches): 16 output columns per workgroup over the whole K, the 8 waves split K; weights straight into registers
     {"skinny_16", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1>},
     {"skinny_32", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2>},
+    // two N-subtiles per workgroup, 17 .. 32 columns (GemmParams::skinny_cols): one round where n / 16 is between one and two rounds
+    {"skinny_16w", 16, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 2>},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>, true, false,
      false, true},
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
@@ -391,7 +393,8 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         const int num_kb = p.k / 128;
         const char* pick = nullptr;
         if (m_for_tiling <= 16 && num_kb >= 16)
-            pick = "skinny_16";
+            pick = (p.n > 16 * num_cus() && p.n <= 32 * num_cus() && !p.accumulate && p.n % 4 == 0) ? "skinny_16w" : "skinny_16";
+        // (m = 1, 7168 x 16384: 448 column tiles = 1.75 rounds of skinny_16 -> 256 tiles of 28 columns)
         else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608)
             pick = "skinny_32";
         if (pick != nullptr)
@@ -629,6 +632,17 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     g_last_config = cfg->name;
     p.num_m_tiles = ceil_div(p.m, cfg->bm);
     p.num_n_tiles = ceil_div(p.n, cfg->bn);
+    if (std::strcmp(cfg->name, "skinny_16w") == 0) {
+        if (p.accumulate) {
+            g_last_error = "config 'skinny_16w' does not implement accumulating outputs (neighbouring workgroups overlap by up to 15 columns)";
+            return 3;
+        }
+        // columns per workgroup: one round over the CUs if that needs at most 32 columns, a multiple of 4 (8-byte BF16 stores)
+        int cols = ceil_div(ceil_div(p.n, num_cus()), 4) * 4;
+        cols = cols < 20 ? 20 : (cols > 32 ? 32 : cols);
+        p.skinny_cols = cols;
+        p.num_n_tiles = ceil_div(p.n, cols);
+    }
     // L2 grouping: with 8 XCDs each chunk of tiles should be a compact rectangle (see swizzled_tile).
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;

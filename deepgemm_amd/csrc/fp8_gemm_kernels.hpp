@@ -81,6 +81,7 @@ struct GemmParams {
     // workgroup derives the tile list itself from one 64-lane load of the blocks' group ids (contiguous_tile_mask: the first blocks of
     // the 256-row tiles (1) or the 128-row remainders and padding blocks (2) as a bit mask).  tile_table stays nullptr.
     int table_mode;
+    int skinny_cols;                // skinny kernel with two N-subtiles: columns per workgroup (17 .. 32, multiple of 4); 0 = 16 x NSUB
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
@@ -2936,17 +2937,29 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
 // (Round 3, negative: MS = 4 / 8 with CH = 2 / 1 K blocks per chunk for M <= 64 / 128 -- every workgroup re-reads the whole A through
 // L2, 16 half-used cache lines per load instruction: 64 x 4096 x 7168 22.5 us against 21.0 on the stream tiles, 128 x 4096 x 7168 41.9
 // against 21.3.  Not instantiated.)
-template <int MS, int CH = 4>
+// NSUB = 2 (round 3): a workgroup owns `p.skinny_cols` (17 .. 32) columns as two N-subtiles at n0 and n0 + 16, so that n / 16 column
+// tiles just above the CU count (m = 1, 7168 x 16384: 448 tiles = 1.75 rounds) become ONE round of 28-column tiles.  The second subtile
+// reaches into the next workgroup's columns: both compute the same bits for them (non-accumulating outputs only).
+template <int MS, int CH = 4, int NSUB = 1>
 __global__ __launch_bounds__(512)
 void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
     constexpr int NW = 8;                                       // CH: K blocks per software-pipeline chunk (two chunks in flight)
-    __shared__ float red[NW][MS][256];
+    static_assert(MS * NSUB <= NW, "one wave per (M-subtile, N-subtile) sums the partial tiles");
+    __shared__ float red[NW][MS * NSUB][256];
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * (NSUB == 1 || p.skinny_cols == 0 ? 16 * NSUB : p.skinny_cols);
     const int num_kb = p.k / 128;
     const int kb_begin = wave * num_kb / NW, kb_end = (wave + 1) * num_kb / NW;
-    const uint8_t* b_ptr = p.b + static_cast<int64_t>(imin(n0 + r, p.n - 1)) * p.b_sn + g * 16;
+    const uint8_t* b_ptr[NSUB];
+    const float* sfb_ptr[NSUB];
+    #pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        b_ptr[s] = p.b + static_cast<int64_t>(imin(n0 + s * 16 + r, p.n - 1)) * p.b_sn + g * 16;
+        // a lane's four output columns are n0 + 16 s + 4 g .. + 3 (n0 is a multiple of 4: they never straddle a 128-column scale block,
+        // the 16-column subtile of the two-subtile form may)
+        sfb_ptr[s] = p.sfb + static_cast<int64_t>(imin(n0 + s * 16 + 4 * g, p.n - 1) / 128) * p.sfb_sn;
+    }
     const uint8_t* a_ptr[MS];
     const float* sfa_ptr[MS];
     #pragma unroll
@@ -2955,42 +2968,49 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
         a_ptr[ms] = p.a + static_cast<int64_t>(row) * p.a_sm + g * 16;
         sfa_ptr[ms] = p.sfa + static_cast<int64_t>(row) * p.sfa_sm;
     }
-    const float* sfb_ptr = p.sfb + static_cast<int64_t>(n0 / 128) * p.sfb_sn;
 
-    struct Chunk { v4i b[CH][2]; v4i a[MS][CH][2]; float sa[MS][CH]; float sb[CH]; };
+    struct Chunk { v4i b[CH][NSUB][2]; v4i a[MS][CH][2]; float sa[MS][CH]; float sb[CH][NSUB]; };
     auto load_chunk = [&](Chunk& c, int kb0) {
         #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int kb = imin(kb0 + j, num_kb - 1);          // past the range: re-read the last block (never used)
             const int64_t off = static_cast<int64_t>(kb) * 128;
-            c.b[j][0] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr + off));
-            c.b[j][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr + off + 64));
+            #pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                c.b[j][s][0] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off));
+                c.b[j][s][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off + 64));
+                c.sb[j][s] = sfb_ptr[s][static_cast<int64_t>(kb) * p.sfb_sk];
+            }
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
                 c.a[ms][j][0] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off);
                 c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off + 64);
                 c.sa[ms][j] = sfa_ptr[ms][static_cast<int64_t>(kb) * p.sfa_sk];
             }
-            c.sb[j] = sfb_ptr[static_cast<int64_t>(kb) * p.sfb_sk];
         }
     };
-    v4f acc[MS];
+    v4f acc[MS][NSUB];
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
-        acc[ms] = v4f{0.f, 0.f, 0.f, 0.f};
+        #pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+            acc[ms][s] = v4f{0.f, 0.f, 0.f, 0.f};
     auto compute_chunk = [&](const Chunk& c, int kb0) {
         #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (kb0 + j < kb_end) {                             // wave-uniform
-                const v8i bf = __builtin_shufflevector(c.b[j][0], c.b[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    const v8i af = __builtin_shufflevector(c.a[ms][j][0], c.a[ms][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const v4f part = mfma_fp8_k128(bf, af);
-                    const float scale = c.sa[ms][j] * c.sb[j];
+                for (int s = 0; s < NSUB; ++s) {
+                    const v8i bf = __builtin_shufflevector(c.b[j][s][0], c.b[j][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[ms][e] = __builtin_fmaf(scale, part[e], acc[ms][e]);
+                    for (int ms = 0; ms < MS; ++ms) {
+                        const v8i af = __builtin_shufflevector(c.a[ms][j][0], c.a[ms][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const v4f part = mfma_fp8_k128(bf, af);
+                        const float scale = c.sa[ms][j] * c.sb[j][s];
+                        #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[ms][s][e] = __builtin_fmaf(scale, part[e], acc[ms][s][e]);
+                    }
                 }
             }
         }
@@ -3006,17 +3026,22 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
     }
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
-        *reinterpret_cast<v4f*>(&red[wave][ms][lane * 4]) = acc[ms];
+        #pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+            *reinterpret_cast<v4f*>(&red[wave][ms * NSUB + s][lane * 4]) = acc[ms][s];
     __syncthreads();
-    if (wave < MS) {
+    if (wave < MS * NSUB) {
         v4f sum = *reinterpret_cast<const v4f*>(&red[0][wave][lane * 4]);
         #pragma unroll
         for (int w = 1; w < NW; ++w)
             sum += *reinterpret_cast<const v4f*>(&red[w][wave][lane * 4]);
-        Tile t;
-        t.m0 = 0; t.n0 = n0; t.group = 0; t.m_begin = 0; t.m_end = p.m; t.zero_from = t.zero_to = p.m; t.valid = true; t.second_pass = false;
-        v4f out[1][1] = {{sum}};
-        store_tile<1, 1, false, false, true>(p, t, 0, out, wave * 16, n0);
+        const int ms = wave / NSUB, sub = wave % NSUB;
+        if (n0 + sub * 16 < p.n) {
+            Tile t;
+            t.m0 = 0; t.n0 = n0 + sub * 16; t.group = 0; t.m_begin = 0; t.m_end = p.m; t.zero_from = t.zero_to = p.m; t.valid = true; t.second_pass = false;
+            v4f out[1][1] = {{sum}};
+            store_tile<1, 1, false, false, true>(p, t, 0, out, ms * 16, n0 + sub * 16);
+        }
     }
 }
 

@@ -1281,3 +1281,33 @@ def test_stream_kernels_need_aligned_scale_rows():
     dg.set_forced_config('stream_64x128')
     assert raw(got) != 0
     dg.set_forced_config('auto')
+
+
+@pytest.mark.parametrize('m,n,k', [(1, 7168, 4096), (9, 4112, 2048), (16, 8192, 2048), (2, 4992, 2560)])
+def test_skinny_two_subtile_form(m, n, k):
+    """n / 16 column tiles between one and two rounds of the chip: workgroups of 17 .. 32 columns as two N-subtiles (`skinny_16w`); the
+    overlap of neighbouring workgroups writes identical bits; accumulating calls stay on the 16-column form; same bits as `skinny_16`."""
+    gen.reset_seed(m + n)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    wide = torch.full((m, n + 40), float('nan'), device='cuda', dtype=torch.bfloat16)
+    d = wide[:, :n]
+    dg.fp8_gemm_nt(case.a, case.b, d)
+    assert dg.last_config() == 'skinny_16w', dg.last_config()
+    assert_close_to_oracle(d, want, 'skinny_16w')
+    assert bool(torch.isnan(wide[:, n:]).all())
+    dg.set_forced_config('skinny_16')
+    dg.fp8_gemm_nt(case.a, case.b, case.d)
+    assert torch.equal(case.d, d.contiguous())
+    dg.set_forced_config('auto')
+    for _ in range(3):
+        again = torch.empty_like(case.d)
+        dg.fp8_gemm_nt(case.a, case.b, again)
+        assert torch.equal(again, case.d)
+    acc_case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float)
+    dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
+    assert dg.last_config() == 'skinny_16'
+    dg.set_forced_config('skinny_16w')
+    with pytest.raises(RuntimeError):
+        dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
+    dg.set_forced_config('auto')

@@ -449,7 +449,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 4096, 4096, 7168, gran_n=1) == 'pipe_pc_256x256'
     assert pick(dense, 4096, 4096, 7168, gran_n=1, a_mn=1, b_mn=1) == 'pipe_pc_mn_256x256'
     # the reference's dense sweep: small M, K tails, few tiles with long K loops, tile-count quantisation
-    assert pick(dense, 1, 7168, 16384) == 'skinny_16' and pick(dense, 128, 4096, 7168) == 'stream_64x32'
+    assert pick(dense, 1, 7168, 16384) == 'skinny_16w' and pick(dense, 1, 4096, 16384) == 'skinny_16' and pick(dense, 128, 4096, 7168) == 'stream_64x32'
     # decode batches: the skinny weight-stream kernel for long K loops, the stream tiles for short ones / wide N
     assert pick(dense, 16, 4096, 7168) == 'skinny_16' and pick(dense, 17, 4096, 7168) == 'skinny_32' and pick(dense, 33, 4096, 7168) == 'stream_64x32'
     assert pick(dense, 1, 24576, 1536) == 'stream_64x128' and pick(dense, 1, 32768, 512) == 'stream_64x128'
