@@ -764,6 +764,16 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         long pieces = std::min<long>(8, base.k / 128);
         if (!split_k_pays(2, base.k / 128))
             pieces = 1;
+        // DG_SK_EXCHANGE=1 (experiment, round 3): cut in TWO and let the second piece add the first one's partial itself
+        // (GemmParams::sk_exchange) -- no reduction kernel, half the partial traffic.  Measured on C4: with agent-scope release / acquire
+        // (a writeback and an invalidate of the whole L2 per workgroup) 151 us against 142 with the reduction kernel; with written-through
+        // stores and cache-bypassing loads 141-143 against 143.5: a 1 % gain does not pay for a spin-wait in the product path.
+        static std::atomic<unsigned> exchange_epoch{0};
+        const bool exchange = in_kernel && pieces >= 2 && static_cast<long>(nb) * n_tiles <= 1024 && getenv("DG_SK_EXCHANGE") != nullptr;
+        if (exchange) {
+            pieces = 2;
+            r.sk_exchange = 0x7fd00000u | (exchange_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu);
+        }
         r.sk_factor = static_cast<int>(std::max<long>(pieces, 1));
         r.sk_first_tile = 0;
         r.sk_tiles = num_cus();              // (table launch: the slot count; the kernels read the tile count from the table)
@@ -772,7 +782,7 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true, false, false, true>), dim3(static_cast<unsigned>(grid)),
                            dim3(512), 0, static_cast<hipStream_t>(stream), r);
         DG_HIP_CHECK(hipGetLastError());
-        if (r.sk_factor >= 2) {
+        if (r.sk_factor >= 2 && r.sk_exchange == 0) {
             // grid: an upper bound on the remainder tiles that can be split at all (capacity / 2 pieces) x 4 subtile rows; surplus
             // workgroups return at once
             const long max_split_tiles = std::min<long>(static_cast<long>(nb) * n_tiles, r.sk_capacity / 2);

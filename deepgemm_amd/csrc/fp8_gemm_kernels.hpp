@@ -82,6 +82,12 @@ struct GemmParams {
     // the 256-row tiles (1) or the 128-row remainders and padding blocks (2) as a bit mask).  tile_table stays nullptr.
     int table_mode;
     int skinny_cols;                // skinny kernel with two N-subtiles: columns per workgroup (17 .. 32, multiple of 4); 0 = 16 x NSUB
+    // K split in two WITHOUT the reduction kernel (table launches of the contiguous layout): piece 0 of a tile writes its FP32 partial and
+    // raises the tile's flag (uint32 at sk_workspace[tile], release at agent scope) to this value; piece 1 -- dispatched later, or run
+    // later by the same persistent workgroup -- waits for it, adds the partial to its own accumulators (the same two-operand sum as the
+    // reduction kernel's), stores the tile and clears the flag.  0 = off.  The value is a NaN bit pattern that changes per launch: nothing
+    // else that ever lands in the workspace header (tile tables, zeros) equals it.
+    unsigned sk_exchange;
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
@@ -743,6 +749,14 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, const Tile& t, i
 // ---------------------------------------------------------------------------------------------------------------
 // (Negative result, round 3: the four promotion FMAs as TWO v_pk_fma_f32 -- half the VALU issue slots -- run C2 at 110 us instead of
 // 91.5 us, C3 36.2 instead of 30.0: packed FP32 FMAs issue at half rate behind a matrix instruction on this part.  -DDG_PK_FMA builds it.)
+// Cache policy of the in-kernel K-split exchange (GemmParams::sk_exchange): 17 = sc0 | sc1 on the partial tile's stores and loads (written
+// through / read past the per-XCD L2) with relaxed flag accesses; 0 = ordinary accesses with release / acquire at agent scope (a writeback
+// and an invalidate of the WHOLE L2 per workgroup: measured 151 us against 142 for C4 with the reduction kernel).
+#ifndef DG_SK_XCHG_AUX
+#define DG_SK_XCHG_AUX 17
+#endif
+#define DG_SK_XCHG_ORDER_REL (DG_SK_XCHG_AUX == 0 ? __ATOMIC_RELEASE : __ATOMIC_RELAXED)
+#define DG_SK_XCHG_ORDER_ACQ (DG_SK_XCHG_AUX == 0 ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mfma_promote_step(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,
                                                   float (&c)[4], float scale, const v4f& part_old) {
@@ -2088,6 +2102,46 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         if constexpr (SPLITK) {
             if (piece.split && !(t.m_end > t.m0)) {
                 store = piece.index == 0;               // an all-padding tile: its zero rows are written once
+            } else if (piece.split && p.sk_exchange != 0 && piece.factor == 2) {
+                // two pieces, exchanged inside the kernel (GemmParams::sk_exchange)
+                unsigned* flag = static_cast<unsigned*>(p.sk_workspace) + piece.tail;
+                uint8_t* slab_bytes = static_cast<uint8_t*>(p.sk_workspace) + 4096 + static_cast<int64_t>(piece.tail) * (BM * BN * 4);
+                const auto slab = __builtin_amdgcn_make_buffer_rsrc(slab_bytes, 0, BM * BN * 4, 0x00020000);
+                const int lane_off = (wave * 64 + lane) * 16;
+                if (piece.index == 0) {
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, out[ms][ns]), slab, lane_off, (ms * NS + ns) * (NW * 1024),
+                                                                   DG_SK_XCHG_AUX);       // sc0 sc1: written through, past the (per-XCD) L2
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                    // every wave's partial stores are acknowledged ...
+                    if (threadIdx.x == 0)               // ... before the flag goes out (no cache-wide writeback: nothing of this sits in a cache)
+                        __hip_atomic_store(flag, p.sk_exchange, DG_SK_XCHG_ORDER_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    store = false;
+                } else {
+                    if (threadIdx.x == 0) {
+                        // the producer was dispatched before this workgroup (its work item precedes this one by the tile count): it is
+                        // resident or done.  Bounded all the same: a lost flag must end in a wrong tile, not in a hung device.
+                        int spins = 0;
+                        while (__hip_atomic_load(flag, DG_SK_XCHG_ORDER_ACQ, __HIP_MEMORY_SCOPE_AGENT) != p.sk_exchange && ++spins < (1 << 22))
+                            __builtin_amdgcn_s_sleep(8);
+                    }
+                    __syncthreads();
+                    if (DG_SK_XCHG_AUX == 0)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns) {
+                            const v4f part0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(slab, lane_off, (ms * NS + ns) * (NW * 1024), DG_SK_XCHG_AUX));
+                            out[ms][ns] = part0 + out[ms][ns];          // piece order, as dg_split_k_reduce_kernel sums
+                        }
+                    __syncthreads();                    // every wave has read the partial before the flag is cleared for the next launch
+                    if (threadIdx.x == 0)
+                        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else if (piece.split) {
                 // FP32 partial tile of this K piece: lane-linear 16-byte stores, [subtile][wave][lane], ordinary (write-back) stores.
                 // The sum over the pieces and the output stores belong to dg_split_k_reduce_kernel, launched behind this kernel on
@@ -2147,6 +2201,8 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
     int sk_first = p.sk_first_tile, sk_factor = p.sk_factor;
     if (p.table_mode != 0)
         walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
+    if (p.sk_exchange != 0)
+        return;                                 // (the two pieces were summed inside the first kernel)
     if (table_launch(p)) {                      // table launch: the grid is an upper bound, tile count and pieces live on the device
         const int sk_tiles = table_count(p, walk) * p.num_n_tiles;
         sk_first = 0;
