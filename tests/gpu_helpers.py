@@ -3,7 +3,7 @@ of the same tensors, and compare under the tolerances stated here.
 
 Tolerances (floating-point path; north star allows 1e-2 rel-err, these are far tighter):
   * vs the oracle ("BF16-simulated FP8 GEMM", same FP32 block-promotion arithmetic):
-      BF16 out: calc_diff <= 2e-6, rel-Frobenius <= 1e-3, and every element within
+      BF16 out: calc_diff <= 2e-6, rel-Frobenius <= 1e-3 (4e-3 below 256 output elements), and every element within
                 |x - y| <= 2^-7 |y| (one BF16 ulp) + 2e-4 rms(y) (matrix-core accumulation noise),
       FP32 out: rel-Frobenius <= 5e-5;
     the sources of difference are the MFMA's internal accumulation of the 128 products of one K block (measured on
@@ -36,7 +36,11 @@ def assert_close_to_oracle(got: torch.Tensor, want: torch.Tensor, label: str = '
     diff = calc_diff(got, want)
     rel = rel_frobenius(got, want)
     assert diff <= 2e-6, f'{label}: calc_diff vs oracle {diff:.3e}'
-    assert rel <= 1e-3, f'{label}: rel-Frobenius vs oracle {rel:.3e}'
+    # (outputs of a few dozen elements: ONE element that rounds to the neighbouring BF16 value -- legitimate, see the element-wise bound
+    # below -- is already 2^-8 / sqrt(numel) of the norm: 1e-3 at 16 elements.  The Frobenius gate is a whole-matrix check; tiny outputs
+    # are held to the element-wise bound and to a gate that admits a couple of such flips.)
+    rel_bound = 1e-3 if want.numel() >= 256 else 4e-3
+    assert rel <= rel_bound, f'{label}: rel-Frobenius vs oracle {rel:.3e}'
     mag = want.abs()
     if addend is not None:
         addend = addend.float().cpu()
