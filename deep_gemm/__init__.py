@@ -4,7 +4,7 @@ import sys
 
 import deepgemm_amd as _impl
 
-for _name in ('utils', 'utils.math', 'utils.layout', 'utils.dist', 'testing', 'testing.bench', 'testing.numeric', 'testing.utils'):
+for _name in ('utils', 'utils.math', 'utils.layout', 'utils.dist', 'testing', 'testing.bench', 'testing.numeric', 'testing.utils', 'mega'):
     sys.modules[f'{__name__}.{_name}'] = sys.modules[f'deepgemm_amd.{_name}']
 globals().update({k: v for k, v in vars(_impl).items() if not k.startswith('__')})
 __version__ = _impl.__version__
