@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -32,9 +32,9 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
-             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused']
+             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
-             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp']
+             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor']
 GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
@@ -125,7 +125,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k}, FP32 power-of-two scales, sf cast mode sm100: whole call (cast branch + GEMM)',
                 'm': m, 'n': n, 'k': k, 'sfa_layout': 'FP32 row-major (as per_token_cast_to_fp8 returns it); cast to packed UE8M0 inside the call'}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
-    elif name in ('dense', 'dense_ue8m0'):
+    elif name in ('dense', 'dense_ue8m0', 'dense_sfa_rowmajor'):
         m, n, k = 4096, 4096, 7168
         packed = name == 'dense_ue8m0'
         for i in range(sets):
@@ -134,6 +134,10 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
             if packed:
                 # power-of-two scales handed over as packed UE8M0 words (the reference's SM100 input format): hardware-scaled MFMA
                 a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+            elif name == 'dense_sfa_rowmajor':
+                # SFA row-major as per_token_cast_to_fp8 returns it (what the reference's own test passes): every call pays the layout
+                # step (csrc/apis/layout.hpp:14-46 -> transpose_fp32): one small transpose launch + the GEMM
+                a, b = case.a, case.b
             else:
                 # Producers hand SFA over in the kernel's MN-major layout (zero-copy branch of the reference's layout step,
                 # smxx_layout.hpp:124-125), so a step is exactly one GEMM launch.
@@ -143,9 +147,10 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         flops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
         desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (DeepSeek-V3 dense shape, BASELINE configs[1])' +
-                            (', packed UE8M0 scales (power-of-two scales, recipe (1, 1, 128))' if packed else ''),
+                            (', packed UE8M0 scales (power-of-two scales, recipe (1, 1, 128))' if packed else '') +
+                            (', SFA row-major as the cast returns it: whole call = layout step (transpose launch) + GEMM' if name == 'dense_sfa_rowmajor' else ''),
                 'm': m, 'n': n, 'k': k,
-                'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'pre-transposed (zero-copy branch): FP32, MN-major, handed over by the producer'}
+                'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'FP32 row-major [M, K/128]: transposed inside the call' if name == 'dense_sfa_rowmajor' else 'pre-transposed (zero-copy branch): FP32, MN-major, handed over by the producer'}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name.startswith('c3_'):
         layout = name[3:]

@@ -770,7 +770,7 @@ def test_import_is_fork_safe_and_bench_runs():
     assert 'zero-copy' in line['config']['sfa_layout']
     # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0 (C2, C5), two dgrad entries
     secondary = line['secondary']
-    assert len(secondary) == 17 and not [s for s in secondary if 'error' in s], secondary
+    assert len(secondary) == 18 and not [s for s in secondary if 'error' in s], secondary
     for rec in secondary:
         assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
     assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
