@@ -18,7 +18,8 @@ from .layout import transform_sf_into_required_layout                 # noqa: F4
 from .quant import (fused_per_token_cast_to_fp8, fused_per_block_cast_to_fp8,      # noqa: F401
                     fused_per_channel_cast_to_fp8)
 from .mega import (transform_weights_for_mega_moe, m_grouped_fp8_gemm_nt_masked_swiglu,       # noqa: F401
-                   fp8_mega_moe_local, empty_intermediate)
+                   fp8_mega_moe_local, empty_intermediate, SymmBuffer, get_symm_buffer_for_mega_moe, fp8_mega_moe, fp8_fp4_mega_moe,
+                   bf16_mega_moe, get_token_alignment_for_mega_moe)
 from . import testing, utils                                          # noqa: F401
 from .utils import *                                                  # noqa: F401,F403
 

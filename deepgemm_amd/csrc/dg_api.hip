@@ -141,6 +141,12 @@ const Config kConfigs[] = {
     {"stream_nt_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4>, true},
+    // round 4: the same tiles with loader waves (4 compute waves + 4 / 12 that only issue LDS-DMA pieces): a stream tile is bound by the
+    // LDS-DMA issue rate of its workgroup, and that rate grows with the number of issuing waves (50 / 80 / 96 GB/s per CU at 4 / 8 / 16)
+    {"stream_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 4>, true},
+    {"stream_l16_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 12>, true},
+    {"stream_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 4>, true},
+    {"stream_nt_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, false, 4>, true},
     // M <= 16 / 32 (decode batches): 16 output columns per workgroup over the whole K, the 8 waves split K; weights straight into registers
     {"skinny_16", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1>},
     {"skinny_32", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2>},
@@ -452,6 +458,11 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
                     pick = "duo_sk_128x256";
             }
         }
+        // round 4: dense 64 x 32 stream tiles run with four loader waves beside the four compute waves (8 waves issue the LDS-DMA pieces:
+        // m = 128, 4096 x 7168: 20.9 -> 18.0 us, 2112 x 7168: 20.4 -> 17.0, 7168 x 2048: 16.8 -> 15.3; profiles/r04_probe/sweep_midm_loader_waves.jsonl;
+        // the 64 x 128 tile and the masked C5 did not move: 39.8 against 38.4, 43.7 against 43.6)
+        if (pick != nullptr && p.gemm_type == dg::kNormal && std::strcmp(pick, "stream_64x32") == 0)
+            pick = "stream_l8_64x32";
         if (pick != nullptr)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)
@@ -1136,9 +1147,17 @@ int dg_m_grouped_fp8_gemm_nt_masked(const void* a, const float* sfa, const void*
     return launch_gemm(p, expected_m < m_max ? expected_m : m_max, stream);
 }
 
+// 256-byte header (word 0: exchange waits that timed out) + one 64-word slot row per 64 x 128 tile
 int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n) {
-    return static_cast<int64_t>(num_groups) * ceil_div(m_max, 64) * (n / 128) * 64 * 4;
+    return 256 + static_cast<int64_t>(num_groups) * ceil_div(m_max, 64) * (n / 128) * 64 * 4;
 }
+
+namespace {
+std::atomic<long long> g_swiglu_timeout_us{10LL * 1000 * 1000};     // 10 s; the reference's grid / NVLink barriers give up after 60 s
+std::atomic<int> g_swiglu_fault{0};
+}
+void dg_set_swiglu_exchange_timeout_us(int64_t us) { g_swiglu_timeout_us.store(us > 0 ? us : 1, std::memory_order_relaxed); }
+void dg_set_swiglu_fault_injection(int mode) { g_swiglu_fault.store(mode, std::memory_order_relaxed); }
 
 int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
                                            float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
@@ -1147,7 +1166,21 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, cons
                                            int64_t sfb_stride_k, int64_t out_stride_g, int64_t out_stride_m, int64_t out_sf_stride_g,
                                            int64_t out_sf_stride_k, float activation_clamp, int use_ue8m0, void* workspace, int64_t workspace_bytes,
                                            void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(a, sfa, b_interleaved, sfb, out_fp8, out_sf, masked_m, num_groups, m_max, n, k, expected_m,
+                                                           a_stride_g, a_stride_m, b_stride_g, b_stride_n, sfa_stride_g, sfa_stride_k, sfb_stride_g,
+                                                           sfb_stride_n, sfb_stride_k, out_stride_g, out_stride_m, out_sf_stride_g, out_sf_stride_k,
+                                                           activation_clamp, use_ue8m0, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
+                                                    float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
+                                                    int64_t a_stride_g, int64_t a_stride_m, int64_t b_stride_g, int64_t b_stride_n,
+                                                    int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t sfb_stride_g, int64_t sfb_stride_n,
+                                                    int64_t sfb_stride_k, int64_t out_stride_g, int64_t out_stride_m, int64_t out_sf_stride_g,
+                                                    int64_t out_sf_stride_k, float activation_clamp, int use_ue8m0, const float* row_weight,
+                                                    int64_t row_weight_stride_g, void* workspace, int64_t workspace_bytes, void* stream) {
     DG_CHECK(expected_m > 0 && m_max > 0 && n > 0 && k > 0 && num_groups > 0);
+    DG_CHECK(row_weight == nullptr || (aligned16(row_weight) && row_weight_stride_g % 4 == 0 && row_weight_stride_g >= ceil_div(m_max, 64) * 64));
     DG_CHECK(a != nullptr && b_interleaved != nullptr && sfa != nullptr && sfb != nullptr && out_fp8 != nullptr && out_sf != nullptr &&
              masked_m != nullptr);
     DG_CHECK(n % 256 == 0);                             // whole pairs of [64 gate | 64 up] column tiles = whole 128-wide blocks of the intermediate
@@ -1178,15 +1211,55 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, cons
         return 3;
     }
     dg::SwigluOut o{};
-    o.amax_ws = static_cast<uint32_t*>(workspace);
+    o.errors = static_cast<uint32_t*>(workspace);
+    o.amax_ws = static_cast<uint32_t*>(workspace) + 64;
+    o.timeout_ticks = g_swiglu_timeout_us.load(std::memory_order_relaxed) * 100;       // s_memrealtime: 100 MHz
+    o.fault = g_swiglu_fault.load(std::memory_order_relaxed);
     o.q = static_cast<uint8_t*>(out_fp8); o.sf = out_sf;
     o.q_sg = out_stride_g; o.q_sm = out_stride_m; o.sf_sg = out_sf_stride_g; o.sf_sk = out_sf_stride_k;
     o.clamp = activation_clamp; o.use_ue8m0 = use_ue8m0 ? 1 : 0;
+    o.row_weight = row_weight; o.rw_sg = row_weight_stride_g;
     const long grid = std::min<long>(max_tiles, std::max(2, num_cus() & ~1));     // even: tile t and its partner t ^ 1 run in the same iteration
     g_last_config = "stream_swiglu_64x128";
     hipLaunchKernelGGL(dg::dg_fp8_gemm_stream_swiglu_kernel<6>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), p, o);
     DG_HIP_CHECK(hipGetLastError());
     (void)expected_m;
+    return 0;
+}
+
+int dg_moe_scatter_to_masked(const void* x_fp8, const float* x_sf, const void* topk_idx, int topk_idx_is_int64, const float* topk_weights,
+                             int tokens, int hidden, int topk, int num_experts, int max_m, int64_t x_stride_m, int64_t x_sf_stride_m,
+                             void* a_out, float* sfa_out, float* row_weight_out, int32_t* slot_out, int32_t* masked_m_out, void* error_word,
+                             int64_t a_stride_g, int64_t a_stride_m, int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t row_weight_stride_g,
+                             void* stream) {
+    DG_CHECK(tokens >= 0 && hidden > 0 && hidden % 128 == 0 && topk > 0 && num_experts > 0 && max_m > 0);
+    DG_CHECK(x_fp8 != nullptr && x_sf != nullptr && topk_idx != nullptr && topk_weights != nullptr && a_out != nullptr && sfa_out != nullptr &&
+             row_weight_out != nullptr && slot_out != nullptr && masked_m_out != nullptr && error_word != nullptr);
+    DG_CHECK(aligned16(x_fp8) && aligned16(a_out) && x_stride_m % 16 == 0 && a_stride_m % 16 == 0 && a_stride_g % 16 == 0);
+    DG_HIP_CHECK(hipMemsetAsync(masked_m_out, 0, sizeof(int32_t) * num_experts, static_cast<hipStream_t>(stream)));
+    if (tokens == 0)
+        return 0;
+    dg::MoeRoute r{};
+    r.x = static_cast<const uint8_t*>(x_fp8); r.x_sf = x_sf; r.topk_idx = topk_idx; r.topk_w = topk_weights;
+    r.tokens = tokens; r.hidden = hidden; r.topk = topk; r.num_experts = num_experts; r.max_m = max_m; r.idx64 = topk_idx_is_int64 ? 1 : 0;
+    r.x_sm = x_stride_m; r.xsf_sm = x_sf_stride_m;
+    r.a = static_cast<uint8_t*>(a_out); r.sfa = sfa_out; r.rw = row_weight_out; r.slot = slot_out; r.counts = masked_m_out;
+    r.errors = static_cast<uint32_t*>(error_word);
+    r.a_sg = a_stride_g; r.a_sm = a_stride_m; r.sfa_sg = sfa_stride_g; r.sfa_sk = sfa_stride_k; r.rw_sg = row_weight_stride_g;
+    hipLaunchKernelGGL(dg::dg_moe_scatter_kernel, dim3(static_cast<unsigned>(tokens)), dim3(256), 0, static_cast<hipStream_t>(stream), r);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int dg_moe_combine_from_masked(const void* y2_bf16, const int32_t* slot, int tokens, int topk, int hidden, int64_t y2_row_stride, void* y_bf16,
+                               int64_t y_stride_m, void* stream) {
+    DG_CHECK(tokens >= 0 && topk > 0 && hidden > 0 && hidden % 8 == 0 && y2_row_stride % 8 == 0 && y_stride_m % 8 == 0);
+    DG_CHECK(y2_bf16 != nullptr && slot != nullptr && y_bf16 != nullptr && aligned16(y2_bf16) && aligned16(y_bf16));
+    if (tokens == 0)
+        return 0;
+    hipLaunchKernelGGL(dg::dg_moe_combine_kernel, dim3(static_cast<unsigned>(tokens)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t*>(y2_bf16), slot, tokens, topk, hidden, y2_row_stride, static_cast<uint16_t*>(y_bf16), y_stride_m);
+    DG_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

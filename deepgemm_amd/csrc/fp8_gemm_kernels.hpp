@@ -1367,6 +1367,29 @@ void dg_fp8_gemm_pipe_pc_kernel(const GemmParams p) {
 }
 
 // A bare s_barrier: __syncthreads() would add a vmcnt(0) fence and drain the LDS-DMA queue.
+// LDS-DMA pieces in groups of four that share ONE M0 value (round 4).  The LDS address of a `buffer_load ... lds` is M0 + the instruction's
+// immediate offset + 16 * lane, and the immediate is added to the memory address as well.  A wave that owns FOUR CONSECUTIVE 1 KiB units of a
+// tile issues them with immediates 0 / 1024 / 2048 / 3072 against one M0 value instead of rewriting M0 (s_mov m0 + the wait state behind
+// it) in front of every piece: tools/ubench/frag_rate.hip measured 733 against 792 cycles per four pieces next to a matrix stream
+// (profiles/r04_probe/frag_rate.log).  The immediate on the memory side is taken back out of the per-lane offset; so that this never
+// goes negative the descriptor's base is moved DOWN by M0_SHARE_BIAS bytes and every offset up by the same amount (the range check
+// is relative to the base: num_records grows by the bias; nothing below the real base is ever addressed).
+#ifndef DG_M0_SHARE
+#define DG_M0_SHARE 1
+#endif
+constexpr int M0_SHARE_BIAS = 4096;
+// (a macro, not a function: hipcc's host pass rejects the gfx950-only 16-byte form of the builtin wherever it is not inside a device template)
+#define DG_LDS_DMA_PIECE_SUB(rsrc, lds_group_base, voff, soff, sub, aux)                                                                  \
+    do {                                                                                                                                  \
+        auto* dg_dst_ = (__attribute__((address_space(3))) void*)(lds_group_base);                                                        \
+        switch ((sub) & 3) { /* the immediate must be a literal; `sub` is a constant after unrolling */                                   \
+        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dg_dst_, 16, voff, soff, 0, aux); break;                                   \
+        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dg_dst_, 16, voff, soff, 1024, aux); break;                                \
+        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dg_dst_, 16, voff, soff, 2048, aux); break;                                \
+        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dg_dst_, 16, voff, soff, 3072, aux); break;                               \
+        }                                                                                                                                 \
+    } while (0)
+
 __device__ __forceinline__ void raw_barrier() {
     // A bare s_barrier: __syncthreads() would add a vmcnt(0) fence and drain the LDS-DMA queue.
     asm volatile("" ::: "memory");
@@ -1518,6 +1541,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
+    // groups of four pieces that share one M0 value (DG_LDS_DMA_PIECE_SUB): K-major operands whose wave share is a multiple of four units
+    constexpr bool M0S_A = DG_M0_SHARE && !A_MN && !STREAM_A && A_ITERS % 4 == 0, M0S_B = DG_M0_SHARE && !B_MN && !STREAM_A && B_ITERS % 4 == 0;
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     static_assert(!A_MN || (BM == 256 && NW == 8), "MN-major A tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     static_assert(!SPLITK || (PERSIST && !A_MN), "the K-split tail belongs to the persistent forms");
@@ -1570,10 +1595,12 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     int a_piece_voff[A_ITERS], b_piece_voff[B_ITERS];
     #pragma unroll
     for (int q = 0; q < A_ITERS; ++q)
-        a_piece_voff[q] = a_voff + a_unit_row(wave + NW * q) * lda;
+        a_piece_voff[q] = M0S_A ? a_voff + a_unit_row(wave * A_ITERS + q) * lda + M0_SHARE_BIAS - (q & 3) * 1024
+                                : a_voff + a_unit_row(wave + NW * q) * lda;
     #pragma unroll
     for (int q = 0; q < B_ITERS; ++q)
-        b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
+        b_piece_voff[q] = M0S_B ? b_row_perm<WN>((wave * B_ITERS + q) * 8 + piece_row) * ldb + src_chunk * 16 + M0_SHARE_BIAS - (q & 3) * 1024
+                                : b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
     // STREAM_A: the 2 * A_ITERS pieces this wave issues per K block in its role (upper half: A units, lower half: B units)
     [[maybe_unused]] int role_piece_voff[STREAM_A ? 2 * A_ITERS : 1];
     if constexpr (STREAM_A) {
@@ -1622,6 +1649,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     };
     auto issue_a_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
+        if constexpr (M0S_A) {
+            DG_LDS_DMA_PIECE_SUB(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base) - M0_SHARE_BIAS, 0, bytes + M0_SHARE_BIAS, 0x00020000),
+                                 lds + slot_off + (wave * A_ITERS + (q & ~3)) * 1024, a_piece_voff[q], (kb0 + imin(j, nkb - 1)) * 128, q, 0);
+            return;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16,
             A_MN ? amn_voff : a_piece_voff[q],
@@ -1629,6 +1661,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     };
     auto issue_b_piece_r = [&](const uint8_t* base, int bytes, int slot_off, int j, int q) {
         const int unit = wave + NW * q;
+        if constexpr (M0S_B) {
+            DG_LDS_DMA_PIECE_SUB(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base) - M0_SHARE_BIAS, 0, bytes + M0_SHARE_BIAS, 0x00020000),
+                                 lds + B_BASE + slot_off + (wave * B_ITERS + (q & ~3)) * 1024, b_piece_voff[q], (kb0 + imin(j, nkb - 1)) * 128, q, 0);
+            return;
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, bytes, 0x00020000), (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
             B_MN ? bmn_voff : b_piece_voff[q],
@@ -2030,6 +2067,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     #pragma unroll
                     for (int q = 0; q < A_ITERS; ++q) {
                         const int unit = wave + NW * q;
+                        if constexpr (M0S_A)
+                            DG_LDS_DMA_PIECE_SUB(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.a_base) - M0_SHARE_BIAS, 0, tm.a_bytes + M0_SHARE_BIAS, 0x00020000),
+                                 lds + (wave * A_ITERS + (q & ~3)) * 1024, a_piece_voff[q] + tail_bias, num_kb * 128, q, 0);
+                        else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.a_base), 0, tm.a_bytes, 0x00020000),
                             (__attribute__((address_space(3))) void*)(lds + unit * 1024), 16,
@@ -2039,6 +2080,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     #pragma unroll
                     for (int q = 0; q < B_ITERS; ++q) {
                         const int unit = wave + NW * q;
+                        if constexpr (M0S_B)
+                            DG_LDS_DMA_PIECE_SUB(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.b_base) - M0_SHARE_BIAS, 0, tm.b_bytes + M0_SHARE_BIAS, 0x00020000),
+                                 lds + B_BASE + (wave * B_ITERS + (q & ~3)) * 1024, b_piece_voff[q] + tail_bias, num_kb * 128, q, 0);
+                        else
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(tm.b_base), 0, tm.b_bytes, 0x00020000),
                             (__attribute__((address_space(3))) void*)(lds + B_BASE + unit * 1024), 16,
@@ -2264,9 +2309,13 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
 // E8: packed UE8M0 scales (one int32 word of four exponent bytes per row of A and per ROW of B per four K blocks; p.sfa / p.sfb hold the
 // words, strides per K quad): every stage carries the words of its K block's quad (64 for A, BN for B), the block's byte is
 // shifted down by VALU and the hardware-scaled MFMA accumulates in place -- the decode-sized form of the packed-UE8M0 path.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false>
+// LW: extra LOADER waves (round 4).  A stream tile is bound by the LDS-DMA issue rate of its workgroup (profiles/r03_fill/NOTES.md: 4 waves
+// fill a CU at ~50 GB/s, 8 at ~80, 16 at ~96 whatever is in flight), not by its matrix work: the NW compute waves keep the tile's MFMA /
+// epilogue geometry, LW more waves do nothing but issue their share of every stage's pieces and join the barriers.  The pieces of a stage
+// (KBS blocks x (BM / 8 + BN / 8) units) are dealt round-robin over all NW + LW waves.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0>
 __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
-    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NW = WAVES_M * WAVES_N, TW = NW + LW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int SFB_PIECES = E8 ? (BN + 63) / 64 : 1;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256 * SFB_PIECES;
@@ -2285,7 +2334,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
     // per wave per stage; GSF: the group pieces (two per four K blocks) are NOT counted -- the counted waits then ask for up to two
     // more of the younger pieces than needed (stricter, never looser; the ring has STAGES - 2 stages of slack)
-    constexpr int PIECES = ((NO_A ? 0 : A_ITERS) + B_ITERS + (GSF ? 0 : 1 + SFB_PIECES)) * KBS;
+    constexpr int A_PER = KBS * (BM / 8) / TW, B_PER = KBS * (BN / 8) / TW;     // LW > 0: pieces per wave and STAGE
+    static_assert(LW == 0 || (GSF && !NO_A && (KBS * (BM / 8)) % TW == 0 && (KBS * (BN / 8)) % TW == 0),
+                  "loader waves: FP32 scales, every wave issues the same number of A and of B pieces per stage");
+    constexpr int PIECES = LW > 0 ? A_PER + B_PER : ((NO_A ? 0 : A_ITERS) + B_ITERS + (GSF ? 0 : 1 + SFB_PIECES)) * KBS;
     static_assert(!GSF || STAGES * KBS <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
     static_assert(!E8 || MS == 4 || MS == 1, "packed-scale form: a lane reads its MS row words with one LDS read");
     constexpr unsigned OOB = 0x80000000u;
@@ -2401,6 +2453,41 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             };
 
             auto issue_stage = [&](int slot_off, int sb) {            // stage sb = K blocks sb * KBS .. + KBS - 1
+                if constexpr (LW > 0) {
+                    // the stage's pieces dealt over all TW waves: piece index wave + TW q -> (block, unit); the group scales as issue_block
+                    #pragma unroll
+                    for (int u = 0; u < KBS; ++u) {
+                        const int j = sb * KBS + u;
+                        if ((j & 3) == 0) {
+                            const unsigned oob = j < num_kb ? 0u : OOB;
+                            uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                                static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
+                                static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), j * sfb_kb_stride, 0, 0);
+                        }
+                    }
+                    #pragma unroll
+                    for (int q = 0; q < A_PER; ++q) {
+                        const int idx = wave + TW * q, u = idx / (BM / 8), unit = idx % (BM / 8), j = sb * KBS + u;
+                        const unsigned oob = j < num_kb ? 0u : OOB;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + u * BLOCK_BYTES + unit * 1024), 16,
+                            static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob)), j * 128, 0, 0);
+                    }
+                    #pragma unroll
+                    for (int q = 0; q < B_PER; ++q) {
+                        const int idx = wave + TW * q, u = idx / (BN / 8), unit = idx % (BN / 8), j = sb * KBS + u;
+                        const unsigned oob = j < num_kb ? 0u : OOB;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            b_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + u * BLOCK_BYTES + A_BYTES + unit * 1024), 16,
+                            static_cast<int>(static_cast<unsigned>(b_row_perm<WN>(unit * 8 + piece_row) * ldb + src_chunk * 16) | oob), j * 128, 0,
+                            B_AUX & 3);
+                    }
+                    return;
+                }
                 #pragma unroll
                 for (int u = 0; u < KBS; ++u)
                     issue_block(slot_off + u * BLOCK_BYTES, sb * KBS + u);
@@ -2417,6 +2504,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((STAGES - 2) * PIECES) : "memory");
                 raw_barrier();
                 issue_stage(fill, sb + STAGES - 1);
+              if (LW == 0 || wave < NW)               // (loader waves: pieces and barriers only)
               #pragma unroll
               for (int u = 0; u < KBS; ++u) {
                 if (sb * KBS + u >= num_kb)
@@ -2487,14 +2575,15 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+        if (LW == 0 || wave < NW)
+            store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64)
 void dg_fp8_gemm_stream_kernel(const GemmParams p) {
-    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8>(p);
+    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8, LW>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

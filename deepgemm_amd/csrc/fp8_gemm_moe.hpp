@@ -49,6 +49,11 @@ struct SwigluOut {
     float clamp;            // <= 0: none
     int use_ue8m0;
     uint32_t* amax_ws;      // [tiles][64] exchange slots, all zero between launches
+    uint32_t* errors;       // workspace header word 0: number of exchange waits that timed out (the rows involved get NaN scales)
+    long long timeout_ticks;    // bound of the partner wait in s_memrealtime ticks (100 MHz); reference: comm/barrier.cuh:12,36-40 (60 s)
+    const float* row_weight;    // optional [G, m_max] FP32 (element (g, m) at row_weight[g * rw_sg + m]): the row's top-k routing weight, applied
+    int64_t rw_sg;              // to the SwiGLU output before the re-quantisation as the reference kernel does (sm100_fp8_fp4_mega_moe.cuh:1019)
+    int fault;              // test hook (dg_set_swiglu_fault_injection): 1 = odd tiles never publish their amax -> their partners time out
 };
 
 template <int STAGES>
@@ -217,6 +222,12 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
             __syncthreads();
             float amax[MS] = {0.f, 0.f, 0.f, 0.f};
             if (wn < 2) {
+                float rw[MS] = {1.f, 1.f, 1.f, 1.f};
+                if (o.row_weight != nullptr) {
+                    // (rows past m_end: whatever the buffer holds -- they are never stored and never meet another row's amax)
+                    const v4f w4 = *reinterpret_cast<const v4f*>(o.row_weight + group * o.rw_sg + t.m0 + (lane & 15) * MS);
+                    rw[0] = w4[0]; rw[1] = w4[1]; rw[2] = w4[2]; rw[3] = w4[3];
+                }
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms)
                     #pragma unroll
@@ -229,7 +240,9 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                                 g = fminf(g, o.clamp);
                                 u = fminf(fmaxf(u, -o.clamp), o.clamp);
                             }
-                            const float y = round_bf16((g / (1.0f + expf(-g))) * u);     // torch: silu(g.float()) * u.float() -> bf16
+                            float y = round_bf16((g / (1.0f + expf(-g))) * u);           // torch: silu(g.float()) * u.float() -> bf16
+                            if (o.row_weight != nullptr)
+                                y = round_bf16(y * rw[ms]);                              // (y.float() * w).to(bf16)
                             acc[ms][ns][e] = y;
                             amax[ms] = fmaxf(amax[ms], fabsf(y));
                         }
@@ -246,17 +259,31 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
             if (wave == 0) {
                 // 3b. the other half of the 128-wide block lives in tile_id ^ 1: publish this tile's row amax, take the partner's, clear its slot
                 const float mine = fmaxf(row_max[lane], row_max[64 + lane]);
-                __hip_atomic_store(o.amax_ws + static_cast<int64_t>(tile_id) * 64 + lane, 0x80000000u | __float_as_uint(mine),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(o.fault == 1 && (tile_id & 1)))
+                    __hip_atomic_store(o.amax_ws + static_cast<int64_t>(tile_id) * 64 + lane, 0x80000000u | __float_as_uint(mine),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t* theirs = o.amax_ws + static_cast<int64_t>(tile_id ^ 1) * 64 + lane;
+                // The partner is resident or already done (adjacent in dispatch order, see the file header), so this wait is short -- but it
+                // is BOUNDED all the same: a workspace that is not all-zero (an aborted launch, two launches sharing one workspace) or a lost
+                // partner must end in an error the host can see and NaN scales, not in a hung device (reference: comm/barrier.cuh:36-40).
                 uint32_t v;
+                const long long t_wait = __builtin_amdgcn_s_memrealtime();
+                bool timed_out = false;
                 do {
                     v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(v & 0x80000000u))
+                    if (!(v & 0x80000000u)) {
                         __builtin_amdgcn_s_sleep(1);
-                } while (!(v & 0x80000000u));
-                __hip_atomic_store(theirs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                row_max[128 + lane] = fmaxf(mine, __uint_as_float(v & 0x7fffffffu));
+                        timed_out = __builtin_amdgcn_s_memrealtime() - t_wait > o.timeout_ticks;
+                    }
+                } while (!(v & 0x80000000u) && !timed_out);
+                if (v & 0x80000000u) {
+                    __hip_atomic_store(theirs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    row_max[128 + lane] = fmaxf(mine, __uint_as_float(v & 0x7fffffffu));
+                } else {
+                    row_max[128 + lane] = __uint_as_float(0x7fc00000u);         // NaN: poisons the row's scale below
+                    if (lane == 0)
+                        atomicAdd(o.errors, 1u);
+                }
             }
             __syncthreads();
             if (wn < 2) {
@@ -265,7 +292,10 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                 for (int ms = 0; ms < MS; ++ms) {
                     const int row_in_tile = (lane & 15) * MS + ms;
                     const int row = t.m0 + row_in_tile;
-                    float scale = fmaxf(row_max[128 + row_in_tile], 1e-4f) * (1.0f / 448.0f);     // the reference kernel (math.cuh:93) and torch's `/ 448.0` on a device both multiply
+                    const float row_amax = row_max[128 + row_in_tile];
+                    float scale = fmaxf(row_amax, 1e-4f) * (1.0f / 448.0f);     // the reference kernel (math.cuh:93) and torch's `/ 448.0` on a device both multiply
+                    if (row_amax != row_amax)
+                        scale = row_amax;                                       // the exchange timed out: NaN scale, NaN bytes (fmaxf drops a NaN)
                     if (o.use_ue8m0) {
                         const uint32_t bits = __float_as_uint(scale);
                         uint32_t e = ((bits >> 23) & 0xffu) + ((bits & 0x7fffffu) != 0 ? 1u : 0u);
@@ -295,6 +325,88 @@ template <int STAGES>
 __global__ __launch_bounds__(256)
 void dg_fp8_gemm_stream_swiglu_kernel(const GemmParams p, const SwigluOut o) {
     stream_swiglu_kernel_body<STAGES>(p, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// World-size-1 routing around the fused expert MLP (the reference-shaped entry fp8_mega_moe, deepgemm_amd/mega.py; reference:
+// the dispatch / combine stages of sm100_fp8_fp4_mega_moe.cuh:357-405, 523-595 -- there they pull / push token rows over NVLink; with
+// one rank they degenerate to a scatter into the masked layout and a gather-sum back).
+// dg_moe_scatter_kernel: one workgroup per token.  For every top-k entry with a valid expert the token claims the next row slot of
+// that expert (atomic counter = masked_m), copies its FP8 row and its K / 128 scales (into the MN-major SF layout the GEMMs read
+// zero-copy), stores the routing weight of the slot and remembers the slot for the combine.  Slot ORDER inside an expert depends on the
+// arrival order of the claims; no RESULT does: every row of the grouped GEMMs and of the per-token re-quantisation is computed
+// independently of its neighbours, and the combine sums a token's rows in top-k order.
+// ---------------------------------------------------------------------------------------------------------------
+struct MoeRoute {
+    const uint8_t* x; const float* x_sf; const void* topk_idx; const float* topk_w;
+    int tokens, hidden, topk, num_experts, max_m, idx64;
+    int64_t x_sm, xsf_sm;
+    uint8_t* a; float* sfa; float* rw; int32_t* slot; int32_t* counts; uint32_t* errors;
+    int64_t a_sg, a_sm, sfa_sg, sfa_sk, rw_sg;
+};
+
+__global__ __launch_bounds__(256)
+void dg_moe_scatter_kernel(const MoeRoute r) {
+    __shared__ int s_pos;
+    const int t = blockIdx.x;
+    for (int j = 0; j < r.topk; ++j) {
+        const int64_t e64 = r.idx64 ? static_cast<const int64_t*>(r.topk_idx)[static_cast<int64_t>(t) * r.topk + j]
+                                    : static_cast<int64_t>(static_cast<const int32_t*>(r.topk_idx)[static_cast<int64_t>(t) * r.topk + j]);
+        const bool valid = e64 >= 0 && e64 < r.num_experts;          // (-1 = no expert for this entry, as the reference's masked top-k)
+        const int e = static_cast<int>(e64);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int pos = -1;
+            if (valid) {
+                pos = atomicAdd(r.counts + e, 1);
+                if (pos >= r.max_m) {                                // more rows than the buffer was sized for: dropped, counted, visible
+                    atomicAdd(r.errors, 1u);
+                    atomicSub(r.counts + e, 1);
+                    pos = -1;
+                }
+            }
+            s_pos = pos;
+            r.slot[static_cast<int64_t>(t) * r.topk + j] = pos < 0 ? -1 : e * r.max_m + pos;
+        }
+        __syncthreads();
+        const int pos = s_pos;
+        if (pos < 0)
+            continue;
+        const uint4* src = reinterpret_cast<const uint4*>(r.x + static_cast<int64_t>(t) * r.x_sm);
+        uint4* dst = reinterpret_cast<uint4*>(r.a + e * r.a_sg + static_cast<int64_t>(pos) * r.a_sm);
+        for (int c = threadIdx.x; c < r.hidden / 16; c += 256)
+            dst[c] = src[c];
+        for (int kb = threadIdx.x; kb < r.hidden / 128; kb += 256)
+            r.sfa[e * r.sfa_sg + kb * r.sfa_sk + pos] = r.x_sf[static_cast<int64_t>(t) * r.xsf_sm + kb];
+        if (threadIdx.x == 0)
+            r.rw[e * r.rw_sg + pos] = r.topk_w[static_cast<int64_t>(t) * r.topk + j];
+    }
+}
+
+// y[t, :] = bf16( sum_j float(y2[slot(t, j), :]) ), j in top-k order, FP32 accumulation, entries without a slot skipped.
+__global__ __launch_bounds__(256)
+void dg_moe_combine_kernel(const uint16_t* y2, const int32_t* slot, int tokens, int topk, int hidden, int64_t y2_row_stride, uint16_t* y,
+                           int64_t y_sm) {
+    const int t = blockIdx.x;
+    for (int c = threadIdx.x * 8; c < hidden; c += 256 * 8) {
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < topk; ++j) {
+            const int s = slot[static_cast<int64_t>(t) * topk + j];
+            if (s < 0)
+                continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(y2 + static_cast<int64_t>(s) * y2_row_stride + c);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sum[2 * i] += bf16_lo(w[i]);
+                sum[2 * i + 1] += bf16_hi(w[i]);
+            }
+        }
+        uint4 out;
+        out.x = pack_bf16(sum[0], sum[1]); out.y = pack_bf16(sum[2], sum[3]);
+        out.z = pack_bf16(sum[4], sum[5]); out.w = pack_bf16(sum[6], sum[7]);
+        *reinterpret_cast<uint4*>(y + static_cast<int64_t>(t) * y_sm + c) = out;
+    }
 }
 
 }  // namespace dg

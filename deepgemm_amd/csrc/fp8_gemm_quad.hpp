@@ -149,6 +149,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
+    constexpr bool M0S = DG_M0_SHARE && !STAGED && A_ITERS % 4 == 0 && B_ITERS % 4 == 0 && (B_ITERS / 2) % 4 == 0;
     constexpr bool NO_DMA = (QV == 1 || QV == 3), NO_READS = (QV == 2 || QV == 3), NO_BARRIER = (QV == 5), HOT_LOADS = (QV == 6), HOT_DMA = (QV == 7);
     static_assert((NS == 8 && (MS == 8 || MS == 4)) || (NS == 4 && MS == 8), "wave tiles 128 x 128, 64 x 128 or (eight waves) 128 x 64");
     constexpr int PRE_STRIDE = PRE / N_PRE, POST_STRIDE = POST / N_POST;
@@ -180,6 +181,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
         #pragma unroll
         for (int q = 0; q < B_ITERS; ++q)
             b_piece_soff[q] = __builtin_amdgcn_readfirstlane(b_row_perm<WN>(q * (NW * 8)) * ldb);
+    } else if constexpr (M0S) {
+        // a wave owns A_ITERS (B_ITERS) CONSECUTIVE units: groups of four pieces share one M0 (DG_LDS_DMA_PIECE_SUB)
+        #pragma unroll
+        for (int q = 0; q < A_ITERS; ++q)
+            a_piece_voff[q] = a_voff + a_unit_row(wave * A_ITERS + q) * lda + M0_SHARE_BIAS - (q & 3) * 1024;
+        #pragma unroll
+        for (int q = 0; q < B_ITERS; ++q)
+            b_piece_voff[q] = b_row_perm<WN>((wave * B_ITERS + q) * 8 + piece_row) * ldb + src_chunk * 16 + M0_SHARE_BIAS - (q & 3) * 1024;
     } else {
         #pragma unroll
         for (int q = 0; q < A_ITERS; ++q)
@@ -253,8 +262,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
             const int a_bytes = __builtin_amdgcn_readfirstlane((imin(t.m_end - t.m0, BM) - 1) * lda + p.k);
             const int b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - t.n0, BN) - 1) * ldb + p.k);
-            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0, a_bytes, 0x00020000);
-            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0, b_bytes, 0x00020000);
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base) - (M0S ? M0_SHARE_BIAS : 0), 0, a_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base) - (M0S ? M0_SHARE_BIAS : 0), 0, b_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             // packed scale words: element (row, kq) at base[kq * stride + row] (int32); rows of the whole A (masked: of the group)
             const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg), (num_kq - 1) * sfa_kq_stride + p.m * 4);
             const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg),
@@ -269,6 +278,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_voff,
                         a_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+                else if constexpr (M0S)
+                    DG_LDS_DMA_PIECE_SUB(a_rsrc, lds + slot_off + (wave * A_ITERS + (q & ~3)) * 1024, a_piece_voff[q],
+                                         (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_piece_voff[q],
@@ -280,6 +292,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
                         b_voff, b_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+                else if constexpr (M0S)
+                    DG_LDS_DMA_PIECE_SUB(b_rsrc, lds + B_BASE + slot_off + (wave * B_ITERS + (q & ~3)) * 1024, b_piece_voff[q],
+                                         (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,

@@ -40,7 +40,12 @@ def transform_weights_for_mega_moe(l1_weights: TensorPair, l2_weights: TensorPai
     scale ROWS are interleaved one by one ([gate 0, up 0, gate 1, up 1, ...]): every weight row keeps the 128 x 128 scale block it was
     quantised in (no re-quantisation).  ``l2_weights`` pass through unchanged."""
     host_assert(activation == 'swiglu', "activation == 'swiglu'")
+    if not isinstance(l1_weights, tuple):
+        raise RuntimeError('transform_weights_for_mega_moe: BF16 weights (bf16_mega_moe) are outside this library (FP8 GEMM path only)')
     w1, sf1 = l1_weights
+    if sf1.dtype in (torch.int, torch.int32, torch.uint8):
+        raise RuntimeError('transform_weights_for_mega_moe: packed UE8M0 / FP4 weight scales (the reference\'s SM100 fp8xfp4 format, recipe '
+                           '(1, 1, 32)) are not supported on gfx950; pass FP8 e4m3 weights with FP32 128 x 128 block scales')
     host_assert(w1.dim() == 3 and sf1.dim() == 3 and w1.dtype == torch.float8_e4m3fn and sf1.dtype == torch.float, 'l1 = (fp8 [G, 2I, K], float [G, 2I/128, K/128])')
     host_assert(w1.size(1) % 256 == 0 and sf1.size(1) * 128 == w1.size(1), 'n % 256 == 0 and sf.size(1) == n / 128')
     return (_interleave_blocks(w1.view(torch.uint8), 64).view(torch.float8_e4m3fn), _interleave_blocks(sf1, 1)), l2_weights
@@ -58,19 +63,57 @@ def empty_intermediate(num_groups: int, m_max: int, intermediate: int, device) -
 _workspaces = {}
 
 
+def swiglu_workspace(num_groups: int, m: int, n: int, device) -> torch.Tensor:
+    """A zeroed exchange workspace for :func:`m_grouped_fp8_gemm_nt_masked_swiglu` (``workspace=`` argument): one per launch that may be
+    in flight at the same time -- two streams, two hipGraphs replayed concurrently, a replay racing an eager call (launches that share
+    one concurrently steal each other's slots).  256-byte header (word 0 = exchange waits that timed out) + one slot row per tile."""
+    return torch.zeros(int(lib.dg_swiglu_workspace_bytes(num_groups, m, n)), dtype=torch.uint8, device=device)
+
+
 def _exchange_workspace(num_groups: int, m: int, n: int, device: torch.device) -> torch.Tensor:
-    """The kernel's amax exchange slots: zeroed once, left zeroed by every launch (include/deepgemm_amd.h); one per (device, stream)."""
+    """The default workspace: one per (device, stream the call is ISSUED on), zeroed once, left zeroed by every launch
+    (include/deepgemm_amd.h).  As gemm._split_k_workspace: never allocated while the stream is being captured (the buffer would land in
+    the graph's private pool and outlive it in this dict) -- warm the call up eagerly on the capture stream first, or pass ``workspace=``.
+    A graph captured on stream S keeps using S's buffer wherever it is replayed; concurrent replays need caller-owned workspaces."""
     need = int(lib.dg_swiglu_workspace_bytes(num_groups, m, n))
     key = (device.index, current_stream_ptr())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('m_grouped_fp8_gemm_nt_masked_swiglu: no exchange workspace for this stream yet and the stream is being captured; '
+                               'run the call once eagerly on this stream before capturing, or pass workspace=swiglu_workspace(...)')
         ws = torch.zeros(need, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
 
+def exchange_timeouts(workspace: Optional[torch.Tensor] = None, reset: bool = True) -> int:
+    """Number of partner waits that timed out since the workspace was last zeroed (synchronises).  The rows involved carry NaN scales.
+    ``workspace=None``: summed over the library's per-stream default workspaces.  ``reset``: re-zero every workspace that reports one
+    (an aborted exchange leaves valid bits behind, which would corrupt the next launch silently)."""
+    total = 0
+    for ws in ([workspace] if workspace is not None else list(_workspaces.values())):
+        count = int(ws[:4].view(torch.int32).item())
+        if count and reset:
+            ws.zero_()
+        total += count
+    return total
+
+
+def set_exchange_timeout_us(us: int) -> None:
+    """Bound of the partner wait of the fused kernel (default 10 s; the reference's barriers give up after 60 s, comm/barrier.cuh:12)."""
+    lib.dg_set_swiglu_exchange_timeout_us(int(us))
+
+
+def _bf16_round(x: float) -> float:
+    """The reference applies the activation clamp with BF16 operands (``__hmin2`` on bf16x2, sm100_fp8_fp4_mega_moe.cuh:993-1020): a bound
+    that is not BF16-representable acts as its BF16 rounding."""
+    return float(torch.tensor(x, dtype=torch.float32).to(torch.bfloat16).float())
+
+
 def m_grouped_fp8_gemm_nt_masked_swiglu(a: TensorPair, b: TensorPair, out: TensorPair, masked_m: torch.Tensor, expected_m: int,
-                                        activation_clamp: Optional[float] = None, use_ue8m0: bool = False) -> None:
+                                        activation_clamp: Optional[float] = None, use_ue8m0: bool = False,
+                                        workspace: Optional[torch.Tensor] = None, row_weight: Optional[torch.Tensor] = None) -> None:
     """``out = per_token_cast_to_fp8( swiglu( a @ b^T ) )`` per expert, rows ``< masked_m[g]`` only: ``a = (A [G, M, K], SFA)``,
     ``b`` = the transformed W1 pair ``([G, 2 I, K], [G, 2 I / 128, K / 128])`` of :func:`transform_weights_for_mega_moe`,
     ``out`` = :func:`empty_intermediate` ``(G, M, I)``.  Bit-identical to ``m_grouped_fp8_gemm_nt_masked`` -> BF16 -> SwiGLU (``silu(g) *
@@ -92,17 +135,25 @@ def m_grouped_fp8_gemm_nt_masked_swiglu(a: TensorPair, b: TensorPair, out: Tenso
     host_assert(masked_m.dtype == torch.int and masked_m.is_contiguous() and expected_m > 0, 'masked_m int32, expected_m > 0')
     sfa = get_mn_major_tma_aligned_tensor(a_sf)
     require_device(a_data, b_data, sfa, b_sf, q, q_sf, masked_m)
-    ws = _exchange_workspace(num_groups, m, n, a_data.device)
-    check(lib.dg_m_grouped_fp8_gemm_nt_masked_swiglu(
+    ws = workspace if workspace is not None else _exchange_workspace(num_groups, m, n, a_data.device)
+    if row_weight is not None:
+        # ``row_weight [G, >= align(m, 64)]`` FP32: the routing weight of every row slot, applied as ``bf16(bf16(silu(g) * u) * w)`` before the
+        # re-quantisation (the reference kernel's placement, sm100_fp8_fp4_mega_moe.cuh:1019)
+        host_assert(row_weight.dtype == torch.float and row_weight.dim() == 2 and row_weight.size(0) == num_groups and row_weight.stride(1) == 1 and
+                    row_weight.size(1) >= -(-m // 64) * 64, 'row_weight: float [G, >= align(m, 64)]')
+        require_device(row_weight)
+    check(lib.dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), q.data_ptr(), q_sf.data_ptr(), masked_m.data_ptr(),
         num_groups, m, n, k, int(expected_m), a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
         sfa.stride(0), sfa.stride(2), b_sf.stride(0), b_sf.stride(1), b_sf.stride(2), q.stride(0), q.stride(1), q_sf.stride(0), q_sf.stride(2),
-        float(activation_clamp) if activation_clamp is not None else 0.0, int(use_ue8m0), ws.data_ptr(), ws.numel(), current_stream_ptr()))
+        _bf16_round(activation_clamp) if activation_clamp is not None else 0.0, int(use_ue8m0),
+        row_weight.data_ptr() if row_weight is not None else None, row_weight.stride(0) if row_weight is not None else 0,
+        ws.data_ptr(), ws.numel(), current_stream_ptr()))
 
 
 def fp8_mega_moe_local(x: TensorPair, l1_weights: TensorPair, l2_weights: TensorPair, y: torch.Tensor, masked_m: torch.Tensor,
                        expected_m: int, activation_clamp: Optional[float] = None,
-                       intermediate: Optional[TensorPair] = None) -> TensorPair:
+                       intermediate: Optional[TensorPair] = None, workspace: Optional[torch.Tensor] = None) -> TensorPair:
     """The expert MLP of the tokens resident on this GPU in the masked layout: ``y[g, :masked_m[g]] = W2_g . swiglu(W1_g . x[g])`` --
     fused GEMM1 (:func:`m_grouped_fp8_gemm_nt_masked_swiglu`) + ``m_grouped_fp8_gemm_nt_masked``.  ``l1_weights`` / ``l2_weights`` as
     returned by :func:`transform_weights_for_mega_moe`.  Returns the intermediate pair (reusable as the ``intermediate`` argument)."""
@@ -110,6 +161,113 @@ def fp8_mega_moe_local(x: TensorPair, l1_weights: TensorPair, l2_weights: Tensor
     inter = l1_weights[0].size(1) // 2
     if intermediate is None:
         intermediate = empty_intermediate(num_groups, m, inter, x[0].device)
-    m_grouped_fp8_gemm_nt_masked_swiglu(x, l1_weights, intermediate, masked_m, expected_m, activation_clamp)
+    m_grouped_fp8_gemm_nt_masked_swiglu(x, l1_weights, intermediate, masked_m, expected_m, activation_clamp, workspace=workspace)
     m_grouped_fp8_gemm_nt_masked(intermediate, l2_weights, y, masked_m, expected_m)
     return intermediate
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference-shaped operator (deep_gemm/mega/__init__.py:18-58, 68-128, 155-173; host side csrc/apis/mega.hpp:30-159) at world
+# size 1: buffer object with the reference's input views, one call = routing -> fused L1 -> L2 -> combine, every step a stream-ordered
+# launch with device-resident counts (hipGraph-capturable).  With more than one rank the dispatch / combine legs are RCCL all-to-alls
+# (deepgemm_amd/ep.py); the in-kernel xGMI peer-to-peer form is not built and asking for it says so.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def get_token_alignment_for_mega_moe() -> int:
+    """Rows per M tile of the fused kernel (reference: csrc/apis/mega.hpp, ``get_token_alignment_for_mega_moe``)."""
+    return 64
+
+
+class SymmBuffer:
+    """The reference's ``SymmBuffer`` (deep_gemm/mega/__init__.py:18-58) for ONE rank: the caller-visible input views ``x [T, H]`` e4m3,
+    ``x_sf [T, H / 128]`` FP32 (per-token 1 x 128 scales), ``topk_idx [T, top_k]`` int64 (-1 = no expert), ``topk_weights [T, top_k]``
+    FP32, and the operator's private staging: the masked-layout activations of both layers, slot map, per-expert counts (= ``masked_m``),
+    routing weights per slot, the BF16 L2 output rows and the fused kernel's exchange workspace."""
+
+    def __init__(self, group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
+                 num_ring_tokens: int = 0, mma_type: str = 'fp8xfp8', activation: str = 'swiglu', device='cuda'):
+        host_assert(activation == 'swiglu', "activation == 'swiglu'")
+        world = 1 if group is None else group.size()
+        if world != 1:
+            raise RuntimeError('SymmBuffer / fp8_mega_moe: only world size 1 is built on gfx950 -- the in-kernel xGMI peer-to-peer dispatch / '
+                               'combine is not (DESIGN.md section 8); shard the experts with deepgemm_amd.ep (RCCL all-to-all) instead')
+        if mma_type not in ('fp8xfp8', 'fp8'):
+            raise RuntimeError(f"SymmBuffer: mma_type '{mma_type}' is not supported on gfx950 (FP8 e4m3 activations x FP8 e4m3 weights only)")
+        host_assert(hidden % 128 == 0 and intermediate_hidden % 128 == 0, 'hidden % 128 == 0 and intermediate_hidden % 128 == 0')
+        self.group, self.num_experts, self.num_topk = group, num_experts, num_topk
+        self.num_max_tokens_per_rank = -(-num_max_tokens_per_rank // 64) * 64
+        self.hidden, self.intermediate_hidden, self.num_ring_tokens = hidden, intermediate_hidden, num_ring_tokens
+        t, e, m = self.num_max_tokens_per_rank, num_experts, self.num_max_tokens_per_rank     # one token meets an expert at most once
+        aligned = get_tma_aligned_size(m, 4)
+        self.x = torch.zeros((t, hidden), dtype=torch.float8_e4m3fn, device=device)
+        self.x_sf = torch.zeros((t, hidden // 128), dtype=torch.float, device=device)
+        self.topk_idx = torch.full((t, num_topk), -1, dtype=torch.int64, device=device)
+        self.topk_weights = torch.zeros((t, num_topk), dtype=torch.float, device=device)
+        self.l1_acts = torch.zeros((e, m, hidden), dtype=torch.float8_e4m3fn, device=device)
+        self.l1_acts_sf = torch.zeros((e, hidden // 128, aligned), dtype=torch.float, device=device).transpose(1, 2)   # [E, m, H/128], MN-major
+        self.l2_acts, self.l2_acts_sf = empty_intermediate(e, m, intermediate_hidden, device)
+        self.l2_out = torch.empty((e, m, hidden), dtype=torch.bfloat16, device=device)
+        self.row_weight = torch.zeros((e, aligned), dtype=torch.float, device=device)
+        self.slot = torch.full((t * num_topk,), -1, dtype=torch.int32, device=device)
+        self.masked_m = torch.zeros((e,), dtype=torch.int32, device=device)
+        self.errors = torch.zeros((4,), dtype=torch.int32, device=device)        # word 0: rows dropped by the routing (more than max_m per expert)
+        self.workspace = swiglu_workspace(e, m, 2 * intermediate_hidden, device)
+        self.buffer = self.x                                                    # (reference attribute; one rank needs no symmetric heap)
+
+    def destroy(self):
+        for name in ('x', 'x_sf', 'topk_idx', 'topk_weights', 'l1_acts', 'l1_acts_sf', 'l2_acts', 'l2_acts_sf', 'l2_out', 'row_weight', 'slot',
+                     'masked_m', 'errors', 'workspace', 'buffer', 'group'):
+            setattr(self, name, None)
+
+
+def get_symm_buffer_for_mega_moe(group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
+                                 use_fp8_dispatch: Optional[bool] = None, mma_type: str = 'fp8xfp8', activation: str = 'swiglu') -> SymmBuffer:
+    """deep_gemm/mega/__init__.py:68-128 (the ring-token sizing of the reference belongs to its NVLink pull pipeline and has no
+    counterpart with one rank)."""
+    return SymmBuffer(group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, 0, mma_type, activation)
+
+
+def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair, sym_buffer: SymmBuffer,
+                 cumulative_local_expert_recv_stats: Optional[torch.Tensor] = None, recipe: Optional[Tuple[int, int, int]] = None,
+                 activation: str = 'swiglu', activation_clamp: Optional[float] = None, fast_math: bool = True) -> None:
+    """``y[t] = sum_j W2[e_j] . fp8( swiglu( W1[e_j] . x[t] ) * w_j )`` over the token's top-k experts ``e_j = topk_idx[t, j] >= 0`` --
+    the reference's ``fp8_fp4_mega_moe(y, l1_weights, l2_weights, sym_buffer, ...)`` (deep_gemm/mega/__init__.py:155-173) with FP8 e4m3
+    weights and FP32 128 x 128 block scales (``transform_weights_for_mega_moe``), world size 1.  Inputs are read from the buffer's views
+    (``x``, ``x_sf``, ``topk_idx``, ``topk_weights``; rows ``[0, y.size(0))``), as the reference's test fills them
+    (tests/test_mega_moe.py:103-121).  Four stream-ordered launches + one memset, nothing returns to the host: scatter into the masked
+    layout, fused L1 (GEMM + SwiGLU + routing weight + per-token FP8 re-quantisation), masked L2, gather-sum in top-k order (FP32).
+    Bit-identical to the unfused pipeline of the same operators (tests/test_mega_gpu.py).  ``fast_math`` is accepted and ignored: this
+    kernel has one SwiGLU form (exact ``expf``).  Rows dropped because an expert got more than ``num_max_tokens_per_rank`` rows are
+    counted in ``sym_buffer.errors[0]`` (cannot happen when a token lists an expert at most once)."""
+    host_assert(activation == 'swiglu', "activation == 'swiglu'")
+    host_assert(recipe is None or tuple(recipe) == (1, 128, 128), 'recipe == (1, 128, 128): FP32 block scales (the (1, 1, 32) UE8M0 / FP4 recipe is SM100-only)')
+    b = sym_buffer
+    tokens = int(y.size(0))
+    host_assert(y.dim() == 2 and y.dtype == torch.bfloat16 and y.size(1) == b.hidden and y.stride(1) == 1 and tokens <= b.num_max_tokens_per_rank,
+                'y: bfloat16 [num_tokens <= num_max_tokens_per_rank, hidden]')
+    host_assert(l1_weights[0].size(0) == b.num_experts and l1_weights[0].size(1) == 2 * b.intermediate_hidden and l1_weights[0].size(2) == b.hidden,
+                'l1_weights[0].shape == (num_experts, 2 * intermediate_hidden, hidden)')
+    host_assert(l2_weights[0].size(0) == b.num_experts and l2_weights[0].size(1) == b.hidden and l2_weights[0].size(2) == b.intermediate_hidden,
+                'l2_weights[0].shape == (num_experts, hidden, intermediate_hidden)')
+    require_device(y, b.x, l1_weights[0], l2_weights[0])
+    stream = current_stream_ptr()
+    m = b.num_max_tokens_per_rank
+    check(lib.dg_moe_scatter_to_masked(
+        b.x.data_ptr(), b.x_sf.data_ptr(), b.topk_idx.data_ptr(), int(b.topk_idx.dtype == torch.int64), b.topk_weights.data_ptr(),
+        tokens, b.hidden, b.num_topk, b.num_experts, m, b.x.stride(0), b.x_sf.stride(0),
+        b.l1_acts.data_ptr(), b.l1_acts_sf.data_ptr(), b.row_weight.data_ptr(), b.slot.data_ptr(), b.masked_m.data_ptr(), b.errors.data_ptr(),
+        b.l1_acts.stride(0), b.l1_acts.stride(1), b.l1_acts_sf.stride(0), b.l1_acts_sf.stride(2), b.row_weight.stride(0), stream))
+    expected_m = max(1, min(m, -(-tokens * b.num_topk // b.num_experts)))
+    m_grouped_fp8_gemm_nt_masked_swiglu((b.l1_acts, b.l1_acts_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m,
+                                        activation_clamp, workspace=b.workspace, row_weight=b.row_weight)
+    m_grouped_fp8_gemm_nt_masked((b.l2_acts, b.l2_acts_sf), l2_weights, b.l2_out, b.masked_m, expected_m)
+    check(lib.dg_moe_combine_from_masked(b.l2_out.data_ptr(), b.slot.data_ptr(), tokens, b.num_topk, b.hidden, b.l2_out.stride(1),
+                                         y.data_ptr(), y.stride(0), stream))
+    if cumulative_local_expert_recv_stats is not None:
+        cumulative_local_expert_recv_stats.add_(b.masked_m.to(cumulative_local_expert_recv_stats.dtype))
+
+
+fp8_fp4_mega_moe = fp8_mega_moe      # the reference's name; FP4 weights (its SM100 default) are rejected by the weight transform
+
+
+def bf16_mega_moe(*args, **kwargs):
+    raise RuntimeError('bf16_mega_moe is outside this library (FP8 GEMM path only; SURVEY.md section 8 scope)')

@@ -137,8 +137,42 @@ int dg_pack_sf_pair_ue8m0(const float* sfa, int32_t* out_a, int batches_a, int m
  *   bit for bit what "dg_m_grouped_fp8_gemm_nt_masked -> BF16 -> SwiGLU -> per_token_cast_to_fp8" produces; other rows are untouched.
  *   workspace: dg_swiglu_workspace_bytes(num_groups, m_max, n) bytes of device memory, ZEROED ONCE by the caller; the kernel leaves it
  *   zeroed (the two workgroups that share a 1 x 128 quantisation block exchange their row amax through it), so one workspace serves every
- *   later launch and hipGraph replay on the same stream.  One workspace per stream that runs this entry concurrently. */
+ *   later launch and hipGraph replay on the same stream.  One workspace per launch that may be in flight at the same time (two
+ *   streams, a graph replay racing an eager call): launches that share a workspace concurrently steal each other's slots.
+ *   The partner wait is BOUNDED (dg_set_swiglu_exchange_timeout_us, default 10 s; reference: comm/barrier.cuh:12,36-40): a wait that
+ *   times out -- a workspace that was not all-zero, a lost partner -- increments the uint32 at workspace[0] and gives the rows involved
+ *   NaN scales and bytes; the caller then re-zeroes the workspace.  dg_set_swiglu_fault_injection(1) (tests only) makes every odd tile
+ *   skip its publish so that the path can be exercised. */
 int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n);
+void dg_set_swiglu_exchange_timeout_us(int64_t us);
+void dg_set_swiglu_fault_injection(int mode);
+/* The same with the row's routing weight applied to the SwiGLU output BEFORE the re-quantisation, as the reference's fused kernel does
+ * (deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:1019): y = bf16( bf16( silu(g) * u ) * row_weight[g, m] );
+ * row_weight FP32 [G, >= align(m_max, 64)] (element (g, m) at row_weight[g * stride_g + m]; 16-byte aligned, stride a multiple of 4);
+ * NULL = the unweighted entry above. */
+int dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
+                                                    float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
+                                                    int64_t a_stride_g, int64_t a_stride_m, int64_t b_stride_g, int64_t b_stride_n,
+                                                    int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t sfb_stride_g, int64_t sfb_stride_n,
+                                                    int64_t sfb_stride_k, int64_t out_stride_g, int64_t out_stride_m, int64_t out_sf_stride_g,
+                                                    int64_t out_sf_stride_k, float activation_clamp, int use_ue8m0, const float* row_weight,
+                                                    int64_t row_weight_stride_g, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* World-size-1 dispatch / combine of the fused MoE operator (reference: the dispatch and combine stages of the Mega-MoE kernel,
+ * sm100_fp8_fp4_mega_moe.cuh:357-405 and :523-595, host side csrc/apis/mega.hpp:30-159; with one rank they are a scatter into the masked
+ * layout and a gather-sum back).  dg_moe_scatter_to_masked: every (token t, top-k entry j) with 0 <= topk_idx[t, j] < num_experts gets
+ * the next free row slot of that expert: a_out[e, slot] = x_fp8[t] (hidden bytes), sfa_out (MN-major: element (e, kb, slot) at
+ * sfa_out[e * stride_g + kb * stride_k + slot]) = x_sf[t, kb], row_weight_out[e, slot] = topk_weights[t, j], slot_out[t * topk + j] =
+ * e * max_m + slot (-1 for an entry without an expert or beyond max_m rows -- the latter also increments *error_word);
+ * masked_m_out[e] = rows of expert e (zeroed by this call, int32: what the masked GEMMs read on the device).
+ * dg_moe_combine_from_masked: y[t] = bf16( sum_j float( y2[slot_out[t, j]] ) ) in top-k order, FP32 accumulation. */
+int dg_moe_scatter_to_masked(const void* x_fp8, const float* x_sf, const void* topk_idx, int topk_idx_is_int64, const float* topk_weights,
+                             int tokens, int hidden, int topk, int num_experts, int max_m, int64_t x_stride_m, int64_t x_sf_stride_m,
+                             void* a_out, float* sfa_out, float* row_weight_out, int32_t* slot_out, int32_t* masked_m_out, void* error_word,
+                             int64_t a_stride_g, int64_t a_stride_m, int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t row_weight_stride_g,
+                             void* stream);
+int dg_moe_combine_from_masked(const void* y2_bf16, const int32_t* slot, int tokens, int topk, int hidden, int64_t y2_row_stride, void* y_bf16,
+                               int64_t y_stride_m, void* stream);
 int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
                                            float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
                                            int64_t a_stride_g, int64_t a_stride_m, int64_t b_stride_g, int64_t b_stride_n,

@@ -12,7 +12,7 @@ from deepgemm_amd.testing import calc_diff, generators as gen
 from gpu_helpers import assert_close_fp32, assert_close_to_oracle, cpu_pair, oracle_dense
 
 pytestmark = pytest.mark.gpu
-FAST = ['stream_64x128', 'stream_nt_64x128', 'stream_64x32', 'duo_256x256', 'duo_p_256x256', 'duo_128x256', 'pipe_256x256', 'pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'pipe_32x256', 'pipe_16x256']
+FAST = ['stream_64x128', 'stream_nt_64x128', 'stream_64x32', 'stream_l8_64x32', 'stream_l16_64x32', 'stream_l8_64x128', 'stream_nt_l8_64x128', 'duo_256x256', 'duo_p_256x256', 'duo_128x256', 'pipe_256x256', 'pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'pipe_32x256', 'pipe_16x256']
 # (superseded forms and ablation variants -- ring, naive, pipe_s*, dabl* ... -- exist only in DG_EXPERIMENTS builds of the library)
 
 
@@ -1311,3 +1311,32 @@ def test_skinny_two_subtile_form(m, n, k):
     with pytest.raises(RuntimeError):
         dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
     dg.set_forced_config('auto')
+
+
+def test_single_ulp_flip_on_a_tiny_output_motivates_the_frobenius_gate():
+    """tests/gpu_helpers.py holds outputs below 256 elements to rel-Frobenius 4e-3 instead of 1e-3.  Why, demonstrated: the matrix core
+    sums the 128 products of a K block in its own order, the oracle rounds the exact block sum; when the two FP32 results straddle a BF16
+    rounding boundary ONE output element lands on the neighbouring BF16 value (2^-8 relative).  On a 16-element output that single,
+    legitimate flip is 2^-8 |w_i| / (4 rms) of the norm -- above 1e-3 whenever the element is larger than the rms -- while the
+    element-wise bound (one BF16 ulp + noise) holds.  The test finds such a case among 150 seeds and checks exactly that."""
+    flips_seen, worst = 0, None
+    for seed in range(150):
+        gen.reset_seed(1000 + seed)
+        case = gen.generate_normal(1, 16, 2048)
+        dg.fp8_gemm_nt(case.a, case.b, case.d)
+        want = oracle_dense(case).float()
+        got = case.d.float().cpu()
+        flips = int((got != want).sum())
+        if flips == 0:
+            continue
+        flips_seen += flips
+        assert bool(((got - want).abs() <= want.abs() * 2.0 ** -7 + 1e-30).all()), f'seed {seed}: a flip is at most one BF16 ulp'
+        assert_close_to_oracle(case.d, want.to(torch.bfloat16), f'seed {seed}: {flips} flip(s)')      # the 4e-3 gate + element-wise bound hold
+        rel = float((got - want).norm() / want.norm())
+        if worst is None or rel > worst[1]:
+            worst = (seed, rel, flips)
+        if flips == 1 and rel > 1e-3:
+            break
+    assert flips_seen > 0, 'no BF16 flip in 150 seeds of a 1 x 16 output'
+    assert worst[1] > 1e-3, f'flips found ({flips_seen}) but none beyond the old 1e-3 gate: worst {worst}'
+    print(f'seed {1000 + worst[0]}: {worst[2]} single-ulp flip(s) on 16 elements -> rel-Frobenius {worst[1]:.2e} (> 1e-3, < 4e-3)')

@@ -127,3 +127,159 @@ def test_fused_kernel_under_a_small_cu_limit():
                 assert torch.equal(got[0][g, :rows].view(torch.uint8), want[0][g, :rows].view(torch.uint8)) and torch.equal(got[1][g, :rows], want[1][g, :rows])
     finally:
         dg.set_num_sms(saved)
+
+
+def _quantised_tokens(tokens, hidden):
+    a = torch.randn((tokens, hidden), device='cuda', dtype=torch.bfloat16)
+    return per_token_cast_to_fp8(a, use_ue8m0=False)
+
+
+def _unfused_moe(x, topk_idx, topk_w, w1, w2, clamp):
+    """The reference-shaped operator spelled out with the plain operators, token by token and expert by expert (the reference's own
+    baseline has the same stages: dispatch -> L1 GEMM -> SwiGLU * weight -> FP8 -> L2 GEMM -> combine, tests/test_mega_moe.py:149-214):
+    masked GEMM -> BF16 -> SwiGLU -> BF16 -> * routing weight -> BF16 -> per_token_cast_to_fp8 -> masked GEMM -> sum in top-k order (FP32)."""
+    tokens, hidden = x[0].shape
+    experts, inter = w1[0].size(0), w1[0].size(1) // 2
+    y = torch.zeros((tokens, hidden), dtype=torch.float, device='cuda')
+    one = torch.tensor([1], dtype=torch.int, device='cuda')
+    for j in range(topk_idx.size(1)):
+        for t in range(tokens):
+            e = int(topk_idx[t, j])
+            if e < 0:
+                continue
+            xa = (x[0][t:t + 1].unsqueeze(0).contiguous(), x[1][t:t + 1].unsqueeze(0).contiguous())
+            h = torch.empty((1, 1, 2 * inter), device='cuda', dtype=torch.bfloat16)
+            dg.m_grouped_fp8_gemm_nt_masked(xa, (w1[0][e:e + 1], w1[1][e:e + 1]), h, one, 1)
+            gate, up = h[0, :, :inter].float(), h[0, :, inter:].float()
+            if clamp is not None:
+                gate, up = gate.clamp(max=clamp), up.clamp(-clamp, clamp)
+            act = (torch.nn.functional.silu(gate) * up).to(torch.bfloat16)
+            act = (act.float() * topk_w[t, j]).to(torch.bfloat16)
+            q, q_sf = per_token_cast_to_fp8(act, use_ue8m0=False)
+            o = torch.empty((1, 1, hidden), device='cuda', dtype=torch.bfloat16)
+            dg.m_grouped_fp8_gemm_nt_masked((q.unsqueeze(0), q_sf.unsqueeze(0)), (w2[0][e:e + 1], w2[1][e:e + 1]), o, one, 1)
+            y[t] += o[0, 0].float()
+    return y.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('tokens,experts,topk,hidden,inter,clamp', [(37, 8, 2, 512, 256, None), (64, 4, 3, 1024, 512, 10.0), (5, 16, 4, 256, 128, None)])
+def test_reference_shaped_mega_moe_entry(tokens, experts, topk, hidden, inter, clamp):
+    """fp8_mega_moe(y, l1, l2, sym_buffer) (deep_gemm/mega/__init__.py:155-173) at world size 1: routing -> fused L1 -> L2 -> combine ==
+    the unfused pipeline bit for bit; entries without an expert (-1) are skipped; the per-expert counts land in the stats tensor; the
+    whole call replays as a hipGraph with different inputs."""
+    gen.reset_seed(tokens + experts)
+    x = _quantised_tokens(tokens, hidden)
+    cast = lambda w: tuple(torch.stack(t) for t in zip(*[per_block_cast_to_fp8(w[g], use_ue8m0=False) for g in range(experts)]))   # noqa: E731
+    w1 = cast(torch.randn((experts, 2 * inter, hidden), device='cuda', dtype=torch.bfloat16) / hidden ** 0.5)
+    w2 = cast(torch.randn((experts, hidden, inter), device='cuda', dtype=torch.bfloat16) / inter ** 0.5)
+    scores = torch.rand((tokens, experts), device='cuda')
+    topk_w, topk_idx = torch.topk(scores, topk, dim=1)
+    topk_idx = topk_idx.to(torch.int64)
+    topk_idx[0, -1] = -1                                   # an entry without an expert
+    topk_w = topk_w.float()
+    buf = dg.get_symm_buffer_for_mega_moe(None, experts, tokens, topk, hidden, inter)
+    assert buf.num_max_tokens_per_rank % dg.get_token_alignment_for_mega_moe() == 0
+    l1_t, l2_t = dg.transform_weights_for_mega_moe(w1, w2)
+
+    def fill(xp, idx, wts):
+        buf.x[:tokens].copy_(xp[0]); buf.x_sf[:tokens].copy_(xp[1])
+        buf.topk_idx[:tokens].copy_(idx); buf.topk_weights[:tokens].copy_(wts)
+
+    fill(x, topk_idx, topk_w)
+    stats = torch.zeros((experts,), dtype=torch.int, device='cuda')
+    y = torch.full((tokens, hidden), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_mega_moe(y, l1_t, l2_t, buf, cumulative_local_expert_recv_stats=stats, activation_clamp=clamp)
+    want = _unfused_moe(x, topk_idx, topk_w, w1, w2, clamp)
+    assert torch.equal(y, want), f'max |diff| {(y.float() - want.float()).abs().max().item():.3e}'
+    counts = torch.bincount(topk_idx[topk_idx >= 0].flatten(), minlength=experts).to(torch.int)
+    assert torch.equal(stats, counts) and int(buf.errors[0]) == 0
+    # hipGraph: capture once (the call above warmed every workspace up), replay on new inputs
+    graph = torch.cuda.CUDAGraph()
+    y2 = torch.empty_like(y)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dg.fp8_mega_moe(y2, l1_t, l2_t, buf, activation_clamp=clamp)          # (the capture stream's own workspaces)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph, stream=side):
+        dg.fp8_mega_moe(y2, l1_t, l2_t, buf, activation_clamp=clamp)
+    x_b = _quantised_tokens(tokens, hidden)
+    idx_b = torch.topk(torch.rand((tokens, experts), device='cuda'), topk, dim=1)[1].to(torch.int64)
+    fill(x_b, idx_b, topk_w)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y2, _unfused_moe(x_b, idx_b, topk_w, w1, w2, clamp))
+    # the reference's names resolve, what is outside this library says so
+    assert dg.fp8_fp4_mega_moe is dg.fp8_mega_moe
+    with pytest.raises(RuntimeError, match='outside this library'):
+        dg.bf16_mega_moe()
+    with pytest.raises(RuntimeError, match='not supported on gfx950'):
+        dg.transform_weights_for_mega_moe((w1[0], torch.zeros((experts, 2 * inter, hidden // 512), dtype=torch.int, device='cuda')), w2)
+    buf.destroy()
+
+
+def test_exchange_wait_is_bounded_and_loud():
+    """A lost partner (fault injection: odd tiles never publish) ends in NaN scales and a host-visible error count within the configured
+    bound -- not in a hung device (reference: comm/barrier.cuh:12,36-40) -- and the workspace is re-zeroed for the next launch."""
+    from deepgemm_amd import mega
+    from deepgemm_amd._lib import lib
+    gen.reset_seed(5)
+    groups, m_max, inter, k = 2, 64, 256, 512
+    masked_ms = [64, 9]
+    a = torch.randn((groups, m_max, k), device='cuda', dtype=torch.bfloat16)
+    xq = [per_token_cast_to_fp8(a[g], use_ue8m0=False) for g in range(groups)]
+    x = (torch.stack([q[0] for q in xq]), torch.stack([q[1] for q in xq]))
+    w1_t, _ = dg.transform_weights_for_mega_moe(_weights(groups, 2 * inter, k), _weights(groups, 2 * inter, k))
+    masked = torch.tensor(masked_ms, dtype=torch.int, device='cuda')
+    ws = mega.swiglu_workspace(groups, m_max, 2 * inter, 'cuda')
+    good = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+    dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, good, masked, 40, workspace=ws)
+    assert mega.exchange_timeouts(ws) == 0 and bool(torch.isfinite(good[1][0, :64]).all())
+    mega.set_exchange_timeout_us(20000)
+    lib.dg_set_swiglu_fault_injection(1)
+    try:
+        bad = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+        dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, bad, masked, 40, workspace=ws)
+        torch.cuda.synchronize()                                    # returns: every wait gave up after 20 ms
+    finally:
+        lib.dg_set_swiglu_fault_injection(0)
+        mega.set_exchange_timeout_us(10_000_000)
+    assert bool(torch.isnan(bad[1][0, :64]).any()), 'rows whose partner never published must carry NaN scales'
+    assert mega.exchange_timeouts(ws, reset=False) > 0
+    assert mega.exchange_timeouts(ws) > 0 and int(ws.view(torch.int32).abs().sum()) == 0      # counted, then re-zeroed
+    again = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+    dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, again, masked, 40, workspace=ws)
+    for g, rows in enumerate(masked_ms):
+        assert torch.equal(again[0][g, :rows].view(torch.uint8), good[0][g, :rows].view(torch.uint8)) and torch.equal(again[1][g, :rows], good[1][g, :rows])
+
+
+def test_fused_swiglu_against_the_c_oracle():
+    """Closes the loop on the fused kernel's oracle: C oracle GEMM (oracle/fp8_gemm_oracle.c) -> SwiGLU -> the reference cast on the CPU;
+    the fused kernel's bytes, dequantised, sit within one FP8 step (2^-3 relative: e4m3 has 3 mantissa bits) + the BF16 step of the
+    intermediate of that pipeline's values, and its scales within the BF16 step of the row amax."""
+    import oracle
+    gen.reset_seed(21)
+    groups, m_max, inter, k = 2, 64, 256, 1024
+    masked_ms = [64, 21]
+    a = torch.randn((groups, m_max, k), device='cuda', dtype=torch.bfloat16)
+    xq = [per_token_cast_to_fp8(a[g], use_ue8m0=False) for g in range(groups)]
+    x = (torch.stack([q[0] for q in xq]), torch.stack([q[1] for q in xq]))
+    w1 = _weights(groups, 2 * inter, k)
+    w1_t, _ = dg.transform_weights_for_mega_moe(w1, w1)
+    masked = torch.tensor(masked_ms, dtype=torch.int, device='cuda')
+    q, q_sf = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+    dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, (q, q_sf), masked, 40)
+    for g, rows in enumerate(masked_ms):
+        h = torch.empty((rows, 2 * inter), dtype=torch.bfloat16)
+        oracle.fp8_gemm_nt(x[0][g, :rows].cpu(), x[1][g, :rows].cpu(), w1[0][g].cpu(), w1[1][g].cpu(), h)
+        y = (torch.nn.functional.silu(h[:, :inter].float()) * h[:, inter:].float()).to(torch.bfloat16)
+        want_q, want_sf = per_token_cast_to_fp8(y, use_ue8m0=False)
+        got = q[g, :rows].cpu().float() * q_sf[g, :rows].cpu().repeat_interleave(128, dim=1)
+        want = want_q.float() * want_sf.repeat_interleave(128, dim=1)
+        block_amax = y.float().abs().view(rows, inter // 128, 128).amax(dim=2).clamp(min=1e-4).repeat_interleave(128, dim=1)
+        # one e4m3 step at the element's own magnitude (2^-3 relative), floored by the block's smallest step (amax / 448 * 2^-9... subnormals),
+        # plus one BF16 step of the intermediate
+        bound = want.abs() * 2.0 ** -3 + block_amax / 448.0 * 2.0 ** -6 + y.float().abs() * 2.0 ** -7
+        assert bool(((got - want).abs() <= bound).all()), f'group {g}: dequantised bytes off by {((got - want).abs() - bound).max().item():.3e}'
+        assert bool(((q_sf[g, :rows].cpu() - want_sf).abs() <= want_sf * 2.0 ** -7).all()), f'group {g}: scales'
+        assert calc_diff(got, want) < 1e-4

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 4, GPU session A: parity of the tree + loader-wave stream tiles (mid-M dense, C5) + the item-1(b) probe.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export PYTHONUNBUFFERED=1
+OUT=gpurun_out/r4a; mkdir -p $OUT
+( timeout 900 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider 2>&1 | tail -15 ) > $OUT/pytest.log 2>&1
+echo "pytest: $(tail -1 $OUT/pytest.log)"
+timeout 120 tools/ubench/frag_rate > $OUT/frag_rate.log 2>&1; cat $OUT/frag_rate.log
+timeout 600 python tools/sweep.py --out $OUT/sweep_midm.jsonl --rounds 5 --iters 20 \
+  --configs stream_64x32,stream_l8_64x32,stream_l16_64x32,stream_64x128,stream_l8_64x128,auto \
+  --shapes 128x4096x7168,128x2112x7168,128x576x7168,128x7168x2048,128x7168x16384,128x24576x1536,128x32768x512,64x4096x7168,256x4096x7168,33x4096x7168 2>&1 | grep -v amdgpu.ids > $OUT/sweep_midm.log
+cat $OUT/sweep_midm.log | python -c "
+import sys, json
+for l in sys.stdin:
+    try: r = json.loads(l)
+    except Exception: continue
+    print(r['shape'], r['config'], r.get('us_median'), r.get('us_min'), r.get('ok', r.get('error')))
+"
+for cfg in stream_nt_64x128 stream_nt_l8_64x128 stream_l8_64x128; do
+  timeout 200 python bench.py --workload masked --config $cfg --no-secondary --no-cpu-baseline --steps 100 --warmup 20 2>&1 | grep -v amdgpu.ids | tail -1 > $OUT/c5_$cfg.json
+  python -c "
+import json,sys
+r=json.loads(open('$OUT/c5_$cfg.json').read()); print('C5', '$cfg', r['ms_per_step']*1e3, r['roofline'].get('kernel_us'), r['roofline'].get('frac'))
+"
+done
