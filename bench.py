@@ -205,8 +205,11 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
             if name == 'expert_mlp':
                 w1_t, w2_t = dg.transform_weights_for_mega_moe(w1, w2)
                 mid = dg.empty_intermediate(groups, m_max, inter, 'cuda')
-                calls.append(lambda x=x, y=y, masked=masked, mid=mid, w1_t=w1_t, w2_t=w2_t:
-                             dg.fp8_mega_moe_local(x, w1_t, w2_t, y, masked, expected, intermediate=mid))
+                # caller-owned exchange workspace: the calls are captured into a hipGraph on torch's capture stream, where the library's
+                # per-stream default must not be allocated (deepgemm_amd/mega.py: _exchange_workspace)
+                ws = dg.mega.swiglu_workspace(groups, m_max, 2 * inter, 'cuda')
+                calls.append(lambda x=x, y=y, masked=masked, mid=mid, w1_t=w1_t, w2_t=w2_t, ws=ws:
+                             dg.fp8_mega_moe_local(x, w1_t, w2_t, y, masked, expected, intermediate=mid, workspace=ws))
             else:
                 h = torch.zeros((groups, m_max, 2 * inter), device='cuda', dtype=torch.bfloat16)
 
@@ -288,10 +291,11 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
             cases.append(case)
             calls.append(lambda c=case: dg.m_grouped_fp8_gemm_nt_contiguous(c.a, c.b, c.d, c.grouped_layout))
         m = cases[0].m
-        flops = 2.0 * m * n * k
+        flops = 2.0 * m * n * k                                     # the reference's own count: padded M (tests/test_fp8_fp4.py:124)
         nbytes = count_bytes(cases[0].a, cases[0].b, cases[0].d)
+        valid_rows = int((cases[0].grouped_layout >= 0).sum().item())      # rows that belong to a group (the rest is alignment padding)
         desc = {'workload': f'm_grouped_fp8_gemm_nt_contiguous G={groups} M_total={m} N={n} K={k} (BASELINE configs[3])',
-                'm': m, 'n': n, 'k': k, 'groups': groups}
+                'm': m, 'n': n, 'k': k, 'groups': groups, 'valid_rows': valid_rows, 'useful_flops': 2.0 * valid_rows * n * k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     else:
         bound = 'hbm'
@@ -319,12 +323,14 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
     return calls, flops, float(nbytes), desc, check, bound
 
 
-def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, traffic=None):
+def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, traffic=None, useful_flops=None):
     tflops, gbs = flops / kernel_s / 1e12, nbytes / kernel_s / 1e9
     rec = ({'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / PEAK_FP8_TFLOPS} if bound == 'mfma' else
            {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
     rec.update({'traffic': traffic, 'kernel': kernel, 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
                 'algorithmic_bytes': nbytes, 'tflops': tflops, 'gbs': gbs})
+    if useful_flops is not None:        # layouts with padding rows: the fraction on the rows that carry data, beside the reference-style count
+        rec.update({'useful_flops': useful_flops, 'frac_useful': useful_flops / kernel_s / 1e12 / PEAK_FP8_TFLOPS})
     return rec
 
 
@@ -390,7 +396,7 @@ def run_secondary(sets: int):
                 extra['fused_us'] = call_s * 1e6
                 other = None
             rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
-                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config()), **extra}
+                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), useful_flops=desc.get('useful_flops')), **extra}
             out.append(rec)
         except Exception as e:                                       # noqa: BLE001  (a secondary line must not take the headline down)
             out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'[:200]})
@@ -482,7 +488,7 @@ def run(rank: int, world: int, local_rank: int, args):
         total_flops = flops * args.steps * world
         value = total_flops / elapsed / 1e12
         traffic = measured_traffic(dg.last_config()) if args.workload.startswith('dense') else None
-        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), traffic)
+        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), traffic, useful_flops=desc.get('useful_flops'))
         if split is not None:
             # the roofline of the EP step is that of its local GEMM (HBM-bound on the expert weights)
             roofline = roofline_record(flops, nbytes, split[1] / 1e6, bound, dg.last_config(), None)

@@ -159,6 +159,13 @@ const Config kConfigs[] = {
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
 #ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
+    // round 4, negative: recipe (1, 1, 128) on the two-segment 128 x 256 duo tile (persistent walk, the 20 scale values of a K block landing
+    // in two alternating register sets, MFMA + 4 v_mul + 4 v_fmac per step in the matrix segment; bit-identical to pipe_pc_256x256, 393 GPU
+    // tests green with it selected): wgrad 4096 x 4096 x 7168 146.4-147.1 us against 141.1 (profiles/r04_probe/wgrad_duo_pc_ab.log).  A step
+    // with EIGHT VALU operations costs ~62 matrix-pipe cycles in either schedule (2.05 k cycles per 16-step K block here, 4.0 k per 64
+    // steps of a SIMD there): the recipe is VALU-issue bound, not schedule bound -- the role split has nothing to hide behind.
+    {"duo_pc_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, false, false, false, true, false, true>,
+     true, false, true, true},
     // round 3, negative: two segments per K block with the A fragments streamed through the matrix segment (STREAM_A: half the barrier
     // round trips, bit-identical) -- 2.65 k cycles per K block against 2.55 k, C2 96.2 us against 93.1 (fragment reads between the MFMAs
     // of a wave that shares its SIMD cost more than the two barriers they save)

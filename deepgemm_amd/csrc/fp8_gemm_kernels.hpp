@@ -1500,6 +1500,60 @@ template <int MS> __device__ __forceinline__ float landed_sfa(const ScaleLanding
 template <int MS, bool NATURAL> struct ScaleLandingSel { typedef ScaleLandingV<MS> type; };
 template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> type; };
 
+// Scale landing registers of the per-column form (PC: recipe (1, 1, 128), one SFB value per ROW of B): the lane's MS = 4 row scales (one
+// dwordx4 of the MN-major SFA, interleaved rows) and its 16 column scales -- N-subtile ns, accumulator register r sits on column
+// wave_n0 + (ns >> 1) * 32 + (lane >> 4) * 8 + (ns & 1) * 4 + r (b_row_perm), i.e. four dwordx4 of the MN-major SFB at byte offsets
+// 0 / 16 / 128 / 144 from the lane's first column.
+struct ScaleLandingPC { v4f sa; v4f sb[4]; };
+
+__device__ __forceinline__ void issue_scale_loads_pc(ScaleLandingPC& l, const v4i& sfa_rsrc, int sfa_voff, const v4i& sfb_rsrc, int sfb_voff) {
+    asm volatile(
+        "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
+        "buffer_load_dwordx4 %0, %5, %6, 0 offen\n\t"
+        "buffer_load_dwordx4 %1, %7, %8, 0 offen\n\t"
+        "buffer_load_dwordx4 %2, %7, %8, 0 offen offset:16\n\t"
+        "buffer_load_dwordx4 %3, %7, %8, 0 offen offset:128\n\t"
+        "buffer_load_dwordx4 %4, %7, %8, 0 offen offset:144"
+        : "=&v"(l.sa), "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3])
+        : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc)
+        : "memory");
+}
+
+template <int ALLOWED>
+__device__ __forceinline__ void wait_landing_pc(ScaleLandingPC& l) {
+    static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
+    asm volatile("" : "+v"(l.sa), "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]) :: "memory");
+}
+
+// MFMA + promotion of an older step with one scale PER accumulator register (the per-column form's ring tail: products formed a K block ago)
+__device__ __forceinline__ void mfma_promote_step_v(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand, float (&c)[4],
+                                                    const float (&s)[4], const v4f& part_old) {
+    asm volatile(
+        "v_mfma_f32_16x16x128_f8f6f4 %0, %5, %6, 0\n\t"
+        "v_fmac_f32 %1, %7, %11\n\t"
+        "v_fmac_f32 %2, %8, %12\n\t"
+        "v_fmac_f32 %3, %9, %13\n\t"
+        "v_fmac_f32 %4, %10, %14"
+        : "=&v"(part_new), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+        : "v"(rows_operand), "v"(cols_operand), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(part_old[0]), "v"(part_old[1]),
+          "v"(part_old[2]), "v"(part_old[3])
+        : "memory");
+}
+
+__device__ __forceinline__ void promote_only_v(float (&c)[4], const float (&s)[4], const v4f& part_old) {
+    asm volatile(
+        "s_nop 3\n\t"
+        "v_fmac_f32 %0, %4, %8\n\t"
+        "v_fmac_f32 %1, %5, %9\n\t"
+        "v_fmac_f32 %2, %6, %10\n\t"
+        "v_fmac_f32 %3, %7, %11"
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(part_old[0]), "v"(part_old[1]), "v"(part_old[2]), "v"(part_old[3])
+        : "memory");
+}
+
 // PERSIST: persistent launch (one workgroup per CU walks the tile list) with cross-tile prologue prefetch.
 // B_MN: operand B is MN-major ([K][N], unit stride along n, row pitch b_sk): the nn / tn layouts without the re-majoring
 // pass.  LDS-DMA pieces are 4 k-rows x 256 bytes, B fragments come through the hardware transpose read, B rows keep their
@@ -1530,14 +1584,15 @@ template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> t
 // of B(kb+1) in its L(kb) (B(kb-1)'s slot: everybody's L(kb-1) reads are done), the UPPER half all pieces of A(kb+2) in its L(kb)
 // (A(kb-1)'s slot: the upper half itself finished M(kb-1) last).  Prologue: A(0) B(0) A(1).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false>
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
+    static_assert(!PC || (MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK && !STREAM_A), "PC: the two-segment 128-row tile, K-major operands");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MERGED ? MS : MS / 2;
     static_assert(!STREAM_A || (BM == 256 && !MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK), "STREAM_A: dense 256-row tiles, K-major operands");
     constexpr int TOTAL = MS * NS, SEG = HS * NS, DEPTH = 3;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = MERGED ? 3 : 2;
-    constexpr int SCALE_LOADS = A_MN ? MS + 1 : MS / 4 + 1;    // vector-memory operations of one issue_scale_loads_any
+    constexpr int SCALE_LOADS = PC ? 5 : (A_MN ? MS + 1 : MS / 4 + 1);    // vector-memory operations of one issue_scale_loads_any / _pc
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
@@ -1587,7 +1642,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     const int k_tail = K_TAIL ? (p.k & 127) : 0;    // a partial last K block (multiple of 16 bytes): handled after the loop, see below
     const int num_sf_kb = num_kb + (k_tail != 0);
     const int sfa_extent = (p.m - 1) * 4 + (num_sf_kb - 1) * sfa_kb_stride + 4;
-    const int sfb_extent = (num_sf_kb - 1) * sfb_kb_stride + 4;
+    // (PC: the lane's 16 column scales of a K block; columns past N read the next block's head or fall out of range -- never stored)
+    const int sfb_extent = (num_sf_kb - 1) * sfb_kb_stride + (PC ? p.n * 4 : 4);
+    [[maybe_unused]] const int sfb_lane_off = (lane >> 4) * 32;
 
     // Per-piece source offsets (rows + chunk: the bounds-checked part of the address) are kernel invariants held in
     // VGPRs; the K block goes in the soffset.  Blocks past the end re-read the last K block into a dead slot -- no
@@ -1638,7 +1695,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         tm.b_bytes = __builtin_amdgcn_readfirstlane(B_MN ? (p.k - 1) * ldb_mn + (p.n - tt.n0) : (imin(p.n - tt.n0, BN) - 1) * ldb + p.k);
         tm.sfa_addr = reinterpret_cast<uint64_t>(p.sfa + adg * p.sfa_sg);
         tm.sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(tt.group) * p.sfb_sg +
-                                                 static_cast<int64_t>((tt.n0 + wn * WN) / 128) * p.sfb_sn);
+                                                 (PC ? static_cast<int64_t>(tt.n0 + wn * WN)           // MN-major SFB: one value per column
+                                                     : static_cast<int64_t>((tt.n0 + wn * WN) / 128) * p.sfb_sn));
         tm.sfa_voff = (tt.m0 + wm * WM + (lane & 15) * (A_MN ? 1 : MS)) * 4;
         return tm;
     };
@@ -1677,6 +1735,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // travels ahead: a VGPR-destination load (the scales) must reach its wait in straight-line code, because hipcc is
     // free to copy the destination registers at any control-flow join in between -- before the data has arrived.
     typename ScaleLandingSel<MS, A_MN>::type land;
+    [[maybe_unused]] ScaleLandingPC land_pc0, land_pc1;        // PC: block kb's scales in one, block kb+1's landing in the other
     auto issue_prologue = [&](const Tile& tt) {
         const TileMem tm = tile_mem(tt);
         #pragma unroll
@@ -1748,9 +1807,15 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // any wait and the stores overlap its first K block instead of standing between the two tiles.
                 const TileMem tmn = tile_mem(tn);
                 issue_prologue(tn);
+                if constexpr (PC) {
+                    issue_scale_loads_pc(land_pc0, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
+                                         scale_rsrc(tmn.sfb_addr, sfb_extent), sfb_lane_off + kb0 * sfb_kb_stride);
+                    wait_landing_pc<0>(land_pc0);
+                } else {
                 issue_scale_loads_any<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
                                           scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
                 wait_landing_any<0, MS>(land);      // the landed values stay in `land` until the next tile's L_a(0) consumes them
+                }
                 next_prefetched = true;
             }
         };
@@ -1789,9 +1854,15 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 // SF(0) first, then the pieces of blocks 0 and 1: the wait leaves block 1's pieces in flight (the first K block's
                 // own counted wait covers them), so the first segment starts as soon as block 0 is in.  (Straight-line from the
                 // scale loads to their wait: hipcc may copy the landing registers at any control-flow join in between.)
+                if constexpr (PC) {
+                    issue_scale_loads_pc(land_pc0, sfa_rsrc, sfa_voff + kb0 * sfa_kb_stride, sfb_rsrc, sfb_lane_off + kb0 * sfb_kb_stride);
+                    issue_prologue(t);
+                    wait_landing_pc<A_ITERS + B_ITERS>(land_pc0);
+                } else {
                 issue_scales(land, 0);
                 issue_prologue(t);
                 wait_landing_any<STREAM_A ? A_ITERS : A_ITERS + B_ITERS, MS>(land);
+                }
             }
             raw_barrier();
             if (upper_half)
@@ -1802,6 +1873,85 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             v8i bf[NS], af[HS];
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
 
+            [[maybe_unused]] float tailp[DEPTH][4];            // PC: scale products of the last DEPTH steps of the previous K block
+            #pragma unroll
+            for (int i = 0; i < DEPTH; ++i)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tailp[i][r] = 0.f;
+            if constexpr (PC) {
+                // The MERGED schedule with one scale per row of A AND per row of B (reference: impls/sm90_fp8_gemm_1d1d.cuh:279-311): a step
+                // is MFMA + 4 v_mul (sfa x sfb) + 4 v_fmac.  The landing registers alternate between two sets (no copies): the loop body
+                // exists twice, for "block kb in set 0 / block kb+1 landing in set 1" and the reverse.
+                auto k_block = [&](ScaleLandingPC& cur, ScaleLandingPC& nxt, int kb) {
+                    const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                    const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
+                    // ---------------- L ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    #pragma unroll
+                    for (int h = 0; h < MS; ++h)
+                        af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                    {
+                        const int jj = kb0 + imin(kb + 1, nkb - 1);   // past the end: the last block's scales again (never consumed)
+                        issue_scale_loads_pc(nxt, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, sfb_lane_off + jj * sfb_kb_stride);
+                    }
+                    #pragma unroll
+                    for (int q = 0; q < A_ITERS; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q)
+                        issue_b_piece(b_fill, kb + 2, q);
+                    // my pieces of block kb+1 (issued one K block ago) have landed; this segment's own loads stay in flight
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(A_ITERS + B_ITERS + SCALE_LOADS, 0));
+                    asm volatile("" ::: "memory");
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        asm volatile("" : "+v"(bf[ns]) :: "memory");
+                    #pragma unroll
+                    for (int h = 0; h < MS; ++h)
+                        asm volatile("" : "+v"(af[h]) :: "memory");
+                    // ---------------- M ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int i = 0; i < TOTAL; ++i) {
+                        const int ns = i % NS, h = i / NS;
+                        const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
+                        if (i < DEPTH)
+                            mfma_promote_step_v(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], tailp[i], part[(i + 1) & DEPTH]);
+                        else
+                            mfma_promote_step_pc_scalar(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], cur.sb[j % NS], cur.sa[j / NS],
+                                                        part[(i + 1) & DEPTH]);
+                    }
+                    // the products the next block's first DEPTH steps (or the drain after the loop) promote this block's last steps with
+                    #pragma unroll
+                    for (int i = 0; i < DEPTH; ++i) {
+                        const int j = TOTAL - DEPTH + i;
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            tailp[i][r] = cur.sa[j / NS] * cur.sb[j % NS][r];
+                            pin_vgpr(tailp[i][r]);
+                        }
+                    }
+                    wait_landing_pc<A_ITERS + B_ITERS>(nxt);          // the scales of block kb+1, in front of the back edge
+                    const int b_next = (b_cur == (B_SLOTS - 1) * B_BYTES) ? 0 : b_cur + B_BYTES;
+                    b_fill = b_cur;
+                    b_cur = b_next;
+                    const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
+                    a_fill = a_cur;
+                    a_cur = a_next;
+                };
+                int kb = 0;
+                for (; kb + 2 <= nkb; kb += 2) {
+                    k_block(land_pc0, land_pc1, kb);
+                    k_block(land_pc1, land_pc0, kb + 1);
+                }
+                if (kb < nkb)
+                    k_block(land_pc0, land_pc1, kb);
+            } else
             if constexpr (STREAM_A) {
                 // One copy of the K loop per wave half, chosen once: the halves differ in which pieces they issue and in two wait
                 // counts (immediates), and no branch may sit between an asm scale load and its wait (the landing-register rule).
@@ -2052,7 +2202,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 #pragma unroll
                 for (int i = 0; i < DEPTH; ++i) {
                     const int j = TOTAL - DEPTH + i;
-                    promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
+                    if constexpr (PC)
+                        promote_only_v(acc[j / NS][j % NS], tailp[i], part[(TOTAL + i + 1) & DEPTH]);
+                    else
+                        promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
                 }
             };
             if constexpr (K_TAIL) {
@@ -2206,7 +2359,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             }
         }
         if (store)
-            store_tile<MS, NS, !A_MN, false, B_MN>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
+            store_tile<MS, NS, !A_MN, false, B_MN, PC>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && first_tile && !next_prefetched) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -2222,10 +2375,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false>
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC>(p);
 }
 
 
