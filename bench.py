@@ -32,9 +32,9 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
-             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor']
+             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
-             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor']
+             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128']
 GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
@@ -235,13 +235,35 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
             q, sf = per_token_cast_to_fp8(act.view(groups * m_max, inter), use_ue8m0=False)
             dg.m_grouped_fp8_gemm_nt_masked((q.view(groups, m_max, inter), sf.view(groups, m_max, inter // 128)), w2, want, masked, expected)
             return calc_diff(y.float(), want.float())
-    elif name in ('dgrad_ktail', 'dgrad_ksplit'):
-        # two dgrad entries of the reference's dense sweep (tests/generators.py:139-145: fp8_gemm_nn with m = 4096 and the (n, k) pairs
-        # swapped): K = 2112 is not a multiple of 128 (K-tail stage), n = 512 with K = 32768 fills a quarter of the chip (K split)
-        m, n, k = (4096, 7168, 2112) if name == 'dgrad_ktail' else (4096, 512, 32768)
+    elif name == 'dense_m128':
+        # a mid-M entry of the reference's forward sweep (tests/generators.py:119-121: m = 128, (n, k) = (4096, 7168)): one weight stream
+        # with too few 64-row tiles for 256 CUs -- the 64 x 32 stream tile with loader waves (round 4)
+        bound = 'hbm'
+        m, n, k = 128, 4096, 7168
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_normal(m, n, k, True, False)
+            case = gen.generate_normal(m, n, k)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            cases.append(case)
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        flops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (mid-M entry of the reference forward sweep, tests/generators.py:119-121)', 'm': m, 'n': n, 'k': k}
+        check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
+    elif name in ('dgrad_ktail', 'dgrad_ksplit', 'dgrad_ktail_ue8m0'):
+        # two dgrad entries of the reference's dense sweep (tests/generators.py:139-145: fp8_gemm_nn with m = 4096 and the (n, k) pairs
+        # swapped): K = 2112 is not a multiple of 128 (K-tail stage), n = 512 with K = 32768 fills a quarter of the chip (K split);
+        # '_ue8m0': the K-tail entry with packed UE8M0 scale words (the reference's SM100 input format; MN-major B is re-majored inside the call)
+        m, n, k = (4096, 512, 32768) if name == 'dgrad_ksplit' else (4096, 7168, 2112)
+        packed = name == 'dgrad_ktail_ue8m0'
+        for i in range(sets):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k, True, False, use_ue8m0=packed)
+            if packed:
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+                cases.append(case)
+                calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d))
+                continue
             a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
             calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
@@ -249,7 +271,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         flops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * m * kb + 4 * (-(-n // 128)) * kb + 2 * m * n
         desc = {'workload': f'fp8_gemm_nn M={m} N={n} K={k} (dgrad entry of the reference sweep, tests/generators.py:139-145; '
-                            + ('K tail on the fast path' if name == 'dgrad_ktail' else 'under-filled launch: K split') + ')',
+                            + ('under-filled launch: K split' if name == 'dgrad_ksplit' else 'K tail on the fast path' + (', packed UE8M0 scales' if packed else '')) + ')',
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name in ('wgrad', 'wgrad_ksplit'):

@@ -48,6 +48,7 @@ SIGNATURES = {
     'dg_last_config': (_cp, []),
     'dg_select_config': (_cp, [_i32] * 12),
     'dg_dense_wants_workspace': (_i32, [_i32] * 6),
+    'dg_dense_rowmajor_sfa_native': (_i32, [_i32] * 3),
     'dg_operand_plan': (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32]),
     'dg_last_error': (_cp, []),
     'dg_version': (_cp, []),

@@ -97,11 +97,16 @@ struct Config {
     bool per_col = false;     // recipe (1, 1, 128): one SFB value per row of B (all other fast kernels: one per 128 rows)
     bool split_k = false;     // persistent launch whose partial last round is cut along K over the idle CUs (needs a workspace)
     bool k_tail = false;      // handles a partial last K block (k % 128 != 0, k % 16 == 0, k > 128): the duo kernels
+    bool sfa_rm = false;      // reads a ROW-major SFA ([M][K / 128], sfa_stride_k == 1) in place -- every other ring kernel wants it MN-major
 };
 
 const Config kConfigs[] = {
     {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true, true},
     {"duo_p_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true>, true, true, true},
+    // round 4: the same kernel reading a row-major SFA as the reference's callers hold it (eight strided dword loads per lane and K block
+    // instead of two dwordx4): the layout step's transpose launch in front of the GEMM disappears (dense problems that pick duo_p_256x256)
+    {"duo_p_rm_256x256", 256, 256, 512, 1, 0.0f, true,
+     dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, false, false, false, false, true>, true, false, true, false, false, false, true},
     // 128-row duo tile: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise
     // badly at 256 x 256.  Measured per-tile: 116 k cycles vs 167 k for twice the work (L2->LDS bytes per flop are 1.5x).
     // Every 128-row form runs the two-segment schedule (MERGED: one load + one 16-step matrix segment per K block, 3-slot B
@@ -232,6 +237,9 @@ const E8Config kE8Configs[] = {
     {"e8_stream_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, true>, 64, 128, 256, false, true, true},
     {"e8_stream_nt_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, true>, 64, 128, 256, false, true, true},
     {"e8_stream_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true>, 64, 32, 256, false, true, true},
+    // round 4: k % 128 != 0 (whole 16-byte chunks, k > 128; dense): the 128-row quad form with the partial last block zero-filled by the
+    // buffer range check -- packed-scale dgrad shapes (K = 2112, 576) no longer leave the hardware-scaled path
+    {"e8_quad_kt_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, true>, 128, 256, 256, false, false, false},
 #ifdef DG_EXPERIMENTS
     {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
@@ -340,6 +348,9 @@ bool split_k_pays(long pieces, long num_kb) {
     return pieces >= 2 && num_kb * (pieces - 1) * 100 > (1100 + 100 * pieces) * pieces;
 }
 
+// SFA as the reference's callers hold it before the layout step: [M][ceil(K / 128)] floats, unit stride along K.
+bool sfa_row_major(const dg::GemmParams& p) { return p.sfa_sk == 1 && p.sfa_sm != 1 && p.m > 1; }
+
 // Picks the configuration with the lowest modelled time: (#rounds of resident blocks) x (tile work / efficiency).
 const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expected_m, int bm_must_divide, bool ignore_forced = false) {
     const std::string forced = ignore_forced ? std::string("auto") : forced_config();
@@ -348,6 +359,19 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             if (forced == kConfigs[i].name)
                 return &kConfigs[i];
         return nullptr;
+    }
+    if (sfa_row_major(p)) {
+        // a row-major SFA: taken in place where the MN-major twin of the problem would run duo_p_256x256 (dg_dense_rowmajor_sfa_native tells
+        // the host layer, which otherwise transposes first)
+        if (p.gemm_type == dg::kNormal && p.sfb_gran_n == 128 && p.head_lr == 0 && fast_eligible(p)) {
+            dg::GemmParams q = p;
+            q.sfa_sm = 1; q.sfa_sk = (p.m + 3) / 4 * 4; q.sk_workspace = nullptr;
+            const Config* twin = select_config(q, m_for_tiling, expected_m, bm_must_divide, true);
+            if (twin != nullptr && std::strcmp(twin->name, "duo_p_256x256") == 0)
+                for (int i = 0; i < kNumConfigs; ++i)
+                    if (std::strcmp(kConfigs[i].name, "duo_p_rm_256x256") == 0)
+                        return &kConfigs[i];
+        }
     }
     if (p.sfb_gran_n == 1) {
         const char* pick = per_col_eligible(p) && p.m > 64 ? "pipe_pc_256x256"
@@ -638,8 +662,9 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
                        (cfg->k_tail ? " (or k % 16 == 0 and k > 128)" : "");
         return 3;
     }
-    if (cfg->ring && p.sfa_sm != 1) {
-        g_last_error = std::string("forced config '") + cfg->name + "' needs MN-major SFA (sfa_stride_m == 1)";
+    if (cfg->sfa_rm ? !(sfa_row_major(p) && p.gemm_type == dg::kNormal && p.sfb_gran_n == 128 && p.head_lr == 0) : (cfg->ring && p.sfa_sm != 1)) {
+        g_last_error = std::string("forced config '") + cfg->name + (cfg->sfa_rm ? "' needs a dense problem with a row-major SFA (sfa_stride_k == 1)"
+                                                                                 : "' needs MN-major SFA (sfa_stride_m == 1)");
         return 3;
     }
     if (bm_must_divide > 0 && bm_must_divide % cfg->bm != 0 &&
@@ -861,8 +886,9 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
 }
 
 int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
-    if (!fast_eligible(p)) {
-        g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0";
+    const bool k_tail = p.k % 128 != 0;
+    if (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal)) {
+        g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0 (dense: or k % 16 == 0 and k > 128)";
         return 3;
     }
     const bool grouped = p.gemm_type != dg::kNormal;
@@ -871,6 +897,18 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     for (const E8Config& c : kE8Configs)
         if (forced == c.name)
             cfg = &c;
+    if (k_tail) {
+        for (const E8Config& c : kE8Configs)
+            if (std::strcmp(c.name, "e8_quad_kt_128x256") == 0) {
+                if (cfg != nullptr && cfg != &c) {
+                    g_last_error = std::string("forced config '") + cfg->name + "' needs k % 128 == 0";
+                    return 3;
+                }
+                cfg = &c;
+            }
+    } else if (cfg != nullptr && std::strcmp(cfg->name, "e8_quad_kt_128x256") == 0) {
+        cfg = nullptr;                              // (the tail form is only for tails; a forced name falls back to the selection)
+    }
     if (cfg == nullptr)
         cfg = select_e8_config(p, expected_m);
     if (cfg->stream && (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum)) {
@@ -1009,8 +1047,8 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
     p.sfb_gran_n = 128; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
     p.sfb_gran_n = 128;                                      // only so that the K-major / alignment test below applies
-    if (!fast_eligible(p)) {
-        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs K-major, 16-byte aligned FP8 operands and k % 128 == 0";
+    if (!fast_eligible(p, p.k % 128 == 0)) {
+        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs K-major, 16-byte aligned FP8 operands and k % 128 == 0 (or k % 16 == 0 and k > 128)";
         return 3;
     }
     return launch_e8(p, 0, stream);
@@ -1656,7 +1694,8 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
     p.sk_workspace = has_workspace ? reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23) : nullptr;
     if (packed_ue8m0) {
         p.sfb_gran_n = 128;
-        name = fast_eligible(p) ? select_e8_config(p, expected_m)->name : "";
+        name = fast_eligible(p) ? select_e8_config(p, expected_m)->name
+                                : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
     } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
         name = per_col_eligible(p) ? "pipe_pc_ks_256x256" : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)
     } else if (gemm_type == dg::kContiguous && m_alignment == 128 && has_workspace && !b_mn_major && sfb_gran_n == 128 && k % 128 == 0 && k >= 1024 &&
@@ -1668,6 +1707,23 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
         name = cfg != nullptr ? cfg->name : "";
     }
     return name.c_str();
+}
+
+int dg_dense_rowmajor_sfa_native(int m, int n, int k) {
+    // would a dense call with K-major 16-byte aligned operands, per-128 SFB and a ROW-major SFA [m][ceil(k / 128)] read the SFA in place
+    // (duo_p_rm_256x256)?  The host layer asks before it launches the layout step's transpose; the rule lives in select_config only.
+    if (m <= 1 || n <= 0 || k <= 0 || forced_config() != "auto")
+        return 0;
+    dg::GemmParams p{};
+    p.a = p.b = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(1) << 20);
+    p.sfa = p.sfb = reinterpret_cast<const float*>(static_cast<uintptr_t>(1) << 21);
+    p.d = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 22);
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = k; p.a_sk = 1; p.b_sn = k; p.b_sk = 1;
+    p.sfa_sm = (k + 127) / 128; p.sfa_sk = 1; p.sfb_sn = (k + 127) / 128; p.sfb_sk = 1;
+    p.d_sm = n; p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.gemm_type = dg::kNormal;
+    const Config* cfg = select_config(p, p.m, 0, 0, true);
+    return cfg != nullptr && cfg->sfa_rm ? 1 : 0;
 }
 
 int dg_dense_wants_workspace(int m, int n, int k, int a_mn_major, int b_mn_major, int sfb_gran_n) {

@@ -1366,7 +1366,6 @@ void dg_fp8_gemm_pipe_pc_kernel(const GemmParams p) {
     pipe_pc_kernel_body<BM, BN, WAVES_M, WAVES_N, SPREAD, MN>(p);
 }
 
-// A bare s_barrier: __syncthreads() would add a vmcnt(0) fence and drain the LDS-DMA queue.
 // LDS-DMA pieces in groups of four that share ONE M0 value (round 4).  The LDS address of a `buffer_load ... lds` is M0 + the instruction's
 // immediate offset + 16 * lane, and the immediate is added to the memory address as well.  A wave that owns FOUR CONSECUTIVE 1 KiB units of a
 // tile issues them with immediates 0 / 1024 / 2048 / 3072 against one M0 value instead of rewriting M0 (s_mov m0 + the wait state behind
@@ -1480,6 +1479,38 @@ __device__ __forceinline__ void issue_scale_loads_n(ScaleLandingN<MS>& l, const 
         : "memory");
 }
 
+// The same landing registers for a ROW-major SFA ([M][K / 128] floats, the layout the reference's callers hold before its layout step:
+// tests/test_fp8_fp4.py:45-55, csrc/jit_kernels/impls/smxx_layout.hpp:120-153 is the transpose this saves): a lane's MS rows lie
+// `row_stride` bytes apart, so the MS dword loads take their row offsets from the scalar offset operand (k * row_stride, formed by SALU
+// inside the block: two SGPRs instead of MS, nothing for hipcc to spill).  voff = first row * row_stride + 4 * K block.
+template <int MS>
+__device__ __forceinline__ void issue_scale_loads_rm(ScaleLandingN<MS>& l, const v4i& sfa_rsrc, int sfa_voff, int row_stride,
+                                                     const v4i& sfb_rsrc, int sfb_voff) {
+    static_assert(MS == 8, "unrolled by hand");
+    int tmp;
+    asm volatile(
+        "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
+        "buffer_load_dword %0, %10, %11, 0 offen\n\t"
+        "buffer_load_dword %1, %10, %11, %12 offen\n\t"
+        "s_mul_i32 %9, %12, 2\n\t"
+        "buffer_load_dword %2, %10, %11, %9 offen\n\t"
+        "s_mul_i32 %9, %12, 3\n\t"
+        "buffer_load_dword %3, %10, %11, %9 offen\n\t"
+        "s_mul_i32 %9, %12, 4\n\t"
+        "buffer_load_dword %4, %10, %11, %9 offen\n\t"
+        "s_mul_i32 %9, %12, 5\n\t"
+        "buffer_load_dword %5, %10, %11, %9 offen\n\t"
+        "s_mul_i32 %9, %12, 6\n\t"
+        "buffer_load_dword %6, %10, %11, %9 offen\n\t"
+        "s_mul_i32 %9, %12, 7\n\t"
+        "buffer_load_dword %7, %10, %11, %9 offen\n\t"
+        "buffer_load_dword %8, %13, %14, 0 offen"
+        : "=&v"(l.s[0]), "=&v"(l.s[1]), "=&v"(l.s[2]), "=&v"(l.s[3]), "=&v"(l.s[4]), "=&v"(l.s[5]), "=&v"(l.s[6]),
+          "=&v"(l.s[7]), "=&v"(l.sb), "=&s"(tmp)
+        : "v"(sfa_voff), "s"(sfa_rsrc), "s"(row_stride), "v"(sfb_voff), "s"(sfb_rsrc)
+        : "memory");
+}
+
 template <int ALLOWED, int MS>
 __device__ __forceinline__ void wait_landing_n(ScaleLandingN<MS>& l) {
     static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
@@ -1584,18 +1615,27 @@ __device__ __forceinline__ void promote_only_v(float (&c)[4], const float (&s)[4
 // of B(kb+1) in its L(kb) (B(kb-1)'s slot: everybody's L(kb-1) reads are done), the UPPER half all pieces of A(kb+2) in its L(kb)
 // (A(kb-1)'s slot: the upper half itself finished M(kb-1) last).  Prologue: A(0) B(0) A(1).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false>
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false, bool SFA_RM = false>
 __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
+    static_assert(!SFA_RM || (BM == 256 && PERSIST && !A_MN && !B_MN && !K_TAIL && !MERGED && !SPLITK && !STREAM_A && !PC),
+                  "SFA_RM: the dense persistent 256-row form reading a row-major SFA in place");
     static_assert(!PC || (MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK && !STREAM_A), "PC: the two-segment 128-row tile, K-major operands");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MERGED ? MS : MS / 2;
     static_assert(!STREAM_A || (BM == 256 && !MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK), "STREAM_A: dense 256-row tiles, K-major operands");
     constexpr int TOTAL = MS * NS, SEG = HS * NS, DEPTH = 3;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = MERGED ? 3 : 2;
-    constexpr int SCALE_LOADS = PC ? 5 : (A_MN ? MS + 1 : MS / 4 + 1);    // vector-memory operations of one issue_scale_loads_any / _pc
+    constexpr int SCALE_LOADS = PC ? 5 : (A_MN || SFA_RM ? MS + 1 : MS / 4 + 1);    // vector-memory operations of one issue_scale_loads_any / _pc
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
-    constexpr int A_EARLY = A_ITERS / 2;        // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b
+#ifdef DG_A_EARLY                               // (tuning builds: DG_VARIANT_FLAGS=-DDG_A_EARLY=n)
+    constexpr int A_EARLY = DG_A_EARLY < A_ITERS ? DG_A_EARLY : A_ITERS;
+#else
+    // A pieces issued in L_a (next to the scale loads); the rest go with B in L_b.  Any split is legal (A(kb-1)'s slot is dead from barrier 4 kb
+    // on, the counted waits only know the total); round 4 same-box A/B on C2 (profiles/r04_probe/a_early_ab.log): 0 / 1 of 4 early 93.8-93.9 us,
+    // 2 (the round-1 choice) 94.0-94.8, 3 / 4 95.0-95.7 -- the scale loads want L_a, the pieces want the segment without them
+    constexpr int A_EARLY = A_ITERS / 4;
+#endif
     // groups of four pieces that share one M0 value (DG_LDS_DMA_PIECE_SUB): K-major operands whose wave share is a multiple of four units
     constexpr bool M0S_A = DG_M0_SHARE && !A_MN && !STREAM_A && A_ITERS % 4 == 0, M0S_B = DG_M0_SHARE && !B_MN && !STREAM_A && B_ITERS % 4 == 0;
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
@@ -1641,7 +1681,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
     const int k_tail = K_TAIL ? (p.k & 127) : 0;    // a partial last K block (multiple of 16 bytes): handled after the loop, see below
     const int num_sf_kb = num_kb + (k_tail != 0);
-    const int sfa_extent = (p.m - 1) * 4 + (num_sf_kb - 1) * sfa_kb_stride + 4;
+    [[maybe_unused]] const int sfa_row_stride = static_cast<int>(p.sfa_sm) * 4;          // SFA_RM: bytes between the scale rows of m and m + 1
+    const int sfa_extent = SFA_RM ? (p.m - 1) * sfa_row_stride + (num_sf_kb - 1) * sfa_kb_stride + 4
+                                  : (p.m - 1) * 4 + (num_sf_kb - 1) * sfa_kb_stride + 4;
     // (PC: the lane's 16 column scales of a K block; columns past N read the next block's head or fall out of range -- never stored)
     const int sfb_extent = (num_sf_kb - 1) * sfb_kb_stride + (PC ? p.n * 4 : 4);
     [[maybe_unused]] const int sfb_lane_off = (lane >> 4) * 32;
@@ -1697,7 +1739,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         tm.sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(tt.group) * p.sfb_sg +
                                                  (PC ? static_cast<int64_t>(tt.n0 + wn * WN)           // MN-major SFB: one value per column
                                                      : static_cast<int64_t>((tt.n0 + wn * WN) / 128) * p.sfb_sn));
-        tm.sfa_voff = (tt.m0 + wm * WM + (lane & 15) * (A_MN ? 1 : MS)) * 4;
+        tm.sfa_voff = (tt.m0 + wm * WM + (lane & 15) * (A_MN ? 1 : MS)) * (SFA_RM ? sfa_row_stride : 4);
         return tm;
     };
     auto scale_rsrc = [&](uint64_t addr, int extent) {
@@ -1734,7 +1776,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // output stores, so that the cold-start latency of a tile and its predecessor's store tail overlap.  Only LDS-DMA
     // travels ahead: a VGPR-destination load (the scales) must reach its wait in straight-line code, because hipcc is
     // free to copy the destination registers at any control-flow join in between -- before the data has arrived.
-    typename ScaleLandingSel<MS, A_MN>::type land;
+    typename ScaleLandingSel<MS, A_MN || SFA_RM>::type land;
     [[maybe_unused]] ScaleLandingPC land_pc0, land_pc1;        // PC: block kb's scales in one, block kb+1's landing in the other
     auto issue_prologue = [&](const Tile& tt) {
         const TileMem tm = tile_mem(tt);
@@ -1811,6 +1853,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                     issue_scale_loads_pc(land_pc0, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
                                          scale_rsrc(tmn.sfb_addr, sfb_extent), sfb_lane_off + kb0 * sfb_kb_stride);
                     wait_landing_pc<0>(land_pc0);
+                } else if constexpr (SFA_RM) {
+                    issue_scale_loads_rm<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride, sfa_row_stride,
+                                             scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
+                    wait_landing_any<0, MS>(land);
                 } else {
                 issue_scale_loads_any<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
                                           scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
@@ -1835,9 +1881,12 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             const int sfa_voff = tm.sfa_voff;
             auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
             auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
-            auto issue_scales = [&](typename ScaleLandingSel<MS, A_MN>::type& l, int j) {
+            auto issue_scales = [&](typename ScaleLandingSel<MS, A_MN || SFA_RM>::type& l, int j) {
                 const int jj = kb0 + imin(j, nkb - 1);   // past the end: the last block's scales again (never consumed)
-                issue_scale_loads_any<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
+                if constexpr (SFA_RM)
+                    issue_scale_loads_rm<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfa_row_stride, sfb_rsrc, jj * sfb_kb_stride);
+                else
+                    issue_scale_loads_any<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfb_rsrc, jj * sfb_kb_stride);
             };
 
             float scale[MS], scale_tail = 0.f;
@@ -2375,10 +2424,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false>
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false, bool SFA_RM = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC>(p);
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC, SFA_RM>(p);
 }
 
 

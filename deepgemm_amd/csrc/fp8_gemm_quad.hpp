@@ -140,8 +140,14 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // WAVES_N = 4 ("octo"): the same single-barrier schedule on EIGHT waves (2 x 4, wave tile 128 x 64, 128 accumulators in AGPRs: two
 // waves per SIMD fit the 512-entry register file).  Twice the waves issue the LDS-DMA pieces (8 per wave and K block: 0.82 us of fill
 // instead of 1.31), at the price of 192 instead of 128 KiB of fragment reads and two waves sharing each matrix pipe.
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2>
+// K_TAIL (128-row form, dense): K need not be a multiple of 128 (whole 16-byte chunks, K > 128 -- the dgrad shapes K = 2112, 576 with packed
+// scales; the reference's SM100 kernels take any K through TMA zero-fill, csrc/jit_kernels/impls/sm100_fp8_fp4_gemm_1d1d.hpp:93).  The partial
+// last block is an ordinary block of the loop whose pieces carry a per-lane offset bias that pushes the chunks at and beyond K out of the
+// descriptor's range: an out-of-range LDS-DMA lane writes ZEROS into the LDS (the duo kernels' tail mechanism; tools/ubench/lds_dma_oob_probe.hip),
+// so neither the row padding nor the next row's bytes reach the matrix core.  Its scale byte is the block's own, picked as for any block.
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
+    static_assert(!K_TAIL || (BM == 128 && !STAGED && QV == 0 && WAVES_N == 2), "K tail: the 128-row production form");
     constexpr int NW = 2 * WAVES_N;
     constexpr int WM = BM / 2, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int PRE = (MS - 2) * NS, POST = 2 * NS;
@@ -162,7 +168,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128, num_kq = (num_kb + 3) / 4;
+    const int num_kb = K_TAIL ? (p.k + 127) / 128 : p.k / 128, num_kq = (num_kb + 3) / 4;
+    const int k_tail = K_TAIL ? (p.k & 127) : 0;
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
@@ -200,6 +207,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int POS = N_PRE + N_POST, DEPTH = POS / 2;            // piece positions per K block; staging registers (each serves two positions)
     static_assert(POS % 2 == 0, "a staging register serves two positions per K block");
     const int lane16 = lane * 16;
+    [[maybe_unused]] const int tail_bias = (K_TAIL && k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;   // bytes per K quad
 
     const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
@@ -279,7 +287,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_voff,
                         a_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
                 else if constexpr (M0S)
-                    DG_LDS_DMA_PIECE_SUB(a_rsrc, lds + slot_off + (wave * A_ITERS + (q & ~3)) * 1024, a_piece_voff[q],
+                    DG_LDS_DMA_PIECE_SUB(a_rsrc, lds + slot_off + (wave * A_ITERS + (q & ~3)) * 1024,
+                                         a_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0),
                                          (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -293,7 +302,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
                         b_voff, b_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
                 else if constexpr (M0S)
-                    DG_LDS_DMA_PIECE_SUB(b_rsrc, lds + B_BASE + slot_off + (wave * B_ITERS + (q & ~3)) * 1024, b_piece_voff[q],
+                    DG_LDS_DMA_PIECE_SUB(b_rsrc, lds + B_BASE + slot_off + (wave * B_ITERS + (q & ~3)) * 1024,
+                                         b_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0),
                                          (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -515,10 +525,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N>(p);
+    static_assert(!K_TAIL || DG_M0_SHARE, "the K-tail bias is applied on the piece path of the M0-sharing form");
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL>(p);
 }
 
 }  // namespace dg

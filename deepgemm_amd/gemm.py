@@ -152,10 +152,15 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
     host_assert((m, n) == tuple(d.shape) and k == k_, 'm == m_ and n == n_ and k == k_')
     if _early_return(m, n, k, d, c):
         return
-    if k % 128 != 0:
-        # A partial last K block (the reference's SM100 kernels take any K: TMA zero-fills): the hardware-scaled kernels need whole
-        # blocks, so the exponents are expanded to FP32 scales -- exactly, they are powers of two -- and the FP32-scale path
-        # computes the same sums (layout-agnostic kernel: correct, not fast).  `c` has been folded into `d` by _early_return.
+    def _tail_operand_ok(t):        # K-major: 16-byte aligned rows; MN-major: re-majored into aligned scratch below
+        return t.stride(-1) != 1 or (t.stride(0) % 16 == 0 and t.data_ptr() % 16 == 0)
+    packed_tail_ok = not fp32_in and k % 16 == 0 and k > 128 and _tail_operand_ok(a_data) and _tail_operand_ok(b_data)
+    if k % 128 != 0 and not packed_tail_ok:
+        # A partial last K block (the reference's SM100 kernels take any K: TMA zero-fills).  Packed words with K-major operands and whole
+        # 16-byte chunks stay on the hardware-scaled path (e8_quad_kt_128x256: the partial block is zero-filled by the buffer range check).
+        # Everything else: the exponents are expanded to FP32 scales -- exactly, they are powers of two -- and the FP32-scale path computes
+        # the same sums (FP32 scales of the 'sm100' mode: truncated, then the duo kernels' tail stage; packed words of an MN-major or
+        # unaligned operand: layout-agnostic kernel, correct, not fast).  `c` has been folded into `d` by _early_return.
         if fp32_in:
             fp8_gemm_nt((a_data, _truncate_to_ue8m0(a_sf)), (b_data, _truncate_to_ue8m0(b_sf)), d, d if c is not None else None,
                         recipe, recipe_a, recipe_b, disable_ue8m0_cast=True)
@@ -301,8 +306,16 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     host_assert(d.dtype in (torch.bfloat16, torch.float), 'd.scalar_type() == torch::kBFloat16 or d.scalar_type() == torch::kFloat')
     if _early_return(m, n, k, d, c):
         return
+    # A row-major SFA [m, k / 128] (how the reference's callers hold it, tests/test_fp8_fp4.py:45-55) stays as it is when the kernel this
+    # call will run reads it in place (the C side decides: dg_dense_rowmajor_sfa_native) -- no transpose launch in front of the GEMM
+    rm_native = bool(a_sf.dtype == torch.float and b_sf.dtype == torch.float and a_sf.dim() == 2 and a_sf.is_contiguous() and
+                     a_sf.size(1) > 1 and a_data.stride(-1) == 1 and b_data.stride(-1) == 1 and
+                     a_data.stride(0) % 16 == 0 and b_data.stride(0) % 16 == 0 and a_data.data_ptr() % 16 == 0 and b_data.data_ptr() % 16 == 0 and
+                     lib.dg_dense_rowmajor_sfa_native(m, n, k))
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
-                                                              None, None, True)     # (FP32 scales stay FP32 on this exit)
+                                                              None, None, True, None, rm_native)     # (FP32 scales stay FP32 on this exit)
+    if rm_native and gran_n != 128:         # (recipe (1, 1, 128): the per-column kernels want the MN-major layout)
+        sfa = get_mn_major_tma_aligned_tensor(sfa)
     require_device(a_data, b_data, sfa, sfb, d)
     if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
         fast_args = None

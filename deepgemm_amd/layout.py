@@ -181,7 +181,7 @@ Recipe = Union[Tuple[int, int, int], Tuple[int, int]]
 def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe: Recipe,
                                       num_groups: Optional[int] = None, is_sfa: Optional[bool] = None,
                                       disable_ue8m0_cast: bool = False,
-                                      psum_layout: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                      psum_layout: Optional[torch.Tensor] = None, keep_row_major: bool = False) -> torch.Tensor:
     recipe = tuple(recipe)
     if len(recipe) == 3:
         host_assert(is_sfa is not None, 'is_sfa.has_value()')
@@ -197,7 +197,9 @@ def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe:
 
     # (FP32, 1, 128) consumed as FP32: MN-major, padded -- csrc/apis/layout.hpp:40-42
     if sf.dtype == torch.float and gran_mn == 1 and gran_k == 128 and fp32_as_is:
-        return get_mn_major_tma_aligned_tensor(sf)
+        # keep_row_major (round 4, gemm.py): the dense kernel the call will run reads a row-major SFA in place (duo_p_rm_256x256) -- checked
+        # as above, handed over as it is: the transpose launch of smxx_layout.hpp:120-153 is not needed
+        return sf if keep_row_major else get_mn_major_tma_aligned_tensor(sf)
     # (FP32, 128, 128) consumed as FP32: only checked -- csrc/apis/layout.hpp:44-46
     if sf.dtype == torch.float and gran_mn == 128 and gran_k == 128 and fp32_as_is:
         return check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups, False, True, torch.float)
@@ -245,7 +247,8 @@ def _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, gran_m, gran_n, num_groups_a, num_
 
 
 def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, recipe_b,
-                                           num_groups_a, num_groups_b, disable_ue8m0_cast=False, psum_layout=None):
+                                           num_groups_a, num_groups_b, disable_ue8m0_cast=False, psum_layout=None,
+                                           keep_sfa_row_major=False):
     """Returns (sfa', sfb', gran_n_of_sfb).  Recipe selection: csrc/apis/layout.hpp:74-80."""
     if recipe_a is None and recipe is None:
         recipe = get_default_recipe(sfa.dtype, sfb.dtype)
@@ -259,14 +262,14 @@ def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, 
         from . import runtime
         if (sfa.dtype == torch.float and sfb.dtype == torch.float and not disable_ue8m0_cast and runtime.get_sf_cast_mode() == 'sm100'):
             return _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, recipe[0], recipe[1], num_groups_a, num_groups_b, psum_layout) + (recipe[1],)
-        t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe, num_groups_a, True, disable_ue8m0_cast, psum_layout)
+        t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe, num_groups_a, True, disable_ue8m0_cast, psum_layout, keep_sfa_row_major)
         t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe, num_groups_b, False, disable_ue8m0_cast)
         gran_n = recipe[1]
     else:
         recipe_a, recipe_b = tuple(recipe_a), tuple(recipe_b)
         host_assert(recipe_a == (1, 128) and recipe_b[1] == 128 and recipe_b[0] in (1, 128),
                     'supported recipes: recipe_a = (1, 128), recipe_b in ((1, 128), (128, 128))')
-        t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe_a, num_groups_a, None, disable_ue8m0_cast, psum_layout)
+        t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe_a, num_groups_a, None, disable_ue8m0_cast, psum_layout, keep_sfa_row_major)
         t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe_b, num_groups_b, None, disable_ue8m0_cast)
         gran_n = recipe_b[0]
     return t_sfa, t_sfb, gran_n

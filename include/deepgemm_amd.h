@@ -332,6 +332,12 @@ const char* dg_last_config(void);
 const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups, int expected_m, int a_mn_major, int b_mn_major,
                              int sfb_gran_n, int m_alignment, int has_workspace, int packed_ue8m0);
 
+/* Would a dense dg_fp8_gemm_nt(_ws) call with K-major 16-byte aligned operands, one SFB value per 128 columns and a ROW-major SFA
+ * ([m][ceil(k / 128)] floats: sfa_stride_m = ceil(k / 128), sfa_stride_k = 1 -- how the reference's callers hold it before the layout
+ * step, tests/test_fp8_fp4.py:45-55) read the SFA in place (config duo_p_rm_256x256)?  1: pass it as it is; 0: transpose first
+ * (dg_transpose_sf_fp32; csrc/jit_kernels/impls/smxx_layout.hpp:120-153 is the launch this saves). */
+int dg_dense_rowmajor_sfa_native(int m, int n, int k);
+
 /* 1 if the automatic selection would cut this dense problem along K given a workspace (dg_fp8_gemm_nt_ws): under-filled launches
  * with long K loops, partial last rounds of 128 x 256 tiles, under-filled recipe-(1, 1, 128) launches.  The host layer asks before it
  * creates and passes its per-stream buffer (dg_split_k_workspace_bytes()); operands assumed 16-byte aligned and densely packed. */

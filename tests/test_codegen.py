@@ -12,19 +12,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM_OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 
-PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC> for the duo kernels
-    'dg_fp8_gemm_duo_kernel<256,256,2,4,0,0,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,0,1,0,0>',
-    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,0,1,0,0>',
-    'dg_fp8_gemm_duo_kernel<128,256,2,4,1,0,1,0,0,1,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,1,1,1,0,0,1,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,1,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,1,0,0,0,0>',
-    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,1,1,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,1,0,0,0>',
-    'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,1,1,0,0>',
+PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC, SFA_RM> for the duo kernels
+    'dg_fp8_gemm_duo_kernel<256,256,2,4,0,0,0,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,0,1,0,0,0>',
+    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,0,1,0,0,0>',
+    'dg_fp8_gemm_duo_kernel<128,256,2,4,1,0,1,0,0,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,1,1,1,0,0,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,1,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,1,0,0,0,0,0>',
+    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,1,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,1,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,1,0,0,0,0>',
+    'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,1,1,0,0,0>',
+    'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,0,0,0,0,1>',   # round 4: row-major SFA read in place (duo_p_rm_256x256)
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,0,0>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,6,2,1,0,0>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,0,0>',
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,1,0>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,6,2,1,1,0>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,0>',
     'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,0,4>',          # round 4: + four loader waves (the dense 64 x 32 pick)
     'dg_fp8_gemm_pipe_kernel<128,128,2,2,2>', 'dg_fp8_gemm_pipe_kernel<64,256,1,4,1>', 'dg_fp8_gemm_pipe_kernel<256,256,2,4,2>',
     'dg_fp8_gemm_pipe_kernel<128,256,2,4,2>', 'dg_fp8_gemm_pipe_kernel<32,256,1,4,0>', 'dg_fp8_gemm_pipe_kernel<16,256,1,4,0>',
     'dg_fp8_gemm_pipe_pc_kernel<256,256,2,4,1,0>', 'dg_fp8_gemm_pipe_pc_kernel<256,256,2,4,1,1>',
-    'dg_fp8_gemm_duo_e8_kernel<256,256,2,4>', 'dg_fp8_gemm_quad_e8_kernel<256,256,0,0,2>', 'dg_fp8_gemm_quad_e8_kernel<128,256,0,0,2>',
+    'dg_fp8_gemm_duo_e8_kernel<256,256,2,4>', 'dg_fp8_gemm_quad_e8_kernel<256,256,0,0,2,0>', 'dg_fp8_gemm_quad_e8_kernel<128,256,0,0,2,0>', 'dg_fp8_gemm_quad_e8_kernel<128,256,0,0,2,1>',
     'dg_fp8_gemm_skinny_kernel<1,4,1>', 'dg_fp8_gemm_skinny_kernel<2,4,1>', 'dg_fp8_gemm_skinny_kernel<1,4,2>', 'dg_fp8_gemm_stream_swiglu_kernel<6>',
 ]
 

@@ -770,7 +770,7 @@ def test_import_is_fork_safe_and_bench_runs():
     assert 'zero-copy' in line['config']['sfa_layout']
     # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0 (C2, C5), two dgrad entries
     secondary = line['secondary']
-    assert len(secondary) == 18 and not [s for s in secondary if 'error' in s], secondary
+    assert len(secondary) == 20 and not [s for s in secondary if 'error' in s], secondary
     for rec in secondary:
         assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
     assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
@@ -993,10 +993,13 @@ def test_packed_ue8m0_m_grouped_contiguous(use_psum):
                 assert calc_diff(torch.nan_to_num(case.d), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
 
 
-@pytest.mark.parametrize('m,n,k', [(256, 384, 576), (130, 264, 2112)])
+@pytest.mark.parametrize('m,n,k', [(256, 384, 576), (130, 264, 2112), (1040, 784, 2112), (512, 1024, 144), (300, 520, 656)])
 def test_packed_ue8m0_k_tail(m, n, k):
-    """Packed UE8M0 scales with K not a multiple of 128 (the reference's SM100 kernels take any K): the exponents are expanded to
-    exact FP32 scales and the recipe (1, 1, 128) path computes the result -- oracle parity, accumulation included."""
+    """Packed UE8M0 scales with K not a multiple of 128 (the reference's SM100 kernels take any K through TMA zero-fill,
+    csrc/jit_kernels/impls/sm100_fp8_fp4_gemm_1d1d.hpp:93): K-major operands with whole 16-byte chunks stay on the hardware-scaled path
+    (round 4: e8_quad_kt_128x256, the partial last block zero-filled by the buffer range check) -- oracle parity, accumulation included,
+    row padding full of FP8 NaNs never reaches the matrix core; operands that path does not take (MN-major: re-majored first; rows off
+    16 bytes: exponents expanded to exact FP32 scales, recipe (1, 1, 128)) give the same answer."""
     gen.reset_seed(m + k)
     for accumulate in (False, True):
         case = gen.generate_normal(m, n, k, use_ue8m0=True, accumulate=accumulate, out_dtype=torch.float if accumulate else torch.bfloat16)
@@ -1004,12 +1007,36 @@ def test_packed_ue8m0_k_tail(m, n, k):
         want = oracle_dense(case, c_cpu=c_cpu)
         a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
         assert a[1].dtype == torch.int and a[1].shape == (m, -(-k // 512))
-        dg.fp8_gemm_nt(a, b, case.d, c=case.c if accumulate else None)
+        # operands inside wider buffers whose padding holds FP8 NaN bytes (0x7f): rows 16-byte aligned, K-major
+        a_wide = torch.full((m, k + 48), 0x7f, dtype=torch.uint8, device='cuda')
+        b_wide = torch.full((n, k + 80), 0x7f, dtype=torch.uint8, device='cuda')
+        a_wide[:, :k] = a[0].view(torch.uint8)
+        b_wide[:, :k] = b[0].view(torch.uint8)
+        a_pad, b_pad = (a_wide[:, :k].view(torch.float8_e4m3fn), a[1]), (b_wide[:, :k].view(torch.float8_e4m3fn), b[1])
+        dg.fp8_gemm_nt(a_pad, b_pad, case.d, c=case.c if accumulate else None)
+        assert dg.last_config() == 'e8_quad_kt_128x256', dg.last_config()
         if accumulate:
             assert_close_fp32(case.d, want, 'packed scales, K tail, accumulate')
         else:
             assert_close_to_oracle(case.d, want, 'packed scales, K tail')
         assert calc_diff(case.d, case.ref_d) < gen.FP8_MAX_DIFF
+        first = case.d.clone()
+        if not accumulate:
+            # bit-repeatable; contiguous operands: same bits; MN-major B (fp8_gemm_nn: re-majored, then the same kernel): same bits
+            d2 = torch.full_like(first, float('nan'))
+            dg.fp8_gemm_nt(a, b, d2)
+            assert dg.last_config() == 'e8_quad_kt_128x256' and torch.equal(d2, first)
+            # rows off 16 bytes: the expanded-scale fallback (FP32 promotion instead of in-core accumulation: equal up to FP32 rounding)
+            a_off = torch.empty((a[0].numel() + 1,), dtype=torch.uint8, device='cuda')[1:].view(torch.float8_e4m3fn).view(a[0].shape)
+            a_off.copy_(a[0])
+            d4 = torch.full_like(first, float('nan'))
+            dg.fp8_gemm_nt((a_off, a[1]), b, d4)
+            assert not dg.last_config().startswith('e8_'), dg.last_config()
+            assert_close_to_oracle(d4, want, 'packed scales, K tail, unaligned rows')
+    dg.set_forced_config('e8_quad_128x256')
+    with pytest.raises(RuntimeError, match='k % 128'):
+        dg.fp8_gemm_nt(a, b, torch.empty((m, n), device='cuda', dtype=torch.bfloat16))
+    dg.set_forced_config('auto')
 
 
 @pytest.mark.parametrize('masked_ms,max_m,n,k', [([5, 0, 64, 33], 64, 256, 384), ([200, 1, 129], 256, 520, 512),
@@ -1340,3 +1367,38 @@ def test_single_ulp_flip_on_a_tiny_output_motivates_the_frobenius_gate():
     assert flips_seen > 0, 'no BF16 flip in 150 seeds of a 1 x 16 output'
     assert worst[1] > 1e-3, f'flips found ({flips_seen}) but none beyond the old 1e-3 gate: worst {worst}'
     print(f'seed {1000 + worst[0]}: {worst[2]} single-ulp flip(s) on 16 elements -> rel-Frobenius {worst[1]:.2e} (> 1e-3, < 4e-3)')
+
+
+@pytest.mark.parametrize('m,n,k,accumulate', [(4096, 4096, 7168, False), (2048, 7168, 2048, False), (4000, 4096, 1024, True), (4096, 4096, 256, False),
+                                               (8192, 4096, 512, False)])
+def test_row_major_sfa_is_read_in_place(m, n, k, accumulate):
+    """A row-major SFA [m, k / 128] -- how the reference's own test hands it over (tests/test_fp8_fp4.py:45-55) -- on the dense 256-row
+    kernel: no transpose launch (round 4: duo_p_rm_256x256 reads it with strided dword loads), same bits as the MN-major hand-over,
+    oracle parity on sampled rows; rows past M, FP32 accumulation, a non-contiguous SFA (transposed first, as before) included."""
+    gen.reset_seed(m + k)
+    case = gen.generate_normal(m, n, k, accumulate=accumulate, out_dtype=torch.float if accumulate else torch.bfloat16)
+    assert case.a[1].is_contiguous() and case.a[1].shape == (m, k // 128)
+    c0 = case.c.clone() if accumulate else None
+    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None)
+    assert dg.last_config() == 'duo_p_rm_256x256', dg.last_config()
+    first = case.d.clone()
+    # the MN-major hand-over (zero-copy branch): the 256-row kernel with vector scale loads
+    d2 = c0.clone() if accumulate else torch.full_like(first, float('nan'))
+    dg.fp8_gemm_nt((case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1])), case.b, d2, c=d2 if accumulate else None)
+    assert dg.last_config() == 'duo_p_256x256' and torch.equal(d2, first)
+    # second call: the cached signature path
+    d3 = c0.clone() if accumulate else torch.full_like(first, float('nan'))
+    dg.fp8_gemm_nt(case.a, case.b, d3, c=d3 if accumulate else None)
+    assert dg.last_config() == 'duo_p_rm_256x256' and torch.equal(d3, first)
+    # a row-major SFA that is a strided view (every other column of a wider tensor): not the in-place form, same answer
+    wide = torch.empty((m, 2 * (k // 128)), device='cuda', dtype=torch.float)
+    wide[:, ::2] = case.a[1]
+    d4 = c0.clone() if accumulate else torch.full_like(first, float('nan'))
+    dg.fp8_gemm_nt((case.a[0], wide[:, ::2]), case.b, d4, c=d4 if accumulate else None)
+    assert dg.last_config() == 'duo_p_256x256' and torch.equal(d4, first)
+    rows = torch.randperm(m)[:64].sort().values
+    want = torch.empty((64, n), dtype=case.d.dtype)
+    sub_c = c0[rows.cuda()].cpu() if accumulate else None
+    oracle.fp8_gemm_nt(case.a[0][rows.cuda()].cpu(), case.a[1][rows.cuda()].cpu(), *cpu_pair(case.b), want, c=sub_c)
+    (assert_close_fp32 if accumulate else assert_close_to_oracle)(first[rows.cuda()], want, 'row-major SFA in place')
+    assert calc_diff(first, case.ref_d) < gen.FP8_MAX_DIFF
