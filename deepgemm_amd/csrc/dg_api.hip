@@ -103,10 +103,6 @@ struct Config {
 const Config kConfigs[] = {
     {"duo_256x256", 256, 256, 512, 1, 1.10f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4>, true, true},
     {"duo_p_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true>, true, true, true},
-    // round 4: the same kernel reading a row-major SFA as the reference's callers hold it (eight strided dword loads per lane and K block
-    // instead of two dwordx4): the layout step's transpose launch in front of the GEMM disappears (dense problems that pick duo_p_256x256)
-    {"duo_p_rm_256x256", 256, 256, 512, 1, 0.0f, true,
-     dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, false, false, false, false, true>, true, false, true, false, false, false, true},
     // 128-row duo tile: grouped-contiguous layouts (BM must divide the 128-row alignment) and tile counts that quantise
     // badly at 256 x 256.  Measured per-tile: 116 k cycles vs 167 k for twice the work (L2->LDS bytes per flop are 1.5x).
     // Every 128-row form runs the two-segment schedule (MERGED: one load + one 16-step matrix segment per K block, 3-slot B
@@ -164,6 +160,13 @@ const Config kConfigs[] = {
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
 #ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
+    // round 4, negative: duo_p_256x256 reading a ROW-major SFA in place (eight strided dword loads per lane and K block -- 16 distinct
+    // rows per instruction -- instead of two dwordx4; bit-identical): C2 141.3 us against 92.2-92.9 with the MN-major hand-over, i.e. far
+    // worse than the transpose launch it was meant to save (~7 us; profiles/r04_probe/sfa_rowmajor_in_place_negative.log): the scattered
+    // loads sit in the same in-order return queue as the LDS-DMA pieces.  With the config out of the production table the selection's
+    // row-major branch finds nothing, dg_dense_rowmajor_sfa_native answers 0 and the host layer transposes as before.
+    {"duo_p_rm_256x256", 256, 256, 512, 1, 0.0f, true,
+     dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, false, false, false, false, true>, true, false, true, false, false, false, true},
     // round 4, negative: recipe (1, 1, 128) on the two-segment 128 x 256 duo tile (persistent walk, the 20 scale values of a K block landing
     // in two alternating register sets, MFMA + 4 v_mul + 4 v_fmac per step in the matrix segment; bit-identical to pipe_pc_256x256, 393 GPU
     // tests green with it selected): wgrad 4096 x 4096 x 7168 146.4-147.1 us against 141.1 (profiles/r04_probe/wgrad_duo_pc_ab.log).  A step

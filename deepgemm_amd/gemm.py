@@ -394,7 +394,8 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     # dg_select_config with has_workspace = 1) -- ordinary grouped calls neither create nor pass the 64 MiB buffer
     picked = lib.dg_select_config(2 if use_psum_layout else 1, m, n, k, num_groups, 0, 0, int(b_data.stride(-1) != 1), 128,
                                   runtime.get_mk_alignment_for_contiguous_layout(), 1, 0)
-    workspace = _split_k_workspace(d.device, stream) if (b'_sk_' in picked or b'_tab_' in picked) else None
+    # (a K-split form forced by name -- tuning runs, tests -- gets the buffer too: dg_select_config answers for the automatic selection)
+    workspace = _split_k_workspace(d.device, stream) if (b'_sk_' in picked or b'_tab_' in picked or b'_sk_' in lib.dg_get_forced_config()) else None
     check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ws(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
         num_groups, m, n, k, a_data.stride(0), a_data.stride(1),

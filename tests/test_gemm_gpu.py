@@ -1367,38 +1367,3 @@ def test_single_ulp_flip_on_a_tiny_output_motivates_the_frobenius_gate():
     assert flips_seen > 0, 'no BF16 flip in 150 seeds of a 1 x 16 output'
     assert worst[1] > 1e-3, f'flips found ({flips_seen}) but none beyond the old 1e-3 gate: worst {worst}'
     print(f'seed {1000 + worst[0]}: {worst[2]} single-ulp flip(s) on 16 elements -> rel-Frobenius {worst[1]:.2e} (> 1e-3, < 4e-3)')
-
-
-@pytest.mark.parametrize('m,n,k,accumulate', [(4096, 4096, 7168, False), (2048, 7168, 2048, False), (4000, 4096, 1024, True), (4096, 4096, 256, False),
-                                               (8192, 4096, 512, False)])
-def test_row_major_sfa_is_read_in_place(m, n, k, accumulate):
-    """A row-major SFA [m, k / 128] -- how the reference's own test hands it over (tests/test_fp8_fp4.py:45-55) -- on the dense 256-row
-    kernel: no transpose launch (round 4: duo_p_rm_256x256 reads it with strided dword loads), same bits as the MN-major hand-over,
-    oracle parity on sampled rows; rows past M, FP32 accumulation, a non-contiguous SFA (transposed first, as before) included."""
-    gen.reset_seed(m + k)
-    case = gen.generate_normal(m, n, k, accumulate=accumulate, out_dtype=torch.float if accumulate else torch.bfloat16)
-    assert case.a[1].is_contiguous() and case.a[1].shape == (m, k // 128)
-    c0 = case.c.clone() if accumulate else None
-    dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None)
-    assert dg.last_config() == 'duo_p_rm_256x256', dg.last_config()
-    first = case.d.clone()
-    # the MN-major hand-over (zero-copy branch): the 256-row kernel with vector scale loads
-    d2 = c0.clone() if accumulate else torch.full_like(first, float('nan'))
-    dg.fp8_gemm_nt((case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1])), case.b, d2, c=d2 if accumulate else None)
-    assert dg.last_config() == 'duo_p_256x256' and torch.equal(d2, first)
-    # second call: the cached signature path
-    d3 = c0.clone() if accumulate else torch.full_like(first, float('nan'))
-    dg.fp8_gemm_nt(case.a, case.b, d3, c=d3 if accumulate else None)
-    assert dg.last_config() == 'duo_p_rm_256x256' and torch.equal(d3, first)
-    # a row-major SFA that is a strided view (every other column of a wider tensor): not the in-place form, same answer
-    wide = torch.empty((m, 2 * (k // 128)), device='cuda', dtype=torch.float)
-    wide[:, ::2] = case.a[1]
-    d4 = c0.clone() if accumulate else torch.full_like(first, float('nan'))
-    dg.fp8_gemm_nt((case.a[0], wide[:, ::2]), case.b, d4, c=d4 if accumulate else None)
-    assert dg.last_config() == 'duo_p_256x256' and torch.equal(d4, first)
-    rows = torch.randperm(m)[:64].sort().values
-    want = torch.empty((64, n), dtype=case.d.dtype)
-    sub_c = c0[rows.cuda()].cpu() if accumulate else None
-    oracle.fp8_gemm_nt(case.a[0][rows.cuda()].cpu(), case.a[1][rows.cuda()].cpu(), *cpu_pair(case.b), want, c=sub_c)
-    (assert_close_fp32 if accumulate else assert_close_to_oracle)(first[rows.cuda()], want, 'row-major SFA in place')
-    assert calc_diff(first, case.ref_d) < gen.FP8_MAX_DIFF
