@@ -146,8 +146,10 @@ const Config kConfigs[] = {
     // LDS-DMA issue rate of its workgroup, and that rate grows with the number of issuing waves (50 / 80 / 96 GB/s per CU at 4 / 8 / 16)
     {"stream_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 4>, true},
     {"stream_l16_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 12>, true},
+    {"stream_nt_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 2, 4, false, 4>, true},
+    {"stream_sc_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 1, 4, false, 4>, true},
+    {"stream_ntsc_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 3, 4, false, 4>, true},
     {"stream_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 4>, true},
-    {"stream_nt_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, false, 4>, true},
     // M <= 16 / 32 (decode batches): 16 output columns per workgroup over the whole K, the 8 waves split K; weights straight into registers
     {"skinny_16", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1>},
     {"skinny_32", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2>},
@@ -160,6 +162,14 @@ const Config kConfigs[] = {
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
 #ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
+    // round 4, negative: split rings (stream2_kernel_body: activation pieces on a short ring, weight pieces on a deep one, issued by separate
+    // wave groups because a wave's vector-memory operations retire in order; bit-identical, 12-16 waves): m = 128, 4096 x 7168 22.4 us
+    // against 18.2 (stream_l8_64x32), C5 49.8 against 44.2 (profiles/r04_probe/sweep_stream2_negative.log) -- bytes in flight per stream
+    // are NOT what holds the stream tiles at ~40 GB/s per CU
+    {"stream2_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 32, 4, 1, 2, 4, 10, 8, 8>, true},
+    {"stream2b_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 32, 4, 1, 2, 3, 12, 8, 8>, true},
+    {"stream2_64x128", 64, 128, 768, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 128, 1, 4, 1, 4, 7, 4, 8>, true},
+    {"stream2_nt_64x128", 64, 128, 768, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 128, 1, 4, 1, 4, 7, 4, 8, 2>, true},
     // round 4, negative: duo_p_256x256 reading a ROW-major SFA in place (eight strided dword loads per lane and K block -- 16 distinct
     // rows per instruction -- instead of two dwordx4; bit-identical): C2 141.3 us against 92.2-92.9 with the MN-major hand-over, i.e. far
     // worse than the transpose launch it was meant to save (~7 us; profiles/r04_probe/sfa_rowmajor_in_place_negative.log): the scattered

@@ -106,6 +106,17 @@ struct Tile {
     bool second_pass; // the tile needs another pass (its two alignment-sized halves belong to different groups)
 };
 
+// Values that are wave-uniform in fact but not provably so (tile coordinates derived from loaded group sizes ...): hipcc wraps every
+// buffer operation whose descriptor is built from them in a waterfall loop (v_readfirstlane x 4, two 64-bit compares, exec save / restore,
+// a branch: ~12 instructions per LDS-DMA piece).  Routing them through readfirstlane makes the descriptor an SGPR value.
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uniform_pointer(T* ptr) {
+    const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+    return reinterpret_cast<T*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -869,14 +880,14 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
         if (t.m_end > t.m0) {
             // Buffer descriptors bound each tile to its valid rows: out-of-range lanes of an edge tile fetch nothing
             // (those rows / columns are never stored), so no per-lane clamping is needed.
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
+            const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
+            const int a_rows = uniform_int(imin(t.m_end - t.m0, BM)), b_rows = uniform_int(imin(p.n - t.n0, BN));
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
                                                                   (a_rows - 1) * lda + p.k, 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
                                                                   (b_rows - 1) * ldb + p.k, 0x00020000);
-            const float* sfa_group = p.sfa + ad_group * p.sfa_sg;
+            const float* sfa_group = uniform_pointer(p.sfa + ad_group * p.sfa_sg);
             const int sfa_rows = (p.gemm_type == kMasked) ? p.m : p.m;
             const int sfa_extent = (static_cast<int>(p.sfa_sm) * (sfa_rows - 1) + static_cast<int>(p.sfa_sk) * (num_kb - 1) + 1) * 4;
             const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sfa_group), 0, sfa_extent, 0x00020000);
@@ -2582,9 +2593,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            // (every descriptor input through readfirstlane: round 4 found waterfall loops around the A and scale pieces of every stream kernel)
+            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
+            const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
+            const int a_rows = uniform_int(imin(t.m_end - t.m0, BM)), b_rows = uniform_int(imin(p.n - t.n0, BN));
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
                                                                   (a_rows - 1) * lda + p.k, 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
@@ -2593,13 +2605,13 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
             // (E8: the strides are per K quad and the "K block" index of a scale row is j >> 2)
             const int num_sf_k = E8 ? (num_kb + 3) / 4 : num_kb;
-            float* sfa_tile = const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0;
-            const int sfa_rows = imin(p.m - t.m0, BM);
+            float* sfa_tile = uniform_pointer(const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0);
+            const int sfa_rows = uniform_int(imin(p.m - t.m0, BM));
             // (GSF: 16-byte requests -- the MN-major layout pads the rows to a multiple of four, so a request that starts below sfa_rows is whole)
             const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_sf_k - 1) * sfa_kb_stride + (GSF ? (sfa_rows + 3) / 4 * 4 : sfa_rows) * 4, 0x00020000);
-            float* sfb_tile = const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg +
-                              (E8 ? static_cast<int64_t>(t.n0) : static_cast<int64_t>(t.n0 / 128) * p.sfb_sn);
-            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_sf_k - 1) * sfb_kb_stride + (E8 ? imin(p.n - t.n0, BN) * 4 : 4),
+            float* sfb_tile = uniform_pointer(const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg +
+                                              (E8 ? static_cast<int64_t>(t.n0) : static_cast<int64_t>(t.n0 / 128) * p.sfb_sn));
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_sf_k - 1) * sfb_kb_stride + (E8 ? uniform_int(imin(p.n - t.n0, BN)) * 4 : 4),
                                                                   0x00020000);
             const int sfg_a_voff = (lane >> 4) * sfa_kb_stride + (lane & 15) * 16, sfg_b_voff = (lane & 3) * sfb_kb_stride;
 
@@ -2789,6 +2801,191 @@ void dg_fp8_gemm_stream_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Split-ring stream kernel (round 4): the 64-row stream tile with the two operands on SEPARATE rings fed by SEPARATE waves.
+//
+// What bounds the single-ring stream tile at mid M (m = 64 .. 256, dense): a stage completes when its slowest piece has landed, and
+// the weight pieces come from HBM (~2 us loaded) while the activation pieces come from the L2 (~0.5 us) -- yet both wait in the same
+// ring: of the 96 KiB a CU keeps in flight on the 64 x 32 tile only a third is weight bytes, 32 KiB / 2 us = 16 GB/s of weight stream
+// per CU (measured: 38-40 GB/s per CU in total whether 4, 8 or 16 waves issue the pieces and whether 128 or 256 CUs are busy:
+// profiles/r04_probe/sweep_midm_loader_waves.jsonl).  The two streams cannot simply get different prefetch distances inside one wave:
+// vector-memory operations retire IN ORDER per wave, so a wait for a young activation piece is a wait for every older weight piece.
+// Per WAVE, though: here waves [0, AW) issue nothing but A pieces (a short ring: SA stages) and waves [AW, AW + BW) nothing but B pieces
+// (a deep ring: SB stages) -- each group waits on its own counter for "my pieces of stage sb" and the stage barrier joins them.
+// Compute waves = the first WAVES_M * WAVES_N of the A loaders (8 MFMAs per K block: nothing).  FP32 scales ride in the group ring
+// of the single-ring kernel (one 16-byte-per-lane piece per four K blocks), issued by the A loaders.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KBS, int SA, int SB, int AW, int BW, int B_AUX = 0>
+__device__ __forceinline__ void stream2_kernel_body(const GemmParams& p) {
+    constexpr int NW = WAVES_M * WAVES_N, TW = AW + BW;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int A_STAGE = KBS * A_BYTES, B_STAGE = KBS * B_BYTES;
+    constexpr int B_RING = SA * A_STAGE, SFG_OFF = B_RING + SB * B_STAGE, SFG_SLOT = 1024 + 256, SFG_SLOTS = 4;
+    constexpr int LDS_BYTES = SFG_OFF + SFG_SLOTS * SFG_SLOT;
+    constexpr int A_PER = KBS * (BM / 8) / AW, B_PER = KBS * (BN / 8) / BW;       // pieces per loader wave and stage
+    static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA row per K block and one SFB value per tile");
+    static_assert((KBS * (BM / 8)) % AW == 0 && (KBS * (BN / 8)) % BW == 0 && A_PER >= 1 && B_PER >= 1, "every loader wave of a group issues the same number of pieces");
+    static_assert(NW <= AW && TW <= 16, "the compute waves are A loaders; 1024 threads at most");
+    static_assert((MS == 4 || MS == 1) && NS % 2 == 0, "a lane reads its MS row scales with one LDS read");
+    static_assert(SA >= 3 && SB >= 3 && SA * KBS <= 4 * (SFG_SLOTS - 1), "ring depths; a scale group slot is refilled only after its last reader");
+    static_assert((SA - 1) * (A_PER + 2) < 64 && (SB - 1) * B_PER < 64, "vmcnt is a 6-bit counter");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    constexpr unsigned OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool a_loader = wave < AW, computes = wave < NW;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int num_kb = p.k / 128;
+    const int piece_row = lane >> 3;
+    const int src_chunk = (lane & 7) ^ piece_row;
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
+    const int a_voff = piece_row * MS * lda + src_chunk * 16;
+
+    MaskedWalk walk;
+    const int num_launched = gridDim.x;
+    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        if (!t.valid)
+            break;
+        const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+
+        v4f acc[MS][NS];
+        #pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        if (t.m_end > t.m0) {
+            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
+            const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
+            const int a_rows = uniform_int(imin(t.m_end - t.m0, BM)), b_rows = uniform_int(imin(p.n - t.n0, BN));
+            const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0, (a_rows - 1) * lda + p.k, 0x00020000);
+            const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0, (b_rows - 1) * ldb + p.k, 0x00020000);
+            const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
+            float* sfa_tile = uniform_pointer(const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0);
+            const int sfa_rows = uniform_int(imin(p.m - t.m0, BM));
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_kb - 1) * sfa_kb_stride + (sfa_rows + 3) / 4 * 4 * 4, 0x00020000);
+            float* sfb_tile = uniform_pointer(const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg + static_cast<int64_t>(t.n0 / 128) * p.sfb_sn);
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_kb - 1) * sfb_kb_stride + 4, 0x00020000);
+            const int sfg_a_voff = (lane >> 4) * sfa_kb_stride + (lane & 15) * 16, sfg_b_voff = (lane & 3) * sfb_kb_stride;
+
+            // stage sb (K blocks sb * KBS ..) of this wave's operand into its ring slot; blocks past the end: out-of-range no-ops (exact counts)
+            auto issue_a_stage = [&](int slot_off, int sb) {
+                #pragma unroll
+                for (int u = 0; u < KBS; ++u) {
+                    const int j = sb * KBS + u;
+                    if ((j & 3) == 0) {                         // the scales of K blocks j .. j + 3 (every A loader: identical destinations)
+                        const unsigned oob = j < num_kb ? 0u : OOB;
+                        uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                                                                 static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
+                                                                 static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), j * sfb_kb_stride, 0, 0);
+                    }
+                }
+                #pragma unroll
+                for (int q = 0; q < A_PER; ++q) {
+                    const int idx = wave + AW * q, u = idx / (BM / 8), unit = idx % (BM / 8), j = sb * KBS + u;
+                    const unsigned oob = j < num_kb ? 0u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + u * A_BYTES + unit * 1024), 16,
+                        static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob)), j * 128, 0, 0);
+                }
+            };
+            auto issue_b_stage = [&](int slot_off, int sb) {
+                #pragma unroll
+                for (int q = 0; q < B_PER; ++q) {
+                    const int idx = (wave - AW) + BW * q, u = idx / (BN / 8), unit = idx % (BN / 8), j = sb * KBS + u;
+                    const unsigned oob = j < num_kb ? 0u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_RING + slot_off + u * B_BYTES + unit * 1024), 16,
+                        static_cast<int>(static_cast<unsigned>(b_row_perm<WN>(unit * 8 + piece_row) * ldb + src_chunk * 16) | oob), j * 128, 0,
+                        B_AUX & 3);
+                }
+            };
+            if (a_loader) {
+                #pragma unroll
+                for (int j = 0; j < SA - 1; ++j)
+                    issue_a_stage(j * A_STAGE, j);
+            } else {
+                #pragma unroll
+                for (int j = 0; j < SB - 1; ++j)
+                    issue_b_stage(j * B_STAGE, j);
+            }
+
+            int a_cur = 0, a_fill = (SA - 1) * A_STAGE, b_cur = 0, b_fill = (SB - 1) * B_STAGE;
+            const int num_sb = (num_kb + KBS - 1) / KBS;
+            for (int sb = 0; sb < num_sb; ++sb) {
+                // my pieces of stage sb have landed (the younger stages of MY ring may still fly; the A loaders' uncounted scale pieces make
+                // their wait stricter, never looser); the barrier joins the two groups and frees the slots of stage sb - 1
+                if (a_loader)
+                    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((SA - 2) * A_PER) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((SB - 2) * B_PER) : "memory");
+                raw_barrier();
+                if (a_loader)
+                    issue_a_stage(a_fill, sb + SA - 1);
+                else
+                    issue_b_stage(b_fill, sb + SB - 1);
+                if (computes) {
+                    #pragma unroll
+                    for (int u = 0; u < KBS; ++u) {
+                        if (sb * KBS + u >= num_kb)
+                            break;
+                        float sa[MS];
+                        const int jb = sb * KBS + u;
+                        const uint8_t* sfg = lds + SFG_OFF + ((jb >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                        if constexpr (MS == 4) {
+                            const v4f q = *reinterpret_cast<const v4f*>(sfg + (jb & 3) * 256 + (wm * WM + (lane & 15) * MS) * 4);
+                            sa[0] = q[0]; sa[1] = q[1]; sa[2] = q[2]; sa[3] = q[3];
+                        } else {
+                            sa[0] = *reinterpret_cast<const float*>(sfg + (jb & 3) * 256 + (wm * WM + (lane & 15)) * 4);
+                        }
+                        const float sb_val = *reinterpret_cast<const float*>(sfg + 1024 + (jb & 3) * 4);
+                        const uint8_t* a_tile = lds + a_cur + u * A_BYTES + (wm * WM) * 128;
+                        const uint8_t* b_tile = lds + B_RING + b_cur + u * B_BYTES + (wn * WN) * 128;
+                        v8i bf[NS];
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                        #pragma unroll
+                        for (int ms = 0; ms < MS; ++ms) {
+                            const v8i af = load_fragment(a_tile + ms * 2048, frag_off);
+                            const float scale = sa[ms] * sb_val;
+                            #pragma unroll
+                            for (int ns = 0; ns < NS; ++ns) {
+                                const v4f part = mfma_fp8_k128(bf[ns], af);
+                                acc[ms][ns] += scale * part;
+                            }
+                        }
+                    }
+                }
+                a_fill = a_cur;
+                a_cur = (a_cur == (SA - 1) * A_STAGE) ? 0 : a_cur + A_STAGE;
+                b_fill = b_cur;
+                b_cur = (b_cur == (SB - 1) * B_STAGE) ? 0 : b_cur + B_STAGE;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (computes)
+            store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KBS, int SA, int SB, int AW, int BW, int B_AUX = 0>
+__global__ __launch_bounds__((AW + BW) * 64)
+void dg_fp8_gemm_stream2_kernel(const GemmParams p) {
+    stream2_kernel_body<BM, BN, WAVES_M, WAVES_N, KBS, SA, SB, AW, BW, B_AUX>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // UE8M0 kernel: scales that are powers of two, handed over as packed exponent bytes (the reference's SM100 input format:
 // int32 = four consecutive 128-K blocks of one row, MN-major; recipe (1, 1, 128): one scale per A row and per B row).
 // The scaled MFMA applies 2^(ea + eb - 254) in hardware and accumulates across K blocks in its own FP32 accumulator:
@@ -2889,9 +3086,9 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm;
-            const uint8_t* b_base = p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn;
-            const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
+            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
+            const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
+            const int a_rows = uniform_int(imin(t.m_end - t.m0, BM)), b_rows = uniform_int(imin(p.n - t.n0, BN));
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
                                                                   (a_rows - 1) * lda + p.k, 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,

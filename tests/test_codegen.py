@@ -77,6 +77,9 @@ def test_no_spill_traffic_inside_the_k_loop_of_production_kernels():
         assert r['mfma_range_instructions'] > 0, name
         assert r['scratch_in_mfma_range'] == 0, f'{name}: {r["scratch_in_mfma_range"]} scratch instructions between the first and last MFMA'
         assert r.get('vgpr_spill_count', 0) <= 16, f'{name}: {r.get("vgpr_spill_count")} VGPR spills'   # (outside the K loop: the range check above is the strict one)
+        # no waterfall loop around the K loop's buffer operations: every descriptor input goes through readfirstlane (round 4: the stream
+        # and pipe kernels carried ~12 extra instructions per LDS-DMA piece of the activation tile and of the scales)
+        assert r['waterfalls_at_k_loop'] == 0, f'{name}: {r["waterfalls_at_k_loop"]} waterfall loops at the K loop (a descriptor is not provably uniform)'
         # the asm-load rule (DESIGN.md "A latent race"): nothing touches a landing VGPR between its buffer_load and the wait that
         # covers it, anywhere in the kernel; inside the K loop no branch is taken while such a load is in flight
         assert not r['landing_touches'], f'{name}: landing registers touched before their wait: {r["landing_touches"][:3]}'

@@ -174,6 +174,10 @@ def report():
                     'mfma_range_instructions': len(loop),
                     'scratch_in_mfma_range': sum(1 for ins in loop if ins.startswith('scratch_')),
                     'lane_ops_in_mfma_range': sum(1 for ins in loop if ins.startswith(('v_readlane', 'v_writelane'))),
+                    # hipcc's waterfall loop around a buffer operation whose descriptor is not provably wave-uniform (v_readfirstlane x 4,
+                    # two v_cmp_eq_u64, exec save / restore, a branch per LDS-DMA piece): round 4 found them in every stream / pipe kernel.
+                    # Counted from 200 instructions ahead of the first MFMA (the stage issue code sits in front of it) to the loop's end.
+                    'waterfalls_at_k_loop': sum(1 for ins in body[max(mfma[0] - 200, 0):end + 1] if ins.startswith('v_cmp_eq_u64')) // 2 if mfma else 0,
                     'landing_touches': [h for h in landing_hazards(body) if h[1] == 'touch'],
                     'sgpr_vmem_hazards': sgpr_vmem_hazards(body),
                     'landing_branches_in_mfma_range': [h for h in landing_hazards(loop) if h[1] == 'branch']})
@@ -188,4 +192,4 @@ if __name__ == '__main__':
         for r in sorted(rows, key=lambda r: r['kernel']):
             print(f"{r['kernel'][:78]:78s} vgpr {r.get('vgpr_count', -1):3d} spill {r.get('vgpr_spill_count', -1):3d} "
                   f"range {r['mfma_range_instructions']:5d} scratch-in-range {r['scratch_in_mfma_range']:3d} "
-                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d} landing-touches {len(r['landing_touches']):2d} sgpr->vmem hazards {len(r['sgpr_vmem_hazards']):2d} branches-in-range-with-loads-in-flight {len(r['landing_branches_in_mfma_range']):2d}")
+                  f"lane-ops-in-range {r['lane_ops_in_mfma_range']:3d} waterfalls {r['waterfalls_at_k_loop']:2d} landing-touches {len(r['landing_touches']):2d} sgpr->vmem hazards {len(r['sgpr_vmem_hazards']):2d} branches-in-range-with-loads-in-flight {len(r['landing_branches_in_mfma_range']):2d}")

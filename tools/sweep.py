@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--out', default='')
     ap.add_argument('--sets', type=int, default=4, help='rotating input sets (1 = operands stay in the Infinity Cache)')
+    ap.add_argument('--pad-a', type=int, default=0, help='extra bytes per row of A (row pitch k + pad: a sub-view of a wider tensor)')
+    ap.add_argument('--pad-b', type=int, default=0, help='extra bytes per row of B')
     args = ap.parse_args()
     configs = args.configs.split(',') if args.configs else [c for c in dg.list_configs() if not c.startswith('generic')]
     out = open(args.out, 'w') if args.out else None
@@ -35,6 +37,14 @@ def main():
             gen.reset_seed(i)
             c_ = gen.generate_normal(m, n, k)
             c_.a = (c_.a[0], dg.get_mn_major_tma_aligned_tensor(c_.a[1]))
+            if args.pad_a:      # the same bytes at a different row pitch (L2 / HBM channel mapping experiments)
+                wide = torch.zeros((m, k + args.pad_a), dtype=torch.uint8, device='cuda')
+                wide[:, :k] = c_.a[0].view(torch.uint8)
+                c_.a = (wide[:, :k].view(torch.float8_e4m3fn), c_.a[1])
+            if args.pad_b:
+                wide = torch.zeros((n, k + args.pad_b), dtype=torch.uint8, device='cuda')
+                wide[:, :k] = c_.b[0].view(torch.uint8)
+                c_.b = (wide[:, :k].view(torch.float8_e4m3fn), c_.b[1])
             cases.append(c_)
         case = cases[0]
         times = {c: [] for c in configs}
