@@ -145,11 +145,6 @@ const Config kConfigs[] = {
     // round 4: the same tiles with loader waves (4 compute waves + 4 / 12 that only issue LDS-DMA pieces): a stream tile is bound by the
     // LDS-DMA issue rate of its workgroup, and that rate grows with the number of issuing waves (50 / 80 / 96 GB/s per CU at 4 / 8 / 16)
     {"stream_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 4>, true},
-    {"stream_l16_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 12>, true},
-    {"stream_nt_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 2, 4, false, 4>, true},
-    {"stream_sc_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 1, 4, false, 4>, true},
-    {"stream_ntsc_l8_64x32", 64, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 3, 4, false, 4>, true},
-    {"stream_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 4>, true},
     // M <= 16 / 32 (decode batches): 16 output columns per workgroup over the whole K, the 8 waves split K; weights straight into registers
     {"skinny_16", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1>},
     {"skinny_32", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2>},
@@ -162,6 +157,11 @@ const Config kConfigs[] = {
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
 #ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
+    // round 4: the other loader-wave forms that were measured (12 loader waves: no better than 4; the 64 x 128 tile: 39.8 us against 38.4 at
+    // m = 128, C5 43.7 against 43.6; cache policies nt / sc on the weight pieces of the 64 x 32 tile: no difference -- profiles/r04_probe/)
+    {"stream_l16_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 12>, true},
+    {"stream_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 4>, true},
+    {"stream_nt_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, false, 4>, true},
     // round 4, negative: split rings (stream2_kernel_body: activation pieces on a short ring, weight pieces on a deep one, issued by separate
     // wave groups because a wave's vector-memory operations retire in order; bit-identical, 12-16 waves): m = 128, 4096 x 7168 22.4 us
     // against 18.2 (stream_l8_64x32), C5 49.8 against 44.2 (profiles/r04_probe/sweep_stream2_negative.log) -- bytes in flight per stream
@@ -462,8 +462,8 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         const char* pick = nullptr;
         if (m_hint <= 64)
             pick = tiles128 >= 96 ? "stream_64x128" : "stream_64x32";
-        else if (m_hint <= 256 && tiles128 < 96)
-            pick = "stream_64x32";
+        else if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal ? 128 : 96))
+            pick = "stream_64x32";      // (dense: up to half a round of 64 x 128 tiles -- m = 128, 7168 x 2048: 13.3 us against 14.0, round 4)
         else if (m_hint <= 256 && tiles128 < 256)
             pick = "stream_64x128";
         else if (m_hint > 256 && tiles128 <= num_cus())

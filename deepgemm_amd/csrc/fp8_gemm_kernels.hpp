@@ -2718,7 +2718,53 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 asm volatile("s_waitcnt vmcnt(%c0)" :: "i"((STAGES - 2) * PIECES) : "memory");
                 raw_barrier();
                 issue_stage(fill, sb + STAGES - 1);
-              if (LW == 0 || wave < NW)               // (loader waves: pieces and barriers only)
+              bool stage_done = false;
+              if constexpr (GSF && KBS > 1 && KBS * MS * NS <= 16) {
+                  // A whole stage (every one of its KBS blocks exists: the common case) as ONE software pipeline -- all fragment and scale reads,
+                  // then the KBS * MS * NS MFMAs back to back, then the promotions in K-block order (the arithmetic of the loop below, same
+                  // bits).  The loop below runs a block at a time with a branch between blocks: read, wait, MFMA, wait, FMA -- four dependent
+                  // latency chains per stage where this form has one (round 4: the 64 x 32 tile spends a third of its time in them).
+                  if ((LW == 0 || wave < NW) && (sb + 1) * KBS <= num_kb) {
+                      v8i bfq[KBS][NS], afq[KBS][MS];
+                      float sc[KBS][MS];
+                      #pragma unroll
+                      for (int u = 0; u < KBS; ++u) {
+                          const int jb = sb * KBS + u;
+                          const uint8_t* stage = lds + cur + u * BLOCK_BYTES;
+                          const uint8_t* sfg = lds + SFG_OFF + ((jb >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                          const float sb_val = *reinterpret_cast<const float*>(sfg + 1024 + (jb & 3) * 4);
+                          if constexpr (MS == 4) {
+                              const v4f q = *reinterpret_cast<const v4f*>(sfg + (jb & 3) * 256 + (wm * WM + (lane & 15) * MS) * 4);
+                              sc[u][0] = q[0] * sb_val; sc[u][1] = q[1] * sb_val; sc[u][2] = q[2] * sb_val; sc[u][3] = q[3] * sb_val;
+                          } else {
+                              sc[u][0] = *reinterpret_cast<const float*>(sfg + (jb & 3) * 256 + (wm * WM + (lane & 15)) * 4) * sb_val;
+                          }
+                          #pragma unroll
+                          for (int ns = 0; ns < NS; ++ns)
+                              bfq[u][ns] = load_fragment(stage + A_BYTES + (wn * WN) * 128 + ns * 2048, frag_off);
+                          #pragma unroll
+                          for (int ms = 0; ms < MS; ++ms)
+                              afq[u][ms] = load_fragment(stage + (wm * WM) * 128 + ms * 2048, frag_off);
+                      }
+                      v4f part[KBS][MS][NS];
+                      #pragma unroll
+                      for (int u = 0; u < KBS; ++u)
+                          #pragma unroll
+                          for (int ms = 0; ms < MS; ++ms)
+                              #pragma unroll
+                              for (int ns = 0; ns < NS; ++ns)
+                                  part[u][ms][ns] = mfma_fp8_k128(bfq[u][ns], afq[u][ms]);
+                      #pragma unroll
+                      for (int u = 0; u < KBS; ++u)
+                          #pragma unroll
+                          for (int ms = 0; ms < MS; ++ms)
+                              #pragma unroll
+                              for (int ns = 0; ns < NS; ++ns)
+                                  acc[ms][ns] += sc[u][ms] * part[u][ms][ns];
+                      stage_done = true;
+                  }
+              }
+              if (!stage_done && (LW == 0 || wave < NW))               // (loader waves: pieces and barriers only)
               #pragma unroll
               for (int u = 0; u < KBS; ++u) {
                 if (sb * KBS + u >= num_kb)

@@ -292,8 +292,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                                          (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16, a_piece_voff[q],
-                        (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+                        a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16,
+                        a_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0), (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
             };
             auto issue_b_piece = [&](int slot_off, int j, int q) {
                 if (NO_DMA) return;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
-                        b_piece_voff[q], (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+                        b_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0), (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
             };
             // STAGED: position `pos` (0 .. POS - 1: N_PRE in rows 0 .. MS-3, N_POST in the last two rows; >= POS: the next block's) of
             // block kb is: second half of B(kb+1) | A(kb+2) | first half of B(kb+2)
@@ -528,7 +528,6 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
 template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    static_assert(!K_TAIL || DG_M0_SHARE, "the K-tail bias is applied on the piece path of the M0-sharing form");
     quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL>(p);
 }
 

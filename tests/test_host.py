@@ -454,7 +454,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 16, 4096, 7168) == 'skinny_16' and pick(dense, 17, 4096, 7168) == 'skinny_32' and pick(dense, 33, 4096, 7168) == 'stream_l8_64x32'
     assert pick(dense, 1, 24576, 1536) == 'stream_64x128' and pick(dense, 1, 32768, 512) == 'stream_64x128'
     assert pick(dense, 32, 7168, 16384) == 'stream_l8_64x32' and pick(dense, 1, 4104, 7168) != 'skinny_16'
-    assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_64x128'
+    assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_l8_64x32'
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256'                                            # K split beats one stream tile per CU
     assert pick(dense, 4096, 7168, 2112, b_mn=1) == 'duo_bmn_kt_256x256' and pick(dense, 4096, 7168, 2112) == 'duo_kt_256x256'
     assert pick(dense, 4096, 512, 32768, b_mn=1) == 'duo_sk_bmn_128x256' and pick(dense, 4096, 576, 7168) == 'duo_sk_128x256'
