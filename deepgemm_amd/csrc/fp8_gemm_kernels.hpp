@@ -1789,17 +1789,24 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     // free to copy the destination registers at any control-flow join in between -- before the data has arrived.
     typename ScaleLandingSel<MS, A_MN || SFA_RM>::type land;
     [[maybe_unused]] ScaleLandingPC land_pc0, land_pc1;        // PC: block kb's scales in one, block kb+1's landing in the other
-    auto issue_prologue = [&](const Tile& tt) {
+    // halves: 0 = block 0 only, 1 = block 1 only, 2 = both.  (Round 4: the FIRST tile of a workgroup issues block 0 the moment its
+    // coordinates are known -- 1.6 k cycles of accumulator zeroing and descriptor set-up used to run in front of the first load:
+    // tools/prologue_stamps.py, profiles/r04_probe/prologue_stamps.log.)
+    auto issue_prologue = [&](const Tile& tt, int halves = 2) {
         const TileMem tm = tile_mem(tt);
-        #pragma unroll
-        for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, 0, 0, q);
-        #pragma unroll
-        for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, 0, 0, q);
-        #pragma unroll
-        for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, A_BYTES, 1, q);
-        if constexpr (!STREAM_A) {          // (STREAM_A: B(1) belongs to the lower half's first load segment)
+        if (halves != 1) {
             #pragma unroll
-            for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, B_BYTES, 1, q);
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, 0, 0, q);
+            #pragma unroll
+            for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, 0, 0, q);
+        }
+        if (halves != 0) {
+            #pragma unroll
+            for (int q = 0; q < A_ITERS; ++q) issue_a_piece_r(tm.a_base, tm.a_bytes, A_BYTES, 1, q);
+            if constexpr (!STREAM_A) {          // (STREAM_A: B(1) belongs to the lower half's first load segment)
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q) issue_b_piece_r(tm.b_base, tm.b_bytes, B_BYTES, 1, q);
+            }
         }
     };
 
@@ -1836,10 +1843,19 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         return get_tile<BM, BN>(p, id, walk, ps);
     };
     Piece piece, piece_next;
+#if defined(DG_STAMP_ISSUE) && DG_STAMP_ISSUE == 3
+    if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
     Tile t = work_of(tile_id, pass, piece);
+#if defined(DG_STAMP_ISSUE) && DG_STAMP_ISSUE == 2
+    if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
     while (t.valid) {
         kb0 = piece.kb0;
         nkb = piece.nkb;
+        const bool early_block0 = !prefetched && t.m_end > t.m0;
+        if (early_block0)
+            issue_prologue(t, 0);               // block 0 flies while the accumulators are zeroed and the scale descriptors are built
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
         Tile tn;
         bool next_prefetched = false;
@@ -1910,17 +1926,21 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
                 scale[ms] = 0.f;
 
             // ---- block 0 and its scales must land before the first segment ----
+#if defined(DG_STAMP_ISSUE) && DG_STAMP_ISSUE == 1     // (tuning builds: how long does a workgroup run before its first load goes out?  slot 2 = this stamp instead of the loop end)
+            if (p.dbg != nullptr && first_tile) t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
             if (!prefetched) {
                 // SF(0) first, then the pieces of blocks 0 and 1: the wait leaves block 1's pieces in flight (the first K block's
                 // own counted wait covers them), so the first segment starts as soon as block 0 is in.  (Straight-line from the
                 // scale loads to their wait: hipcc may copy the landing registers at any control-flow join in between.)
+                // (block 0's pieces went out at the top of the tile: older than the scale loads, so the counted wait still covers them)
                 if constexpr (PC) {
                     issue_scale_loads_pc(land_pc0, sfa_rsrc, sfa_voff + kb0 * sfa_kb_stride, sfb_rsrc, sfb_lane_off + kb0 * sfb_kb_stride);
-                    issue_prologue(t);
+                    issue_prologue(t, 1);
                     wait_landing_pc<A_ITERS + B_ITERS>(land_pc0);
                 } else {
                 issue_scales(land, 0);
-                issue_prologue(t);
+                issue_prologue(t, 1);
                 wait_landing_any<STREAM_A ? A_ITERS : A_ITERS + B_ITERS, MS>(land);
                 }
             }
@@ -2255,7 +2275,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
             }
             if (!upper_half)
                 raw_barrier();              // pairs with the barrier in front of the upper half's last segment
+#ifndef DG_STAMP_ISSUE
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's re-read pieces: the ring is about to be reused
             __syncthreads();                                    // every wave is done with the LDS
             auto promote_pending = [&]() {
