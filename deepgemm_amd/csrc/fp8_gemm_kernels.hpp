@@ -122,16 +122,28 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // Block b runs on XCD b % 8 (observed, speed only): give each XCD a contiguous chunk of the tile order, then walk
 // the tiles in groups of `group_m` m-tiles so that a chunk is a compact rectangle sharing A and B panels in its L2.
+// a / b for 0 <= a < 2^22, 0 < b < 2^22 (tile counts): one reciprocal and a one-step correction instead of the ~40-instruction integer
+// division sequence -- three of those sat between a workgroup's entry and its first load (~1.1 k cycles, tools/prologue_stamps.py).
+// (a + 0.5) / b is at least 0.5 / b away from an integer and the float error is below a * 2^-22 / b, so the truncation is already exact;
+// the correction makes it independent of the reciprocal's accuracy.
+__device__ __forceinline__ int div_small(int a, int b) {
+    int q = static_cast<int>((static_cast<float>(a) + 0.5f) * __builtin_amdgcn_rcpf(static_cast<float>(b)));
+    const int rem = a - q * b;
+    q += (rem >= b ? 1 : 0) - (rem < 0 ? 1 : 0);
+    return __builtin_amdgcn_readfirstlane(q);              // (tile ids are wave-uniform; the float detour hides that from the compiler)
+}
+
 __device__ __forceinline__ void swizzled_tile(int bid, int nwg, int num_m_tiles, int num_n_tiles, int group_m,
                                               int& mt, int& nt) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int per_group = group_m * num_n_tiles;
-    const int grp = lin / per_group, in_grp = lin - grp * per_group;
+    const bool small = nwg < (1 << 22);                   // (more tiles than that: > 17 GB of output even with the smallest tile)
+    const int grp = small ? div_small(lin, per_group) : lin / per_group, in_grp = lin - grp * per_group;
     const int first_m = grp * group_m;
     const int h = imin(num_m_tiles - first_m, group_m);
-    mt = first_m + in_grp % h;
-    nt = in_grp / h;
+    nt = small ? div_small(in_grp, h) : in_grp / h;
+    mt = first_m + in_grp - nt * h;
 }
 
 // K pieces per tile of a table launch with SPLITK: the host's wish (sk_factor) capped by what the workspace holds for the tile count the
@@ -1897,10 +1909,18 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
         #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
             #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
+            for (int ns = 0; ns < NS; ++ns) {
                 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[ms][ns][r] = 0.f;
+#ifndef DG_NO_ZERO_TIE
+                // materialised HERE, under the flight of block 0: hipcc sinks a plain zero-initialisation to the first MFMA -- behind the
+                // landing wait and the barrier, ~125 v_mov per wave on the critical path of every tile
+                // (the non-persistent 256-row form -- selectable by name only -- answers the tie with 27 prologue spills: left alone)
+                if constexpr (PERSIST || MERGED)
+                    asm volatile("" : "+v"(acc[ms][ns][0]), "+v"(acc[ms][ns][1]), "+v"(acc[ms][ns][2]), "+v"(acc[ms][ns][3]));
+#endif
+            }
 
         if (t.m_end > t.m0) {
             const TileMem tm = tile_mem(t);

@@ -258,12 +258,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             continue;
         }
 
-        v4f acc[MS][NS];
-        #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-            #pragma unroll
-            for (int ns = 0; ns < NS; ++ns)
-                acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4f acc[MS][NS];        // (zeroed below, AFTER the prologue's loads have been issued: the 128 accumulator writes fly under the memory latency)
 
         {
             const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
@@ -345,6 +340,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
             #pragma unroll
             for (int q = 0; q < B_ITERS / 2; ++q) issue_b_piece(B_BYTES, 1, q);
+            asm volatile("" ::: "memory");
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" : "+a"(acc[ms][ns]));          // materialised HERE (hipcc sinks plain zero-initialisation to the first MFMA: behind the wait)
+                }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
             tie_e8q_landing<MS, NS>(cur);
