@@ -796,15 +796,18 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         q.d_nt = output_streams_past_l2(q);
         q.dbg = g_debug_buffer.load(std::memory_order_relaxed);
     };
+    // ONE launch for both walks (dg_fp8_gemm_duo_tab_fused_kernel) when the tile list is derived in the kernel; DG_TAB_UNFUSED=1 keeps
+    // the two launches of round 3 (A/B)
+    const bool fused = in_kernel && getenv("DG_TAB_UNFUSED") == nullptr && getenv("DG_SK_EXCHANGE") == nullptr;
+    dg::GemmParams q = base;
     {   // the 256-row tiles
-        dg::GemmParams q = base;
         q.tile_table = in_kernel ? nullptr : big;
         q.table_mode = in_kernel ? 1 : 0;
         q.sk_workspace = nullptr; q.sk_first_tile = 0; q.sk_tiles = 0; q.sk_factor = 1; q.sk_capacity = 0;
         common(q, 256);
         const long items = static_cast<long>(nb / 2) * n_tiles;
         const long grid = std::min<long>(items, num_cus());
-        if (grid > 0)
+        if (grid > 0 && !fused)
             hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
                                static_cast<hipStream_t>(stream), q);
         DG_HIP_CHECK(hipGetLastError());
@@ -835,8 +838,12 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         r.sk_tiles = num_cus();              // (table launch: the slot count; the kernels read the tile count from the table)
         const long max_items = static_cast<long>(nb) * n_tiles * r.sk_factor;
         const long grid = std::min<long>(max_items, num_cus());
-        hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true, false, false, true>), dim3(static_cast<unsigned>(grid)),
-                           dim3(512), 0, static_cast<hipStream_t>(stream), r);
+        if (fused)          // every workgroup slot: both walks are persistent (stride = the grid) and end on their own
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_tab_fused_kernel<256, 128, 256, 2, 4>), dim3(static_cast<unsigned>(num_cus())), dim3(512), 0,
+                               static_cast<hipStream_t>(stream), q, r);
+        else
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, true, false, false, true>), dim3(static_cast<unsigned>(grid)),
+                               dim3(512), 0, static_cast<hipStream_t>(stream), r);
         DG_HIP_CHECK(hipGetLastError());
         if (r.sk_factor >= 2 && r.sk_exchange == 0) {
             // grid: an upper bound on the remainder tiles that can be split at all (capacity / 2 pieces) x 4 subtile rows; surplus

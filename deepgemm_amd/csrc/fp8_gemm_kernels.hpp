@@ -1146,7 +1146,8 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     static_assert(TOTAL >= DEPTH + 1 && (TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
     static_assert(SPREAD * (A_ITERS + B_ITERS) <= TOTAL, "not enough steps to spread the LDS-DMA pieces");
 
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[SC_BASE + 2 * SC_STAGE];
+    constexpr int TOUCH_BASE = SC_BASE + 2 * SC_STAGE;             // 256 bytes nobody reads: where the touch-ahead loads of C land
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[TOUCH_BASE + 256];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1263,6 +1264,43 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                                                              16, lane * 16, kb * sfb_kb_stride, 0, 0);
             };
 
+            // Touch-ahead of C (round 4).  An accumulating call (D += A B^T: every wgrad and K-grouped call) ends with a read-modify-write
+            // of the whole output tile -- 256 KiB per workgroup fetched cold from HBM and written back while nothing else runs (21.7 us
+            // of the 134 us wgrad call).  The old values are known to be needed from the first cycle on: one dword of every line of the
+            // tile is pulled through the L2 while the K loop runs, spread evenly over the K blocks (LDS-DMA into a dummy slot: no
+            // register, no data dependency; the block's closing vmcnt(0) covers it), so that the epilogue's reads are served by the
+            // Infinity Cache and HBM only has the writes left.  touch_units wave-instructions of 64 lines cover the tile.
+            // NEGATIVE (same-box A/B, profiles/r04_probe/c_touch_ahead_negative.log): the epilogue shrinks 41.0 k -> 36.0 k ticks but the K loop
+            // grows 4171 -> 4343 ticks per block (one more VMEM instruction under the block's closing vmcnt(0)): wgrad 142.5-144.0 -> 144.2 us,
+            // K-grouped 1258 -> 1321 us; 64-byte granules: worse.  Compiled in only with -DDG_C_TOUCH.
+#ifndef DG_C_TOUCH_BYTES
+#define DG_C_TOUCH_BYTES 128
+#endif
+            const int d_elem = p.d_dtype == 0 ? 2 : 4;
+            const int touch_per_row = BN * d_elem / DG_C_TOUCH_BYTES;                 // touches per tile row (a power of two)
+            const int touch_shift = __builtin_ctz(touch_per_row);
+            const int touch_units = p.accumulate && p.head_lr == 0 ? BM * touch_per_row / 64 : 0;
+            const int d_rows = imin(t.m_end - t.m0, BM);
+            const int64_t d_tile_off = ((p.gemm_type == kKGrouped ? t.group : ad_group) * p.d_sg + static_cast<int64_t>(t.m0) * p.d_sm + t.n0) * d_elem;
+            const auto d_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_pointer(reinterpret_cast<uint8_t*>(p.d) + d_tile_off), 0,
+                uniform_int(((d_rows - 1) * static_cast<int>(p.d_sm) + imin(p.n - t.n0, BN)) * d_elem), 0x00020000);
+            [[maybe_unused]] int touch_next = 0, touch_credit = 0;
+            [[maybe_unused]] auto touch_c = [&](int kb_total) {
+                // Bresenham: touch_units instructions over kb_total K blocks; unit u belongs to wave u % NW
+                touch_credit += touch_units;
+                while (touch_credit >= kb_total && touch_next < touch_units) {
+                    touch_credit -= kb_total;
+                    if ((touch_next % NW) == wave) {
+                        const int line = touch_next * 64 + lane;
+                        const int row = line >> touch_shift, in_row = line & (touch_per_row - 1);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsrc, (__attribute__((address_space(3))) void*)(lds + TOUCH_BASE), 4,
+                                                                 row * static_cast<int>(p.d_sm) * d_elem + in_row * DG_C_TOUCH_BYTES, 0, 0, 0);
+                    }
+                    ++touch_next;
+                }
+            };
+
             v4f part[DEPTH + 1];
             #pragma unroll
             for (int i = 0; i <= DEPTH; ++i)
@@ -1305,6 +1343,9 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                 }
                 if (has_next)
                     issue_scale_piece(cur ^ 1, kb + 1);
+#ifdef DG_C_TOUCH                   // (tuning builds only -- negative, see above)
+                touch_c(num_kb);
+#endif
 
                 const uint8_t* a_tile = MN ? lds + cur * STAGE_BYTES : lds + cur * STAGE_BYTES + (wm * WM) * 128;
                 const uint8_t* b_tile = MN ? lds + cur * STAGE_BYTES + A_BYTES : lds + cur * STAGE_BYTES + A_BYTES + (wn * WN) * 128;
@@ -1637,9 +1678,12 @@ __device__ __forceinline__ void promote_only_v(float (&c)[4], const float (&s)[4
 // by role so that the 3-slot A ring / 2-slot B ring still suffice with the halves one segment apart: the LOWER half issues all pieces
 // of B(kb+1) in its L(kb) (B(kb-1)'s slot: everybody's L(kb-1) reads are done), the UPPER half all pieces of A(kb+2) in its L(kb)
 // (A(kb-1)'s slot: the upper half itself finished M(kb-1) last).  Prologue: A(0) B(0) A(1).
+// LDS bytes of a duo body: three A slots, two B slots (MERGED: three)
+constexpr int duo_lds_bytes(int bm, int bn, bool merged) { return 3 * bm * 128 + (merged ? 3 : 2) * bn * 128; }
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
-          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false, bool SFA_RM = false>
-__device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
+          bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false, bool SFA_RM = false, int CALLER = 0>
+__device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* const lds) {
     static_assert(!SFA_RM || (BM == 256 && PERSIST && !A_MN && !B_MN && !K_TAIL && !MERGED && !SPLITK && !STREAM_A && !PC),
                   "SFA_RM: the dense persistent 256-row form reading a row-major SFA in place");
     static_assert(!PC || (MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK && !STREAM_A), "PC: the two-segment 128-row tile, K-major operands");
@@ -1674,7 +1718,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p) {
     static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
                   "the row permutation of a B piece must be lane-independent");
 
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[LDS_BYTES];
+    static_assert(LDS_BYTES == duo_lds_bytes(BM, BN, MERGED), "the kernel wrappers size the LDS array with duo_lds_bytes");
+    // (`lds`: the calling kernel's __shared__ array -- a kernel that runs two bodies one after the other gives both the same bytes)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2480,7 +2525,25 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B
           bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false, bool SFA_RM = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_kernel(const GemmParams p) {
-    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC, SFA_RM>(p);
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[duo_lds_bytes(BM, BN, MERGED)];
+    duo_kernel_body<BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K_TAIL, MERGED, STREAM_A, PC, SFA_RM>(p, lds);
+}
+
+// The two GEMM launches of launch_contiguous_tabled as ONE: every workgroup walks the 256-row tiles of the in-kernel tile list (q) and then
+// the K-split pieces of the 128-row remainders (r) -- no kernel boundary between the two (drain, launch latency, a second evaluation of the
+// tile list against a cold layout read), and a workgroup whose 256-row walk ends early starts on its piece at once.  Both bodies use the
+// same LDS bytes; the barrier between them is the only coupling.  The reduction over the pieces stays a separate launch.
+// (CALLER = 1: the host pass of hipcc accepts ONE reference per body specialization in a translation unit -- the body's gfx950-only
+// builtins make its host-side instantiation invalid, the first reference defers that, a second one from another kernel is answered with an
+// unexplained substitution failure or a silently missing launch stub.  The tag makes these two their own specializations.)
+template <int BIG_BM, int REM_BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void dg_fp8_gemm_duo_tab_fused_kernel(const GemmParams q, const GemmParams r) {
+    static_assert(duo_lds_bytes(REM_BM, BN, true) <= duo_lds_bytes(BIG_BM, BN, false), "the remainder body fits in the 256-row body's LDS");
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[duo_lds_bytes(BIG_BM, BN, false)];
+    duo_kernel_body<BIG_BM, BN, WAVES_M, WAVES_N, true, false, false, false, false, false, false, false, false, 1>(q, lds);
+    __syncthreads();
+    duo_kernel_body<REM_BM, BN, WAVES_M, WAVES_N, true, false, true, false, false, true, false, false, false, 1>(r, lds);
 }
 
 

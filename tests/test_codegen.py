@@ -18,6 +18,7 @@ PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K
     'dg_fp8_gemm_duo_kernel<128,256,2,4,1,0,1,0,0,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,1,1,1,0,0,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,1,0,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,1,0,0,0,0,0>',
     'dg_fp8_gemm_duo_kernel<256,256,2,4,1,0,0,0,1,0,0,0,0>', 'dg_fp8_gemm_duo_kernel<128,256,2,4,0,0,0,0,1,1,0,0,0>', 'dg_fp8_gemm_duo_kernel<256,256,2,4,1,1,0,0,1,0,0,0,0>',
     'dg_fp8_gemm_duo_kernel<128,256,2,4,0,1,0,0,1,1,0,0,0>',
+    'dg_fp8_gemm_duo_tab_fused_kernel<256,128,256,2,4>',                   # round 4: C4's 256-row walk and K-split remainder walk in one launch
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,0,0>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,6,2,1,0,0>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,0,0>',
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,1,0>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,6,2,1,1,0>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,0>',
     'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,0,4>',          # round 4: + four loader waves (the dense 64 x 32 pick)
