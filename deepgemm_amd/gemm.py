@@ -382,6 +382,10 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
             sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), sfb.stride(2), d.stride(0), int(use_psum_layout),
             runtime.get_mk_alignment_for_contiguous_layout(), current_stream_ptr()))
         return
+    if _casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast):
+        # 'sm100' mode with a K tail: the FP32-scale kernels on TRUNCATED scales -- the values the cast branch keeps -- as the dense entry does
+        # (one mode, one arithmetic, whatever the entry point and K)
+        a_sf, b_sf = _truncate_to_ue8m0(a_sf), _truncate_to_ue8m0(b_sf)
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b,
                                                               None, num_groups, True)
     host_assert(gran_n == 128, 'gran_n == 128 (the grouped kernels read one SFB value per 128 columns; per-column SFB takes packed UE8M0 scales)')
@@ -421,6 +425,8 @@ def m_grouped_fp8_gemm_nt_masked(a: TensorPair, b: TensorPair, d: torch.Tensor, 
     (a_data, a_sf), (b_data, b_sf) = a, b
     if a_sf.dtype == torch.int or b_sf.dtype == torch.int or (_casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast) and a_data.size(-1) % 128 == 0):
         return _m_grouped_masked_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, masked_m, expected_m, recipe, recipe_a, recipe_b)
+    if _casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast):         # 'sm100' mode, K tail: truncated scales on the FP32-scale kernels (see the contiguous entry)
+        a_sf, b_sf = _truncate_to_ue8m0(a_sf), _truncate_to_ue8m0(b_sf)
     key = (_sig(a_data), _sig(a_sf), _sig(b_data), _sig(b_sf), _sig(d), _sig(masked_m), expected_m > 0,
            recipe if recipe is None else tuple(recipe), recipe_a if recipe_a is None else tuple(recipe_a),
            recipe_b if recipe_b is None else tuple(recipe_b))
@@ -625,7 +631,10 @@ def fp8_gemm_nt_skip_head_mid(a: TensorPair, b: TensorPair, d: torch.Tensor, hea
                 'n % (left + right) == 0 and n_ == n + n / (left + right) * mid')
     if m == 0:
         return
-    # (the head-split epilogue lives on the FP32-scale kernels: FP32 scales are consumed as FP32 in either scaling-factor mode)
+    # (the head-split epilogue lives on the FP32-scale kernels; in the 'sm100' scaling-factor mode they get the TRUNCATED scales -- the
+    #  values the reference's cast branch keeps, csrc/apis/layout.hpp:48-54 -- so that the mode means one arithmetic at every entry point)
+    if _casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast):
+        a_sf, b_sf = _truncate_to_ue8m0(a_sf), _truncate_to_ue8m0(b_sf)
     sfa, sfb, gran_n = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, None, None, None, None, True)
     require_device(a_data, b_data, sfa, sfb, d)
     check(lib.dg_fp8_gemm_nt_skip_head_mid(

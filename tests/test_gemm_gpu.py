@@ -1,6 +1,7 @@
 """GPU parity tests of the FP8 GEMM path: the HIP kernels (through the public operators / C ABI) against the CPU
 oracle on the same seeded inputs, the committed golden fixtures, the reference's own gate, and size-independent
 properties at BASELINE.json's full sizes.  Modeled on the reference's tests/test_fp8_fp4.py."""
+import os
 import random
 
 import pytest
@@ -1273,6 +1274,16 @@ def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
             assert_close_to_oracle(outs[0][rows], want, f'group {g}')
         assert bool((outs[0][start + actual:start + aligned] == 0).all()), f'group {g}: padding rows must be zeros'
         start += aligned
+    # round 4: the 256-row walk and the remainder walk share ONE launch; the two-launch form of round 3 must give the same bits
+    os.environ['DG_TAB_UNFUSED'] = '1'
+    try:
+        two = guarded[128:128 + m]
+        two.fill_(float('nan'))
+        dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, two, case.grouped_layout)
+        assert dg.last_config() == 'duo_tab_256x256'
+        assert torch.equal(two, outs[0]), 'one launch and two launches differ'
+    finally:
+        del os.environ['DG_TAB_UNFUSED']
     dg.set_forced_config('duo_128x256')
     fixed = torch.empty_like(case.d)
     dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, fixed, case.grouped_layout)

@@ -144,6 +144,47 @@ def test_dense_sm100_mode_truncates_non_power_of_two_scales():
     assert_close_to_oracle(d, want, 'sm100 mode, truncated scales, K tail')
 
 
+def test_sm100_mode_is_one_arithmetic_at_every_entry():
+    """'sm100' mode with scales that are not powers of two, at the entries that cannot take the hardware-scaled kernels (a K tail on the
+    grouped entries, the head-split epilogue): the FP32-scale kernels run on the truncated scales -- bit-identical to the same call in
+    'sm90' mode with the truncation done by the caller, and different from the untruncated result (round 3 let these fall through)."""
+    trunc = lambda s: (s.view(torch.int) & 0x7f800000).view(torch.float)   # noqa: E731
+    n, k = 512, 576                                                        # 4.5 K blocks
+    gen.reset_seed(11)
+    cont = gen.generate_m_grouped_contiguous(3, 0, n, k, actual_ms=[130, 256, 90])
+    gen.reset_seed(12)
+    masked = gen.generate_m_grouped_masked(3, 64, 40, n, k, masked_ms=[33, 64, 0])
+    gen.reset_seed(13)
+    head = gen.generate_normal(96, 4 * (128 + 64), 1024)
+    splits = (128, 64, 64)
+
+    def run_all(ta, tb):
+        outs = []
+        d = torch.zeros_like(cont.d)
+        dg.m_grouped_fp8_gemm_nt_contiguous((cont.a[0], ta(cont.a[1])), (cont.b[0], tb(cont.b[1])), d, cont.grouped_layout)
+        outs.append(d)
+        d = torch.zeros_like(masked.d)
+        dg.m_grouped_fp8_gemm_nt_masked((masked.a[0], ta(masked.a[1])), (masked.b[0], tb(masked.b[1])), d, masked.masked_m, 40)
+        outs.append(d)
+        d = torch.zeros((96, 4 * (128 + 64 + 64)), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt_skip_head_mid((head.a[0], ta(head.a[1])), (head.b[0], tb(head.b[1])), d, splits)
+        outs.append(d)
+        return outs
+
+    ident = lambda s: s                                                     # noqa: E731
+    plain = run_all(ident, ident)                                           # 'sm90': FP32 scales as they are
+    by_hand = run_all(trunc, trunc)                                         # 'sm90' on truncated scales
+    dg.set_sf_cast_mode('sm100')
+    mode = run_all(ident, ident)
+    for name, got, want, other in zip(('contiguous', 'masked', 'skip_head_mid'), mode, by_hand, plain):
+        assert torch.equal(got, want), f'{name}: sm100 mode != truncated scales'
+        assert not torch.equal(got, other), f'{name}: truncation had no effect (scales already powers of two?)'
+    # and the keyword of the reference switches it off per call
+    d = torch.zeros_like(cont.d)
+    dg.m_grouped_fp8_gemm_nt_contiguous(cont.a, cont.b, d, cont.grouped_layout, disable_ue8m0_cast=True)
+    assert torch.equal(d, plain[0])
+
+
 @pytest.mark.parametrize('use_psum', [False, True])
 def test_contiguous_sm100_mode_is_the_packed_int_call(use_psum):
     gen.reset_seed(16)

@@ -6,6 +6,11 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${OUT:-r04_final}
 mkdir -p $OUT
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+# the round-end gate as the driver runs it, without a profiler: the whole GPU suite, then the default bench line
+( time timeout 1500 python -m pytest tests/ -q -m gpu -p no:cacheprovider 2>&1 | tail -8 ) > $OUT/pytest_gpu.log 2>&1
+echo "pytest: $(grep -E 'passed|failed' $OUT/pytest_gpu.log | tail -1)"
+timeout 600 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 > $OUT/bench_default_run.json
+echo "bench: $(cut -c1-300 $OUT/bench_default_run.json)"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -o bench -- python bench.py --no-secondary > $OUT/bench_stats_headline.log 2>&1
 echo "headline stats exit $?"
 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py > $OUT/bench_stats.log 2>&1
@@ -25,7 +30,7 @@ timeout 600 python tools/survey.py > $OUT/survey_reference_sweeps.jsonl 2> $OUT/
 echo "survey exit $?"
 timeout 200 python tools/mlp_bench.py > $OUT/expert_mlp.log 2>&1
 echo "mlp exit $?"
-find $OUT -type f ! -name "*.csv" ! -name "*.log" ! -name "*.txt" ! -name "*.jsonl" ! -name "*.err" -delete
+find $OUT -type f ! -name "*.csv" ! -name "*.log" ! -name "*.txt" ! -name "*.jsonl" ! -name "*.json" ! -name "*.err" -delete
 python tools/summarize_prof.py $OUT > $OUT/SUMMARY.txt 2>&1
 for f in $(find $OUT -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do head -400 $f > $f.tmp && mv $f.tmp $f; done
 cat $OUT/SUMMARY.txt | cut -c1-250 | head -80

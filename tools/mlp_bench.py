@@ -21,7 +21,8 @@ groups, m_max, hidden, inter = 8, 64, 7168, 2048
 calls = bench.make_workload('expert_mlp', 2)[0]
 sets = [c.__defaults__ for c in calls]                         # (x, y, masked, mid, w1_t, w2_t)
 plain = [c.__defaults__ for c in bench.make_workload('expert_mlp_unfused', 2)[0]]     # (x, y, masked, h, w1, w2)
-for label, fns in (('gemm1_fused', [lambda s=s: dg.m_grouped_fp8_gemm_nt_masked_swiglu(s[0], s[4], s[3], s[2], 48) for s in sets]),
+ws = dg.mega.swiglu_workspace(groups, m_max, 2 * inter, 'cuda')        # caller-owned: the library never allocates one under graph capture
+for label, fns in (('gemm1_fused', [lambda s=s: dg.m_grouped_fp8_gemm_nt_masked_swiglu(s[0], s[4], s[3], s[2], 48, workspace=ws) for s in sets]),
                    ('gemm1_plain', [lambda s=s: dg.m_grouped_fp8_gemm_nt_masked(s[0], s[4], s[3], s[2], 48) for s in plain]),
                    ('gemm2', [lambda s=s: dg.m_grouped_fp8_gemm_nt_masked(s[3], s[5], s[1], s[2], 48) for s in sets])):
     fns[0]()
