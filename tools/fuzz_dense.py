@@ -2,7 +2,7 @@
 """More seeds of tests/test_gemm_gpu.py::test_dense_random_shapes_and_layouts_vs_oracle (random dense problems through the automatic
 selection, each against the oracle).   python tools/fuzz_dense.py [first_seed] [count]"""
 import sys, random, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import tests.test_gemm_gpu as t
 import deepgemm_amd as dg
 bad = 0
