@@ -552,3 +552,25 @@ def test_mega_weight_transform_and_validation_on_the_host():
         dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, (w_t, sf_t), dg.empty_intermediate(groups, 8, inter, 'cpu'), masked, 0)
     with pytest.raises(RuntimeError, match='no CPU path'):   # valid arguments: fails loudly for want of a GPU, no CPU path
         dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, (w_t, sf_t), dg.empty_intermediate(groups, 8, inter, 'cpu'), masked, 1)
+
+
+def test_reciprocal_tile_mapping_division_is_exact():
+    """fp8_gemm_kernels.hpp `div_small`: the tile mapping divides through ONE float reciprocal and a one-step correction instead of the
+    integer-division sequence (round 4).  The same arithmetic in numpy float32 -- with the reciprocal pushed one ulp either way, which is
+    more than `v_rcp_f32` may be off -- equals a // b for every (a, b) below 2^22, the range the kernels use it in."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    a = np.concatenate([rng.integers(0, 1 << 22, 200000), np.arange(0, 4096), np.full(64, (1 << 22) - 1)]).astype(np.int64)
+    b = np.concatenate([rng.integers(1, 1 << 22, 100000), rng.integers(1, 64, 100000), np.arange(1, 4097), np.arange(1, 65)]).astype(np.int64)
+    # edge cases: exact multiples and one below them
+    mult = (rng.integers(1, 1 << 11, 50000) * rng.integers(1, 1 << 11, 50000)).astype(np.int64)
+    div = rng.integers(1, 1 << 11, 50000).astype(np.int64)
+    a = np.concatenate([a, (mult // div) * div, np.maximum((mult // div) * div - 1, 0)])
+    b = np.concatenate([b, div, div])
+    for ulps in (-1, 0, 1):
+        rcp = (np.float32(1.0) / b.astype(np.float32)).astype(np.float32)
+        rcp = np.nextafter(rcp, np.float32(np.inf if ulps > 0 else -np.inf)) if ulps else rcp
+        q = ((a.astype(np.float32) + np.float32(0.5)) * rcp).astype(np.float32).astype(np.int64)      # v_cvt_i32_f32 truncates
+        rem = a - q * b
+        q = q + (rem >= b) - (rem < 0)
+        assert np.array_equal(q, a // b), f'reciprocal off by {ulps} ulp'
