@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -32,9 +32,9 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
-             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128']
+             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
-             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128']
+             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0']
 GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
@@ -153,17 +153,21 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
                 'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'FP32 row-major [M, K/128]: transposed inside the call' if name == 'dense_sfa_rowmajor' else 'pre-transposed (zero-copy branch): FP32, MN-major, handed over by the producer'}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name.startswith('c3_'):
-        layout = name[3:]
+        layout, packed = name[3:5], name.endswith('_ue8m0')
         m, n, k = 2048, 7168, 2048
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_normal(m, n, k, layout[0] == 'n', layout[1] == 't')
-            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            case = gen.generate_normal(m, n, k, layout[0] == 'n', layout[1] == 't', use_ue8m0=packed)
+            if packed:          # packed UE8M0 words with the operands' majorness as it is (nn: B [K][N] read in place by e8_duo_bmn_256x256)
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+            else:
+                a, b = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1])), case.b
             cases.append(case)
-            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+            calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d))
         flops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
-        desc = {'workload': f'fp8_gemm_{layout} M={m} N={n} K={k} (BASELINE configs[2]; whole operator call, majorness from strides)',
+        desc = {'workload': f'fp8_gemm_{layout} M={m} N={n} K={k} (BASELINE configs[2]; whole operator call, majorness from strides)' +
+                            (', packed UE8M0 scales' if packed else ''),
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name in ('decode_m1', 'decode_m1_long'):

@@ -253,6 +253,9 @@ const E8Config kE8Configs[] = {
     // round 4: k % 128 != 0 (whole 16-byte chunks, k > 128; dense): the 128-row quad form with the partial last block zero-filled by the
     // buffer range check -- packed-scale dgrad shapes (K = 2112, 576) no longer leave the hardware-scaled path
     {"e8_quad_kt_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, true>, 128, 256, 256, false, false, false},
+    // round 4: operand B MN-major ([K][N]: the nn layout of a packed-scale dgrad) read in place by the 8-wave hardware-scaled kernel
+    // (transpose reads, natural column order) -- instead of a re-majoring pass over B in front of the quad kernel
+    {"e8_duo_bmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true>, 256, 256, 512, false, false, false},
 #ifdef DG_EXPERIMENTS
     {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
@@ -312,6 +315,19 @@ bool amn_eligible(const dg::GemmParams& p) {
                             p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
     return p.sfb_gran_n == 128 && p.gemm_type == dg::kNormal && p.k % 128 == 0 && p.sfa_sm == 1 && a_ok &&
            (b_k_major || b_mn_major);
+}
+
+// Packed-UE8M0 dense problem with A K-major and B MN-major that e8_duo_bmn_256x256 reads in place (whole K blocks; scale words MN-major).
+bool e8_bmn_eligible(const dg::GemmParams& p) {
+    return p.gemm_type == dg::kNormal && p.k % 128 == 0 && p.a_sk == 1 && p.b_sn == 1 && p.b_sk != 1 && p.sfa_sm == 1 && p.sfb_sn == 1 &&
+           aligned16(p.a) && aligned16(p.b) && p.a_sm % 16 == 0 && p.b_sk % 16 == 0 && p.n % 16 == 0 && p.head_lr == 0 &&
+           p.a_sm <= (1 << 22) && p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
+}
+// ... and is better off there than re-majored in front of the quad kernel: tile-kernel territory (the stream tiles of small M want K-major
+// weights) and not so many rows that the 8-wave kernel's slower K loop (~17 %) outweighs one pass over B (model: 3 us + 2 n k bytes at
+// 4.5 TB/s against 0.17 x 2 m n k / 3 PFLOP/s: break-even near m = 4000).
+bool e8_bmn_pays(const dg::GemmParams& p) {
+    return p.m > 256 && p.m <= 4096 && 2L * ((p.m + 255) / 256) * ((p.n + 255) / 256) >= num_cus();
 }
 
 // Recipe (1, 1, 128) on the fast path: both scale tensors MN-major with 16-byte aligned K-block rows (each block's 256
@@ -907,7 +923,8 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
 
 int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     const bool k_tail = p.k % 128 != 0;
-    if (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal)) {
+    const bool b_mn = p.b_sk != 1 && e8_bmn_eligible(p);
+    if (!b_mn && (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal))) {
         g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0 (dense: or k % 16 == 0 and k > 128)";
         return 3;
     }
@@ -928,6 +945,19 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
             }
     } else if (cfg != nullptr && std::strcmp(cfg->name, "e8_quad_kt_128x256") == 0) {
         cfg = nullptr;                              // (the tail form is only for tails; a forced name falls back to the selection)
+    }
+    if (b_mn) {                                     // MN-major B: one kernel reads it (a forced name of another one is refused)
+        for (const E8Config& c : kE8Configs)
+            if (std::strcmp(c.name, "e8_duo_bmn_256x256") == 0) {
+                if (cfg != nullptr && cfg != &c) {
+                    g_last_error = std::string("forced config '") + cfg->name + "' needs a K-major operand B";
+                    return 3;
+                }
+                cfg = &c;
+            }
+    } else if (cfg != nullptr && std::strcmp(cfg->name, "e8_duo_bmn_256x256") == 0) {
+        g_last_error = "config 'e8_duo_bmn_256x256' reads an MN-major operand B";
+        return 3;
     }
     if (cfg == nullptr)
         cfg = select_e8_config(p, expected_m);
@@ -1067,11 +1097,29 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
     p.sfb_gran_n = 128; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
     p.sfb_gran_n = 128;                                      // only so that the K-major / alignment test below applies
-    if (!fast_eligible(p, p.k % 128 == 0)) {
-        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs K-major, 16-byte aligned FP8 operands and k % 128 == 0 (or k % 16 == 0 and k > 128)";
+    if (!fast_eligible(p, p.k % 128 == 0) && !e8_bmn_eligible(p)) {
+        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs 16-byte aligned FP8 operands, A K-major, B K-major (k % 128 == 0, or k % 16 == 0 and k > 128) "
+                       "or MN-major (k % 128 == 0, n % 16 == 0)";
         return 3;
     }
     return launch_e8(p, 0, stream);
+}
+
+int dg_ue8m0_dense_reads_b_mn_major(const void* a, const void* b, int m, int n, int k, int64_t a_stride_m, int64_t a_stride_k,
+                                    int64_t b_stride_n, int64_t b_stride_k) {
+    // Should the caller leave an MN-major operand B of a packed-UE8M0 dense problem as it is (1) or re-major it into K-major scratch (0)?
+    // The predicates launch_e8 applies, plus the model of when reading it in place pays (e8_bmn_pays) -- the host layer keeps no copy.
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b);
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = a_stride_m; p.a_sk = a_stride_k; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sm = 1; p.sfb_sn = 1; p.gemm_type = dg::kNormal;
+    if (!e8_bmn_eligible(p))
+        return 0;
+    const std::string forced = forced_config();
+    if (forced == "e8_duo_bmn_256x256")
+        return 1;
+    return forced == "auto" && e8_bmn_pays(p) ? 1 : 0;
 }
 
 int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,

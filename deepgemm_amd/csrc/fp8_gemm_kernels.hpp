@@ -3177,10 +3177,14 @@ __device__ __forceinline__ void wait_e8_landing(E8Landing& l) {
 // the hardware-scaled MFMA of dg_fp8_gemm_e8_kernel in the matrix segments (16 MFMAs, nothing else) and the packed scale
 // words of block kb+1 loaded in L_a(kb), consumed (shifted to byte 0) in L_a(kb+1).
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// B_MN (round 4): operand B MN-major ([K][N], unit stride along n) read in place -- the nn layout of a packed-scale caller without the
+// re-majoring pass: the LDS-DMA pieces (4 k-rows x 256 bytes), the hardware transpose reads and the natural column order of the B_MN form
+// of dg_fp8_gemm_duo_kernel; a lane's row slot i of N-subtile ns is weight row ns * 16 + i, and so is its scale word.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false>
 __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
+    static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW, A_EARLY = A_ITERS / 2;
@@ -3218,6 +3222,11 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
         b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
     const int num_kq = (num_kb + 3) / 4;
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;
+    // MN-major B (see duo_kernel_body): lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k)
+    [[maybe_unused]] const int ldb_mn = static_cast<int>(p.b_sk);
+    [[maybe_unused]] const int bmn_voff = (lane >> 4) * ldb_mn + (((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3))) << 4);
+    [[maybe_unused]] const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
+    [[maybe_unused]] const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
     const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
 
@@ -3238,12 +3247,15 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
 
         if (t.m_end > t.m0) {
             const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
-            const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
+            const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * (B_MN ? 1 : p.b_sn));
             const int a_rows = uniform_int(imin(t.m_end - t.m0, BM)), b_rows = uniform_int(imin(p.n - t.n0, BN));
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
                                                                   (a_rows - 1) * lda + p.k, 0x00020000);
+            // (B_MN: the descriptor ends with the last k-row's valid bytes; a lane past N inside an earlier row reads the next row's head --
+            //  finite bytes that only reach columns which are never stored)
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
-                                                                  (b_rows - 1) * ldb + p.k, 0x00020000);
+                                                                  B_MN ? uniform_int((p.k - 1) * ldb_mn + (p.n - t.n0)) : (b_rows - 1) * ldb + p.k,
+                                                                  0x00020000);
             const uint64_t sfa_addr = reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg);
             const uint64_t sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg);
             const v4i sfa_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfa_addr)),
@@ -3257,7 +3269,8 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 const int i = lane & 15;
-                sfb_voff[ns] = (t.n0 + wn * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)) * 4;
+                sfb_voff[ns] = B_MN ? (t.n0 + wn * WN + ns * 16 + i) * 4          // natural row order
+                                    : (t.n0 + wn * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)) * 4;
             }
             auto issue_a_piece = [&](int slot_off, int j, int q) {
                 const int unit = wave + NW * q;
@@ -3269,7 +3282,8 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 const int unit = wave + NW * q;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + unit * 1024), 16,
-                    b_piece_voff[q], imin(j, num_kb - 1) * 128, 0, 0);
+                    B_MN ? bmn_voff : b_piece_voff[q],
+                    B_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * ldb_mn : imin(j, num_kb - 1) * 128, 0, 0);
             };
             E8Landing land;
             auto issue_scales = [&](int j) {
@@ -3313,9 +3327,12 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
 
                 // ---------------- L_a ----------------
                 seg_barrier();
+                [[maybe_unused]] FragTr bfq[NS];
                 #pragma unroll
-                for (int ns = 0; ns < NS; ++ns)
-                    bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                for (int ns = 0; ns < NS; ++ns) {
+                    if constexpr (B_MN) bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                    else bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                }
                 #pragma unroll
                 for (int h = 0; h < HS; ++h)
                     af[h] = load_fragment(a_tile + h * 2048, frag_off);
@@ -3328,6 +3345,11 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 for (int q = 0; q < A_EARLY; ++q)
                     issue_a_piece(a_fill, kb + 2, q);
                 __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+                if constexpr (B_MN) {               // the transpose reads have landed: now they may become MFMA operands
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        bf[ns] = assemble_fragment_tr(bfq[ns]);
+                }
                 asm volatile("" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
                              :: "memory");
 
@@ -3376,7 +3398,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+        store_tile<MS, NS, true, false, B_MN>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -3387,10 +3409,10 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_e8_kernel(const GemmParams p) {
-    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N>(p);
+    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N, B_MN>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

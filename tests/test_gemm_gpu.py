@@ -771,7 +771,7 @@ def test_import_is_fork_safe_and_bench_runs():
     assert 'zero-copy' in line['config']['sfa_layout']
     # the driver-visible record of the other configurations: C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0 (C2, C5), two dgrad entries
     secondary = line['secondary']
-    assert len(secondary) == 20 and not [s for s in secondary if 'error' in s], secondary
+    assert len(secondary) == 21 and not [s for s in secondary if 'error' in s], secondary
     for rec in secondary:
         assert 0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0, rec
     assert {s['roofline']['bound'] for s in secondary} == {'mfma', 'hbm'}
@@ -956,6 +956,30 @@ def test_packed_ue8m0_every_kernel_and_per_row_sfb(m, n, k):
         assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
         first = d if first is None else first
         assert torch.equal(d, first), f'{cfg} differs from {E8_DENSE_CONFIGS[0]}'
+    # round 4: the nn layout -- B MN-major ([K][N]) with packed scales -- read in place by the 8-wave hardware-scaled kernel (transpose
+    # reads, natural column order, one scale word per weight row): the same bits as every K-major kernel above; the automatic choice
+    # between that and a re-majoring pass in front of the quad kernel gives those bits either way
+    b_kn = b[0].t().contiguous()                                            # [K, N] storage
+    sfb_kn = b[1].t().contiguous()                                          # the scale words travel transposed with it
+    dg.set_forced_config('e8_duo_bmn_256x256')
+    d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    if n % 16 == 0:
+        dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
+        assert dg.last_config() == 'e8_duo_bmn_256x256', dg.last_config()
+        assert torch.equal(d, first), 'MN-major B read in place differs from the K-major kernels'
+    else:                               # k-rows of B not 16-byte aligned: the host layer re-majors, and the MN-major kernel refuses a K-major B
+        with pytest.raises(RuntimeError, match='MN-major operand B'):
+            dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
+    dg.set_forced_config('auto')
+    d.fill_(float('nan'))
+    dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
+    assert dg.last_config().startswith('e8_') and torch.equal(d, first)
+    if 256 < m <= 4096 and 2 * -(-m // 256) * -(-n // 256) >= 256:
+        assert dg.last_config() == 'e8_duo_bmn_256x256', dg.last_config()
+    dg.set_forced_config('e8_quad_128x256')                                  # a K-major kernel forced onto the MN-major operand: re-majored first
+    d.fill_(float('nan'))
+    dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
+    assert dg.last_config() == 'e8_quad_128x256' and torch.equal(d, first)
     dg.set_forced_config('e8_quad_256x256')
     if k % 512 != 0:
         with pytest.raises(RuntimeError, match='k % 512'):
