@@ -256,6 +256,9 @@ const E8Config kE8Configs[] = {
     // round 4: operand B MN-major ([K][N]: the nn layout of a packed-scale dgrad) read in place by the 8-wave hardware-scaled kernel
     // (transpose reads, natural column order) -- instead of a re-majoring pass over B in front of the quad kernel
     {"e8_duo_bmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true>, 256, 256, 512, false, false, false},
+    // ... and A MN-major ([K][M]: the tt layout), both (tn): scale words of A in natural row order
+    {"e8_duo_amn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, false, true>, 256, 256, 512, false, false, false},
+    {"e8_duo_abmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true, true>, 256, 256, 512, false, false, false},
 #ifdef DG_EXPERIMENTS
     {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
@@ -317,17 +320,35 @@ bool amn_eligible(const dg::GemmParams& p) {
            (b_k_major || b_mn_major);
 }
 
-// Packed-UE8M0 dense problem with A K-major and B MN-major that e8_duo_bmn_256x256 reads in place (whole K blocks; scale words MN-major).
-bool e8_bmn_eligible(const dg::GemmParams& p) {
-    return p.gemm_type == dg::kNormal && p.k % 128 == 0 && p.a_sk == 1 && p.b_sn == 1 && p.b_sk != 1 && p.sfa_sm == 1 && p.sfb_sn == 1 &&
-           aligned16(p.a) && aligned16(p.b) && p.a_sm % 16 == 0 && p.b_sk % 16 == 0 && p.n % 16 == 0 && p.head_lr == 0 &&
-           p.a_sm <= (1 << 22) && p.b_sk <= (1 << 22) && static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31);
+// Packed-UE8M0 dense problem with at least one MN-major operand that the 8-wave hardware-scaled kernel reads in place (e8_duo_bmn / _amn /
+// _abmn_256x256: whole K blocks, scale words MN-major, 16-byte aligned rows / k-rows).
+bool e8_mn_eligible(const dg::GemmParams& p) {
+    const bool a_mn = p.a_sk != 1, b_mn = p.b_sk != 1;
+    if (!(a_mn || b_mn) || p.gemm_type != dg::kNormal || p.k % 128 != 0 || p.sfa_sm != 1 || p.sfb_sn != 1 || p.head_lr != 0)
+        return false;
+    const bool a_ok = a_mn ? (p.a_sm == 1 && aligned16(p.a) && p.a_sk % 16 == 0 && p.m % 16 == 0 && p.a_sk <= (1 << 22) &&
+                              static_cast<int64_t>(p.k) * p.a_sk < (1LL << 31))
+                           : (aligned16(p.a) && p.a_sm % 16 == 0 && p.a_sm <= (1 << 22));
+    const bool b_ok = b_mn ? (p.b_sn == 1 && aligned16(p.b) && p.b_sk % 16 == 0 && p.n % 16 == 0 && p.b_sk <= (1 << 22) &&
+                              static_cast<int64_t>(p.k) * p.b_sk < (1LL << 31))
+                           : (aligned16(p.b) && p.b_sn % 16 == 0 && p.b_sn <= (1 << 22));
+    return a_ok && b_ok;
+}
+const char* e8_mn_config_name(const dg::GemmParams& p) {
+    return p.a_sk != 1 ? (p.b_sk != 1 ? "e8_duo_abmn_256x256" : "e8_duo_amn_256x256") : "e8_duo_bmn_256x256";
 }
 // ... and is better off there than re-majored in front of the quad kernel: tile-kernel territory (the stream tiles of small M want K-major
-// weights) and not so many rows that the 8-wave kernel's slower K loop (~17 %) outweighs one pass over B (model: 3 us + 2 n k bytes at
-// 4.5 TB/s against 0.17 x 2 m n k / 3 PFLOP/s: break-even near m = 4000).
-bool e8_bmn_pays(const dg::GemmParams& p) {
-    return p.m > 256 && p.m <= 4096 && 2L * ((p.m + 255) / 256) * ((p.n + 255) / 256) >= num_cus();
+// weights), and the pass(es) over the MN-major operand(s) -- 3 us + twice their bytes at 4.5 TB/s each -- cost more than the 8-wave
+// kernel's slower K loop (a quarter of the quad kernel's time at 3 PFLOP/s).  Measured (profiles/r04_probe/e8_mn_in_place_ab.log): nn
+// 2048 x 7168 x 2048 35.1 against 43.1 us, tn 35.7 / 44.4; 4096 x 4096 x 7168: nn 102.0 / 100.8, tt 106.5 / 101.3 (re-majored: what the
+// model picks), tn 106.0 / 115.4.
+bool e8_mn_pays(const dg::GemmParams& p) {
+    if (p.m <= 256 || 2L * ((p.m + 255) / 256) * ((p.n + 255) / 256) < num_cus())
+        return false;
+    double remajor_us = 0;
+    if (p.a_sk != 1) remajor_us += 3.0 + static_cast<double>(p.m) * p.k / 2.25e6;
+    if (p.b_sk != 1) remajor_us += 3.0 + static_cast<double>(p.n) * p.k / 2.25e6;
+    return remajor_us > static_cast<double>(p.m) * p.n * p.k / 6e9;
 }
 
 // Recipe (1, 1, 128) on the fast path: both scale tensors MN-major with 16-byte aligned K-block rows (each block's 256
@@ -923,8 +944,8 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
 
 int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     const bool k_tail = p.k % 128 != 0;
-    const bool b_mn = p.b_sk != 1 && e8_bmn_eligible(p);
-    if (!b_mn && (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal))) {
+    const bool mn_form = e8_mn_eligible(p);           // an MN-major operand read in place
+    if (!mn_form && (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal))) {
         g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0 (dense: or k % 16 == 0 and k > 128)";
         return 3;
     }
@@ -946,17 +967,18 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     } else if (cfg != nullptr && std::strcmp(cfg->name, "e8_quad_kt_128x256") == 0) {
         cfg = nullptr;                              // (the tail form is only for tails; a forced name falls back to the selection)
     }
-    if (b_mn) {                                     // MN-major B: one kernel reads it (a forced name of another one is refused)
+    if (mn_form) {                                  // MN-major operand(s): one kernel reads this combination (a forced name of another one is refused)
+        const char* want = e8_mn_config_name(p);
         for (const E8Config& c : kE8Configs)
-            if (std::strcmp(c.name, "e8_duo_bmn_256x256") == 0) {
+            if (std::strcmp(c.name, want) == 0) {
                 if (cfg != nullptr && cfg != &c) {
-                    g_last_error = std::string("forced config '") + cfg->name + "' needs a K-major operand B";
+                    g_last_error = std::string("forced config '") + cfg->name + "' does not read this operand majorness (" + want + " does)";
                     return 3;
                 }
                 cfg = &c;
             }
-    } else if (cfg != nullptr && std::strcmp(cfg->name, "e8_duo_bmn_256x256") == 0) {
-        g_last_error = "config 'e8_duo_bmn_256x256' reads an MN-major operand B";
+    } else if (cfg != nullptr && std::strncmp(cfg->name, "e8_duo_", 7) == 0 && std::strstr(cfg->name, "mn_") != nullptr) {
+        g_last_error = std::string("config '") + cfg->name + "' reads MN-major operands";
         return 3;
     }
     if (cfg == nullptr)
@@ -1097,29 +1119,33 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
     p.sfb_gran_n = 128; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
     p.sfb_gran_n = 128;                                      // only so that the K-major / alignment test below applies
-    if (!fast_eligible(p, p.k % 128 == 0) && !e8_bmn_eligible(p)) {
-        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs 16-byte aligned FP8 operands, A K-major, B K-major (k % 128 == 0, or k % 16 == 0 and k > 128) "
-                       "or MN-major (k % 128 == 0, n % 16 == 0)";
+    if (!fast_eligible(p, p.k % 128 == 0) && !e8_mn_eligible(p)) {
+        g_last_error = "dg_fp8_gemm_nt_ue8m0 needs 16-byte aligned FP8 operands: K-major (k % 128 == 0, or k % 16 == 0 and k > 128) or, with "
+                       "k % 128 == 0, MN-major (m resp. n % 16 == 0)";
         return 3;
     }
     return launch_e8(p, 0, stream);
 }
 
-int dg_ue8m0_dense_reads_b_mn_major(const void* a, const void* b, int m, int n, int k, int64_t a_stride_m, int64_t a_stride_k,
-                                    int64_t b_stride_n, int64_t b_stride_k) {
-    // Should the caller leave an MN-major operand B of a packed-UE8M0 dense problem as it is (1) or re-major it into K-major scratch (0)?
-    // The predicates launch_e8 applies, plus the model of when reading it in place pays (e8_bmn_pays) -- the host layer keeps no copy.
+int dg_ue8m0_dense_operand_plan(const void* a, const void* b, int m, int n, int k, int64_t a_stride_m, int64_t a_stride_k,
+                                int64_t b_stride_n, int64_t b_stride_k) {
+    // Which MN-major FP8 operands of a packed-UE8M0 dense problem the caller should re-major into K-major scratch first (bit 0: A, bit 1: B);
+    // 0 = hand them over as they are.  The predicates launch_e8 applies, plus the model of when reading in place pays (e8_mn_pays) -- the
+    // host layer keeps no copy.  (One kernel per majorness combination: either every MN-major operand stays, or all are re-majored.)
+    const int all = (a_stride_k != 1 ? 1 : 0) | (b_stride_k != 1 ? 2 : 0);
+    if (all == 0)
+        return 0;
     dg::GemmParams p{};
     p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b);
     p.m = m; p.n = n; p.k = k; p.num_groups = 1;
     p.a_sm = a_stride_m; p.a_sk = a_stride_k; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
     p.sfa_sm = 1; p.sfb_sn = 1; p.gemm_type = dg::kNormal;
-    if (!e8_bmn_eligible(p))
-        return 0;
+    if (!e8_mn_eligible(p))
+        return all;
     const std::string forced = forced_config();
-    if (forced == "e8_duo_bmn_256x256")
-        return 1;
-    return forced == "auto" && e8_bmn_pays(p) ? 1 : 0;
+    if (forced == e8_mn_config_name(p))
+        return 0;
+    return forced == "auto" && e8_mn_pays(p) ? 0 : all;
 }
 
 int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,

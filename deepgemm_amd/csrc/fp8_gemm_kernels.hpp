@@ -3165,6 +3165,44 @@ __device__ __forceinline__ void issue_e8_scale_loads(E8Landing& l, const v4i& sf
         : "memory");
 }
 
+// A_MN: the rows of a wave tile keep their natural order (subtile ms = rows 16 ms .. + 15), so a lane's MS scale words lie 16 rows apart:
+// MS dword loads instead of two dwordx4 (the ScaleLandingN of the FP32-scale kernels)
+struct E8LandingN { int sa[8]; int sb[4]; };
+
+__device__ __forceinline__ void issue_e8_scale_loads(E8LandingN& l, const v4i& sfa_rsrc, int sfa_voff, const v4i& sfb_rsrc,
+                                                     int sfb_voff0, int sfb_voff1, int sfb_voff2, int sfb_voff3) {
+    asm volatile(
+        "s_nop 4\n\t"
+        "buffer_load_dword %0, %12, %13, 0 offen\n\t"
+        "buffer_load_dword %1, %12, %13, 0 offen offset:64\n\t"
+        "buffer_load_dword %2, %12, %13, 0 offen offset:128\n\t"
+        "buffer_load_dword %3, %12, %13, 0 offen offset:192\n\t"
+        "buffer_load_dword %4, %12, %13, 0 offen offset:256\n\t"
+        "buffer_load_dword %5, %12, %13, 0 offen offset:320\n\t"
+        "buffer_load_dword %6, %12, %13, 0 offen offset:384\n\t"
+        "buffer_load_dword %7, %12, %13, 0 offen offset:448\n\t"
+        "buffer_load_dword %8, %14, %18, 0 offen\n\t"
+        "buffer_load_dword %9, %15, %18, 0 offen\n\t"
+        "buffer_load_dword %10, %16, %18, 0 offen\n\t"
+        "buffer_load_dword %11, %17, %18, 0 offen"
+        : "=&v"(l.sa[0]), "=&v"(l.sa[1]), "=&v"(l.sa[2]), "=&v"(l.sa[3]), "=&v"(l.sa[4]), "=&v"(l.sa[5]), "=&v"(l.sa[6]), "=&v"(l.sa[7]),
+          "=&v"(l.sb[0]), "=&v"(l.sb[1]), "=&v"(l.sb[2]), "=&v"(l.sb[3])
+        : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff0), "v"(sfb_voff1), "v"(sfb_voff2), "v"(sfb_voff3), "s"(sfb_rsrc)
+        : "memory");
+}
+
+template <int ALLOWED>
+__device__ __forceinline__ void wait_e8_landing(E8LandingN& l) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
+    asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sa[2]), "+v"(l.sa[3]), "+v"(l.sa[4]), "+v"(l.sa[5]), "+v"(l.sa[6]), "+v"(l.sa[7]),
+                      "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]) :: "memory");
+}
+__device__ __forceinline__ int e8_landed_sfa(const E8Landing& l, int ms) { return l.sa[ms / 4][ms % 4]; }
+__device__ __forceinline__ int e8_landed_sfa(const E8LandingN& l, int ms) { return l.sa[ms]; }
+template <bool NATURAL> struct E8LandingSel { typedef E8Landing type; };
+template <> struct E8LandingSel<true> { typedef E8LandingN type; };
+
 template <int ALLOWED>
 __device__ __forceinline__ void wait_e8_landing(E8Landing& l) {
     asm volatile("" ::: "memory");
@@ -3180,11 +3218,14 @@ __device__ __forceinline__ void wait_e8_landing(E8Landing& l) {
 // B_MN (round 4): operand B MN-major ([K][N], unit stride along n) read in place -- the nn layout of a packed-scale caller without the
 // re-majoring pass: the LDS-DMA pieces (4 k-rows x 256 bytes), the hardware transpose reads and the natural column order of the B_MN form
 // of dg_fp8_gemm_duo_kernel; a lane's row slot i of N-subtile ns is weight row ns * 16 + i, and so is its scale word.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false>
+// A_MN: operand A MN-major ([K][M]: the tt / tn layouts) likewise; A rows in natural order (scale words as MS dword loads, epilogue without
+// the row interleave).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false, bool A_MN = false>
 __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
     static_assert(!B_MN || (BN == 256 && NW == 8), "MN-major B tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
+    static_assert(!A_MN || (BM == 256 && NW == 8), "MN-major A tile: 128 k-rows x 256 bytes, 32 pieces over 8 waves");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW, A_EARLY = A_ITERS / 2;
@@ -3223,8 +3264,9 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     const int num_kq = (num_kb + 3) / 4;
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;
     // MN-major B (see duo_kernel_body): lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k)
-    [[maybe_unused]] const int ldb_mn = static_cast<int>(p.b_sk);
-    [[maybe_unused]] const int bmn_voff = (lane >> 4) * ldb_mn + (((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3))) << 4);
+    [[maybe_unused]] const int ldb_mn = static_cast<int>(p.b_sk), lda_mn = static_cast<int>(p.a_sk);
+    [[maybe_unused]] const int mn_chunk = ((lane & 15) ^ (((4 * (wave & 1) + (lane >> 4)) & 7) | (((wave >> 2) & 1) << 3))) << 4;
+    [[maybe_unused]] const int bmn_voff = (lane >> 4) * ldb_mn + mn_chunk, amn_voff = (lane >> 4) * lda_mn + mn_chunk;
     [[maybe_unused]] const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
     [[maybe_unused]] const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
     const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
@@ -3246,11 +3288,12 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
+            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * (A_MN ? 1 : p.a_sm));
             const uint8_t* b_base = uniform_pointer(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * (B_MN ? 1 : p.b_sn));
             const int a_rows = uniform_int(imin(t.m_end - t.m0, BM)), b_rows = uniform_int(imin(p.n - t.n0, BN));
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base), 0,
-                                                                  (a_rows - 1) * lda + p.k, 0x00020000);
+                                                                  A_MN ? uniform_int((p.k - 1) * lda_mn + (p.m - t.m0)) : (a_rows - 1) * lda + p.k,
+                                                                  0x00020000);
             // (B_MN: the descriptor ends with the last k-row's valid bytes; a lane past N inside an earlier row reads the next row's head --
             //  finite bytes that only reach columns which are never stored)
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base), 0,
@@ -3264,7 +3307,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             const v4i sfb_rsrc = {__builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr)),
                                   __builtin_amdgcn_readfirstlane(static_cast<int>(sfb_addr >> 32) & 0xffff),
                                   __builtin_amdgcn_readfirstlane((num_kq - 1) * sfb_kq_stride + p.n * 4), 0x00020000};
-            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
+            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * (A_MN ? 1 : MS)) * 4;        // A_MN: + ms * 64 bytes in the loads
             int sfb_voff[NS];
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
@@ -3275,8 +3318,9 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             auto issue_a_piece = [&](int slot_off, int j, int q) {
                 const int unit = wave + NW * q;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16, a_piece_voff[q],
-                    imin(j, num_kb - 1) * 128, 0, 0);
+                    a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + unit * 1024), 16,
+                    A_MN ? amn_voff : a_piece_voff[q],
+                    A_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * lda_mn : imin(j, num_kb - 1) * 128, 0, 0);
             };
             auto issue_b_piece = [&](int slot_off, int j, int q) {
                 const int unit = wave + NW * q;
@@ -3285,7 +3329,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                     B_MN ? bmn_voff : b_piece_voff[q],
                     B_MN ? (imin(j, num_kb - 1) * 128 + 4 * unit) * ldb_mn : imin(j, num_kb - 1) * 128, 0, 0);
             };
-            E8Landing land;
+            typename E8LandingSel<A_MN>::type land;
             auto issue_scales = [&](int j) {
                 const int kq = imin(j, num_kb - 1) >> 2;
                 issue_e8_scale_loads(land, sfa_rsrc, sfa_voff + kq * sfa_kq_stride, sfb_rsrc, sfb_voff[0] + kq * sfb_kq_stride,
@@ -3297,7 +3341,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 const int shift = (imin(j, num_kb - 1) & 3) * 8;
                 #pragma unroll
                 for (int ms = 0; ms < MS; ++ms)
-                    sa_cur[ms] = static_cast<int>(static_cast<unsigned>(land.sa[ms / 4][ms % 4]) >> shift);
+                    sa_cur[ms] = static_cast<int>(static_cast<unsigned>(e8_landed_sfa(land, ms)) >> shift);
                 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
                     sb_cur[ns] = static_cast<int>(static_cast<unsigned>(land.sb[ns]) >> shift);
@@ -3333,9 +3377,12 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                     if constexpr (B_MN) bfq[ns] = load_fragment_tr(lds + B_BASE + b_cur, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
                     else bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
                 }
+                [[maybe_unused]] FragTr afq[HS];
                 #pragma unroll
-                for (int h = 0; h < HS; ++h)
-                    af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                for (int h = 0; h < HS; ++h) {
+                    if constexpr (A_MN) afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + h) ^ tr_swz) << 4);
+                    else af[h] = load_fragment(a_tile + h * 2048, frag_off);
+                }
                 take_scales(kb);                    // the words landed before the previous L_b's wait (or the prologue's)
                 // (A packed word covers four K blocks, so three of four of these fetches are redundant -- but issuing them
                 // conditionally puts a control-flow join between the asm loads and their wait, where hipcc copies the landing
@@ -3349,6 +3396,11 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
                         bf[ns] = assemble_fragment_tr(bfq[ns]);
+                }
+                if constexpr (A_MN) {
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h)
+                        af[h] = assemble_fragment_tr(afq[h]);
                 }
                 asm volatile("" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])
                              :: "memory");
@@ -3366,15 +3418,22 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
                 // ---------------- L_b ----------------
                 seg_barrier();
                 #pragma unroll
-                for (int h = 0; h < HS; ++h)
-                    af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                for (int h = 0; h < HS; ++h) {
+                    if constexpr (A_MN) afq[h] = load_fragment_tr(lds + a_cur, tr_lane_base, ((wm * MS + HS + h) ^ tr_swz) << 4);
+                    else af[h] = load_fragment(a_tile + (HS + h) * 2048, frag_off);
+                }
                 #pragma unroll
                 for (int q = A_EARLY; q < A_ITERS; ++q)
                     issue_a_piece(a_fill, kb + 2, q);
                 #pragma unroll
                 for (int q = 0; q < B_ITERS; ++q)
                     issue_b_piece(b_cur, kb + 2, q);
-                wait_e8_landing<A_ITERS + B_ITERS>(land);       // block kb+1 and its scale words: my pieces have landed
+                wait_e8_landing<A_ITERS + B_ITERS>(land);       // block kb+1 and its scale words: my pieces have landed (lgkmcnt(0) too)
+                if constexpr (A_MN) {
+                    #pragma unroll
+                    for (int h = 0; h < HS; ++h)
+                        af[h] = assemble_fragment_tr(afq[h]);
+                }
                 asm volatile("" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]) :: "memory");
 
                 // ---------------- M_b ----------------
@@ -3398,7 +3457,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        store_tile<MS, NS, true, false, B_MN>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
+        store_tile<MS, NS, !A_MN, false, B_MN>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
@@ -3409,10 +3468,10 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false, bool A_MN = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_e8_kernel(const GemmParams p) {
-    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N, B_MN>(p);
+    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N, B_MN, A_MN>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -176,11 +176,14 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
     else:
         sfa, sfb = _packed_sf_mn_major(a_sf, m, k), _packed_sf_mn_major(b_sf, n, k)
     require_device(a_data, b_data, sfa, sfb, d)
-    a_data = a_data if a_data.stride(-1) == 1 else _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
-    # MN-major B (the nn layout): read in place by the 8-wave hardware-scaled kernel where the library says that beats a re-majoring pass
-    if b_data.stride(-1) != 1 and not lib.dg_ue8m0_dense_reads_b_mn_major(a_data.data_ptr(), b_data.data_ptr(), m, n, k, a_data.stride(0),
-                                                                         a_data.stride(1), b_data.stride(0), b_data.stride(1)):
-        b_data = _as_k_major(b_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
+    # MN-major operands (nn / tn / tt): read in place by the 8-wave hardware-scaled kernels where the library says that beats a re-majoring pass
+    if a_data.stride(-1) != 1 or b_data.stride(-1) != 1:
+        plan = lib.dg_ue8m0_dense_operand_plan(a_data.data_ptr(), b_data.data_ptr(), m, n, k, a_data.stride(0), a_data.stride(1),
+                                               b_data.stride(0), b_data.stride(1))
+        if plan & 1:
+            a_data = _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
+        if plan & 2:
+            b_data = _as_k_major(b_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
     check(lib.dg_fp8_gemm_nt_ue8m0(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),

@@ -61,19 +61,21 @@ int dg_fp8_gemm_nt_skip_head_mid(const void* a, const float* sfa, const void* b,
  * scale of K block 4 kq + j of that row of A / B (127 = 1.0); element (row, kq) at ptr[row * stride_mn + kq * stride_kq],
  * stride_mn must be 1 (MN-major).  The scaled MFMA applies the scales in hardware and accumulates in place over K: no FP32
  * promotion pass (4 waves per 256 x 256 tile, 128 x 128 wave tiles in AGPRs; 128 x 256 tiles for small problems and K tails).
- * A must be K-major with 16-byte aligned rows; B K-major (k % 128 == 0, or a dense K tail: k % 16 == 0 and k > 128) or -- round 4 --
- * MN-major ([K][N], b_stride_n == 1, 16-byte aligned k-rows, k % 128 == 0, n % 16 == 0): the nn layout read in place by the 8-wave
- * hardware-scaled kernel (the reference's SM100 kernels take either majorness through UMMA descriptors: csrc/apis/gemm.hpp:126-164). */
+ * Operands: K-major with 16-byte aligned rows (k % 128 == 0, or a dense K tail: k % 16 == 0 and k > 128) or -- round 4 -- MN-major
+ * ([K][M] / [K][N], unit stride along m / n, 16-byte aligned k-rows, k % 128 == 0, m resp. n % 16 == 0): the nn / tn / tt layouts read in
+ * place by the 8-wave hardware-scaled kernels (the reference's SM100 kernels take either majorness through UMMA descriptors:
+ * csrc/apis/gemm.hpp:126-164). */
 int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
                          int m, int n, int k,
                          int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                          int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
 
-/* 1 if dg_fp8_gemm_nt_ue8m0 should be handed this MN-major operand B as it is (it has a kernel for it and reading it in place beats a
- * re-majoring pass at this size), 0 if the caller should re-major it into K-major scratch first.  Pointers are only tested for alignment. */
-int dg_ue8m0_dense_reads_b_mn_major(const void* a, const void* b, int m, int n, int k, int64_t a_stride_m, int64_t a_stride_k,
-                                    int64_t b_stride_n, int64_t b_stride_k);
+/* Which MN-major operands of a dg_fp8_gemm_nt_ue8m0 call the caller should re-major into K-major scratch first (bit 0: A, bit 1: B); 0 = hand
+ * them over as they are (the library has a kernel for this majorness combination and reading in place beats the extra pass at this size).
+ * Pointers are only tested for alignment. */
+int dg_ue8m0_dense_operand_plan(const void* a, const void* b, int m, int n, int k, int64_t a_stride_m, int64_t a_stride_k,
+                                int64_t b_stride_n, int64_t b_stride_k);
 
 /* M-grouped GEMMs with packed UE8M0 scales (the reference's SM100 drivers sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d /
  * _masked_1d1d, impls/sm100_fp8_fp4_gemm_1d1d.hpp:161,244, reached from csrc/apis/gemm.hpp:217-231,280-296 with int scale

@@ -968,18 +968,35 @@ def test_packed_ue8m0_every_kernel_and_per_row_sfb(m, n, k):
         assert dg.last_config() == 'e8_duo_bmn_256x256', dg.last_config()
         assert torch.equal(d, first), 'MN-major B read in place differs from the K-major kernels'
     else:                               # k-rows of B not 16-byte aligned: the host layer re-majors, and the MN-major kernel refuses a K-major B
-        with pytest.raises(RuntimeError, match='MN-major operand B'):
+        with pytest.raises(RuntimeError, match='MN-major'):
             dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
     dg.set_forced_config('auto')
     d.fill_(float('nan'))
     dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
     assert dg.last_config().startswith('e8_') and torch.equal(d, first)
-    if 256 < m <= 4096 and 2 * -(-m // 256) * -(-n // 256) >= 256:
+    if (m, n, k) == (4096, 4096, 1536):                                      # (the model's verdict at this size: in place)
         assert dg.last_config() == 'e8_duo_bmn_256x256', dg.last_config()
     dg.set_forced_config('e8_quad_128x256')                                  # a K-major kernel forced onto the MN-major operand: re-majored first
     d.fill_(float('nan'))
     dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d)
     assert dg.last_config() == 'e8_quad_128x256' and torch.equal(d, first)
+    # ... and the tt / tn layouts: A MN-major ([K][M]; its scale words in natural row order), alone and together with an MN-major B
+    a_km, sfa_km = a[0].t().contiguous(), a[1].t().contiguous()
+    for op, name, b_arg, ok in ((dg.fp8_gemm_tt, 'e8_duo_amn_256x256', b, m % 16 == 0),
+                                (dg.fp8_gemm_tn, 'e8_duo_abmn_256x256', (b_kn, sfb_kn), m % 16 == 0 and n % 16 == 0)):
+        dg.set_forced_config(name)
+        d.fill_(float('nan'))
+        if ok:
+            op((a_km, sfa_km), b_arg, d)
+            assert dg.last_config() == name, dg.last_config()
+            assert torch.equal(d, first), f'{name}: MN-major operands read in place differ from the K-major kernels'
+        else:
+            with pytest.raises(RuntimeError, match='MN-major'):
+                op((a_km, sfa_km), b_arg, d)
+        dg.set_forced_config('auto')
+        d.fill_(float('nan'))
+        op((a_km, sfa_km), b_arg, d)
+        assert dg.last_config().startswith('e8_') and torch.equal(d, first), dg.last_config()
     dg.set_forced_config('e8_quad_256x256')
     if k % 512 != 0:
         with pytest.raises(RuntimeError, match='k % 512'):

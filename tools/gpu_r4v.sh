@@ -6,7 +6,7 @@ export PYTHONUNBUFFERED=1
 OUT=gpurun_out/r4v; mkdir -p $OUT
 ( timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_sf_cast_mode_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider -k "packed or ue8m0 or sm100" 2>&1 | tail -15 ) > $OUT/pytest.log 2>&1
 echo "pytest: $(tail -1 $OUT/pytest.log)"; grep -E "^FAILED|^ERROR|Error|assert" $OUT/pytest.log | head
-timeout 300 python tools/e8_bmn_ab.py 2>&1 | grep -v amdgpu.ids | tee $OUT/e8_bmn_ab.log
+timeout 400 python tools/e8_mn_ab.py 2048x7168x2048 tt 2>&1 | grep -v amdgpu.ids | tee $OUT/e8_mn_ab.log
 for r in 1; do for w in c3_nn_ue8m0; do for f in auto; do
   if [ $w = c3_nn ] && [ $f != auto ]; then continue; fi
   line=$(DG_FORCED=$f timeout 200 python - <<PY 2>/dev/null | tail -1
