@@ -738,6 +738,8 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     }
     // L2 grouping: with 8 XCDs each chunk of tiles should be a compact rectangle (see swizzled_tile).
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    if (const char* gm = getenv("DG_GROUP_M"))       // (tuning runs: M tiles per L2 group of the tile walk)
+        p.group_m = std::max(1, std::min(atoi(gm), p.num_m_tiles));
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
     p.d_nt = output_streams_past_l2(p);
