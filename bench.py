@@ -150,7 +150,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
                             (', packed UE8M0 scales (power-of-two scales, recipe (1, 1, 128))' if packed else '') +
                             (', SFA row-major as the cast returns it: whole call = layout step (transpose launch) + GEMM' if name == 'dense_sfa_rowmajor' else ''),
                 'm': m, 'n': n, 'k': k,
-                'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'FP32 row-major [M, K/128]: transposed inside the call' if name == 'dense_sfa_rowmajor' else 'pre-transposed (zero-copy branch): FP32, MN-major, handed over by the producer'}
+                'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'FP32 row-major [M, K/128]: transposed inside the call' if name == 'dense_sfa_rowmajor' else 'FP32 MN-major (zero-copy branch)'}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name.startswith('c3_'):
         layout, packed = name[3:5], name.endswith('_ue8m0')
@@ -360,6 +360,11 @@ def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, ke
     return rec
 
 
+def _sig(x: float, digits: int = 4) -> float:
+    """x rounded to `digits` significant digits (compact records)."""
+    return float(f'{x:.{digits}g}')
+
+
 def graph_replay_seconds(calls, per_graph: int) -> float:
     """Seconds per call of `per_graph` calls captured into one hipGraph and replayed (every operator call is stream-ordered and
     capturable): what a decode loop that replays its step as a graph pays -- kernel plus kernel boundary, no host path."""
@@ -447,8 +452,8 @@ def cpu_baseline(workload: str):
         if i:
             best = min(best, dt)
     return {'value': 2.0 * m * n * k / best / 1e12, 'unit': 'TFLOPS', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'full M={m} N={n} K={k} problem, reference test expression (a.float() @ b.float().t()).to(bf16), '
-                      f'min of 2 timed runs after 1 warm-up, {best:.2f} s per run, os.cpu_count()={os.cpu_count()}'}
+            'sample': f'full {m}x{n}x{k}, reference test expr (a.float() @ b.float().t()).to(bf16), min of 2 runs, {best:.2f} s each, '
+                      f'os.cpu_count()={os.cpu_count()}'}
 
 
 def run(rank: int, world: int, local_rank: int, args):
@@ -535,10 +540,23 @@ def run(rank: int, world: int, local_rank: int, args):
             line['ep_time_split_us'] = {'dispatch_all_to_all': split[0], 'local_masked_gemm': split[1], 'combine_all_to_all_and_topk_reduce': split[2],
                                         'note': 'HIP events on the launch stream, mean per step, max over ranks'}
         if world == 1 and headline and not args.no_secondary:
-            line['secondary'] = run_secondary(args.sets)
+            detail = run_secondary(args.sets)
+            # The driver keeps the last 2000 characters of stdout: the full records go out FIRST, on a line of their own that is not
+            # a JSON line (prefix), the headline line carries {workload: [roofline.frac, us per call, 'mfma' | 'hbm']} and comes LAST.
+            print('secondary_detail: ' + json.dumps(detail), flush=True)
+            line['secondary'] = {name: ([_sig(rec['roofline']['frac']), _sig(rec['roofline']['kernel_us']), rec['roofline']['bound'][0]] +
+                                        ([_sig(rec['roofline']['frac_useful'])] if 'frac_useful' in rec['roofline'] else [])
+                                        if 'roofline' in rec else rec.get('error', '?')[:40])
+                                 for name, rec in zip(SECONDARY, detail)}
+            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us per call, bound, frac on data rows]'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
-        print(json.dumps(line), flush=True)
+        if 'secondary' in line:         # keep the whole headline line inside the driver's 2000-character tail
+            line['roofline'] = {k: (_sig(v, 6) if isinstance(v, float) else v) for k, v in roofline.items()
+                                if k not in ('tflops', 'gbs', 'algorithmic_flops', 'algorithmic_bytes')}
+            line['pct_of_mfma_peak'] = _sig(line['pct_of_mfma_peak'], 5)
+            line['calc_diff_vs_reference_expr'] = _sig(diff, 3)
+        print(json.dumps(line, separators=(',', ':')), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
