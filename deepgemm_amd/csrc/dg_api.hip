@@ -259,6 +259,10 @@ const E8Config kE8Configs[] = {
     // ... and A MN-major ([K][M]: the tt layout), both (tn): scale words of A in natural row order
     {"e8_duo_amn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, false, true>, 256, 256, 512, false, false, false},
     {"e8_duo_abmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true, true>, 256, 256, 512, false, false, false},
+    // round 5: the quad kernel with all sixteen fragments of a K block register-resident, two LDS buffers per operand, three barriers per
+    // K block, fragment reads and LDS-DMA pieces in separate phases (fp8_gemm_quad.hpp, HS)
+    {"e8_quad_h_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 1>, 256, 256, 256, true, true, false},
+    {"e8_quad_h2_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 2>, 256, 256, 256, true, true, false},
 #ifdef DG_EXPERIMENTS
     {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},

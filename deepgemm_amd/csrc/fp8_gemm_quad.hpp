@@ -145,13 +145,14 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // last block is an ordinary block of the loop whose pieces carry a per-lane offset bias that pushes the chunks at and beyond K out of the
 // descriptor's range: an out-of-range LDS-DMA lane writes ZEROS into the LDS (the duo kernels' tail mechanism; tools/ubench/lds_dma_oob_probe.hip),
 // so neither the row padding nor the next row's bytes reach the matrix core.  Its scale byte is the block's own, picked as for any block.
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     static_assert(!K_TAIL || (BM == 128 && !STAGED && QV == 0 && WAVES_N == 2), "K tail: the 128-row production form");
+    static_assert(HS == 0 || (BM == 256 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL), "HS: the 256 x 256 four-wave form");
     constexpr int NW = 2 * WAVES_N;
     constexpr int WM = BM / 2, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int PRE = (MS - 2) * NS, POST = 2 * NS;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = HS ? 2 : 3, B_SLOTS = 2;
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr int N_PRE = B_ITERS / 2 + A_ITERS, N_POST = B_ITERS / 2;
@@ -330,6 +331,131 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 issue_e8q_scale_loads<MS, NS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
             };
 
+            if constexpr (HS != 0) {
+                // ---- the register-resident schedule (round 5; the loop structure of the fastest third-party 256 x 256 FP8 kernel on this
+                // part, profiles/r03_ceiling/NOTES.md (d)): ALL sixteen fragments of a K block live in registers (128 VGPRs), so an LDS
+                // buffer is free as soon as its second-half fragments have been read -- two buffers per operand carry a prefetch distance of
+                // ~1.5 K blocks (A 3-slot / B 2-slot ring of the default schedule: 0.6 - 1), and fragment reads and LDS-DMA pieces sit in
+                // SEPARATE phases of the block (a piece issued beside fragment reads costs its wave 100-185 cycles, alone 60).
+                //   phase 1  (a0..3 x b0..3)  reads b4..7 of B[u]                     | lgkmcnt(0), barrier 1: B[u] is free
+                //   phase 2  (a0..3 x b4..7)  pieces B(kb+2) -> B[u]; reads a4..7     | lgkmcnt(0), barrier 2: A[u] is free
+                //   phase 3  (a4..7 x b0..3)  pieces A(kb+2) -> A[u]                  | vmcnt(16): my pieces of block kb+1 are in; barrier 3
+                //   phase 4  (a4..7 x b4..7)  reads b0..3, a0..3 of block kb+1 from the other buffers
+                // HS == 1: one piece per MFMA gap (the first eight of a phase); HS == 2: one per two gaps. ----
+                static_assert(A_ITERS == 8 && B_ITERS == 8 && MS == 8 && NS == 8, "two M0 groups of four pieces per operand and wave");
+                #pragma unroll
+                for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
+                issue_scales(cur, 0);
+                #pragma unroll
+                for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
+                #pragma unroll
+                for (int q = 0; q < B_ITERS; ++q) issue_b_piece(B_BYTES, 1, q);
+                asm volatile("" ::: "memory");
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        acc[ms][ns] = v4f{0.f, 0.f, 0.f, 0.f};
+                        asm volatile("" : "+a"(acc[ms][ns]));
+                    }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(waitcnt_imm(A_ITERS + B_ITERS, 15));
+                tie_e8q_landing<MS, NS>(cur);
+                raw_barrier();
+                int a_cur = 0, b_cur = 0;
+                v8i bf[NS], af[MS];
+                #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf[i] = load_fragment(lds + B_BASE + (wn * WN + i * 16) * 128, frag_off);
+                    af[i] = load_fragment(lds + (wm * WM + i * 16) * 128, frag_off);
+                }
+                if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
+                auto block = [&](auto jc, auto load_next, const E8LandingQ& w, int kb) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr bool LOAD_NEXT = decltype(load_next)::value;
+                    constexpr int GAP = HS;                          // MFMA gaps per piece
+                    const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                    const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
+                    const uint8_t* a_next_tile = lds + (a_cur ^ A_BYTES) + (wm * WM) * 128;
+                    const uint8_t* b_next_tile = lds + B_BASE + (b_cur ^ B_BYTES) + (wn * WN) * 128;
+                    if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);    // older than every piece of this block: in by its vmcnt(16)
+                    // ---- phase 1 ----
+                    #pragma unroll
+                    for (int step = 0; step < 16; ++step) {
+                        const int ms = step >> 2, ns = step & 3;
+                        mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                        if (step < 4) bf[4 + step] = load_fragment(b_tile + (4 + step) * 2048, frag_off);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+                    raw_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- phase 2 ----
+                    #pragma unroll
+                    for (int step = 0; step < 16; ++step) {
+                        const int ms = step >> 2, ns = 4 + (step & 3);
+                        mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                        if constexpr (GAP == 1) {
+                            if (step < 8) issue_b_piece(b_cur, kb + 2, step);
+                            else if (step < 12) af[step - 4] = load_fragment(a_tile + (step - 4) * 2048, frag_off);
+                        } else {
+                            if (step % 2 == 0) issue_b_piece(b_cur, kb + 2, step / 2);
+                            else if (step >= 7) af[4 + (step - 7) / 2] = load_fragment(a_tile + (4 + (step - 7) / 2) * 2048, frag_off);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+                    raw_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- phase 3 ----
+                    #pragma unroll
+                    for (int step = 0; step < 16; ++step) {
+                        const int ms = 4 + (step >> 2), ns = step & 3;
+                        mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                        if constexpr (GAP == 1) {
+                            if (step < 8) issue_a_piece(a_cur, kb + 2, step);
+                        } else {
+                            if (step % 2 == 0) issue_a_piece(a_cur, kb + 2, step / 2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(waitcnt_imm(A_ITERS + B_ITERS, 15));     // everything but this block's sixteen pieces
+                    if (LOAD_NEXT) tie_e8q_landing<MS, NS>(nxt);
+                    raw_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- phase 4 ----
+                    #pragma unroll
+                    for (int step = 0; step < 16; ++step) {
+                        const int ms = 4 + (step >> 2), ns = 4 + (step & 3);
+                        mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                        if (step < 4) bf[step] = load_fragment(b_next_tile + step * 2048, frag_off);
+                        else if (step < 8) af[step - 4] = load_fragment(a_next_tile + (step - 4) * 2048, frag_off);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    a_cur ^= A_BYTES;
+                    b_cur ^= B_BYTES;
+                };
+                using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+                using Yes = std::true_type; using No = std::false_type;
+                for (int kb = 0; kb + 4 <= num_kb; kb += 4) {
+                    block(I0{}, No{}, cur, kb);
+                    block(I1{}, Yes{}, cur, kb + 1);
+                    block(I2{}, No{}, cur, kb + 2);
+                    block(I3{}, No{}, cur, kb + 3);
+                    cur = nxt;
+                    asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> MFMA
+                }
+                if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else {
             // ---- prologue: A(0) B(0) words(0) | A(1) B(1)[first half]; wait for the first group only ----
             #pragma unroll
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
@@ -482,6 +608,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA -> accumulator reads; the tail's re-read pieces
             __syncthreads();
+            }   // (default schedule)
         }
         if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
             // BF16 full-line stores, one M-subtile at a time: 32 accumulator registers leave the AGPRs, are packed, exchanged and
@@ -528,10 +655,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS>(p);
 }
 
 }  // namespace dg

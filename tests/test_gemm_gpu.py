@@ -931,7 +931,8 @@ def test_packed_ue8m0_scales_hw_path(m, n, k):
     assert_close_fp32(d32, want32, 'packed ue8m0 fp32 accumulate')
 
 
-E8_DENSE_CONFIGS = ['auto', 'e8_quad_256x256', 'e8_quad_128x256', 'e8_duo_256x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32']
+E8_QUAD_256 = ['e8_quad_256x256', 'e8_quad_h_256x256', 'e8_quad_h2_256x256']     # whole K quads only; _h*: the register-resident schedule (round 5)
+E8_DENSE_CONFIGS = ['auto', *E8_QUAD_256, 'e8_quad_128x256', 'e8_duo_256x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32']
 
 
 @pytest.mark.parametrize('m,n,k', [(512, 768, 1024), (300, 520, 896), (4096, 4096, 1536), (129, 4096, 384)])
@@ -946,7 +947,7 @@ def test_packed_ue8m0_every_kernel_and_per_row_sfb(m, n, k):
     oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want, gran_n=1)
     first = None
     for cfg in E8_DENSE_CONFIGS:
-        if cfg == 'e8_quad_256x256' and k % 512 != 0:
+        if cfg in E8_QUAD_256 and k % 512 != 0:
             continue                                    # whole packed words only (the other kernels take the K tail)
         dg.set_forced_config(cfg)
         d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
@@ -1015,7 +1016,7 @@ def test_packed_ue8m0_m_grouped_contiguous(use_psum):
         oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), use_psum)
         a = gen.packed_ue8m0_operand(*case.a)
         b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
-        cfgs = ['auto', 'e8_quad_128x256'] + (['e8_quad_256x256'] if not use_psum and k % 512 == 0 else [])
+        cfgs = ['auto', 'e8_quad_128x256'] + (E8_QUAD_256 if not use_psum and k % 512 == 0 else [])
         for cfg in cfgs:
             for nn in (False, True):
                 dg.set_forced_config(cfg)
@@ -1092,7 +1093,7 @@ def test_packed_ue8m0_m_grouped_masked(masked_ms, max_m, n, k):
     oracle.m_grouped_fp8_gemm_nt_masked(*cpu_pair(case.a), *cpu_pair(case.b), want, case.masked_m.cpu())
     a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
     expected_m = max(1, int(sum(masked_ms) / len(masked_ms)))
-    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32'] + (['e8_quad_256x256'] if k % 512 == 0 else []):
+    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32'] + (E8_QUAD_256 if k % 512 == 0 else []):
         dg.set_forced_config(cfg)
         case.d.fill_(float('nan'))
         dg.m_grouped_fp8_gemm_nt_masked(a, b, case.d, case.masked_m, expected_m)

@@ -210,13 +210,13 @@ def test_packed_ue8m0_at_c2_size():
     case = gen.generate_normal(m, n, k, use_ue8m0=True)
     a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
     outs = {}
-    for cfg in ('auto', 'e8_quad_256x256', 'e8_quad_128x256', 'e8_duo_256x256'):
+    for cfg in ('auto', 'e8_quad_256x256', 'e8_quad_h_256x256', 'e8_quad_h2_256x256', 'e8_quad_128x256', 'e8_duo_256x256'):
         dg.set_forced_config(cfg)
         d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
         dg.fp8_gemm_nt(a, b, d)
         outs[cfg] = d
         if cfg == 'auto':
-            assert dg.last_config() == 'e8_quad_256x256'
+            assert dg.last_config() in ('e8_quad_256x256', 'e8_quad_h_256x256', 'e8_quad_h2_256x256')
     assert calc_diff(outs['auto'], case.ref_d) < gen.FP8_MAX_DIFF
     _check_sampled(outs['auto'], case, 128, 'e8 c2', rows_n=16)
     for cfg, d in outs.items():

@@ -18,6 +18,8 @@ for i in range(4):
     sets.append((a_q, pa, b_q, pb, torch.empty((m, n), device='cuda', dtype=torch.bfloat16)))
 dbg = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device='cuda')
 lib.dg_set_debug_buffer(dbg.data_ptr())
+if len(sys.argv) > 1:
+    dg.set_forced_config(sys.argv[1])
 def call(s): dg.fp8_gemm_nt((s[0], s[1]), (s[2], s[3]), s[4])
 for i in range(5): call(sets[i % 4])
 start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
