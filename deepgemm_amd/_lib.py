@@ -43,6 +43,7 @@ SIGNATURES = {
     'dg_set_num_cus': (_i32, [_i32]),
     'dg_get_num_cus': (_i32, []),
     'dg_set_forced_config': (_i32, [_cp]),
+    'dg_reload_env': (None, []),
     'dg_get_forced_config': (_cp, []),
     'dg_set_debug_buffer': (_i32, [_vp]),
     'dg_list_configs': (_cp, []),

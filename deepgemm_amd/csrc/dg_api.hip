@@ -282,6 +282,21 @@ const E8Config kE8Configs[] = {
 #endif
 };
 
+// Tuning / diagnostic environment variables are read ONCE (first use): the launch paths are hot (a cached dense call is ~8 us of host time).
+struct EnvKnobs {
+    bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks;
+    int group_m;
+    EnvKnobs()
+        : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
+          tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
+          sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr),
+          group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0) {}
+};
+EnvKnobs& env_knobs() {
+    static EnvKnobs knobs;
+    return knobs;
+}
+
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 // whole_k_blocks = false: a partial last K block of whole 16-byte chunks is allowed (the duo kernels' tail stage)
@@ -414,7 +429,8 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
                 return &kConfigs[i];
         return nullptr;
     }
-    if (sfa_row_major(p)) {
+    if (sfa_row_major(p) && env_knobs().sfa_rowmajor_in_place) {
+        // (DG_SFA_ROWMAJOR_IN_PLACE=1 + a DG_EXPERIMENTS build only: a measured negative, 141 against 92 us -- never part of the automatic selection)
         // a row-major SFA: taken in place where the MN-major twin of the problem would run duo_p_256x256 (dg_dense_rowmajor_sfa_native tells
         // the host layer, which otherwise transposes first)
         if (p.gemm_type == dg::kNormal && p.sfb_gran_n == 128 && p.head_lr == 0 && fast_eligible(p)) {
@@ -660,7 +676,7 @@ int launch_per_col_split(const dg::GemmParams& dense, int pieces, void* stream) 
                        parts, pieces, static_cast<int64_t>(dense.m) * dense.n, dense.d, dense.m, dense.n, dense.d_sm, dense.d_dtype,
                        dense.accumulate, vec_ok);
     DG_HIP_CHECK(hipGetLastError());
-    if (getenv("DG_PRINT_CONFIGS") != nullptr)
+    if (env_knobs().print_configs)
         fprintf(stderr, "[deepgemm_amd] type=%d m=%d n=%d k=%d -> %s pieces=%d grid=%ld\n", dense.gemm_type, dense.m, dense.n, dense.k,
                 g_last_config.c_str(), pieces, grid);
     return 0;
@@ -742,8 +758,8 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     }
     // L2 grouping: with 8 XCDs each chunk of tiles should be a compact rectangle (see swizzled_tile).
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
-    if (const char* gm = getenv("DG_GROUP_M"))       // (tuning runs: M tiles per L2 group of the tile walk)
-        p.group_m = std::max(1, std::min(atoi(gm), p.num_m_tiles));
+    if (env_knobs().group_m > 0)                     // (tuning runs, DG_GROUP_M: M tiles per L2 group of the tile walk)
+        p.group_m = std::max(1, std::min(env_knobs().group_m, p.num_m_tiles));
     const size_t elem = p.d_dtype == DG_BF16 ? 2 : 4;
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
     p.d_nt = output_streams_past_l2(p);
@@ -796,7 +812,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         hipLaunchKernelGGL(reduce, dim3(static_cast<unsigned>(p.sk_tiles * 4)), dim3(512), 0, static_cast<hipStream_t>(stream), p);
         DG_HIP_CHECK(hipGetLastError());
     }
-    if (getenv("DG_PRINT_CONFIGS") != nullptr)
+    if (env_knobs().print_configs)
         fprintf(stderr, "[deepgemm_amd] type=%d m=%d n=%d k=%d groups=%d -> %s grid=%ld\n", p.gemm_type, p.m, p.n, p.k,
                 p.num_groups, cfg->name, grid);
     return 0;
@@ -824,7 +840,7 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
     int32_t* rem = header + 512;             // at most nb entries (nb <= 500)
     // up to 64 blocks (M <= 8192: C4 has 36) every workgroup derives the tile list itself (GemmParams::table_mode): no table kernel and no
     // kernel boundary in front of the GEMM (the builder cost C4 6.2 us of 141.5)
-    const bool in_kernel = nb <= 64 && getenv("DG_TABLE_KERNEL") == nullptr;
+    const bool in_kernel = nb <= 64 && !env_knobs().table_kernel;
     if (!in_kernel) {
         hipLaunchKernelGGL(dg::dg_build_contiguous_tile_table_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
                            base.layout, base.m, big, rem);
@@ -841,7 +857,7 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
     };
     // ONE launch for both walks (dg_fp8_gemm_duo_tab_fused_kernel) when the tile list is derived in the kernel; DG_TAB_UNFUSED=1 keeps
     // the two launches of round 3 (A/B)
-    const bool fused = in_kernel && getenv("DG_TAB_UNFUSED") == nullptr && getenv("DG_SK_EXCHANGE") == nullptr;
+    const bool fused = in_kernel && !env_knobs().tab_unfused && !env_knobs().sk_exchange;
     dg::GemmParams q = base;
     {   // the 256-row tiles
         q.tile_table = in_kernel ? nullptr : big;
@@ -871,7 +887,7 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         // (a writeback and an invalidate of the whole L2 per workgroup) 151 us against 142 with the reduction kernel; with written-through
         // stores and cache-bypassing loads 141-143 against 143.5: a 1 % gain does not pay for a spin-wait in the product path.
         static std::atomic<unsigned> exchange_epoch{0};
-        const bool exchange = in_kernel && pieces >= 2 && static_cast<long>(nb) * n_tiles <= 1024 && getenv("DG_SK_EXCHANGE") != nullptr;
+        const bool exchange = in_kernel && pieces >= 2 && static_cast<long>(nb) * n_tiles <= 1024 && env_knobs().sk_exchange;
         if (exchange) {
             pieces = 2;
             r.sk_exchange = 0x7fd00000u | (exchange_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu);
@@ -896,7 +912,7 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
                                static_cast<hipStream_t>(stream), r);
             DG_HIP_CHECK(hipGetLastError());
         }
-        if (getenv("DG_PRINT_CONFIGS") != nullptr)
+        if (env_knobs().print_configs)
             fprintf(stderr, "[deepgemm_amd] contiguous m=%d n=%d k=%d groups=%d -> duo_tab_256x256 + duo_sk_128x256 (pieces <= %d)\n", base.m, base.n,
                     base.k, base.num_groups, r.sk_factor);
     }
@@ -1022,7 +1038,7 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
         return 0;
     hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
     DG_HIP_CHECK(hipGetLastError());
-    if (getenv("DG_PRINT_CONFIGS") != nullptr)
+    if (env_knobs().print_configs)
         fprintf(stderr, "[deepgemm_amd] ue8m0 type=%d m=%d n=%d k=%d groups=%d -> %s grid=%ld\n", p.gemm_type, p.m, p.n, p.k,
                 p.num_groups, cfg->name, grid);
     return 0;
@@ -1359,7 +1375,7 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(const void* a, const float* 
     o.errors = static_cast<uint32_t*>(workspace);
     o.amax_ws = static_cast<uint32_t*>(workspace) + 64;
     o.timeout_ticks = g_swiglu_timeout_us.load(std::memory_order_relaxed) * 100;       // s_memrealtime: 100 MHz
-    o.fault = g_swiglu_fault.load(std::memory_order_relaxed);
+    o.fault = env_knobs().test_hooks ? g_swiglu_fault.load(std::memory_order_relaxed) : 0;     // (honoured only under DG_TEST_HOOKS)
     o.q = static_cast<uint8_t*>(out_fp8); o.sf = out_sf;
     o.q_sg = out_stride_g; o.q_sm = out_stride_m; o.sf_sg = out_sf_stride_g; o.sf_sk = out_sf_stride_k;
     o.clamp = activation_clamp; o.use_ue8m0 = use_ue8m0 ? 1 : 0;
@@ -1599,6 +1615,14 @@ int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int s
     DG_CHECK(sf != nullptr && out != nullptr);
     DG_CHECK(batches <= 65535);
     const int aligned_mn = (mn + 3) / 4 * 4;
+    if (sf_k % 4 == 0 && aligned16(sf) && sf_k / 4 <= 65535) {
+        // (rows of sf_k floats behind a 16-byte aligned base: every row is 16-byte aligned)
+        const dim3 grid((mn + 255) / 256, sf_k / 4, batches);
+        hipLaunchKernelGGL(dg::dg_transpose_sf_fp32_vec4_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                           sf, out, mn, sf_k, aligned_mn);
+        DG_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((mn + 63) / 64, (sf_k + 63) / 64, batches);
     hipLaunchKernelGGL(dg::dg_transpose_sf_fp32_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        sf, out, mn, sf_k, aligned_mn);
@@ -1735,6 +1759,8 @@ int dg_set_num_cus(int n) {
 
 int dg_get_num_cus(void) { return num_cus(); }
 
+void dg_reload_env(void) { env_knobs() = EnvKnobs(); }
+
 int dg_set_forced_config(const char* name) {
     if (name == nullptr)
         return fail(__FILE__, __LINE__, "name != nullptr");
@@ -1812,7 +1838,7 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
 int dg_dense_rowmajor_sfa_native(int m, int n, int k) {
     // would a dense call with K-major 16-byte aligned operands, per-128 SFB and a ROW-major SFA [m][ceil(k / 128)] read the SFA in place
     // (duo_p_rm_256x256)?  The host layer asks before it launches the layout step's transpose; the rule lives in select_config only.
-    if (m <= 1 || n <= 0 || k <= 0 || forced_config() != "auto")
+    if (m <= 1 || n <= 0 || k <= 0 || forced_config() != "auto" || !env_knobs().sfa_rowmajor_in_place)
         return 0;
     dg::GemmParams p{};
     p.a = p.b = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(1) << 20);

@@ -240,9 +240,11 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                                 g = fminf(g, o.clamp);
                                 u = fminf(fmaxf(u, -o.clamp), o.clamp);
                             }
-                            float y = round_bf16((g / (1.0f + expf(-g))) * u);           // torch: silu(g.float()) * u.float() -> bf16
-                            if (o.row_weight != nullptr)
-                                y = round_bf16(y * rw[ms]);                              // (y.float() * w).to(bf16)
+                            float y = (g / (1.0f + expf(-g))) * u;                       // silu(g.float()) * u.float()
+                            // without a routing weight the operator stands for "... -> BF16 intermediate -> per_token_cast_to_fp8": round to
+                            // BF16 as the unfused pipeline stores it; with one it is the reference kernel's epilogue, which keeps
+                            // silu(gate) * up * weight in FP32 up to the amax and the FP8 cast (sm100_fp8_fp4_mega_moe.cuh:1001-1020)
+                            y = o.row_weight != nullptr ? y * rw[ms] : round_bf16(y);
                             acc[ms][ns][e] = y;
                             amax[ms] = fmaxf(amax[ms], fabsf(y));
                         }
@@ -281,6 +283,9 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                     row_max[128 + lane] = fmaxf(mine, __uint_as_float(v & 0x7fffffffu));
                 } else {
                     row_max[128 + lane] = __uint_as_float(0x7fc00000u);         // NaN: poisons the row's scale below
+                    // take this tile's own slot back: nobody may find a valid bit from an aborted exchange in the workspace of the next launch
+                    // (a partner that was merely slow then times out as well -- both rows are poisoned and counted)
+                    __hip_atomic_store(o.amax_ws + static_cast<int64_t>(tile_id) * 64 + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0)
                         atomicAdd(o.errors, 1u);
                 }

@@ -108,6 +108,10 @@ __device__ __forceinline__ void tie_e8q_landing(E8LandingQ& l) {
 template <int J>
 __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operand, const v8i& cols_operand, int rows_scale,
                                                 int cols_scale) {
+#ifdef DG_QUAD_NOSCALE     // timing probe (results are garbage): the plain MFMA in the same stream -- what does the scale operand pair cost?
+    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc) : "v"(rows_operand), "v"(cols_operand), "v"(rows_scale), "v"(cols_scale) : "memory");
+    return;
+#endif
     if constexpr (J == 0)
         asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
                      : "+a"(acc) : "v"(rows_operand), "v"(cols_operand), "v"(rows_scale), "v"(cols_scale) : "memory");

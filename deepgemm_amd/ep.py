@@ -138,24 +138,27 @@ def combine(d: torch.Tensor, plan: DispatchPlan, tokens: int, top_k: int, group=
 class FixedPlan:
     """Bookkeeping of one fixed-capacity dispatch (device tensors only: nothing here ever reached the host)."""
     send_order: torch.Tensor          # [P] permutation that sorts this rank's (row, expert) pairs by destination expert
-    pair_rank: torch.Tensor           # [P] destination rank of every sorted pair
-    pair_expert: torch.Tensor         # [P] local expert index on that rank
-    pair_pos: torch.Tensor            # [P] slot inside the (this rank -> expert) block, clamped to capacity - 1
+    pair_dest: torch.Tensor           # [P] flat slot (rank, local expert, position) of every sorted pair in the exchanged blocks;
+                                      #     world * per_rank * capacity = the dump slot (no expert, or over capacity: the pair's result is zeros)
     recv_expert: torch.Tensor         # [world * per_rank * capacity] local expert of every received slot
     recv_slot: torch.Tensor           # same shape: row inside that expert's masked block (invalid slots: clamped, never read back)
     masked_m: torch.Tensor            # [G_local] int32 rows per local expert
     overflow: torch.Tensor            # 0-dim bool: a block or an expert was over capacity (rows were dropped)
+    row_extra: Optional[torch.Tensor] = None   # [G_local, max_m] FP32: the per-pair value that travelled with the rows (routing weight)
 
 
 def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, max_m: int, capacity: int,
-                   group=None) -> Tuple[TensorPair, FixedPlan]:
+                   group=None, row_extra: Optional[torch.Tensor] = None) -> Tuple[TensorPair, FixedPlan]:
     """The dispatch without any host synchronisation (a decode step that is captured into a hipGraph cannot read split sizes back):
     every rank sends every peer a block of fixed shape ``[experts per rank, capacity, K + K / 32 bytes]`` plus the row counts of its
     blocks -- two equal-split all-to-alls -- and the receiver compacts the valid rows into the masked layout with index arithmetic
     on the device.  ``capacity`` = the most rows one rank may send to one expert (``tokens`` is always enough: a token names an
     expert at most once); the price is the padding on the wire, ``world * experts_per_rank * capacity`` rows per rank instead of
     ``tokens * top_k``.  Rows over capacity (or over ``max_m`` on the receiver) are dropped and ``plan.overflow`` is set -- check it
-    where a synchronisation is affordable.  Returns the local masked operand and the plan for :func:`combine_fixed`."""
+    where a synchronisation is affordable.  Entries ``expert_ids[t, j] < 0`` name no expert (the reference's ``-1``,
+    tests/test_mega_moe.py:103-121): nothing travels for them and :func:`combine_fixed` returns zeros in their place.
+    ``row_extra [T, top_k]`` FP32 rides with the rows (4 more bytes per row: the routing weight the fused expert MLP applies before its
+    re-quantisation) and arrives as ``plan.row_extra [G_local, max_m]``.  Returns the local masked operand and the plan."""
     x_fp8, x_sf = x
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     first, last = expert_range(num_experts, rank, world)
@@ -163,25 +166,33 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
     tokens, top_k = expert_ids.shape
     device = x_fp8.device
     k, sf_bytes = x_fp8.size(1), 4 * x_sf.size(1)
+    extra_bytes = 4 if row_extra is not None else 0
+    row_bytes = k + sf_bytes + extra_bytes
 
     flat_expert = expert_ids.reshape(-1).to(torch.int64)
+    key = torch.where(flat_expert < 0, torch.full_like(flat_expert, num_experts), flat_expert)      # "no expert" sorts behind every expert
     flat_row = torch.arange(tokens, device=device).repeat_interleave(top_k)
-    order = torch.argsort(flat_expert, stable=True)
-    sorted_expert = flat_expert[order]
+    order = torch.argsort(key, stable=True)
+    sorted_key = key[order]
     # (not torch.bincount: it reads the maximum back to size its output -- a device-to-host synchronisation, illegal under stream capture)
-    per_expert = torch.zeros(num_experts, dtype=torch.int64, device=device).scatter_add_(0, flat_expert, torch.ones_like(flat_expert))
+    per_expert = torch.zeros(num_experts + 1, dtype=torch.int64, device=device).scatter_add_(0, key, torch.ones_like(key))
     run_begin = torch.cumsum(per_expert, dim=0) - per_expert
-    pos = torch.arange(sorted_expert.numel(), device=device) - run_begin[sorted_expert]
+    pos = torch.arange(sorted_key.numel(), device=device) - run_begin[sorted_key]
+    per_expert = per_expert[:num_experts]
     overflow = (per_expert > capacity).any()
-    pair_rank, pair_expert = sorted_expert // per_rank, sorted_expert % per_rank
-    pair_pos = pos.clamp(max=capacity - 1)                 # (over capacity: collides with the last slot; overflow says so)
+    dump = world * per_rank * capacity
+    # flat slot of a pair: ((rank * per_rank + local expert) * capacity + position) = sorted_key * capacity + pos
+    pair_dest = torch.where((sorted_key < num_experts) & (pos < capacity), sorted_key * capacity + pos, torch.full_like(pos, dump))
 
     rows = flat_row[order]
-    send = torch.zeros((world, per_rank, capacity, k + sf_bytes), dtype=torch.uint8, device=device)
-    packed = torch.empty((rows.numel(), k + sf_bytes), dtype=torch.uint8, device=device)
+    packed = torch.empty((rows.numel(), row_bytes), dtype=torch.uint8, device=device)
     packed[:, :k] = x_fp8.view(torch.uint8)[rows]
-    packed[:, k:] = x_sf.contiguous().view(torch.uint8).view(tokens, sf_bytes)[rows]
-    send[pair_rank, pair_expert, pair_pos] = packed
+    packed[:, k:k + sf_bytes] = x_sf.contiguous().view(torch.uint8).view(tokens, sf_bytes)[rows]
+    if row_extra is not None:
+        packed[:, k + sf_bytes:] = row_extra.to(torch.float).reshape(-1, 1).contiguous().view(torch.uint8)[order]
+    send_flat = torch.zeros((dump + 1, row_bytes), dtype=torch.uint8, device=device)
+    send_flat[pair_dest] = packed
+    send = send_flat[:dump].view(world, per_rank, capacity, row_bytes)
     send_counts = per_expert.clamp(max=capacity).view(world, per_rank).to(torch.int32)
 
     recv = torch.empty_like(send)
@@ -203,10 +214,15 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
 
     a_store = torch.zeros((per_rank * max_m + 1, k), dtype=torch.uint8, device=device)
     sf_store = torch.zeros((per_rank * max_m + 1, x_sf.size(1)), dtype=torch.float, device=device)
-    flat = recv.view(-1, k + sf_bytes)
+    flat = recv.view(-1, row_bytes)
     a_store[flat_row] = flat[:, :k]
-    sf_store[flat_row] = flat[:, k:].contiguous().view(torch.float)
-    plan = FixedPlan(order, pair_rank, pair_expert, pair_pos, recv_expert, recv_slot, masked_m, overflow)
+    sf_store[flat_row] = flat[:, k:k + sf_bytes].contiguous().view(torch.float)
+    extra = None
+    if row_extra is not None:
+        extra_store = torch.zeros((per_rank * max_m + 1,), dtype=torch.float, device=device)
+        extra_store[flat_row] = flat[:, k + sf_bytes:].contiguous().view(torch.float).reshape(-1)
+        extra = extra_store[:per_rank * max_m].view(per_rank, max_m)
+    plan = FixedPlan(order, pair_dest, recv_expert, recv_slot, masked_m, overflow, extra)
     a = a_store[:per_rank * max_m].view(torch.float8_e4m3fn).view(per_rank, max_m, k)
     return (a, sf_store[:per_rank * max_m].view(per_rank, max_m, x_sf.size(1))), plan
 
@@ -214,14 +230,15 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
 def combine_fixed(d: torch.Tensor, plan: FixedPlan, tokens: int, top_k: int, world: int, capacity: int, group=None,
                   topk_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The return path of :func:`dispatch_fixed`: result rows travel back in the same fixed-shape blocks (one equal-split all-to-all),
-    every rank picks its pairs' rows out of the blocks it gets back.  Same outputs as :func:`combine`."""
+    every rank picks its pairs' rows out of the blocks it gets back (zeros for pairs without an expert or over capacity).  Same outputs
+    as :func:`combine`."""
     per_rank, max_m, n = d.size(0), d.size(1), d.size(2)
     # (invalid entries read some valid row: those slots of the blocks are never picked by their source rank)
     blocks = d[plan.recv_expert, plan.recv_slot].view(world, per_rank, capacity, n).contiguous()
-    back = torch.empty_like(blocks)
-    dist.all_to_all_single(back, blocks, group=group)
+    back = torch.zeros((world * per_rank * capacity + 1, n), dtype=d.dtype, device=d.device)           # last row: the dump slot's zeros
+    dist.all_to_all_single(back[:-1].view(world, per_rank, capacity, n), blocks, group=group)
     out = torch.empty((tokens * top_k, n), dtype=d.dtype, device=d.device)
-    out[plan.send_order] = back[plan.pair_rank, plan.pair_expert, plan.pair_pos]
+    out[plan.send_order] = back[plan.pair_dest]
     out = out.view(tokens, top_k, n)
     if topk_weights is None:
         return out

@@ -4,10 +4,11 @@ without the BF16 intermediate going through memory.
 Reference: ``deep_gemm/mega/__init__.py`` (``transform_weights_for_mega_moe`` :131-151, ``fp8_fp4_mega_moe`` :155-173), kernel
 ``deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh`` (the L1 -> L2 hand-off in GEMM1's epilogue), host driver
 ``csrc/apis/mega.hpp:30-159``.  What is here: the fused L1 operator (``m_grouped_fp8_gemm_nt_masked_swiglu``), the weight transform
-this library's kernel wants, and ``fp8_mega_moe_local`` = fused L1 + masked L2 on the tokens already resident on this GPU.  What is
-NOT here: the reference kernel's in-kernel dispatch / combine over NVLink symmetric memory -- on MI355X the exchange is two RCCL
-all-to-alls around these operators (``deepgemm_amd/ep.py``); fusing it needs xGMI peer access inside the kernel and a multi-GPU node to
-measure it on.
+this library's kernel wants, ``fp8_mega_moe_local`` = fused L1 + masked L2 on the tokens already resident on this GPU, and the
+reference-shaped ``fp8_mega_moe(y, l1, l2, sym_buffer)`` for any group size: with more than one rank the dispatch / combine legs are
+fixed-shape RCCL all-to-alls (``deepgemm_amd/ep.py``: no host synchronisation, capturable), the routing weight travels with each row and
+is applied before the re-quantisation exactly as at world size 1.  What is NOT here: the reference kernel's IN-KERNEL dispatch / combine
+over NVLink symmetric memory -- that needs xGMI peer access inside the kernel and a multi-GPU node to measure it on.
 """
 from typing import Optional, Tuple
 
@@ -117,7 +118,10 @@ def m_grouped_fp8_gemm_nt_masked_swiglu(a: TensorPair, b: TensorPair, out: Tenso
     """``out = per_token_cast_to_fp8( swiglu( a @ b^T ) )`` per expert, rows ``< masked_m[g]`` only: ``a = (A [G, M, K], SFA)``,
     ``b`` = the transformed W1 pair ``([G, 2 I, K], [G, 2 I / 128, K / 128])`` of :func:`transform_weights_for_mega_moe`,
     ``out`` = :func:`empty_intermediate` ``(G, M, I)``.  Bit-identical to ``m_grouped_fp8_gemm_nt_masked`` -> BF16 -> SwiGLU (``silu(g) *
-    u`` in FP32 on the BF16 values, optional clamp ``g <= c``, ``|u| <= c``, result rounded to BF16) -> ``per_token_cast_to_fp8``."""
+    u`` in FP32 on the BF16 values, optional clamp ``g <= c'``, ``|u| <= c'`` with ``c'`` = ``activation_clamp`` ROUNDED TO BF16 -- the
+    reference clamps with BF16 operands, sm100_fp8_fp4_mega_moe.cuh:1003-1008, so a bound that is not BF16-representable acts as its BF16
+    rounding, e.g. 10.1 as 10.125 -- result rounded to BF16) -> ``per_token_cast_to_fp8``.  With ``row_weight`` the product
+    ``silu(g) * u * w`` stays in FP32 up to the cast (the reference kernel's arithmetic; no BF16 intermediate exists in that pipeline)."""
     (a_data, a_sf), (b_data, b_sf), (q, q_sf) = a, b, out
     host_assert(is_k_major(a_data) and is_k_major(b_data), 'major_a == cute::UMMA::Major::K and major_b == cute::UMMA::Major::K')
     host_assert(a_data.dim() == 3 and b_data.dim() == 3 and q.dim() == 3, 'a.dim() == 3 and b.dim() == 3 and out.dim() == 3')
@@ -137,8 +141,8 @@ def m_grouped_fp8_gemm_nt_masked_swiglu(a: TensorPair, b: TensorPair, out: Tenso
     require_device(a_data, b_data, sfa, b_sf, q, q_sf, masked_m)
     ws = workspace if workspace is not None else _exchange_workspace(num_groups, m, n, a_data.device)
     if row_weight is not None:
-        # ``row_weight [G, >= align(m, 64)]`` FP32: the routing weight of every row slot, applied as ``bf16(bf16(silu(g) * u) * w)`` before the
-        # re-quantisation (the reference kernel's placement, sm100_fp8_fp4_mega_moe.cuh:1019)
+        # ``row_weight [G, >= align(m, 64)]`` FP32: the routing weight of every row slot: ``silu(g) * u * w`` in FP32 (g, u the BF16-rounded
+        # GEMM outputs) straight into the amax and the FP8 cast -- the reference kernel's epilogue, sm100_fp8_fp4_mega_moe.cuh:1001-1020
         host_assert(row_weight.dtype == torch.float and row_weight.dim() == 2 and row_weight.size(0) == num_groups and row_weight.stride(1) == 1 and
                     row_weight.size(1) >= -(-m // 64) * 64, 'row_weight: float [G, >= align(m, 64)]')
         require_device(row_weight)
@@ -178,40 +182,61 @@ def get_token_alignment_for_mega_moe() -> int:
 
 
 class SymmBuffer:
-    """The reference's ``SymmBuffer`` (deep_gemm/mega/__init__.py:18-58) for ONE rank: the caller-visible input views ``x [T, H]`` e4m3,
-    ``x_sf [T, H / 128]`` FP32 (per-token 1 x 128 scales), ``topk_idx [T, top_k]`` int64 (-1 = no expert), ``topk_weights [T, top_k]``
-    FP32, and the operator's private staging: the masked-layout activations of both layers, slot map, per-expert counts (= ``masked_m``),
-    routing weights per slot, the BF16 L2 output rows and the fused kernel's exchange workspace."""
+    """The reference's ``SymmBuffer`` (deep_gemm/mega/__init__.py:18-58): the caller-visible input views ``x [T, H]`` e4m3,
+    ``x_sf [T, H / 128]`` FP32 (per-token 1 x 128 scales), ``topk_idx [T, top_k]`` int64 GLOBAL expert indices (-1 = no expert),
+    ``topk_weights [T, top_k]`` FP32, and the operator's private staging.
+
+    ``group`` = ``None`` or a one-rank group: every expert is local; staging = the masked-layout activations of both layers
+    (``[E, T, H]`` e4m3 + ``[E, T, I]`` e4m3 + ``[E, T, H]`` BF16), slot map, per-expert counts, routing weight per slot.
+    A group of ``R > 1`` ranks: this rank owns experts ``[rank * E / R, (rank + 1) * E / R)`` (``l1_weights`` / ``l2_weights`` hold only
+    those); rows are exchanged in fixed-shape blocks of ``exchange_capacity`` rows per (rank, expert) (default ``T``: a token names an
+    expert at most once) and an expert takes at most ``expert_capacity`` rows (default ``R * T``, the worst case).  Footprint per rank
+    with the defaults: ``(E / R) * R * T * (2 H + I + 2 H)`` bytes of staging + ``2 * E * T * (H + H / 32 + 4)`` bytes on the wire per
+    call -- at E = 256, R = 8, T = 8192, H = 7168 that is ~70 GB: size ``expert_capacity`` / ``exchange_capacity`` for the routing you
+    actually have (the reference's ring buffer is O(T * top_k * H); rows over a capacity are dropped and counted in ``errors[0]``)."""
 
     def __init__(self, group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
-                 num_ring_tokens: int = 0, mma_type: str = 'fp8xfp8', activation: str = 'swiglu', device='cuda'):
+                 num_ring_tokens: int = 0, mma_type: str = 'fp8xfp8', activation: str = 'swiglu', device='cuda',
+                 expert_capacity: Optional[int] = None, exchange_capacity: Optional[int] = None):
         host_assert(activation == 'swiglu', "activation == 'swiglu'")
-        world = 1 if group is None else group.size()
-        if world != 1:
-            raise RuntimeError('SymmBuffer / fp8_mega_moe: only world size 1 is built on gfx950 -- the in-kernel xGMI peer-to-peer dispatch / '
-                               'combine is not (DESIGN.md section 8); shard the experts with deepgemm_amd.ep (RCCL all-to-all) instead')
+        self.world = 1 if group is None else group.size()
         if mma_type not in ('fp8xfp8', 'fp8'):
             raise RuntimeError(f"SymmBuffer: mma_type '{mma_type}' is not supported on gfx950 (FP8 e4m3 activations x FP8 e4m3 weights only)")
         host_assert(hidden % 128 == 0 and intermediate_hidden % 128 == 0, 'hidden % 128 == 0 and intermediate_hidden % 128 == 0')
+        host_assert(num_experts % self.world == 0, 'num_experts % num_ranks == 0')
         self.group, self.num_experts, self.num_topk = group, num_experts, num_topk
+        self.num_local_experts = num_experts // self.world
         self.num_max_tokens_per_rank = -(-num_max_tokens_per_rank // 64) * 64
         self.hidden, self.intermediate_hidden, self.num_ring_tokens = hidden, intermediate_hidden, num_ring_tokens
-        t, e, m = self.num_max_tokens_per_rank, num_experts, self.num_max_tokens_per_rank     # one token meets an expert at most once
-        aligned = get_tma_aligned_size(m, 4)
+        t, e = self.num_max_tokens_per_rank, self.num_local_experts
         self.x = torch.zeros((t, hidden), dtype=torch.float8_e4m3fn, device=device)
         self.x_sf = torch.zeros((t, hidden // 128), dtype=torch.float, device=device)
         self.topk_idx = torch.full((t, num_topk), -1, dtype=torch.int64, device=device)
         self.topk_weights = torch.zeros((t, num_topk), dtype=torch.float, device=device)
-        self.l1_acts = torch.zeros((e, m, hidden), dtype=torch.float8_e4m3fn, device=device)
-        self.l1_acts_sf = torch.zeros((e, hidden // 128, aligned), dtype=torch.float, device=device).transpose(1, 2)   # [E, m, H/128], MN-major
-        self.l2_acts, self.l2_acts_sf = empty_intermediate(e, m, intermediate_hidden, device)
-        self.l2_out = torch.empty((e, m, hidden), dtype=torch.bfloat16, device=device)
-        self.row_weight = torch.zeros((e, aligned), dtype=torch.float, device=device)
-        self.slot = torch.full((t * num_topk,), -1, dtype=torch.int32, device=device)
+        self.errors = torch.zeros((4,), dtype=torch.int32, device=device)        # word 0: rows dropped by the routing (over a capacity)
+        self.buffer = self.x                                                    # (reference attribute; no symmetric heap here)
+        if self.world == 1:
+            m = t                                                               # one token meets an expert at most once
+            self.exchange_capacity = 0
+        else:
+            self.exchange_capacity = min(t, exchange_capacity) if exchange_capacity else t
+            m = -(-min(self.world * self.exchange_capacity, expert_capacity or self.world * t) // 64) * 64
+        self.expert_capacity = m
+        aligned = get_tma_aligned_size(m, 4)
         self.masked_m = torch.zeros((e,), dtype=torch.int32, device=device)
-        self.errors = torch.zeros((4,), dtype=torch.int32, device=device)        # word 0: rows dropped by the routing (more than max_m per expert)
-        self.workspace = swiglu_workspace(e, m, 2 * intermediate_hidden, device)
-        self.buffer = self.x                                                    # (reference attribute; one rank needs no symmetric heap)
+        self.l2_out = torch.empty((e, m, hidden), dtype=torch.bfloat16, device=device)
+        self.workspace = None
+        self.l2_acts = self.l2_acts_sf = None
+        if torch.device(device).type == 'cuda':
+            self.l2_acts, self.l2_acts_sf = empty_intermediate(e, m, intermediate_hidden, device)
+            self.workspace = swiglu_workspace(e, m, 2 * intermediate_hidden, device)
+        if self.world == 1:
+            self.l1_acts = torch.zeros((e, m, hidden), dtype=torch.float8_e4m3fn, device=device)
+            self.l1_acts_sf = torch.zeros((e, hidden // 128, aligned), dtype=torch.float, device=device).transpose(1, 2)   # [E, m, H/128], MN-major
+            self.row_weight = torch.zeros((e, aligned), dtype=torch.float, device=device)
+            self.slot = torch.full((t * num_topk,), -1, dtype=torch.int32, device=device)
+        else:
+            self.l1_acts = self.l1_acts_sf = self.row_weight = self.slot = None     # (the exchange hands these over per call: ep.dispatch_fixed)
 
     def destroy(self):
         for name in ('x', 'x_sf', 'topk_idx', 'topk_weights', 'l1_acts', 'l1_acts_sf', 'l2_acts', 'l2_acts_sf', 'l2_out', 'row_weight', 'slot',
@@ -221,33 +246,42 @@ class SymmBuffer:
 
 def get_symm_buffer_for_mega_moe(group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
                                  use_fp8_dispatch: Optional[bool] = None, mma_type: str = 'fp8xfp8', activation: str = 'swiglu') -> SymmBuffer:
-    """deep_gemm/mega/__init__.py:68-128 (the ring-token sizing of the reference belongs to its NVLink pull pipeline and has no
-    counterpart with one rank)."""
+    """deep_gemm/mega/__init__.py:68-128 (the ring-token sizing of the reference belongs to its NVLink pull pipeline; the capacities of
+    the fixed-shape exchange are :class:`SymmBuffer` arguments)."""
     return SymmBuffer(group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, 0, mma_type, activation)
 
 
 def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair, sym_buffer: SymmBuffer,
                  cumulative_local_expert_recv_stats: Optional[torch.Tensor] = None, recipe: Optional[Tuple[int, int, int]] = None,
-                 activation: str = 'swiglu', activation_clamp: Optional[float] = None, fast_math: bool = True) -> None:
+                 activation: str = 'swiglu', activation_clamp: Optional[float] = None, fast_math: bool = True,
+                 local_ops=None) -> None:
     """``y[t] = sum_j W2[e_j] . fp8( swiglu( W1[e_j] . x[t] ) * w_j )`` over the token's top-k experts ``e_j = topk_idx[t, j] >= 0`` --
     the reference's ``fp8_fp4_mega_moe(y, l1_weights, l2_weights, sym_buffer, ...)`` (deep_gemm/mega/__init__.py:155-173) with FP8 e4m3
-    weights and FP32 128 x 128 block scales (``transform_weights_for_mega_moe``), world size 1.  Inputs are read from the buffer's views
+    weights and FP32 128 x 128 block scales (``transform_weights_for_mega_moe``).  With a group of more than one rank the weights are this
+    rank's experts and the rows travel through two fixed-shape RCCL all-to-alls (:func:`_mega_moe_ep`; same arithmetic, same bits as
+    one rank holding every expert: tests/test_mega_gloo.py).  ``local_ops``: test hook -- ``(l1, l2)`` callables replacing the two HIP
+    operators (the gloo CPU tests put the oracle there, as ``ep.py``'s ``local_gemm``); the product path never sets it.  Inputs are read from the buffer's views
     (``x``, ``x_sf``, ``topk_idx``, ``topk_weights``; rows ``[0, y.size(0))``), as the reference's test fills them
     (tests/test_mega_moe.py:103-121).  Four stream-ordered launches + one memset, nothing returns to the host: scatter into the masked
     layout, fused L1 (GEMM + SwiGLU + routing weight + per-token FP8 re-quantisation), masked L2, gather-sum in top-k order (FP32).
     Bit-identical to the unfused pipeline of the same operators (tests/test_mega_gpu.py).  ``fast_math`` is accepted and ignored: this
-    kernel has one SwiGLU form (exact ``expf``).  Rows dropped because an expert got more than ``num_max_tokens_per_rank`` rows are
-    counted in ``sym_buffer.errors[0]`` (cannot happen when a token lists an expert at most once)."""
+    kernel has one SwiGLU form (exact ``expf``).  ``sym_buffer.errors`` (device int32 [4], never read by this call): word 0 = rows dropped
+    by the routing (over a capacity; cannot happen with the default capacities when a token lists an expert at most once), word 1 =
+    partner waits of the fused L1 kernel that timed out (those rows carry NaN; re-zero ``sym_buffer.workspace`` after one)."""
     host_assert(activation == 'swiglu', "activation == 'swiglu'")
     host_assert(recipe is None or tuple(recipe) == (1, 128, 128), 'recipe == (1, 128, 128): FP32 block scales (the (1, 1, 32) UE8M0 / FP4 recipe is SM100-only)')
     b = sym_buffer
     tokens = int(y.size(0))
     host_assert(y.dim() == 2 and y.dtype == torch.bfloat16 and y.size(1) == b.hidden and y.stride(1) == 1 and tokens <= b.num_max_tokens_per_rank,
                 'y: bfloat16 [num_tokens <= num_max_tokens_per_rank, hidden]')
-    host_assert(l1_weights[0].size(0) == b.num_experts and l1_weights[0].size(1) == 2 * b.intermediate_hidden and l1_weights[0].size(2) == b.hidden,
-                'l1_weights[0].shape == (num_experts, 2 * intermediate_hidden, hidden)')
-    host_assert(l2_weights[0].size(0) == b.num_experts and l2_weights[0].size(1) == b.hidden and l2_weights[0].size(2) == b.intermediate_hidden,
-                'l2_weights[0].shape == (num_experts, hidden, intermediate_hidden)')
+    host_assert(l1_weights[0].size(0) == b.num_local_experts and l1_weights[0].size(1) == 2 * b.intermediate_hidden and l1_weights[0].size(2) == b.hidden,
+                'l1_weights[0].shape == (num_experts / num_ranks, 2 * intermediate_hidden, hidden)')
+    host_assert(l2_weights[0].size(0) == b.num_local_experts and l2_weights[0].size(1) == b.hidden and l2_weights[0].size(2) == b.intermediate_hidden,
+                'l2_weights[0].shape == (num_experts / num_ranks, hidden, intermediate_hidden)')
+    host_assert(l1_weights[0].size(0) == b.num_local_experts, 'l1_weights[0].size(0) == num_experts / num_ranks')
+    if b.world > 1:
+        _mega_moe_ep(y, l1_weights, l2_weights, b, cumulative_local_expert_recv_stats, activation_clamp, local_ops)
+        return
     require_device(y, b.x, l1_weights[0], l2_weights[0])
     stream = current_stream_ptr()
     m = b.num_max_tokens_per_rank
@@ -259,11 +293,48 @@ def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair
     expected_m = max(1, min(m, -(-tokens * b.num_topk // b.num_experts)))
     m_grouped_fp8_gemm_nt_masked_swiglu((b.l1_acts, b.l1_acts_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m,
                                         activation_clamp, workspace=b.workspace, row_weight=b.row_weight)
+    b.errors[1:2] += b.workspace[:4].view(torch.int32)        # word 1: partner waits of the fused kernel that timed out (rows carry NaN)
     m_grouped_fp8_gemm_nt_masked((b.l2_acts, b.l2_acts_sf), l2_weights, b.l2_out, b.masked_m, expected_m)
     check(lib.dg_moe_combine_from_masked(b.l2_out.data_ptr(), b.slot.data_ptr(), tokens, b.num_topk, b.hidden, b.l2_out.stride(1),
                                          y.data_ptr(), y.stride(0), stream))
     if cumulative_local_expert_recv_stats is not None:
         cumulative_local_expert_recv_stats.add_(b.masked_m.to(cumulative_local_expert_recv_stats.dtype))
+
+
+def _mega_moe_ep(y, l1_weights, l2_weights, b: SymmBuffer, stats, activation_clamp, local_ops) -> None:
+    """``fp8_mega_moe`` over a group of R > 1 ranks (reference: the dispatch / L1 / L2 / combine stages of
+    sm100_fp8_fp4_mega_moe.cuh:357-405, 523-595, 1019; baseline with the same stages: tests/test_mega_moe.py:149-214):
+
+      1. fixed-shape dispatch (``ep.dispatch_fixed``): every (token, expert) pair's FP8 row + its 1 x 128 scales + its routing weight go to
+         the expert's owner -- two equal-split all-to-alls (counts, payload), receiver-side compaction into the masked layout on the
+         device, no host synchronisation (hipGraph-capturable; rows over a capacity are dropped and counted in ``b.errors[0]``);
+      2. fused L1 on the local experts (GEMM + SwiGLU + routing weight + per-token FP8 re-quantisation), masked L2 -- the launches of
+         the one-rank path on ``E / R`` groups;
+      3. fixed-shape combine: BF16 result rows return in the same blocks; the token's owner sums its ``top_k`` rows in top-k order in FP32
+         (what ``dg_moe_combine_from_masked`` does at one rank), pairs without an expert contribute zeros."""
+    from . import ep
+    tokens = int(y.size(0))
+    x = (b.x[:tokens], b.x_sf[:tokens])
+    (a, a_sf), plan = ep.dispatch_fixed(x, b.topk_idx[:tokens], b.num_experts, b.expert_capacity, b.exchange_capacity, b.group,
+                                        row_extra=b.topk_weights[:tokens])
+    b.masked_m.copy_(plan.masked_m)
+    b.errors[0] += plan.overflow.to(torch.int32)
+    expected_m = max(1, min(b.expert_capacity, -(-tokens * b.num_topk // b.num_local_experts)))
+    if local_ops is None:
+        m_grouped_fp8_gemm_nt_masked_swiglu((a, a_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m, activation_clamp,
+                                            workspace=b.workspace, row_weight=plan.row_extra)
+        b.errors[1:2] += b.workspace[:4].view(torch.int32)
+        m_grouped_fp8_gemm_nt_masked((b.l2_acts, b.l2_acts_sf), l2_weights, b.l2_out, b.masked_m, expected_m)
+    else:
+        inter = local_ops[0]((a, a_sf), l1_weights, b.masked_m, activation_clamp, plan.row_extra)
+        local_ops[1](inter, l2_weights, b.l2_out, b.masked_m)
+    rows = ep.combine_fixed(b.l2_out, plan, tokens, b.num_topk, b.world, b.exchange_capacity, b.group)        # [T, top_k, H]
+    acc = rows[:, 0].float()
+    for j in range(1, b.num_topk):
+        acc += rows[:, j].float()
+    y.copy_(acc.to(torch.bfloat16))
+    if stats is not None:
+        stats.add_(b.masked_m.to(stats.dtype))
 
 
 fp8_fp4_mega_moe = fp8_mega_moe      # the reference's name; FP4 weights (its SM100 default) are rejected by the weight transform

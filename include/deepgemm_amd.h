@@ -150,13 +150,15 @@ int dg_pack_sf_pair_ue8m0(const float* sfa, int32_t* out_a, int batches_a, int m
  *   streams, a graph replay racing an eager call): launches that share a workspace concurrently steal each other's slots.
  *   The partner wait is BOUNDED (dg_set_swiglu_exchange_timeout_us, default 10 s; reference: comm/barrier.cuh:12,36-40): a wait that
  *   times out -- a workspace that was not all-zero, a lost partner -- increments the uint32 at workspace[0] and gives the rows involved
- *   NaN scales and bytes; the caller then re-zeroes the workspace.  dg_set_swiglu_fault_injection(1) (tests only) makes every odd tile
- *   skip its publish so that the path can be exercised. */
+ *   NaN scales and bytes and takes its own slot back; the caller re-zeroes the workspace all the same before the next launch on it.
+ *   dg_set_swiglu_fault_injection(1) makes every odd tile skip its publish so that the path can be exercised: a TEST hook, honoured only
+ *   when the process runs with DG_TEST_HOOKS set (dg_reload_env); ignored otherwise. */
 int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n);
 void dg_set_swiglu_exchange_timeout_us(int64_t us);
 void dg_set_swiglu_fault_injection(int mode);
 /* The same with the row's routing weight applied to the SwiGLU output BEFORE the re-quantisation, as the reference's fused kernel does
- * (deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:1019): y = bf16( bf16( silu(g) * u ) * row_weight[g, m] );
+ * (deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:1001-1020): gate and up rounded to BF16 (and clamped there), then
+ * y = silu(g) * u * row_weight[g, m] in FP32 -- no BF16 rounding of the product -- into the row amax and the FP8 cast;
  * row_weight FP32 [G, >= align(m_max, 64)] (element (g, m) at row_weight[g * stride_g + m]; 16-byte aligned, stride a multiple of 4);
  * NULL = the unweighted entry above. */
 int dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
@@ -321,6 +323,11 @@ int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols
  * persistent launch may occupy, 0 = all CUs of the device). */
 int dg_set_num_cus(int num_cus);
 int dg_get_num_cus(void);
+
+/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE,
+ * DG_SFA_ROWMAJOR_IN_PLACE) are read once, at the first launch; a process that changes them afterwards calls this to have them read again
+ * (tests, tuning scripts).  No reference counterpart (its knobs are read per call, csrc/utils/system.hpp get_env). */
+void dg_reload_env(void);
 
 /* Tuning / test hook: force a kernel configuration by name for subsequent calls of the process ("auto" restores the
  * heuristic; like the reference's runtime knobs the setting is process-wide and may be changed from any thread).

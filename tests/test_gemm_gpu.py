@@ -9,6 +9,7 @@ import torch
 
 import deepgemm_amd as dg
 import oracle
+from deepgemm_amd._lib import lib as dg_lib
 from deepgemm_amd.testing import calc_diff, generators as gen
 from gpu_helpers import assert_close_fp32, assert_close_to_oracle, cpu_pair, oracle_dense
 
@@ -1318,6 +1319,7 @@ def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
         start += aligned
     # round 4: the 256-row walk and the remainder walk share ONE launch; the two-launch form of round 3 must give the same bits
     os.environ['DG_TAB_UNFUSED'] = '1'
+    dg_lib.dg_reload_env()                          # (the library reads its tuning variables once)
     try:
         two = guarded[128:128 + m]
         two.fill_(float('nan'))
@@ -1326,6 +1328,7 @@ def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
         assert torch.equal(two, outs[0]), 'one launch and two launches differ'
     finally:
         del os.environ['DG_TAB_UNFUSED']
+        dg_lib.dg_reload_env()
     dg.set_forced_config('duo_128x256')
     fixed = torch.empty_like(case.d)
     dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, fixed, case.grouped_layout)

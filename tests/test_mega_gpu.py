@@ -2,6 +2,8 @@
 impls/sm100_fp8_fp4_mega_moe.cuh): GEMM1 with SwiGLU + per-token FP8 re-quantisation in its epilogue against the UNFUSED pipeline
 ``m_grouped_fp8_gemm_nt_masked -> BF16 -> torch SwiGLU -> reference per_token_cast_to_fp8`` -- bit-exact on the re-quantised bytes and
 scales -- and the two-GEMM expert MLP end to end."""
+import os
+
 import pytest
 import torch
 
@@ -36,7 +38,8 @@ def _unfused(x, w1, masked_ms, clamp, use_ue8m0):
     for g, rows in enumerate(masked_ms):
         gate, up = h[g, :rows, :inter].float(), h[g, :rows, inter:].float()
         if clamp is not None:
-            gate, up = gate.clamp(max=clamp), up.clamp(-clamp, clamp)
+            c = float(torch.tensor(clamp).to(torch.bfloat16))      # the reference clamps with BF16 operands: 10.1 acts as 10.125
+            gate, up = gate.clamp(max=c), up.clamp(-c, c)
         y = (torch.nn.functional.silu(gate) * up).to(torch.bfloat16)
         out.append(per_token_cast_to_fp8(y, use_ue8m0=use_ue8m0) if rows else None)
     return out
@@ -45,7 +48,7 @@ def _unfused(x, w1, masked_ms, clamp, use_ue8m0):
 @pytest.mark.parametrize('masked_ms,m_max,inter,k', [([5, 0, 64, 33], 64, 256, 512), ([200, 1, 129], 256, 384, 1024),
                                                       ([48, 64, 17, 0, 64, 33, 2, 60], 64, 2048, 7168)])
 @pytest.mark.parametrize('use_ue8m0', [False, True])
-@pytest.mark.parametrize('clamp', [None, 10.0])
+@pytest.mark.parametrize('clamp', [None, 10.0, 0.3])          # 0.3 is not BF16-representable (acts as 0.30078125) and actually clips
 def test_fused_swiglu_requant_is_the_unfused_pipeline(masked_ms, m_max, inter, k, use_ue8m0, clamp):
     gen.reset_seed(len(masked_ms) + inter)
     groups = len(masked_ms)
@@ -137,7 +140,7 @@ def _quantised_tokens(tokens, hidden):
 def _unfused_moe(x, topk_idx, topk_w, w1, w2, clamp):
     """The reference-shaped operator spelled out with the plain operators, token by token and expert by expert (the reference's own
     baseline has the same stages: dispatch -> L1 GEMM -> SwiGLU * weight -> FP8 -> L2 GEMM -> combine, tests/test_mega_moe.py:149-214):
-    masked GEMM -> BF16 -> SwiGLU -> BF16 -> * routing weight -> BF16 -> per_token_cast_to_fp8 -> masked GEMM -> sum in top-k order (FP32)."""
+    masked GEMM -> BF16 -> SwiGLU * routing weight in FP32 -> per_token_cast_to_fp8 -> masked GEMM -> sum in top-k order (FP32)."""
     tokens, hidden = x[0].shape
     experts, inter = w1[0].size(0), w1[0].size(1) // 2
     y = torch.zeros((tokens, hidden), dtype=torch.float, device='cuda')
@@ -152,9 +155,9 @@ def _unfused_moe(x, topk_idx, topk_w, w1, w2, clamp):
             dg.m_grouped_fp8_gemm_nt_masked(xa, (w1[0][e:e + 1], w1[1][e:e + 1]), h, one, 1)
             gate, up = h[0, :, :inter].float(), h[0, :, inter:].float()
             if clamp is not None:
-                gate, up = gate.clamp(max=clamp), up.clamp(-clamp, clamp)
-            act = (torch.nn.functional.silu(gate) * up).to(torch.bfloat16)
-            act = (act.float() * topk_w[t, j]).to(torch.bfloat16)
+                c = float(torch.tensor(clamp).to(torch.bfloat16))
+                gate, up = gate.clamp(max=c), up.clamp(-c, c)
+            act = torch.nn.functional.silu(gate) * up * topk_w[t, j]          # FP32 up to the cast (sm100_fp8_fp4_mega_moe.cuh:1001-1020)
             q, q_sf = per_token_cast_to_fp8(act, use_ue8m0=False)
             o = torch.empty((1, 1, hidden), device='cuda', dtype=torch.bfloat16)
             dg.m_grouped_fp8_gemm_nt_masked((q.unsqueeze(0), q_sf.unsqueeze(0)), (w2[0][e:e + 1], w2[1][e:e + 1]), o, one, 1)
@@ -236,7 +239,12 @@ def test_exchange_wait_is_bounded_and_loud():
     dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, good, masked, 40, workspace=ws)
     assert mega.exchange_timeouts(ws) == 0 and bool(torch.isfinite(good[1][0, :64]).all())
     mega.set_exchange_timeout_us(20000)
-    lib.dg_set_swiglu_fault_injection(1)
+    lib.dg_set_swiglu_fault_injection(1)                               # without DG_TEST_HOOKS the hook is ignored: a production process cannot arm it
+    ignored = dg.empty_intermediate(groups, m_max, inter, 'cuda')
+    dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, ignored, masked, 40, workspace=ws)
+    assert mega.exchange_timeouts(ws) == 0 and torch.equal(ignored[1][0, :64], good[1][0, :64])
+    os.environ['DG_TEST_HOOKS'] = '1'
+    lib.dg_reload_env()
     try:
         bad = dg.empty_intermediate(groups, m_max, inter, 'cuda')
         dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, bad, masked, 40, workspace=ws)
@@ -244,6 +252,8 @@ def test_exchange_wait_is_bounded_and_loud():
     finally:
         lib.dg_set_swiglu_fault_injection(0)
         mega.set_exchange_timeout_us(10_000_000)
+        del os.environ['DG_TEST_HOOKS']
+        lib.dg_reload_env()
     assert bool(torch.isnan(bad[1][0, :64]).any()), 'rows whose partner never published must carry NaN scales'
     assert mega.exchange_timeouts(ws, reset=False) > 0
     assert mega.exchange_timeouts(ws) > 0 and int(ws.view(torch.int32).abs().sum()) == 0      # counted, then re-zeroed
