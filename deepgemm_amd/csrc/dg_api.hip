@@ -259,6 +259,8 @@ const E8Config kE8Configs[] = {
     // ... and A MN-major ([K][M]: the tt layout), both (tn): scale words of A in natural row order
     {"e8_duo_amn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, false, true>, 256, 256, 512, false, false, false},
     {"e8_duo_abmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true, true>, 256, 256, 512, false, false, false},
+    // round 5: ... with a partial last K block (the nn layout of a packed-scale dgrad whose K is not a multiple of 128: 2112, 576)
+    {"e8_duo_bmn_kt_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true, false, true>, 256, 256, 512, false, false, false},
     // round 5: the quad kernel with all sixteen fragments of a K block register-resident, two LDS buffers per operand, three barriers per
     // K block, fragment reads and LDS-DMA pieces in separate phases (fp8_gemm_quad.hpp, HS)
     {"e8_quad_h_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 1>, 256, 256, 256, true, true, false},
@@ -343,7 +345,10 @@ bool amn_eligible(const dg::GemmParams& p) {
 // _abmn_256x256: whole K blocks, scale words MN-major, 16-byte aligned rows / k-rows).
 bool e8_mn_eligible(const dg::GemmParams& p) {
     const bool a_mn = p.a_sk != 1, b_mn = p.b_sk != 1;
-    if (!(a_mn || b_mn) || p.gemm_type != dg::kNormal || p.k % 128 != 0 || p.sfa_sm != 1 || p.sfb_sn != 1 || p.head_lr != 0)
+    if (!(a_mn || b_mn) || p.gemm_type != dg::kNormal || p.sfa_sm != 1 || p.sfb_sn != 1 || p.head_lr != 0)
+        return false;
+    // K tail (whole 16-byte chunks, K > 128): the nn layout only -- A K-major, B [K][N] (round 5: e8_duo_bmn_kt_256x256, the packed-scale dgrad shapes)
+    if (p.k % 128 != 0 && (a_mn || p.k % 16 != 0 || p.k <= 128))
         return false;
     const bool a_ok = a_mn ? (p.a_sm == 1 && aligned16(p.a) && p.a_sk % 16 == 0 && p.m % 16 == 0 && p.a_sk <= (1 << 22) &&
                               static_cast<int64_t>(p.k) * p.a_sk < (1LL << 31))
@@ -354,6 +359,8 @@ bool e8_mn_eligible(const dg::GemmParams& p) {
     return a_ok && b_ok;
 }
 const char* e8_mn_config_name(const dg::GemmParams& p) {
+    if (p.k % 128 != 0)
+        return "e8_duo_bmn_kt_256x256";
     return p.a_sk != 1 ? (p.b_sk != 1 ? "e8_duo_abmn_256x256" : "e8_duo_amn_256x256") : "e8_duo_bmn_256x256";
 }
 // ... and is better off there than re-majored in front of the quad kernel: tile-kernel territory (the stream tiles of small M want K-major
@@ -364,6 +371,8 @@ const char* e8_mn_config_name(const dg::GemmParams& p) {
 bool e8_mn_pays(const dg::GemmParams& p) {
     if (p.m <= 256 || 2L * ((p.m + 255) / 256) * ((p.n + 255) / 256) < num_cus())
         return false;
+    if (p.k % 128 != 0)         // K tail: the alternative is a pass over B in front of the 128-ROW quad kernel (fp8_gemm_nn 4096 x 7168 x 2112:
+        return true;            // 86 us against the FP32-scale kernel's 71 on the same operands) -- reading in place always pays
     double remajor_us = 0;
     if (p.a_sk != 1) remajor_us += 3.0 + static_cast<double>(p.m) * p.k / 2.25e6;
     if (p.b_sk != 1) remajor_us += 3.0 + static_cast<double>(p.n) * p.k / 2.25e6;
@@ -977,7 +986,7 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     for (const E8Config& c : kE8Configs)
         if (forced == c.name)
             cfg = &c;
-    if (k_tail) {
+    if (k_tail && !mn_form) {
         for (const E8Config& c : kE8Configs)
             if (std::strcmp(c.name, "e8_quad_kt_128x256") == 0) {
                 if (cfg != nullptr && cfg != &c) {
@@ -1820,8 +1829,13 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
     p.sk_workspace = has_workspace ? reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23) : nullptr;
     if (packed_ue8m0) {
         p.sfb_gran_n = 128;
-        name = fast_eligible(p) ? select_e8_config(p, expected_m)->name
-                                : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
+        if (e8_mn_eligible(p) && e8_mn_pays(p))     // an MN-major operand read in place (otherwise the host re-majors it: the K-major choice below)
+            name = e8_mn_config_name(p);
+        else {
+            p.a_sm = k; p.a_sk = 1; p.b_sn = k; p.b_sk = 1;
+            name = fast_eligible(p) ? select_e8_config(p, expected_m)->name
+                                    : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
+        }
     } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
         name = per_col_eligible(p) ? "pipe_pc_ks_256x256" : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)
     } else if (gemm_type == dg::kContiguous && m_alignment == 128 && has_workspace && !b_mn_major && sfb_gran_n == 128 && k % 128 == 0 && k >= 1024 &&

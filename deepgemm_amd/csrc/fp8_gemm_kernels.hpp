@@ -3220,7 +3220,11 @@ __device__ __forceinline__ void wait_e8_landing(E8Landing& l) {
 // of dg_fp8_gemm_duo_kernel; a lane's row slot i of N-subtile ns is weight row ns * 16 + i, and so is its scale word.
 // A_MN: operand A MN-major ([K][M]: the tt / tn layouts) likewise; A rows in natural order (scale words as MS dword loads, epilogue without
 // the row interleave).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false, bool A_MN = false>
+// K_TAIL (round 5): K need not be a multiple of 128 (whole 16-byte chunks, K > 128): the partial last block is computed once per tile after
+// the loop, as in duo_kernel_body -- K-major chunks at and beyond K pushed out of the descriptor's range (an out-of-range LDS-DMA lane writes
+// zeros), MN-major k-rows >= K beyond the extent by themselves; its scale byte is byte (K / 128) & 3 of the last packed word.  The packed-scale
+// dgrad shape fp8_gemm_nn 4096 x 7168 x 2112 then reads its MN-major B in place instead of re-majoring it in front of the 128-row quad kernel.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false, bool A_MN = false, bool K_TAIL = false>
 __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MS / 2;
@@ -3261,7 +3265,8 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     #pragma unroll
     for (int q = 0; q < B_ITERS; ++q)
         b_piece_voff[q] = b_voff + b_row_perm<WN>(q * (NW * 8)) * ldb;
-    const int num_kq = (num_kb + 3) / 4;
+    const int k_tail = K_TAIL ? (p.k & 127) : 0;
+    const int num_kq = (num_kb + (k_tail != 0) + 3) / 4;
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;
     // MN-major B (see duo_kernel_body): lane l of piece u carries k-row 4u + (l >> 4), source chunk (l & 15) ^ f(k)
     [[maybe_unused]] const int ldb_mn = static_cast<int>(p.b_sk), lda_mn = static_cast<int>(p.a_sk);
@@ -3456,6 +3461,72 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if constexpr (K_TAIL) {
+                if (k_tail != 0) {
+                    const int tail_bias = (src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
+                    #pragma unroll
+                    for (int q = 0; q < A_ITERS; ++q) {
+                        const int unit = wave + NW * q;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            a_rsrc, (__attribute__((address_space(3))) void*)(lds + unit * 1024), 16,
+                            A_MN ? amn_voff : a_piece_voff[q] + tail_bias,
+                            A_MN ? (num_kb * 128 + 4 * unit) * lda_mn : num_kb * 128, 0, 0);
+                    }
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q) {
+                        const int unit = wave + NW * q;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + unit * 1024), 16,
+                            B_MN ? bmn_voff : b_piece_voff[q] + tail_bias,
+                            B_MN ? (num_kb * 128 + 4 * unit) * ldb_mn : num_kb * 128, 0, 0);
+                    }
+                    {
+                        const int kq = num_kb >> 2;
+                        issue_e8_scale_loads(land, sfa_rsrc, sfa_voff + kq * sfa_kq_stride, sfb_rsrc, sfb_voff[0] + kq * sfb_kq_stride,
+                                             sfb_voff[1] + kq * sfb_kq_stride, sfb_voff[2] + kq * sfb_kq_stride,
+                                             sfb_voff[3] + kq * sfb_kq_stride);
+                    }
+                    wait_e8_landing<0>(land);                   // straight-line from the loads; also lands the pieces
+                    __syncthreads();
+                    {
+                        const int shift = (num_kb & 3) * 8;
+                        #pragma unroll
+                        for (int ms = 0; ms < MS; ++ms)
+                            sa_cur[ms] = static_cast<int>(static_cast<unsigned>(e8_landed_sfa(land, ms)) >> shift);
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            sb_cur[ns] = static_cast<int>(static_cast<unsigned>(land.sb[ns]) >> shift);
+                    }
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        if constexpr (B_MN) {
+                            FragTr fq = load_fragment_tr(lds + B_BASE, tr_lane_base, ((wn * (WN / 16) + ns) ^ tr_swz) << 4);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            bf[ns] = assemble_fragment_tr(fq);
+                        } else {
+                            bf[ns] = load_fragment(lds + B_BASE + (wn * WN) * 128 + ns * 2048, frag_off);
+                        }
+                    }
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms) {
+                        __builtin_amdgcn_sched_barrier(0);      // one subtile row at a time
+                        v8i a_frag;
+                        if constexpr (A_MN) {
+                            FragTr fq = load_fragment_tr(lds, tr_lane_base, ((wm * MS + ms) ^ tr_swz) << 4);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            a_frag = assemble_fragment_tr(fq);
+                        } else {
+                            a_frag = load_fragment(lds + (wm * WM) * 128 + ms * 2048, frag_off);
+                        }
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            acc[ms][ns] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[ns], a_frag, acc[ms][ns], 0, 0, 0, sb_cur[ns],
+                                                                                           0, sa_cur[ms]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                }
+            }
         }
         store_tile<MS, NS, !A_MN, false, B_MN>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && tile_id == blockIdx.x) {
@@ -3468,10 +3539,10 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false, bool A_MN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool B_MN = false, bool A_MN = false, bool K_TAIL = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_e8_kernel(const GemmParams p) {
-    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N, B_MN, A_MN>(p);
+    duo_e8_kernel_body<BM, BN, WAVES_M, WAVES_N, B_MN, A_MN, K_TAIL>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

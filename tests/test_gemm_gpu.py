@@ -1077,6 +1077,19 @@ def test_packed_ue8m0_k_tail(m, n, k):
             d2 = torch.full_like(first, float('nan'))
             dg.fp8_gemm_nt(a, b, d2)
             assert dg.last_config() == 'e8_quad_kt_128x256' and torch.equal(d2, first)
+            # round 5: MN-major B ([K][N]: fp8_gemm_nn, the packed-scale dgrad layout) read IN PLACE by the 8-wave hardware-scaled kernel with
+            # the same zero-filled partial block: the same bits (the matrix core accumulates the K blocks in place, in the same order)
+            if n % 16 == 0:
+                b_kn, sfb_kn = b[0].t().contiguous(), b[1].t().contiguous()         # [K, N] storage; the scale words travel transposed with it
+                dg.set_forced_config('e8_duo_bmn_kt_256x256')
+                d3 = torch.full_like(first, float('nan'))
+                dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d3)
+                assert dg.last_config() == 'e8_duo_bmn_kt_256x256', dg.last_config()
+                assert torch.equal(d3, first), 'MN-major B in place differs from the K-major tail kernel'
+                dg.set_forced_config('auto')
+                d3.fill_(float('nan'))
+                dg.fp8_gemm_nn(a, (b_kn, sfb_kn), d3)                                # automatic: in place where that pays, re-majored otherwise
+                assert dg.last_config() in ('e8_duo_bmn_kt_256x256', 'e8_quad_kt_128x256') and torch.equal(d3, first)
             # rows off 16 bytes: the expanded-scale fallback (FP32 promotion instead of in-core accumulation: equal up to FP32 rounding)
             a_off = torch.empty((a[0].numel() + 1,), dtype=torch.uint8, device='cuda')[1:].view(torch.float8_e4m3fn).view(a[0].shape)
             a_off.copy_(a[0])

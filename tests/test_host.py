@@ -440,6 +440,10 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 4096, 4096, 7168, packed=1) == 'e8_quad_256x256'
     assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48, packed=1) == 'e8_stream_nt_64x128'
     assert pick(dense, 128, 4096, 7168, packed=1) == 'e8_stream_64x32'
+    # packed scales with MN-major operands: read in place where that beats a re-majoring pass (e8_mn_pays); a K tail in the nn layout (the
+    # packed-scale dgrad shapes) always stays in place (round 5)
+    assert pick(dense, 2048, 7168, 2048, b_mn=1, packed=1) == 'e8_duo_bmn_256x256' and pick(dense, 4096, 4096, 7168, b_mn=1, packed=1) == 'e8_quad_256x256'
+    assert pick(dense, 4096, 7168, 2112, b_mn=1, packed=1) == 'e8_duo_bmn_kt_256x256' and pick(dense, 4096, 7168, 2112, packed=1) == 'e8_quad_kt_128x256'
     # recipe (1, 1, 128): the per-column kernel; the narrow-layer wgrad entry of the reference sweep runs its K pieces as groups
     assert pick(dense, 4096, 4096, 7168, gran_n=1) == 'pipe_pc_256x256' and pick(dense, 4096, 4096, 7168, a_mn=1, b_mn=1, gran_n=1) == 'pipe_pc_mn_256x256'
     assert pick(dense, 576, 4096, 7168, gran_n=1) == 'pipe_pc_ks_256x256' and pick(dense, 576, 4096, 7168, a_mn=1, b_mn=1, gran_n=1) == 'pipe_pc_mn_ks_256x256'
