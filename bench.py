@@ -379,16 +379,18 @@ def graph_replay_seconds(calls, per_graph: int) -> float:
     with torch.cuda.graph(graph):
         for i in range(per_graph):
             calls[i % len(calls)]()
-    for _ in range(3):
+    # (the first replays of a freshly instantiated graph run ~10 % slower than the steady state -- tools/decode_replay_probe.py: 30.4 us per
+    #  call in the first 10 replays, 27.4-27.7 afterwards, the same as back-to-back eager calls: warm it up like any other timed loop)
+    for _ in range(12):
         graph.replay()
     torch.cuda.synchronize()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
-    for _ in range(10):
+    for _ in range(20):
         graph.replay()
     end.record()
     torch.cuda.synchronize()
-    return start.elapsed_time(end) / 1e3 / (10 * per_graph)
+    return start.elapsed_time(end) / 1e3 / (20 * per_graph)
 
 
 def run_secondary(sets: int):
