@@ -31,6 +31,10 @@ from deepgemm_amd.testing import calc_diff, count_bytes, generators as gen   # n
 
 PEAK_FP8_TFLOPS = 5000.0      # dense FP8 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+# Recipe (1, 1, 128) -- a distinct scale per accumulator ELEMENT per K block -- costs two VALU operations per element: 4 v_mul + 4 v_fmac per
+# 16x16x128 MFMA, measured ~62 matrix-pipe cycles per step in either schedule (profiles/r04_probe/wgrad_duo_pc_ab.log) against the MFMA's
+# own 32: the arithmetic roof of that recipe on this part is 32 / 62 of the matrix rate.  Reported beside the MFMA fraction.
+RECIPE_1_1_128_ROOF = 32.0 / 62.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
              'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
@@ -291,7 +295,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         flops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * (m + n) * (k // 128) + 8 * m * n           # FP32 D read and written
         desc = {'workload': f'fp8_gemm_nt recipe (1, 1, 128), FP32 accumulate into D, M={m} N={n} K={k} (wgrad form, tests/generators.py:146-153)',
-                'm': m, 'n': n, 'k': k}
+                'm': m, 'n': n, 'k': k, 'recipe_roof': RECIPE_1_1_128_ROOF}
         check = lambda: float('nan')                               # noqa: E731  (D keeps accumulating: parity is the tests' job)
     elif name == 'kgrouped':
         import random
@@ -306,7 +310,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         flops = 2.0 * m * n * sum(ks)
         nbytes = (m + n) * sum(ks) * (1 + 4 / 128) + 8.0 * g * m * n
         desc = {'workload': f'k_grouped_fp8_gemm_nt_contiguous G={g} M={m} N={n} sum_k={sum(ks)} (reference sweep entry, tests/generators.py:200-202)',
-                'm': m, 'n': n, 'sum_k': sum(ks), 'groups': g}
+                'm': m, 'n': n, 'sum_k': sum(ks), 'groups': g, 'recipe_roof': RECIPE_1_1_128_ROOF}
         check = lambda: float('nan')                               # noqa: E731
     elif name == 'contiguous':
         groups, expected, n, k = 8, 512, 4096, 7168
@@ -349,7 +353,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
     return calls, flops, float(nbytes), desc, check, bound
 
 
-def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, traffic=None, useful_flops=None):
+def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, traffic=None, useful_flops=None, recipe_roof=None):
     tflops, gbs = flops / kernel_s / 1e12, nbytes / kernel_s / 1e9
     rec = ({'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / PEAK_FP8_TFLOPS} if bound == 'mfma' else
            {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
@@ -357,6 +361,8 @@ def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, ke
                 'algorithmic_bytes': nbytes, 'tflops': tflops, 'gbs': gbs})
     if useful_flops is not None:        # layouts with padding rows: the fraction on the rows that carry data, beside the reference-style count
         rec.update({'useful_flops': useful_flops, 'frac_useful': useful_flops / kernel_s / 1e12 / PEAK_FP8_TFLOPS})
+    if recipe_roof is not None:         # recipe (1, 1, 128): the fraction of that recipe's own VALU-issue roof
+        rec.update({'recipe_roof_frac_of_peak': recipe_roof, 'frac_of_recipe_roof': tflops / (PEAK_FP8_TFLOPS * recipe_roof)})
     return rec
 
 
@@ -429,7 +435,8 @@ def run_secondary(sets: int):
                 extra['fused_us'] = call_s * 1e6
                 other = None
             rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
-                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), useful_flops=desc.get('useful_flops')), **extra}
+                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), useful_flops=desc.get('useful_flops'),
+                                               recipe_roof=desc.get('recipe_roof')), **extra}
             out.append(rec)
         except Exception as e:                                       # noqa: BLE001  (a secondary line must not take the headline down)
             out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'[:200]})
@@ -521,7 +528,8 @@ def run(rank: int, world: int, local_rank: int, args):
         total_flops = flops * args.steps * world
         value = total_flops / elapsed / 1e12
         traffic = measured_traffic(dg.last_config()) if args.workload.startswith('dense') else None
-        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), traffic, useful_flops=desc.get('useful_flops'))
+        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), traffic, useful_flops=desc.get('useful_flops'),
+                                   recipe_roof=desc.get('recipe_roof'))
         if split is not None:
             # the roofline of the EP step is that of its local GEMM (HBM-bound on the expert weights)
             roofline = roofline_record(flops, nbytes, split[1] / 1e6, bound, dg.last_config(), None)
@@ -547,10 +555,11 @@ def run(rank: int, world: int, local_rank: int, args):
             # a JSON line (prefix), the headline line carries {workload: [roofline.frac, us per call, 'mfma' | 'hbm']} and comes LAST.
             print('secondary_detail: ' + json.dumps(detail), flush=True)
             line['secondary'] = {name: ([_sig(rec['roofline']['frac']), _sig(rec['roofline']['kernel_us']), rec['roofline']['bound'][0]] +
-                                        ([_sig(rec['roofline']['frac_useful'])] if 'frac_useful' in rec['roofline'] else [])
+                                        ([_sig(rec['roofline']['frac_useful'])] if 'frac_useful' in rec['roofline'] else []) +
+                                        ([_sig(rec['roofline']['frac_of_recipe_roof'])] if 'frac_of_recipe_roof' in rec['roofline'] else [])
                                         if 'roofline' in rec else rec.get('error', '?')[:40])
                                  for name, rec in zip(SECONDARY, detail)}
-            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us per call, bound, frac on data rows]'
+            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us/call, bound, 4th: frac on data rows (contiguous) | of the (1,1,128) recipe roof]'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
         if 'secondary' in line:         # keep the whole headline line inside the driver's 2000-character tail

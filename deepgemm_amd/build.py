@@ -13,7 +13,7 @@ SOURCES = ['dg_api.hip']
 HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_moe.hpp', 'fp8_gemm_experiments.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
-# DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that DESIGN.md section 5 quotes (tools/cycles.py,
+# DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that HISTORY.md quotes (tools/cycles.py,
 # tools/sustained.py, tools/trace*.py take their names); they roughly triple the compile time and are never selected.
 if os.environ.get('DG_EXPERIMENTS', '') not in ('', '0'):
     FLAGS.append('-DDG_EXPERIMENTS')

@@ -155,7 +155,7 @@ const Config kConfigs[] = {
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
      false, false, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
-#ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants;
+#ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants (HISTORY.md);
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
     // round 4: the other loader-wave forms that were measured (12 loader waves: no better than 4; the 64 x 128 tile: 39.8 us against 38.4 at
     // m = 128, C5 43.7 against 43.6; cache policies nt / sc on the weight pieces of the 64 x 32 tile: no difference -- profiles/r04_probe/)

@@ -1,5 +1,5 @@
 // Lab notebook of the gfx950 FP8 GEMM kernels: superseded production forms, timing ablations and rejected variants.
-// Compiled only with DG_EXPERIMENTS=1 (python __graft_entry__.py), never selected by the heuristics; DESIGN.md quotes their
+// Compiled only with DG_EXPERIMENTS=1 (python __graft_entry__.py), never selected by the heuristics; HISTORY.md quotes their
 // configuration names (naive_256x256, ring_256x256, rabl*, ring_p*, dabl*, duo_pprio, e8_ring, quad_128x256, ...) as evidence.
 // The production kernels live in fp8_gemm_kernels.hpp / fp8_gemm_quad.hpp and carry none of these hooks.
 //
@@ -1153,7 +1153,7 @@ void dg_fp8_gemm_e8_kernel(const GemmParams p) {
 //   scale loads of block kb+1 (inline asm, VGPR landing), then S-rows 6, 7 R-major -- steps (r, 6), (r, 7) -- so that R
 //   fragment r is dead after its pair and is re-read from block kb+1 at once; S fragments 0, 1 of block kb+1 follow;
 //   LDS-DMA: first half of B(kb+2); the vmcnt(B_ITERS / 2) at the end of the block lands the scales (straight-line from
-//   their issue: see "A latent race" in DESIGN.md).
+//   their issue: see "A latent race" in HISTORY.md).
 // ---------------------------------------------------------------------------------------------------------------
 template <bool ROWS_AGPR, bool COLS_AGPR, bool NO_FMA = false>
 __device__ __forceinline__ void mfma_promote_step_q(v4f& part_new, const v8i& rows_operand, const v8i& cols_operand,

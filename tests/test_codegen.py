@@ -2,7 +2,7 @@
 
 The fast kernels sit at the edge of the register file; a spill that lands inside the K loop costs far more than its
 instruction (scratch traffic counts towards vmcnt and tightens every counted wait) and does not show up in any
-correctness test -- only in sustained throughput.  It happened once ("Measure sustained, and watch the register
+correctness test -- only in sustained throughput.  It happened once (HISTORY.md, "Measure sustained, and watch the register
 allocator"): this test keeps it from happening silently again."""
 import importlib.util
 import os
@@ -82,7 +82,7 @@ def test_no_spill_traffic_inside_the_k_loop_of_production_kernels():
         # no waterfall loop around the K loop's buffer operations: every descriptor input goes through readfirstlane (round 4: the stream
         # and pipe kernels carried ~12 extra instructions per LDS-DMA piece of the activation tile and of the scales)
         assert r['waterfalls_at_k_loop'] == 0, f'{name}: {r["waterfalls_at_k_loop"]} waterfall loops at the K loop (a descriptor is not provably uniform)'
-        # the asm-load rule (DESIGN.md "A latent race"): nothing touches a landing VGPR between its buffer_load and the wait that
+        # the asm-load rule (HISTORY.md "A latent race"): nothing touches a landing VGPR between its buffer_load and the wait that
         # covers it, anywhere in the kernel; inside the K loop no branch is taken while such a load is in flight
         assert not r['landing_touches'], f'{name}: landing registers touched before their wait: {r["landing_touches"][:3]}'
         # (the skinny kernels' loads are ordinary compiler-tracked loads -- hipcc places their waits itself, also across its own branches)

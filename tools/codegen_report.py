@@ -34,7 +34,7 @@ def landing_hazards(body):
     """The "asm load" rule, checked on the instruction stream: a vector-memory load that lands in VGPRs makes them valid only
     after an s_waitcnt whose vmcnt leaves no more operations outstanding than were issued after it (vector-memory operations
     of a wave retire in order).  Until then no instruction may touch those registers (hipcc treats the destinations of an
-    inline-asm load as ordinary values and has copied them early once, DESIGN.md "A latent race"), and no branch may be taken:
+    inline-asm load as ordinary values and has copied them early once, HISTORY.md "A latent race"), and no branch may be taken:
     the rule the kernels follow is "an asm load reaches its wait in straight-line code".  Returns the violations found in the
     linear instruction sequence `body`: (index, kind, instruction) with kind 'touch' or 'branch'."""
     outstanding = []            # per vector-memory operation in issue order: set of landing VGPRs (empty for stores / LDS-DMA)

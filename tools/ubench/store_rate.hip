@@ -1,5 +1,5 @@
 // Round 4 probe: what bounds the output tail of a one-tile-per-CU GEMM (256 workgroups each writing a 256 x 256 BF16 tile = 128 KiB,
-// 33.5 MB chip-wide)?  DESIGN.md measured 10.2 k cycles for it (~12.8 B/clk/CU, 5.6 TB/s chip-wide) with plain stores.
+// 33.5 MB chip-wide)?  HISTORY.md measured 10.2 k cycles for it (~12.8 B/clk/CU, 5.6 TB/s chip-wide) with plain stores.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/store_rate tools/ubench/store_rate.hip && tools/ubench/store_rate
 // Every workgroup (8 waves) writes its tile of a 4096 x 4096 BF16 matrix the way store_rows_full_line does: one wave instruction =
 // 8 rows x 128 contiguous bytes (16 bytes per lane).  Modes = the cache-policy bits of the store (none / nt / sc0 / sc1 / sc0 sc1 /
