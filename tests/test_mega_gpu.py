@@ -169,7 +169,12 @@ def _unfused_moe(x, topk_idx, topk_w, w1, w2, clamp):
 def test_reference_shaped_mega_moe_entry(tokens, experts, topk, hidden, inter, clamp):
     """fp8_mega_moe(y, l1, l2, sym_buffer) (deep_gemm/mega/__init__.py:155-173) at world size 1: routing -> fused L1 -> L2 -> combine ==
     the unfused pipeline bit for bit; entries without an expert (-1) are skipped; the per-expert counts land in the stats tensor; the
-    whole call replays as a hipGraph with different inputs."""
+    whole call replays as a hipGraph with different inputs.
+    The comparator (`_unfused_moe`) is THIS LIBRARY's own operators called row by row plus torch -- not the oracle: it proves the
+    orchestration (scatter, slots, weights, combine order) and the fusion, not the GEMM arithmetic.  Each stage is pinned to the C oracle
+    elsewhere: the masked GEMM in tests/test_gemm_gpu.py / test_full_output_parity_gpu.py (every element of C5), the fused SwiGLU +
+    re-quantisation in test_fused_swiglu_against_the_c_oracle below, the casts in tests/test_quant_gpu.py; the multi-rank form of the
+    same operator is checked against the oracle directly in tests/test_mega_gloo.py."""
     gen.reset_seed(tokens + experts)
     x = _quantised_tokens(tokens, hidden)
     cast = lambda w: tuple(torch.stack(t) for t in zip(*[per_block_cast_to_fp8(w[g], use_ue8m0=False) for g in range(experts)]))   # noqa: E731
