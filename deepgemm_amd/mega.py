@@ -197,9 +197,12 @@ class SymmBuffer:
 
     def __init__(self, group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
                  num_ring_tokens: int = 0, mma_type: str = 'fp8xfp8', activation: str = 'swiglu', device='cuda',
-                 expert_capacity: Optional[int] = None, exchange_capacity: Optional[int] = None):
+                 expert_capacity: Optional[int] = None, exchange_capacity: Optional[int] = None, force_exchange: bool = False):
         host_assert(activation == 'swiglu', "activation == 'swiglu'")
         self.world = 1 if group is None else group.size()
+        # force_exchange: take the multi-rank path (fixed-shape all-to-alls around the two GEMMs) even with one rank -- how the 1-GPU test box
+        # runs the HIP side of that path over RCCL (tests/test_ep_gpu.py); needs an initialised process group
+        self.exchange = self.world > 1 or force_exchange
         if mma_type not in ('fp8xfp8', 'fp8'):
             raise RuntimeError(f"SymmBuffer: mma_type '{mma_type}' is not supported on gfx950 (FP8 e4m3 activations x FP8 e4m3 weights only)")
         host_assert(hidden % 128 == 0 and intermediate_hidden % 128 == 0, 'hidden % 128 == 0 and intermediate_hidden % 128 == 0')
@@ -215,7 +218,7 @@ class SymmBuffer:
         self.topk_weights = torch.zeros((t, num_topk), dtype=torch.float, device=device)
         self.errors = torch.zeros((4,), dtype=torch.int32, device=device)        # word 0: rows dropped by the routing (over a capacity)
         self.buffer = self.x                                                    # (reference attribute; no symmetric heap here)
-        if self.world == 1:
+        if not self.exchange:
             m = t                                                               # one token meets an expert at most once
             self.exchange_capacity = 0
         else:
@@ -230,7 +233,7 @@ class SymmBuffer:
         if torch.device(device).type == 'cuda':
             self.l2_acts, self.l2_acts_sf = empty_intermediate(e, m, intermediate_hidden, device)
             self.workspace = swiglu_workspace(e, m, 2 * intermediate_hidden, device)
-        if self.world == 1:
+        if not self.exchange:
             self.l1_acts = torch.zeros((e, m, hidden), dtype=torch.float8_e4m3fn, device=device)
             self.l1_acts_sf = torch.zeros((e, hidden // 128, aligned), dtype=torch.float, device=device).transpose(1, 2)   # [E, m, H/128], MN-major
             self.row_weight = torch.zeros((e, aligned), dtype=torch.float, device=device)
@@ -279,7 +282,7 @@ def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair
     host_assert(l2_weights[0].size(0) == b.num_local_experts and l2_weights[0].size(1) == b.hidden and l2_weights[0].size(2) == b.intermediate_hidden,
                 'l2_weights[0].shape == (num_experts / num_ranks, hidden, intermediate_hidden)')
     host_assert(l1_weights[0].size(0) == b.num_local_experts, 'l1_weights[0].size(0) == num_experts / num_ranks')
-    if b.world > 1:
+    if b.exchange:
         _mega_moe_ep(y, l1_weights, l2_weights, b, cumulative_local_expert_recv_stats, activation_clamp, local_ops)
         return
     require_device(y, b.x, l1_weights[0], l2_weights[0])

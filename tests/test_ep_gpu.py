@@ -60,3 +60,55 @@ def test_ep_step_single_rank_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_mega_moe_exchange_path_single_rank_nccl():
+    """The multi-rank form of fp8_mega_moe (fixed-shape all-to-alls + routing weight travelling with the rows + the two HIP GEMM launches
+    + FP32 top-k sum; deepgemm_amd/mega.py::_mega_moe_ep) on the GPU: one rank over RCCL, forced onto that path -- the same bits as the
+    one-rank scatter / combine kernels, no host synchronisation.  (More than one rank: tests/test_mega_gloo.py on CPU, oracle as the
+    local operators; an N > 1 GPU run needs a multi-GPU node.)"""
+    import deepgemm_amd as dg
+    from deepgemm_amd import mega
+    from deepgemm_amd.utils.math import per_block_cast_to_fp8, per_token_cast_to_fp8
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29711')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(11)
+        tokens, experts, topk, hidden, inter = 37, 8, 3, 512, 256
+        x = per_token_cast_to_fp8(torch.randn((tokens, hidden), device='cuda', dtype=torch.bfloat16), use_ue8m0=False)
+        cast = lambda w: tuple(torch.stack(t) for t in zip(*[per_block_cast_to_fp8(w[g], use_ue8m0=False) for g in range(experts)]))   # noqa: E731
+        w1 = cast(torch.randn((experts, 2 * inter, hidden), device='cuda', dtype=torch.bfloat16) / hidden ** 0.5)
+        w2 = cast(torch.randn((experts, hidden, inter), device='cuda', dtype=torch.bfloat16) / inter ** 0.5)
+        topk_w, topk_idx = torch.topk(torch.rand((tokens, experts), device='cuda'), topk, dim=1)
+        topk_idx = topk_idx.to(torch.int64)
+        topk_idx[0, -1] = -1
+        l1_t, l2_t = dg.transform_weights_for_mega_moe(w1, w2)
+        outs = []
+        for force in (False, True):
+            buf = mega.SymmBuffer(dist.group.WORLD, experts, tokens, topk, hidden, inter, force_exchange=force)
+            assert buf.exchange == force
+            buf.x[:tokens].copy_(x[0]); buf.x_sf[:tokens].copy_(x[1])
+            buf.topk_idx[:tokens].copy_(topk_idx); buf.topk_weights[:tokens].copy_(topk_w.float())
+            stats = torch.zeros((experts,), dtype=torch.int, device='cuda')
+            y = torch.full((tokens, hidden), float('nan'), device='cuda', dtype=torch.bfloat16)
+            dg.fp8_mega_moe(y, l1_t, l2_t, buf, cumulative_local_expert_recv_stats=stats, activation_clamp=10.0)     # warm-up (workspaces)
+            torch.cuda.synchronize()
+            if force:
+                stats.zero_()
+                torch.cuda.set_sync_debug_mode('error')
+                try:
+                    dg.fp8_mega_moe(y, l1_t, l2_t, buf, cumulative_local_expert_recv_stats=stats, activation_clamp=10.0)
+                finally:
+                    torch.cuda.set_sync_debug_mode('default')
+                torch.cuda.synchronize()
+            assert int(buf.errors[0]) == 0 and int(buf.errors[1]) == 0
+            counts = torch.bincount(topk_idx[topk_idx >= 0].flatten(), minlength=experts).to(torch.int)
+            assert torch.equal(stats, counts)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), f'max |diff| {(outs[0].float() - outs[1].float()).abs().max().item():.3e}'
+    finally:
+        if created:
+            dist.destroy_process_group()
