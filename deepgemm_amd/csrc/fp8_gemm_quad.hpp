@@ -510,8 +510,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 // ---- rows 0 .. MS-3 ----
                 #pragma unroll
                 for (int step = 0; step < PRE; ++step) {
-                    const int ms = step / NS, ns = step % NS;
-                    if (ns == 0 && !NO_READS)
+                    // boustrophedon order (round 5): at a row change the B fragment stays, so one operand of EVERY MFMA equals its predecessor's --
+                    // on this power-limited part worth 0.4-0.5 us of 79 (same box, 3 of 4 pairs: profiles/r05_probe/quad_serpentine_order_ab.log);
+                    // the accumulators are independent: same bits
+                    const int ms = step / NS, ns = (ms & 1) ? NS - 1 - step % NS : step % NS;
+                    if (step % NS == 0 && !NO_READS)
                         af[(ms + 2) & 3] = load_fragment(a_tile + (ms + 2) * 2048, frag_off);
                     mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
                     // pieces: one per PRE_STRIDE steps: second half of B(kb+1), then A(kb+2)
@@ -552,7 +555,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 // ---- rows MS-2, MS-1, ns-major ----
                 #pragma unroll
                 for (int step = 0; step < POST; ++step) {
-                    const int ms = MS - 2 + (step & 1), ns = step >> 1;
+                    const int ns = step >> 1, ms = MS - 2 + ((step & 1) ^ (ns & 1));
                     mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
                     if ((step & 1) && !NO_READS)
                         bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
