@@ -385,11 +385,14 @@ def graph_replay_seconds(calls, per_graph: int) -> float:
     with torch.cuda.graph(graph):
         for i in range(per_graph):
             calls[i % len(calls)]()
-    # (the first replays of a freshly instantiated graph run ~10 % slower than the steady state -- tools/decode_replay_probe.py: 30.4 us per
-    #  call in the first 10 replays, 27.4-27.7 afterwards, the same as back-to-back eager calls: warm it up like any other timed loop)
-    for _ in range(12):
-        graph.replay()
-    torch.cuda.synchronize()
+    # (capturing leaves the GPU idle for a few milliseconds and its clocks fall back: the first ~11 replays -- ~7 ms of load -- of a fresh graph
+    #  run 30.4 us per call, every later one 27.4, the back-to-back eager rate; tools/decode_replay_probe2.py,
+    #  profiles/r05_probe/decode_graph_replay_vs_eager.log.  Warm up by TIME, as the main loop does, then measure)
+    t_warm = time.perf_counter() + 0.05
+    while time.perf_counter() < t_warm:
+        for _ in range(4):
+            graph.replay()
+        torch.cuda.synchronize()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(20):

@@ -1679,6 +1679,15 @@ __device__ __forceinline__ void promote_only_v(float (&c)[4], const float (&s)[4
 // of B(kb+1) in its L(kb) (B(kb-1)'s slot: everybody's L(kb-1) reads are done), the UPPER half all pieces of A(kb+2) in its L(kb)
 // (A(kb-1)'s slot: the upper half itself finished M(kb-1) last).  Prologue: A(0) B(0) A(1).
 // LDS bytes of a duo body: three A slots, two B slots (MERGED: three)
+// Step i of a matrix segment of the duo forms -> its N-subtile: boustrophedon order (round 5), so that the B-side operand of a step equals its
+// predecessor's at every change of the A fragment -- one operand of EVERY MFMA is then unchanged from the step before.  The part is power-limited:
+// same box, four alternating pairs, C2 93.76 -> 93.16 us, C3 nt 30.65 -> 30.42 (profiles/r05_probe/duo_serpentine_order_ab.log); every
+// accumulator still sees its own K blocks in order: same bits.  -DDG_DUO_ROWMAJOR restores the old order.
+#ifndef DG_DUO_ROWMAJOR
+#define DUO_NS(i) ((((i) / NS) & 1) ? NS - 1 - (i) % NS : (i) % NS)
+#else
+#define DUO_NS(i) ((i) % NS)
+#endif
 constexpr int duo_lds_bytes(int bm, int bn, bool merged) { return 3 * bm * 128 + (merged ? 3 : 2) * bn * 128; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
@@ -2232,10 +2241,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                     raw_barrier();
                     #pragma unroll
                     for (int i = 0; i < TOTAL; ++i) {
-                        const int ns = i % NS, h = i / NS;
+                        const int ns = DUO_NS(i), h = i / NS;
                         const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
                         const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
-                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][DUO_NS(j)], jscale, part[(i + 1) & DEPTH]);
                     }
                     wait_landing_any<A_ITERS + B_ITERS, MS>(land);      // the scales of block kb+1, in front of the back edge
                     const int b_next = (b_cur == (B_SLOTS - 1) * B_BYTES) ? 0 : b_cur + B_BYTES;
@@ -2288,10 +2297,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                     raw_barrier();
                     #pragma unroll
                     for (int i = 0; i < SEG; ++i) {
-                        const int ns = i % NS, h = i / NS;
+                        const int ns = DUO_NS(i), h = i / NS;
                         const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
                         const float jscale = (i >= DEPTH) ? scale[j / NS] : scale_tail;
-                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], jscale, part[(i + 1) & DEPTH]);
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][DUO_NS(j)], jscale, part[(i + 1) & DEPTH]);
                     }
 
                     // ---------------- L_b ----------------
@@ -2327,9 +2336,9 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                     #pragma unroll
                     for (int i2 = 0; i2 < SEG; ++i2) {
                         const int i = SEG + i2;
-                        const int ns = i % NS, h = i2 / NS;
+                        const int ns = DUO_NS(i), h = i2 / NS;
                         const int j = i - DEPTH;
-                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][j % NS], scale[j / NS], part[(i + 1) & DEPTH]);
+                        mfma_promote_step(part[i & DEPTH], bf[ns], af[h], acc[j / NS][DUO_NS(j)], scale[j / NS], part[(i + 1) & DEPTH]);
                     }
 
                     b_cur ^= B_BYTES;
@@ -2352,7 +2361,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                     if constexpr (PC)
                         promote_only_v(acc[j / NS][j % NS], tailp[i], part[(TOTAL + i + 1) & DEPTH]);
                     else
-                        promote_only(acc[j / NS][j % NS], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
+                        promote_only(acc[j / NS][STREAM_A ? j % NS : DUO_NS(j)], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
                 }
             };
             if constexpr (K_TAIL) {
