@@ -287,12 +287,12 @@ const E8Config kE8Configs[] = {
 // Tuning / diagnostic environment variables are read ONCE (first use): the launch paths are hot (a cached dense call is ~8 us of host time).
 struct EnvKnobs {
     bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks;
-    int group_m;
+    int group_m, ks_pieces;
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
           sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr),
-          group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0) {}
+          group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0) {}
 };
 EnvKnobs& env_knobs() {
     static EnvKnobs knobs;
@@ -644,10 +644,12 @@ int per_col_split_pieces(const dg::GemmParams& p, size_t workspace_bytes, bool i
     const long tiles = static_cast<long>(ceil_div(p.m, 256)) * ceil_div(p.n, 256), num_kb = p.k / 128;
     const size_t per_piece = static_cast<size_t>(p.m) * p.n * sizeof(float);
     long pieces = std::min<long>(std::min<long>(8, num_cus() / tiles), num_kb / 4);
-    if (workspace_bytes > 0)
-        pieces = std::min<long>(pieces, workspace_bytes > 4096 ? static_cast<long>((workspace_bytes - 4096) / per_piece) : 0);
+    const long fit = workspace_bytes > 0 ? (workspace_bytes > 4096 ? static_cast<long>((workspace_bytes - 4096) / per_piece) : 0) : 8;
+    pieces = std::min<long>(pieces, fit);
     if (pieces < 2 || num_kb < 24)
         return 0;
+    if (env_knobs().ks_pieces >= 2)             // (tuning runs, DG_KS_PIECES: force the number of K pieces)
+        return static_cast<int>(std::min<long>(std::min<long>(env_knobs().ks_pieces, fit), std::min<long>(8, num_kb / 4)));
     const double t_one = 15.0 + 2.2 * num_kb;
     const double t_split = 30.0 + 2.2 * ((num_kb + pieces - 1) / pieces) + static_cast<double>(pieces) * per_piece / 4.0e6;
     return t_split < 0.75 * t_one ? static_cast<int>(pieces) : 0;
