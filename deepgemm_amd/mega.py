@@ -296,7 +296,7 @@ def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair
     expected_m = max(1, min(m, -(-tokens * b.num_topk // b.num_experts)))
     m_grouped_fp8_gemm_nt_masked_swiglu((b.l1_acts, b.l1_acts_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m,
                                         activation_clamp, workspace=b.workspace, row_weight=b.row_weight)
-    b.errors[1:2] += b.workspace[:4].view(torch.int32)        # word 1: partner waits of the fused kernel that timed out (rows carry NaN)
+    b.errors[1:2].copy_(b.workspace[:4].view(torch.int32))   # word 1: partner waits of the fused kernel that timed out since the workspace was zeroed
     m_grouped_fp8_gemm_nt_masked((b.l2_acts, b.l2_acts_sf), l2_weights, b.l2_out, b.masked_m, expected_m)
     check(lib.dg_moe_combine_from_masked(b.l2_out.data_ptr(), b.slot.data_ptr(), tokens, b.num_topk, b.hidden, b.l2_out.stride(1),
                                          y.data_ptr(), y.stride(0), stream))
@@ -326,7 +326,7 @@ def _mega_moe_ep(y, l1_weights, l2_weights, b: SymmBuffer, stats, activation_cla
     if local_ops is None:
         m_grouped_fp8_gemm_nt_masked_swiglu((a, a_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m, activation_clamp,
                                             workspace=b.workspace, row_weight=plan.row_extra)
-        b.errors[1:2] += b.workspace[:4].view(torch.int32)
+        b.errors[1:2].copy_(b.workspace[:4].view(torch.int32))
         m_grouped_fp8_gemm_nt_masked((b.l2_acts, b.l2_acts_sf), l2_weights, b.l2_out, b.masked_m, expected_m)
     else:
         inter = local_ops[0]((a, a_sf), l1_weights, b.masked_m, activation_clamp, plan.row_extra)
