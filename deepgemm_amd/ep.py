@@ -141,7 +141,8 @@ class FixedPlan:
     pair_dest: torch.Tensor           # [P] flat slot (rank, local expert, position) of every sorted pair in the exchanged blocks;
                                       #     world * per_rank * capacity = the dump slot (no expert, or over capacity: the pair's result is zeros)
     recv_expert: torch.Tensor         # [world * per_rank * capacity] local expert of every received slot
-    recv_slot: torch.Tensor           # same shape: row inside that expert's masked block (invalid slots: clamped, never read back)
+    recv_slot: torch.Tensor           # same shape: row inside that expert's masked block (invalid slots: clamped)
+    recv_valid: torch.Tensor          # same shape, bool: the slot holds a row this rank kept (not padding, not over ``max_m``)
     masked_m: torch.Tensor            # [G_local] int32 rows per local expert
     overflow: torch.Tensor            # 0-dim bool: a block or an expert was over capacity (rows were dropped)
     row_extra: Optional[torch.Tensor] = None   # [G_local, max_m] FP32: the per-pair value that travelled with the rows (routing weight)
@@ -222,7 +223,7 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
         extra_store = torch.zeros((per_rank * max_m + 1,), dtype=torch.float, device=device)
         extra_store[flat_row] = flat[:, k + sf_bytes:].contiguous().view(torch.float).reshape(-1)
         extra = extra_store[:per_rank * max_m].view(per_rank, max_m)
-    plan = FixedPlan(order, pair_dest, recv_expert, recv_slot, masked_m, overflow, extra)
+    plan = FixedPlan(order, pair_dest, recv_expert, recv_slot, valid.reshape(-1), masked_m, overflow, extra)
     a = a_store[:per_rank * max_m].view(torch.float8_e4m3fn).view(per_rank, max_m, k)
     return (a, sf_store[:per_rank * max_m].view(per_rank, max_m, x_sf.size(1))), plan
 
@@ -230,11 +231,11 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
 def combine_fixed(d: torch.Tensor, plan: FixedPlan, tokens: int, top_k: int, world: int, capacity: int, group=None,
                   topk_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The return path of :func:`dispatch_fixed`: result rows travel back in the same fixed-shape blocks (one equal-split all-to-all),
-    every rank picks its pairs' rows out of the blocks it gets back (zeros for pairs without an expert or over capacity).  Same outputs
-    as :func:`combine`."""
+    every rank picks its pairs' rows out of the blocks it gets back (zeros for pairs without an expert, over ``capacity`` on the sender
+    or over ``max_m`` on the receiver -- a dropped pair never returns somebody else's row).  Same outputs as :func:`combine`."""
     per_rank, max_m, n = d.size(0), d.size(1), d.size(2)
-    # (invalid entries read some valid row: those slots of the blocks are never picked by their source rank)
-    blocks = d[plan.recv_expert, plan.recv_slot].view(world, per_rank, capacity, n).contiguous()
+    picked = d[plan.recv_expert, plan.recv_slot]
+    blocks = torch.where(plan.recv_valid.unsqueeze(-1), picked, torch.zeros_like(picked)).view(world, per_rank, capacity, n).contiguous()
     back = torch.zeros((world * per_rank * capacity + 1, n), dtype=d.dtype, device=d.device)           # last row: the dump slot's zeros
     dist.all_to_all_single(back[:-1].view(world, per_rank, capacity, n), blocks, group=group)
     out = torch.empty((tokens * top_k, n), dtype=d.dtype, device=d.device)

@@ -70,9 +70,23 @@ def _worker(rank: int, world: int, port: int, num_experts: int, tokens: int, top
         flag_local = torch.tensor([int(busiest > 2)])
         assert bool(plan_fixed.overflow) or int(flag_local) == 0                 # my own over-full blocks are always reported
 
-        # capacity overflow is an error, not silent truncation
+        # an expert over max_m on the RECEIVER: the rows that fitted come back right, the dropped ones as zeros (never another pair's row)
+        small = 4
+        to_zero = torch.zeros((x.size(0), 1), dtype=torch.int64)
+        (a_small, sf_small), plan_small = ep.dispatch_fixed(xq, to_zero, num_experts, small, tokens + world)
+        d_small = torch.zeros((last - first, small, n), dtype=torch.bfloat16)
+        _oracle_local_gemm((a_small, sf_small), b_local, d_small, plan_small.masked_m, small)
+        back = ep.combine_fixed(d_small, plan_small, x.size(0), 1, world, tokens + world)
+        kept = small if rank == 0 else 0                                # slots go to the rows of earlier sources first
+        for t in range(x.size(0)):
+            want = torch.zeros((1, n), dtype=torch.bfloat16)
+            if t < kept:
+                oracle.fp8_gemm_nt(xq[0][t:t + 1], xq[1][t:t + 1], b_all[0][0], b_all[0][1], want)
+            assert torch.equal(back[t, 0], want[0]), (rank, t)
         if rank == 0:
-            pass
+            assert bool(plan_small.overflow) and int(plan_small.masked_m[0]) == small
+
+        # capacity overflow is an error, not silent truncation
         crowded = torch.zeros((max_m + 1, 1), dtype=torch.int64)  # every row to expert 0
         xs = per_token_cast_to_fp8(torch.randn((max_m + 1, k), dtype=torch.bfloat16), use_ue8m0=False)
         try:
