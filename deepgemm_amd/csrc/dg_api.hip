@@ -140,6 +140,10 @@ const Config kConfigs[] = {
     // the same with the non-temporal policy on the weight stream's LDS-DMA: +3-5 % when the weights of one launch exceed the 256 MiB
     // Infinity Cache anyway (32 experts x 6144 x 7168: 254 -> 245 us), neutral to -8 % below that (they would have stayed resident)
     {"stream_nt_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2>, true},
+    // round 5: a 3-stage ring (77 KiB of LDS) so that TWO workgroups share a CU: 257 .. 512 tiles of 64 x 128 are then ONE resident round
+    // instead of a full round and a mostly idle one (the masked GEMM2 of the expert MLP: 8 experts x 7168 x 2048 = 448 tiles)
+    {"stream2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3>, true},
+    {"stream_nt2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
     {"stream_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4>, true},
     // round 4: the same tiles with loader waves (4 compute waves + 4 / 12 that only issue LDS-DMA pieces): a stream tile is bound by the
@@ -241,7 +245,7 @@ const Config kConfigs[] = {
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 // Kernels of the packed-UE8M0 entry points (hardware-scaled MFMA); selected by launch_e8, forced by name for A/B runs.
-struct E8Config { const char* name; KernelFn fn; int bm, bn, threads; bool whole_quads; bool grouped_ok; bool stream; };
+struct E8Config { const char* name; KernelFn fn; int bm, bn, threads; bool whole_quads; bool grouped_ok; bool stream; int per_cu = 1; };
 const E8Config kE8Configs[] = {
     {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, 256, 256, true, true, false},
     {"e8_quad_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>, 128, 256, 256, false, true, false},
@@ -265,6 +269,9 @@ const E8Config kE8Configs[] = {
     // K block, fragment reads and LDS-DMA pieces in separate phases (fp8_gemm_quad.hpp, HS)
     {"e8_quad_h_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 1>, 256, 256, 256, true, true, false},
     {"e8_quad_h2_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 2>, 256, 256, 256, true, true, false},
+    // round 5: the stream tile on a 3-stage ring (74 KiB of LDS), two workgroups per CU (stream2_64x128 above)
+    {"e8_stream2_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 0, 1, true>, 64, 128, 256, false, true, true, 2},
+    {"e8_stream_nt2_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2, 1, true>, 64, 128, 256, false, true, true, 2},
 #ifdef DG_EXPERIMENTS
     {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
     {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
@@ -286,12 +293,12 @@ const E8Config kE8Configs[] = {
 
 // Tuning / diagnostic environment variables are read ONCE (first use): the launch paths are hot (a cached dense call is ~8 us of host time).
 struct EnvKnobs {
-    bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks;
+    bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks, swiglu_one_per_cu;
     int group_m, ks_pieces;
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
-          sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr),
+          sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
           group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0) {}
 };
 EnvKnobs& env_knobs() {
@@ -539,24 +546,17 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // 1024 x 512 x 8192: 30.5 / 42.8; break-even near K = 7168 -- 512 x 4096 x 7168: 38.7 / 39.7, 4096 x 512 x 4096: 32.6 / 25.3).
         // Model: stream = 5 us + 0.66 (64 x 128) or 0.27 (64 x 32, four K blocks per stage) us per K block, split = 16 us + 1.05 us per K block of a piece
         // (two-phase exchange: 1024 x 512 x 8192 21.8 us, 1024 x 1024 x 16384 33.2, 512 x 4096 x 7168 31.3, 4096 x 512 x 4096 25.2 / stream 24.2).
-        // Decode-sized M with MORE 64 x 128 tiles than CUs: the second round of one-tile-per-CU stream tiles is mostly idle, while the
-        // 128 x 256 duo tile (two-segment schedule, 3 x 32 KiB weight ring) covers the same columns in half as many tiles and reaches
-        // the HBM floor -- 6 experts x 6144 x 7168: 72.1 -> 48.0 us, x 7168 x 3072: 37.2 -> 26.4 (tools/masked_bench.py); with at most
-        // one round (C5: 256 tiles) or many rounds (32 experts: HBM-bound either way) the stream tile stays.  Model (us): stream
-        // 5 + rounds x K blocks x 0.62, duo 6 + rounds x K blocks x 0.80, both floored by the weight bytes at 5.8 TB/s.
-        if (pick != nullptr && m_hint <= 64 && std::strcmp(pick, "stream_64x128") == 0 && tiles128 > num_cus()) {
-            const long slots = num_cus();
-            const long num_kb = p.k / 128;
-            const long rounds_s = (tiles128 + slots - 1) / slots;
-            const long rounds_d = (static_cast<long>(groups) * ceil_div(p.n, 256) + slots - 1) / slots;
-            const double floor_us = static_cast<double>(groups) * p.n * p.k / 5.8e6;
-            const double t_s = std::max(floor_us, 5.0 + rounds_s * num_kb * 0.62), t_d = std::max(floor_us, 6.0 + rounds_d * num_kb * 0.80);
-            if (t_d < 0.9 * t_s)
-                pick = "duo_128x256";
-        }
-        if (pick != nullptr && std::strcmp(pick, "stream_64x128") == 0 &&
-            static_cast<double>(groups) * p.n * p.k >= 200e6)
-            pick = "stream_nt_64x128";
+        // (Rounds 2-4 sent decode-sized M with MORE 64 x 128 tiles than CUs to the 128 x 256 duo tile -- the second round of one-tile-per-CU
+        // stream tiles was mostly idle.  With two workgroups per CU, below, the stream tile wins or ties on every shape of that class:
+        // 8 experts x 7168 x 2048 25.5 us against 29.9, 6 x 7168 x 3072 33.8 / 36.7, 16 x 7168 x 2048 49.4 / 56.1, 8 x 7168 x 4096 49.8 / 57.6,
+        // 12 x 4096 x 7168 71.5 / 73.3, 6 x 6144 x 7168 64.9 / 64.0, 32 x 4096 x 7168 164.7 / 165.8 -- profiles/r05_probe/stream2_masked.jsonl.)
+        // round 5: the 64 x 128 stream tile runs with a 3-stage ring and TWO workgroups per CU (stream2_64x128): 8 waves issue the CU's LDS-DMA
+        // pieces instead of 4, 257 .. 512 tiles are one resident round, and ramps of one workgroup hide behind the other's steady state --
+        // rotating input sets, same box: C5 43.4 -> 41.6 us, dense 64 x 24576 x 1536 13.1 -> 11.2, 256 x 7168 x 2048 14.6 -> 12.9
+        // (profiles/r05_probe/stream2_masked.jsonl, stream2_dense.jsonl).  Non-temporal weight stream from 80 MB of weights per launch
+        // (117 MB: 25.5 us against 28.3 with the default policy; 59 MB: 14.3 against 14.0).
+        if (pick != nullptr && std::strcmp(pick, "stream_64x128") == 0)
+            pick = static_cast<double>(groups) * p.n * p.k >= 80e6 ? "stream_nt2_64x128" : "stream2_64x128";
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && m_hint > 64) {
             const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
             const long num_kb = p.k / 128;
@@ -935,6 +935,13 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
 // the 4-wave in-place-accumulating quad kernels -- 256 x 256 tiles for dense problems of whole K quads that fill the chip and
 // for contiguous layouts with several rounds of two-pass tiles, 128 x 256 tiles otherwise; the 8-wave forms only by name.
 // Automatic choice among the packed-UE8M0 kernels (forced names are resolved by the caller).
+const E8Config* e8_config_by_name(const char* name) {
+    for (const E8Config& c : kE8Configs)
+        if (std::strcmp(c.name, name) == 0)
+            return &c;
+    return nullptr;
+}
+
 const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
     const E8Config* cfg = nullptr;
     {
@@ -959,15 +966,8 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
                 pick = &kE8Configs[5];
             else if (m_hint <= 256 && tiles128 < 256)
                 pick = &kE8Configs[3];
-            if (pick == &kE8Configs[3] && tiles128 > num_cus()) {   // more stream tiles than CUs: the round model of select_config (128 x 256 tile = the quad form)
-                const long slots = num_cus(), num_kb = p.k / 128;
-                const long rounds_s = (tiles128 + slots - 1) / slots, rounds_d = (groups * ceil_div(p.n, 256) + slots - 1) / slots;
-                const double floor_us = static_cast<double>(groups) * p.n * p.k / 5.8e6;
-                if (std::max(floor_us, 6.0 + rounds_d * num_kb * 0.80) < 0.9 * std::max(floor_us, 5.0 + rounds_s * num_kb * 0.62))
-                    pick = nullptr;
-            }
-            if (pick == &kE8Configs[3] && static_cast<double>(groups) * p.n * p.k >= 200e6)
-                pick = &kE8Configs[4];
+            if (pick == &kE8Configs[3])         // two workgroups per CU on a 3-stage ring, non-temporal weights from 80 MB per launch (select_config)
+                pick = e8_config_by_name(static_cast<double>(groups) * p.n * p.k >= 80e6 ? "e8_stream_nt2_64x128" : "e8_stream2_64x128");
             if (pick != nullptr)
                 cfg = pick;
         }
@@ -1044,7 +1044,8 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
     if (p.gemm_type == dg::kMasked)
         total *= p.num_groups;
-    const long grid = total < num_cus() ? total : num_cus();          // every kernel walks tile_id += gridDim.x
+    const long slots = static_cast<long>(num_cus()) * cfg->per_cu;
+    const long grid = total < slots ? total : slots;                  // every kernel walks tile_id += gridDim.x
     if (grid <= 0)
         return 0;
     hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(grid)), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
@@ -1391,9 +1392,15 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(const void* a, const float* 
     o.q_sg = out_stride_g; o.q_sm = out_stride_m; o.sf_sg = out_sf_stride_g; o.sf_sk = out_sf_stride_k;
     o.clamp = activation_clamp; o.use_ue8m0 = use_ue8m0 ? 1 : 0;
     o.row_weight = row_weight; o.rw_sg = row_weight_stride_g;
-    const long grid = std::min<long>(max_tiles, std::max(2, num_cus() & ~1));     // even: tile t and its partner t ^ 1 run in the same iteration
-    g_last_config = "stream_swiglu_64x128";
-    hipLaunchKernelGGL(dg::dg_fp8_gemm_stream_swiglu_kernel<6>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), p, o);
+    // round 5: 3-stage ring, two workgroups per CU (the stream2_64x128 form of select_config); DG_SWIGLU_ONE_PER_CU=1 keeps the 6-stage ring (A/B)
+    const bool two = !env_knobs().swiglu_one_per_cu;
+    const long slots = two ? 2L * num_cus() : num_cus();
+    const long grid = std::min<long>(max_tiles, std::max<long>(2, slots & ~1L));  // even: tile t and its partner t ^ 1 run in the same iteration
+    g_last_config = two ? "stream_swiglu2_64x128" : "stream_swiglu_64x128";
+    if (two)
+        hipLaunchKernelGGL(dg::dg_fp8_gemm_stream_swiglu_kernel<3>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), p, o);
+    else
+        hipLaunchKernelGGL(dg::dg_fp8_gemm_stream_swiglu_kernel<6>, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), p, o);
     DG_HIP_CHECK(hipGetLastError());
     (void)expected_m;
     return 0;

@@ -14,7 +14,7 @@ from deepgemm_amd.testing import calc_diff, generators as gen
 from gpu_helpers import assert_close_fp32, assert_close_to_oracle, cpu_pair, oracle_dense
 
 pytestmark = pytest.mark.gpu
-FAST = ['stream_64x128', 'stream_nt_64x128', 'stream_64x32', 'stream_l8_64x32', 'duo_256x256', 'duo_p_256x256', 'duo_128x256', 'pipe_256x256', 'pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'pipe_32x256', 'pipe_16x256']
+FAST = ['stream_64x128', 'stream_nt_64x128', 'stream2_64x128', 'stream_nt2_64x128', 'stream_64x32', 'stream_l8_64x32', 'duo_256x256', 'duo_p_256x256', 'duo_128x256', 'pipe_256x256', 'pipe_128x256', 'pipe_128x128', 'pipe_64x256', 'pipe_32x256', 'pipe_16x256']
 # (superseded forms and ablation variants -- ring, naive, pipe_s*, dabl* ... -- exist only in DG_EXPERIMENTS builds of the library)
 
 
@@ -940,7 +940,7 @@ def test_packed_ue8m0_scales_hw_path(m, n, k):
 
 
 E8_QUAD_256 = ['e8_quad_256x256', 'e8_quad_h_256x256', 'e8_quad_h2_256x256']     # whole K quads only; _h*: the register-resident schedule (round 5)
-E8_DENSE_CONFIGS = ['auto', *E8_QUAD_256, 'e8_quad_128x256', 'e8_duo_256x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32']
+E8_DENSE_CONFIGS = ['auto', *E8_QUAD_256, 'e8_quad_128x256', 'e8_duo_256x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream2_64x128', 'e8_stream_nt2_64x128', 'e8_stream_64x32']
 
 
 @pytest.mark.parametrize('m,n,k', [(512, 768, 1024), (300, 520, 896), (4096, 4096, 1536), (129, 4096, 384)])
@@ -1114,7 +1114,7 @@ def test_packed_ue8m0_m_grouped_masked(masked_ms, max_m, n, k):
     oracle.m_grouped_fp8_gemm_nt_masked(*cpu_pair(case.a), *cpu_pair(case.b), want, case.masked_m.cpu())
     a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
     expected_m = max(1, int(sum(masked_ms) / len(masked_ms)))
-    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream_64x32'] + (E8_QUAD_256 if k % 512 == 0 else []):
+    for cfg in ['auto', 'e8_quad_128x256', 'e8_stream_64x128', 'e8_stream_nt_64x128', 'e8_stream2_64x128', 'e8_stream_nt2_64x128', 'e8_stream_64x32'] + (E8_QUAD_256 if k % 512 == 0 else []):
         dg.set_forced_config(cfg)
         case.d.fill_(float('nan'))
         dg.m_grouped_fp8_gemm_nt_masked(a, b, case.d, case.masked_m, expected_m)

@@ -435,10 +435,10 @@ def test_automatic_kernel_selection_is_pinned():
         ['duo_p_256x256', 'duo_bmn_256x256', 'duo_abmn_256x256', 'duo_amn_256x256']
     assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128) == 'duo_tab_256x256'             # group-relative 256-row tiles + K-split remainders
     assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128, workspace=0) == 'duo_128x256'
-    assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48) == 'stream_nt_64x128'                  # 235 MB of weights: non-temporal stream
+    assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48) == 'stream_nt2_64x128'                 # two workgroups per CU; 235 MB of weights: non-temporal stream
     # packed UE8M0 scales
     assert pick(dense, 4096, 4096, 7168, packed=1) == 'e8_quad_256x256'
-    assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48, packed=1) == 'e8_stream_nt_64x128'
+    assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48, packed=1) == 'e8_stream_nt2_64x128'
     assert pick(dense, 128, 4096, 7168, packed=1) == 'e8_stream_64x32'
     # packed scales with MN-major operands: read in place where that beats a re-majoring pass (e8_mn_pays); a K tail in the nn layout (the
     # packed-scale dgrad shapes) always stays in place (round 5)
@@ -456,7 +456,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 1, 7168, 16384) == 'skinny_16w' and pick(dense, 1, 4096, 16384) == 'skinny_16' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32'
     # decode batches: the skinny weight-stream kernel for long K loops, the stream tiles for short ones / wide N
     assert pick(dense, 16, 4096, 7168) == 'skinny_16' and pick(dense, 17, 4096, 7168) == 'skinny_32' and pick(dense, 33, 4096, 7168) == 'stream_l8_64x32'
-    assert pick(dense, 1, 24576, 1536) == 'stream_64x128' and pick(dense, 1, 32768, 512) == 'stream_64x128'
+    assert pick(dense, 1, 24576, 1536) == 'stream2_64x128' and pick(dense, 1, 32768, 512) == 'stream2_64x128'
     assert pick(dense, 32, 7168, 16384) == 'stream_l8_64x32' and pick(dense, 1, 4104, 7168) != 'skinny_16'
     assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_l8_64x32'
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256'                                            # K split beats one stream tile per CU
@@ -471,9 +471,10 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128, workspace=0) == 'duo_p_256x256'  # no workspace: persistent two-pass walk
     assert pick(contiguous, 34048, 4096, 2048, groups=8, alignment=128, b_mn=1) == 'duo_bmn_256x256'
     assert pick(masked, 4096, 4096, 4096, groups=32, expected_m=192) == 'duo_p_256x256'
-    assert pick(masked, 4096, 6144, 7168, groups=6, expected_m=20) == 'duo_128x256'                     # 288 stream tiles > 256 CUs
-    assert pick(masked, 4096, 4096, 4096, groups=6, expected_m=20) == 'stream_64x128'
-    assert pick(masked, 4096, 6144, 7168, groups=32, expected_m=20) == 'stream_nt_64x128'
+    assert pick(masked, 4096, 6144, 7168, groups=6, expected_m=20) == 'stream_nt2_64x128'               # 288 stream tiles: one resident round at two per CU (round 5)
+    assert pick(masked, 64, 7168, 2048, groups=8, expected_m=48) == 'stream_nt2_64x128'                 # the expert MLP's GEMM2: 448 tiles, 117 MB
+    assert pick(masked, 4096, 4096, 4096, groups=6, expected_m=20) == 'stream_nt2_64x128' and pick(masked, 4096, 4096, 2048, groups=6, expected_m=20) == 'stream2_64x128'
+    assert pick(masked, 4096, 6144, 7168, groups=32, expected_m=20) == 'stream_nt2_64x128'
 
 
 def test_k_grouped_packed_ue8m0_scale_layout():

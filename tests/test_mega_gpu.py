@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import deepgemm_amd as dg
+from deepgemm_amd._lib import lib
 from deepgemm_amd.testing import calc_diff, generators as gen
 from deepgemm_amd.utils.math import per_block_cast_to_fp8, per_token_cast_to_fp8
 
@@ -49,7 +50,13 @@ def _unfused(x, w1, masked_ms, clamp, use_ue8m0):
                                                       ([48, 64, 17, 0, 64, 33, 2, 60], 64, 2048, 7168)])
 @pytest.mark.parametrize('use_ue8m0', [False, True])
 @pytest.mark.parametrize('clamp', [None, 10.0, 0.3])          # 0.3 is not BF16-representable (acts as 0.30078125) and actually clips
-def test_fused_swiglu_requant_is_the_unfused_pipeline(masked_ms, m_max, inter, k, use_ue8m0, clamp):
+@pytest.mark.parametrize('one_per_cu', [False, True])         # the 3-stage ring with two workgroups per CU (default) / the 6-stage ring, one per CU
+def test_fused_swiglu_requant_is_the_unfused_pipeline(masked_ms, m_max, inter, k, use_ue8m0, clamp, one_per_cu, monkeypatch):
+    if one_per_cu:
+        if clamp == 10.0:
+            pytest.skip('the 6-stage form: two of the three clamp cases are enough')
+        monkeypatch.setenv('DG_SWIGLU_ONE_PER_CU', '1')
+    lib.dg_reload_env()
     gen.reset_seed(len(masked_ms) + inter)
     groups = len(masked_ms)
     a = torch.randn((groups, m_max, k), device='cuda', dtype=torch.bfloat16)
@@ -66,7 +73,9 @@ def test_fused_swiglu_requant_is_the_unfused_pipeline(masked_ms, m_max, inter, k
     q.view(torch.uint8).fill_(0x7f)                       # NaN poison: rows >= masked_m must stay untouched
     q_sf.fill_(float('nan'))
     dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, (q, q_sf), masked, max(1, max(masked_ms)), activation_clamp=clamp, use_ue8m0=use_ue8m0)
-    assert dg.last_config() == 'stream_swiglu_64x128'
+    assert dg.last_config() == ('stream_swiglu_64x128' if one_per_cu else 'stream_swiglu2_64x128')
+    monkeypatch.delenv('DG_SWIGLU_ONE_PER_CU', raising=False)
+    lib.dg_reload_env()
     want = _unfused(x, w1, masked_ms, clamp, use_ue8m0)
     for g, rows in enumerate(masked_ms):
         if rows:
