@@ -154,10 +154,18 @@ const Config kConfigs[] = {
     {"skinny_32", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2>},
     // two N-subtiles per workgroup, 17 .. 32 columns (GemmParams::skinny_cols): one round where n / 16 is between one and two rounds
     {"skinny_16w", 16, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 2>},
+    // round 5: the same three with coalesced weight loads (8 rows x 128 bytes per instruction) turned into MFMA operands through wave-private LDS
+    {"skinny_16c", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true>},
+    {"skinny_32c", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2, 4, 1, true>},
+    {"skinny_16wc", 16, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 2, true>},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>, true, false,
      false, true},
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
      false, false, true},
+    // round 5: 192-row tiles (wave tile 96 x 64, 24 steps per K block) where they cover M with fewer rows than 256-row tiles do -- the
+    // recipe is VALU-issue bound, so a row that is not computed is time saved (576 rows: 3 x 192 against 3 x 256; per_col_bm)
+    {"pipe_pc_192x256", 192, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<192, 256, 2, 4, 1, false>, true, false,
+     false, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
 #ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants (HISTORY.md);
                         // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
@@ -259,7 +267,8 @@ const E8Config kE8Configs[] = {
     {"e8_quad_kt_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, true>, 128, 256, 256, false, false, false},
     // round 4: operand B MN-major ([K][N]: the nn layout of a packed-scale dgrad) read in place by the 8-wave hardware-scaled kernel
     // (transpose reads, natural column order) -- instead of a re-majoring pass over B in front of the quad kernel
-    {"e8_duo_bmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true>, 256, 256, 512, false, false, false},
+    // (round 5: also the contiguous layout -- grouped nn with packed scales, the weights [G][K][N] read in place; launch_e8 refuses the other grouped forms)
+    {"e8_duo_bmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true>, 256, 256, 512, false, true, false},
     // ... and A MN-major ([K][M]: the tt layout), both (tn): scale words of A in natural row order
     {"e8_duo_amn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, false, true>, 256, 256, 512, false, false, false},
     {"e8_duo_abmn_256x256", dg::dg_fp8_gemm_duo_e8_kernel<256, 256, 2, 4, true, true>, 256, 256, 512, false, false, false},
@@ -294,12 +303,13 @@ const E8Config kE8Configs[] = {
 // Tuning / diagnostic environment variables are read ONCE (first use): the launch paths are hot (a cached dense call is ~8 us of host time).
 struct EnvKnobs {
     bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks, swiglu_one_per_cu;
-    int group_m, ks_pieces;
+    int group_m, ks_pieces, pc_bm;
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
           sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
-          group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0) {}
+          group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0),
+          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0) {}
 };
 EnvKnobs& env_knobs() {
     static EnvKnobs knobs;
@@ -352,7 +362,11 @@ bool amn_eligible(const dg::GemmParams& p) {
 // _abmn_256x256: whole K blocks, scale words MN-major, 16-byte aligned rows / k-rows).
 bool e8_mn_eligible(const dg::GemmParams& p) {
     const bool a_mn = p.a_sk != 1, b_mn = p.b_sk != 1;
-    if (!(a_mn || b_mn) || p.gemm_type != dg::kNormal || p.sfa_sm != 1 || p.sfb_sn != 1 || p.head_lr != 0)
+    // round 5: also the contiguous layout (not psum) with MN-major weights [G][K][N] -- the grouped nn form; 256-row tiles, two passes over a
+    // tile whose 128-row halves belong to two groups (alignment 128) or one (alignment a multiple of 256)
+    const bool grouped_nn = p.gemm_type == dg::kContiguous && !a_mn && b_mn && p.k % 128 == 0 && p.b_sg % 16 == 0 &&
+                            (p.m_alignment == 128 || p.m_alignment % 256 == 0);
+    if (!(a_mn || b_mn) || (p.gemm_type != dg::kNormal && !grouped_nn) || p.sfa_sm != 1 || p.sfb_sn != 1 || p.head_lr != 0)
         return false;
     // K tail (whole 16-byte chunks, K > 128): the nn layout only -- A K-major, B [K][N] (round 5: e8_duo_bmn_kt_256x256, the packed-scale dgrad shapes)
     if (p.k % 128 != 0 && (a_mn || p.k % 16 != 0 || p.k <= 128))
@@ -381,8 +395,9 @@ bool e8_mn_pays(const dg::GemmParams& p) {
     if (p.k % 128 != 0)         // K tail: the alternative is a pass over B in front of the 128-ROW quad kernel (fp8_gemm_nn 4096 x 7168 x 2112:
         return true;            // 86 us against the FP32-scale kernel's 71 on the same operands) -- reading in place always pays
     double remajor_us = 0;
+    const double b_mats = p.gemm_type == dg::kNormal ? 1.0 : static_cast<double>(p.num_groups);     // (grouped: the pass covers every group's weights)
     if (p.a_sk != 1) remajor_us += 3.0 + static_cast<double>(p.m) * p.k / 2.25e6;
-    if (p.b_sk != 1) remajor_us += 3.0 + static_cast<double>(p.n) * p.k / 2.25e6;
+    if (p.b_sk != 1) remajor_us += 3.0 + b_mats * p.n * p.k / 2.25e6;
     return remajor_us > static_cast<double>(p.m) * p.n * p.k / 6e9;
 }
 
@@ -404,6 +419,20 @@ bool per_col_mn_eligible(const dg::GemmParams& p) {
 }
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Tile height of the K-major recipe-(1, 1, 128) kernel, 256 or 192 rows.  The recipe is VALU-issue bound, so time follows the rows a
+// workgroup computes: with the K axis split over the idle CUs (`split`) the total counts -- ceil(m / bm) * bm, m = 576: 576 against 768 --,
+// otherwise the rounds of resident tiles times the tile height (m = 2112, n = 4096: one round of 176 tiles of 192 rows against one round of
+// 144 tiles of 256; m = 4096: 352 tiles = two rounds of 192 against one of 256).
+int per_col_bm(const dg::GemmParams& p, bool split) {
+    if (env_knobs().pc_bm == 192 || env_knobs().pc_bm == 256)          // (tuning runs, DG_PC_BM)
+        return env_knobs().pc_bm;
+    const long nt = ceil_div(p.n, 256), cus = num_cus();
+    const long t192 = ceil_div(p.m, 192) * nt, t256 = ceil_div(p.m, 256) * nt;
+    const long c192 = split ? ceil_div(p.m, 192) * 192L : (t192 + cus - 1) / cus * 192;
+    const long c256 = split ? ceil_div(p.m, 256) * 256L : (t256 + cus - 1) / cus * 256;
+    return c192 < c256 ? 192 : 256;
+}
 
 // Non-temporal output stores (GemmParams::d_nt): when one launch writes at least half of the chip's 32 MiB of L2 the output cannot stay
 // cache-resident for its consumer anyway, and streaming it out is 5-6 % of a C2 call (see store_rows_full_line_packed).
@@ -460,7 +489,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         }
     }
     if (p.sfb_gran_n == 1) {
-        const char* pick = per_col_eligible(p) && p.m > 64 ? "pipe_pc_256x256"
+        const char* pick = per_col_eligible(p) && p.m > 64 ? (per_col_bm(p, false) == 192 ? "pipe_pc_192x256" : "pipe_pc_256x256")
                          : (per_col_mn_eligible(p) && p.m > 64 ? "pipe_pc_mn_256x256" : "generic_128x128");
         for (int i = 0; i < kNumConfigs; ++i)
             if (std::strcmp(kConfigs[i].name, pick) == 0)
@@ -515,11 +544,14 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
     if (fast_ok && p.gemm_type == dg::kNormal && p.sfb_gran_n == 128 && p.head_lr == 0 && p.n % 16 == 0) {
         const int num_kb = p.k / 128;
         const char* pick = nullptr;
+        // round 5: the coalesced-load forms ('c': 8 weight rows x 128 bytes per load instruction, operands through wave-private LDS) -- same
+        // bits, 10-18 % faster on every shape measured (profiles/r05_probe/skinny_coalesced_ab.jsonl: m = 1, 4096 x 7168 9.2 -> 8.3 us,
+        // 7168 x 16384 27.8 -> 24.4 / 23.7, m = 16 11.9 -> 10.0, m = 32 15.8 -> 13.4)
         if (m_for_tiling <= 16 && num_kb >= 16)
-            pick = (p.n > 16 * num_cus() && p.n <= 32 * num_cus() && !p.accumulate && p.n % 4 == 0) ? "skinny_16w" : "skinny_16";
+            pick = (p.n > 16 * num_cus() && p.n <= 32 * num_cus() && !p.accumulate && p.n % 4 == 0) ? "skinny_16wc" : "skinny_16c";
         // (m = 1, 7168 x 16384: 448 column tiles = 1.75 rounds of skinny_16 -> 256 tiles of 28 columns)
         else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608)
-            pick = "skinny_32";
+            pick = "skinny_32c";
         if (pick != nullptr)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)
@@ -641,7 +673,7 @@ int per_col_split_pieces(const dg::GemmParams& p, size_t workspace_bytes, bool i
         return 0;
     if (!per_col_eligible(p) && !per_col_mn_eligible(p))
         return 0;
-    const long tiles = static_cast<long>(ceil_div(p.m, 256)) * ceil_div(p.n, 256), num_kb = p.k / 128;
+    const long tiles = static_cast<long>(ceil_div(p.m, per_col_eligible(p) ? per_col_bm(p, true) : 256)) * ceil_div(p.n, 256), num_kb = p.k / 128;
     const size_t per_piece = static_cast<size_t>(p.m) * p.n * sizeof(float);
     long pieces = std::min<long>(std::min<long>(8, num_cus() / tiles), num_kb / 4);
     const long fit = workspace_bytes > 0 ? (workspace_bytes > 4096 ? static_cast<long>((workspace_bytes - 4096) / per_piece) : 0) : 8;
@@ -665,15 +697,19 @@ int launch_per_col_split(const dg::GemmParams& dense, int pieces, void* stream) 
     const int num_kb = dense.k / 128;
     for (int i = 0; i <= pieces; ++i)
         p.kg_prefix[i] = 128 * static_cast<int>(static_cast<long>(i) * num_kb / pieces);
-    p.num_m_tiles = ceil_div(p.m, 256);
+    const int bm = mn_major ? 256 : per_col_bm(dense, true);
+    p.num_m_tiles = ceil_div(p.m, bm);
     p.num_n_tiles = ceil_div(p.n, 256);
     p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
     p.d_vec_ok = dense.n % 4 == 0;
     p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
     const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * pieces;
-    g_last_config = mn_major ? "pipe_pc_mn_ks_256x256" : "pipe_pc_ks_256x256";
+    g_last_config = mn_major ? "pipe_pc_mn_ks_256x256" : (bm == 192 ? "pipe_pc_ks_192x256" : "pipe_pc_ks_256x256");
     if (mn_major)
         hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), p);
+    else if (bm == 192)
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<192, 256, 2, 4, 1, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
                            static_cast<hipStream_t>(stream), p);
     else
         hipLaunchKernelGGL((dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>), dim3(static_cast<unsigned>(grid)), dim3(512), 0,
@@ -756,7 +792,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     g_last_config = cfg->name;
     p.num_m_tiles = ceil_div(p.m, cfg->bm);
     p.num_n_tiles = ceil_div(p.n, cfg->bn);
-    if (std::strcmp(cfg->name, "skinny_16w") == 0) {
+    if (std::strncmp(cfg->name, "skinny_16w", 10) == 0) {
         if (p.accumulate) {
             g_last_error = "config 'skinny_16w' does not implement accumulating outputs (neighbouring workgroups overlap by up to 15 columns)";
             return 3;
@@ -1024,8 +1060,9 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = std::string("config '") + cfg->name + "' needs k % 512 == 0 (whole packed scale words)";
         return 3;
     }
-    if (grouped && !cfg->grouped_ok) {
-        g_last_error = std::string("config '") + cfg->name + "' implements the dense form only";
+    if (grouped && (!cfg->grouped_ok || (std::strncmp(cfg->name, "e8_duo_", 7) == 0 && p.gemm_type != dg::kContiguous))) {
+        g_last_error = std::string("config '") + cfg->name + "' implements the dense form only" +
+                       (cfg->grouped_ok ? " (and the contiguous layout without psum)" : "");
         return 3;
     }
     if ((p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum) && p.m_alignment % cfg->bm != 0 &&
@@ -1193,7 +1230,9 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
     if (m == 0)
         return 0;
     DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr && grouped_layout != nullptr);
-    DG_CHECK(a_stride_k == 1 && b_stride_k == 1);       // K-major operands (reference gemm.hpp:181; B is re-majored by the host layer)
+    // K-major A (reference gemm.hpp:181); B K-major or -- round 5 -- MN-major ([G][K][N], the nn form) where dg_ue8m0_grouped_operand_plan
+    // answered 0 (launch_e8 refuses what no kernel reads in place)
+    DG_CHECK(a_stride_k == 1 && (b_stride_k == 1 || b_stride_n == 1));
     DG_CHECK(sfa_stride_m == 1 && sfb_stride_n == 1);   // MN-major packed scale words
     DG_CHECK(m_alignment > 0 && m_alignment % 128 == 0);
     DG_CHECK(d_stride_m >= n);
@@ -1203,14 +1242,37 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
     p.layout = grouped_layout;
     p.m = m; p.n = n; p.k = k; p.num_groups = num_groups;
     p.a_sm = a_stride_m; p.a_sk = 1;
-    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = 1;
+    p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
     p.sfa_sm = 1; p.sfa_sk = sfa_stride_kq;
     p.sfb_sg = sfb_stride_g; p.sfb_sn = 1; p.sfb_sk = sfb_stride_kq;
     p.d_sm = d_stride_m;
     p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
     p.gemm_type = use_psum ? dg::kContiguousPsum : dg::kContiguous;
     p.m_alignment = m_alignment;
+    if (b_stride_k != 1 && !e8_mn_eligible(p)) {
+        g_last_error = "dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0: MN-major B is read in place only in the contiguous layout without psum, with "
+                       "k % 128 == 0, n % 16 == 0, 16-byte aligned k-rows and an M alignment of 128 or a multiple of 256 (dg_ue8m0_grouped_operand_plan)";
+        return 3;
+    }
     return launch_e8(p, 0, stream);
+}
+
+int dg_ue8m0_grouped_operand_plan(const void* a, const void* b, int num_groups, int m, int n, int k, int64_t a_stride_m,
+                                  int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k, int use_psum, int m_alignment) {
+    // The grouped (contiguous-layout) twin of dg_ue8m0_dense_operand_plan: 2 = re-major B into K-major scratch first, 0 = hand it over as it is.
+    if (b_stride_k == 1)
+        return 0;
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b);
+    p.m = m; p.n = n; p.k = k; p.num_groups = num_groups;
+    p.a_sm = a_stride_m; p.a_sk = 1; p.b_sg = b_stride_g; p.b_sn = b_stride_n; p.b_sk = b_stride_k;
+    p.sfa_sm = 1; p.sfb_sn = 1; p.gemm_type = use_psum ? dg::kContiguousPsum : dg::kContiguous; p.m_alignment = m_alignment;
+    if (!e8_mn_eligible(p))
+        return 2;
+    const std::string forced = forced_config();
+    if (forced == e8_mn_config_name(p))
+        return 0;
+    return forced == "auto" && e8_mn_pays(p) ? 0 : 2;
 }
 
 int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
@@ -1846,7 +1908,7 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
                                     : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
         }
     } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
-        name = per_col_eligible(p) ? "pipe_pc_ks_256x256" : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)
+        name = per_col_eligible(p) ? (per_col_bm(p, true) == 192 ? "pipe_pc_ks_192x256" : "pipe_pc_ks_256x256") : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)
     } else if (gemm_type == dg::kContiguous && m_alignment == 128 && has_workspace && !b_mn_major && sfb_gran_n == 128 && k % 128 == 0 && k >= 1024 &&
                (m + 127) / 128 <= 500 && static_cast<long>((m + 127) / 128) * ((n + 255) / 256) >= num_cus()) {
         name = "duo_tab_256x256";           // launch_contiguous_tabled: group-relative 256-row tiles + K-split remainders (_sk_: needs the workspace)

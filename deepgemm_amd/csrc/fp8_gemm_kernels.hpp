@@ -1141,7 +1141,9 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     constexpr int A_UNITS = BM / 8, B_UNITS = BN / 8;
     constexpr int A_ITERS = A_UNITS / NW, B_ITERS = B_UNITS / NW;
     constexpr int SC_BASE = 2 * STAGE_BYTES, SC_STAGE = 2048;      // per stage: 256 row scales of A, 256 of B
-    static_assert(BM == 256 && BN == 256, "one 1 KiB scale piece per operand per K block");
+    // (BM = 192, round 5: 576-row wgrads are three exact tile rows instead of 2.25 of three; the A scale piece still fetches 256 values --
+    //  the 64 beyond the tile are the next rows' or lie outside the descriptor -- and nothing reads them)
+    static_assert((BM == 256 || (BM == 192 && !MN)) && BN == 256, "one 1 KiB scale piece per operand per K block");
     static_assert(MS % 2 == 0 && NS % 2 == 0 && NW >= 2 && A_UNITS % NW == 0 && B_UNITS % NW == 0, "tile shape");
     static_assert(TOTAL >= DEPTH + 1 && (TOTAL - DEPTH) / NS == MS - 1, "the ring tail must lie within the last M-subtile");
     static_assert(SPREAD * (A_ITERS + B_ITERS) <= TOTAL, "not enough steps to spread the LDS-DMA pieces");
@@ -1221,23 +1223,24 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                     accs[ms][ns][r] = 0.f;
 
         if (t.m_end > t.m0) {
-            const uint8_t* a_base = p.a + ad_group * p.a_sg + kg_a_off + static_cast<int64_t>(t.m0) * (MN ? 1 : lda);
-            const uint8_t* b_base = p.b + bs_group * p.b_sg + kg_b_off + static_cast<int64_t>(t.n0) * (MN ? 1 : ldb);
+            // (every descriptor input through readfirstlane: tile coordinates are wave-uniform in fact, not provably -- see uniform_int)
+            const uint8_t* a_base = uniform_pointer(p.a + ad_group * p.a_sg + kg_a_off + static_cast<int64_t>(t.m0) * (MN ? 1 : lda));
+            const uint8_t* b_base = uniform_pointer(p.b + bs_group * p.b_sg + kg_b_off + static_cast<int64_t>(t.n0) * (MN ? 1 : ldb));
             const int a_rows = imin(t.m_end - t.m0, BM), b_rows = imin(p.n - t.n0, BN);
             // MN: the descriptor ends with the last k-row's valid bytes; a lane past M (N) inside an earlier row reads the
             // next row's head -- finite bytes that only reach rows / columns which are never stored
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint8_t*>(a_base), 0, MN ? (k_extent - 1) * lda + (p.m - t.m0) : (a_rows - 1) * lda + k_extent, 0x00020000);
+                const_cast<uint8_t*>(a_base), 0, uniform_int(MN ? (k_extent - 1) * lda + (p.m - t.m0) : (a_rows - 1) * lda + k_extent), 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint8_t*>(b_base), 0, MN ? (k_extent - 1) * ldb + (p.n - t.n0) : (b_rows - 1) * ldb + k_extent, 0x00020000);
+                const_cast<uint8_t*>(b_base), 0, uniform_int(MN ? (k_extent - 1) * ldb + (p.n - t.n0) : (b_rows - 1) * ldb + k_extent), 0x00020000);
             // scale rows: MN-major (stride 1 along m / n), one K block = one contiguous run; lanes past the end of the
             // last run fall outside the descriptor and fetch zeros (rows / columns that are never stored)
-            const float* sfa_tile = p.sfa + ad_group * p.sfa_sg + kg_sf_blocks * p.sfa_sk + t.m0;
-            const float* sfb_tile = p.sfb + bs_group * p.sfb_sg + kg_sf_blocks * p.sfb_sk + t.n0;
+            const float* sfa_tile = uniform_pointer(p.sfa + ad_group * p.sfa_sg + kg_sf_blocks * p.sfa_sk + t.m0);
+            const float* sfb_tile = uniform_pointer(p.sfb + bs_group * p.sfb_sg + kg_sf_blocks * p.sfb_sk + t.n0);
             const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(sfa_tile), 0, (num_kb - 1) * sfa_kb_stride + (p.m - t.m0) * 4, 0x00020000);
+                const_cast<float*>(sfa_tile), 0, uniform_int((num_kb - 1) * sfa_kb_stride + (p.m - t.m0) * 4), 0x00020000);
             const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(sfb_tile), 0, (num_kb - 1) * sfb_kb_stride + (p.n - t.n0) * 4, 0x00020000);
+                const_cast<float*>(sfb_tile), 0, uniform_int((num_kb - 1) * sfb_kb_stride + (p.n - t.n0) * 4), 0x00020000);
 
             auto issue_piece = [&](int stage, int kb, int q) {
                 uint8_t* stage_base = lds + stage * STAGE_BYTES;
@@ -3288,8 +3291,11 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
 
     MaskedWalk walk;
     const int num_launched = gridDim.x;
-    for (int tile_id = blockIdx.x;; tile_id += num_launched) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+    // (tile_id, pass): contiguous layout with BM = 2 x alignment -- a tile whose halves belong to two groups is walked twice, once per
+    // half with that group's B (round 5: the grouped nn form with packed scales reads its MN-major weights in place)
+    int tile_id = blockIdx.x, pass = 0;
+    for (;;) {
+        const Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
         if (!t.valid)
             break;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
@@ -3538,12 +3544,18 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             }
         }
         store_tile<MS, NS, !A_MN, false, B_MN>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
-        if (p.dbg != nullptr && tile_id == blockIdx.x) {
+        if (p.dbg != nullptr && tile_id == static_cast<int>(blockIdx.x)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
             dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+        }
+        if (t.second_pass) {
+            pass = 1;
+        } else {
+            pass = 0;
+            tile_id += num_launched;
         }
     }
 }
@@ -3796,22 +3808,37 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
 // NSUB = 2 (round 3): a workgroup owns `p.skinny_cols` (17 .. 32) columns as two N-subtiles at n0 and n0 + 16, so that n / 16 column
 // tiles just above the CU count (m = 1, 7168 x 16384: 448 tiles = 1.75 rounds) become ONE round of 28-column tiles.  The second subtile
 // reaches into the next workgroup's columns: both compute the same bits for them (non-accumulating outputs only).
-template <int MS, int CH = 4, int NSUB = 1>
+// COAL (round 5): the weight loads in a COALESCED lane order -- lane l fetches 16-byte chunk l & 7 of weight row (l >> 3) + 8 h, so one load
+// instruction covers 8 rows x 128 contiguous bytes (8 cache lines, each asked for once) instead of 16 rows x 64 bytes with the 16 lanes of
+// every quarter-wave on 16 different lines (64 requests per instruction) -- and reach the MFMA's operand layout (lane (r, g): row r, chunks
+// g and g + 4) through 2 KiB of wave-private LDS at the moment they are consumed: two ds_write_b128 + two ds_read_b128 per K block in the
+// chunk-swizzled image of the tile kernels (lds_chunk_offset), no barrier (a wave's LDS operations complete in order).  Same operands, same
+// bits as the register-direct form.
+template <int MS, int CH = 4, int NSUB = 1, bool COAL = false>
 __global__ __launch_bounds__(512)
 void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
     constexpr int NW = 8;                                       // CH: K blocks per software-pipeline chunk (two chunks in flight)
     static_assert(MS * NSUB <= NW, "one wave per (M-subtile, N-subtile) sums the partial tiles");
     __shared__ float red[NW][MS * NSUB][256];
+    __shared__ __attribute__((aligned(16))) uint8_t staging[COAL ? NW : 1][COAL ? 2 : 1][COAL ? 2048 : 16];
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * (NSUB == 1 || p.skinny_cols == 0 ? 16 * NSUB : p.skinny_cols);
     const int num_kb = p.k / 128;
     const int kb_begin = wave * num_kb / NW, kb_end = (wave + 1) * num_kb / NW;
     const uint8_t* b_ptr[NSUB];
+    [[maybe_unused]] const uint8_t* b_ptr_hi[NSUB];             // COAL: rows (l >> 3) and (l >> 3) + 8
     const float* sfb_ptr[NSUB];
+    [[maybe_unused]] const int st_write = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);        // + 1024 for the upper eight rows
+    [[maybe_unused]] const int st_read_lo = r * 128 + ((g ^ (r & 7)) << 4), st_read_hi = r * 128 + (((g + 4) ^ (r & 7)) << 4);
     #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
-        b_ptr[s] = p.b + static_cast<int64_t>(imin(n0 + s * 16 + r, p.n - 1)) * p.b_sn + g * 16;
+        if constexpr (COAL) {
+            b_ptr[s] = p.b + static_cast<int64_t>(imin(n0 + s * 16 + (lane >> 3), p.n - 1)) * p.b_sn + (lane & 7) * 16;
+            b_ptr_hi[s] = p.b + static_cast<int64_t>(imin(n0 + s * 16 + 8 + (lane >> 3), p.n - 1)) * p.b_sn + (lane & 7) * 16;
+        } else {
+            b_ptr[s] = p.b + static_cast<int64_t>(imin(n0 + s * 16 + r, p.n - 1)) * p.b_sn + g * 16;
+        }
         // a lane's four output columns are n0 + 16 s + 4 g .. + 3 (n0 is a multiple of 4: they never straddle a 128-column scale block,
         // the 16-column subtile of the two-subtile form may)
         sfb_ptr[s] = p.sfb + static_cast<int64_t>(imin(n0 + s * 16 + 4 * g, p.n - 1) / 128) * p.sfb_sn;
@@ -3834,7 +3861,8 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
             #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
                 c.b[j][s][0] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off));
-                c.b[j][s][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off + 64));
+                if constexpr (COAL) c.b[j][s][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr_hi[s] + off));
+                else c.b[j][s][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off + 64));
                 c.sb[j][s] = sfb_ptr[s][static_cast<int64_t>(kb) * p.sfb_sk];
             }
             #pragma unroll
@@ -3857,7 +3885,18 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
             if (kb0 + j < kb_end) {                             // wave-uniform
                 #pragma unroll
                 for (int s = 0; s < NSUB; ++s) {
-                    const v8i bf = __builtin_shufflevector(c.b[j][s][0], c.b[j][s][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    v4i b_lo = c.b[j][s][0], b_hi = c.b[j][s][1];
+                    if constexpr (COAL) {
+                        uint8_t* st = staging[wave][(j * NSUB + s) & 1];
+                        *reinterpret_cast<v4i*>(st + st_write) = b_lo;
+                        *reinterpret_cast<v4i*>(st + st_write + 1024) = b_hi;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // other lanes' bytes: keep the reads behind the writes
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        b_lo = *reinterpret_cast<const v4i*>(st + st_read_lo);
+                        b_hi = *reinterpret_cast<const v4i*>(st + st_read_hi);
+                    }
+                    const v8i bf = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     #pragma unroll
                     for (int ms = 0; ms < MS; ++ms) {
                         const v8i af = __builtin_shufflevector(c.a[ms][j][0], c.a[ms][j][1], 0, 1, 2, 3, 4, 5, 6, 7);

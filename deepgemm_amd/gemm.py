@@ -381,7 +381,13 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
         sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, num_groups,
                                    grouped_layout if use_psum_layout and a_sf.dtype == torch.float else None)
         require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
-        b_km = b_data if b_data.stride(-1) == 1 else _remajor(b_data)
+        # MN-major weights ([G, K, N]: the nn form) stay as they are where the library reads them in place and that beats a pass over every
+        # group's weights (dg_ue8m0_grouped_operand_plan: its predicates and model, no copy here)
+        b_km = b_data
+        if b_data.stride(-1) != 1 and lib.dg_ue8m0_grouped_operand_plan(
+                a_data.data_ptr(), b_data.data_ptr(), num_groups, m, n, k, a_data.stride(0), b_data.stride(0), b_data.stride(1),
+                b_data.stride(2), int(use_psum_layout), runtime.get_mk_alignment_for_contiguous_layout()):
+            b_km = _remajor(b_data)
         check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(
             a_data.data_ptr(), sfa.data_ptr(), b_km.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
             num_groups, m, n, k, a_data.stride(0), a_data.stride(1), b_km.stride(0), b_km.stride(1), b_km.stride(2),

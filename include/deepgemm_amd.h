@@ -82,7 +82,9 @@ int dg_ue8m0_dense_operand_plan(const void* a, const void* b, int m, int n, int 
  * tensors).  Tensors and grouped_layout / masked_m as in the FP32-scale entry points below; sfa_packed: one word per row of A
  * per four K blocks, element (row, kq) at ptr[row * stride_m + kq * stride_kq] (masked: + group * stride_g), stride_m must
  * be 1; sfb_packed: one word per ROW of B (recipe (1, 1, 128)), element (g, n, kq) at ptr[g * stride_g + n * stride_n +
- * kq * stride_kq], stride_n must be 1.  A and B K-major with 16-byte aligned rows, k % 128 == 0, m_alignment % 128 == 0. */
+ * kq * stride_kq], stride_n must be 1.  A and B K-major with 16-byte aligned rows, k % 128 == 0, m_alignment % 128 == 0.  The
+ * contiguous entry also takes MN-major weights ([G][K][N]: b_stride_n == 1, the reference's m_grouped_fp8_gemm_nn_contiguous,
+ * csrc/apis/gemm.hpp:234-248) where dg_ue8m0_grouped_operand_plan answers 0 -- read in place, no re-majoring pass. */
 int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
                                               void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
                                               int64_t a_stride_m, int64_t a_stride_k,
@@ -90,6 +92,11 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
                                               int64_t sfa_stride_m, int64_t sfa_stride_kq,
                                               int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                                               int64_t d_stride_m, int use_psum, int m_alignment, void* stream);
+/* 2 = re-major the MN-major B of a dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0 call into K-major scratch first, 0 = hand it over as it is (the
+ * grouped twin of dg_ue8m0_dense_operand_plan: eligibility of the in-place kernel + the model of when the pass over all groups' weights costs
+ * more than the slower K loop).  Pointers are only tested for alignment. */
+int dg_ue8m0_grouped_operand_plan(const void* a, const void* b, int num_groups, int m, int n, int k, int64_t a_stride_m,
+                                  int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k, int use_psum, int m_alignment);
 int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
                                           void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
                                           int expected_m,

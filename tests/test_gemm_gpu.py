@@ -64,7 +64,7 @@ def test_skinny_decode_kernel(m, n, k):
     dg.fp8_gemm_nt(case.a, case.b, case.d)                        # automatic pick first (short K loops stay on the stream tiles)
     assert_close_to_oracle(case.d, want, f'auto: {dg.last_config()}')
     if k >= 2048 and (m <= 16 or (4096 <= k <= 8192 and n <= 4608)):
-        assert dg.last_config() == cfg, dg.last_config()
+        assert dg.last_config() in (cfg, cfg + 'c'), dg.last_config()          # ('c': the coalesced-load form, round 5)
     dg.set_forced_config(cfg)
     wide = torch.full((m, n + 24), float('nan'), device='cuda', dtype=torch.bfloat16)
     d = wide[:, :n]
@@ -83,6 +83,42 @@ def test_skinny_decode_kernel(m, n, k):
     with pytest.raises(RuntimeError, match='m <= its row count'):
         big = gen.generate_normal(40, n, k)
         dg.fp8_gemm_nt(big.a, big.b, big.d)
+
+
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 7168), (1, 7168, 16384), (9, 4112, 2048), (16, 2112, 7168), (24, 1024, 8192), (3, 64, 640), (5, 4100, 1024)])
+def test_skinny_coalesced_weight_loads_same_bits(m, n, k):
+    """Round 5: the skinny kernels with weight loads in a coalesced lane order (8 rows x 128 contiguous bytes per instruction) that reach the
+    MFMA operand layout through wave-private LDS (`skinny_16c / _32c / _16wc`): the same operands in the same order, so the same bits as the
+    register-direct forms -- BF16 and accumulating FP32 outputs, ragged N (rows clamped at n - 1), against the oracle."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    pairs = [('skinny_16', 'skinny_16c')] if m <= 16 else []
+    pairs += [('skinny_32', 'skinny_32c')]
+    pairs += [('skinny_16w', 'skinny_16wc')] if m <= 16 and n % 4 == 0 else []
+    for plain, coal in pairs:
+        outs = []
+        for cfg in (plain, coal):
+            dg.set_forced_config(cfg)
+            wide = torch.full((m, n + 24), float('nan'), device='cuda', dtype=torch.bfloat16)
+            dg.fp8_gemm_nt(case.a, case.b, wide[:, :n])
+            assert dg.last_config() == cfg
+            assert bool(torch.isnan(wide[:, n:]).all())
+            outs.append(wide[:, :n].contiguous())
+        dg.set_forced_config('auto')
+        assert torch.equal(outs[0], outs[1]), f'{coal} differs from {plain}'
+        assert_close_to_oracle(outs[1], want, coal)
+    if m <= 16:
+        acc_case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float)
+        c0 = acc_case.c.clone()
+        outs = []
+        for cfg in ('skinny_16', 'skinny_16c'):
+            dg.set_forced_config(cfg)
+            d = c0.clone()
+            dg.fp8_gemm_nt(acc_case.a, acc_case.b, d, c=d)
+            outs.append(d)
+        dg.set_forced_config('auto')
+        assert torch.equal(outs[0], outs[1])
 
 
 DENSE_SHAPES = [(1, 128, 128), (7, 136, 256), (128, 2112, 512), (129, 576, 384), (256, 256, 1024), (300, 520, 384),
@@ -178,7 +214,15 @@ def test_wgrad_recipe_per_column_sfb():
     assert_close_to_oracle(case.d, want, 'recipe_a/recipe_b')
 
 
-@pytest.mark.parametrize('m,n,k', [(256, 256, 128), (300, 520, 896), (1024, 768, 2048), (65, 4096, 512)])
+def per_col_tile_name(m, n, split=False):
+    """The K-major recipe-(1, 1, 128) kernel takes 192-row tiles where they mean fewer computed rows (K split: in total; otherwise per round
+    of resident tiles) -- the rule of dg_api.hip's per_col_bm, 256 CUs."""
+    nt = -(-n // 256)
+    cost = lambda bm: -(-m // bm) * bm if split else -(-(-(-m // bm) * nt) // 256) * bm
+    return ('pipe_pc_ks_' if split else 'pipe_pc_') + ('192x256' if cost(192) < cost(256) else '256x256')
+
+
+@pytest.mark.parametrize('m,n,k', [(256, 256, 128), (300, 520, 896), (1024, 768, 2048), (65, 4096, 512), (576, 512, 1024), (190, 300, 384)])
 @pytest.mark.parametrize('out_dtype,accumulate', [(torch.float, True), (torch.bfloat16, False)])
 def test_per_column_sfb_fast_kernel(m, n, k, out_dtype, accumulate):
     """Recipe (1, 1, 128) on the LDS-DMA path: both scale vectors of a K block ride along as 1 KiB pieces, the scale
@@ -188,7 +232,7 @@ def test_per_column_sfb_fast_kernel(m, n, k, out_dtype, accumulate):
     c_cpu = case.c.cpu().clone() if accumulate else None
     want = oracle_dense(case, gran_n=1, c_cpu=c_cpu)
     dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None, recipe=(1, 1, 128))
-    assert dg.last_config() == 'pipe_pc_256x256'
+    assert dg.last_config() == per_col_tile_name(m, n)
     if out_dtype == torch.float:
         assert_close_fp32(case.d, want, 'per-column SFB')
     else:
@@ -220,7 +264,7 @@ def test_per_column_sfb_mn_major_operands(m, n, k):
     a_km = (case.a[0].contiguous(), case.a[1])
     b_km = (case.b[0].contiguous(), case.b[1])
     dg.fp8_gemm_nt(a_km, b_km, d2, c=d2, recipe=(1, 1, 128))
-    assert dg.last_config() == 'pipe_pc_256x256'
+    assert dg.last_config() == per_col_tile_name(m, n)
     assert torch.equal(d2, case.d)
 
 
@@ -237,7 +281,7 @@ def test_per_column_sfb_k_split(m, n, k, mn_major, out_dtype, accumulate):
     c_cpu = case.c.cpu().clone() if accumulate else None
     want = oracle_dense(case, gran_n=1, c_cpu=c_cpu)
     dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None, recipe=(1, 1, 128))
-    assert dg.last_config() == ('pipe_pc_mn_ks_256x256' if mn_major else 'pipe_pc_ks_256x256'), dg.last_config()
+    assert dg.last_config() == ('pipe_pc_mn_ks_256x256' if mn_major else per_col_tile_name(m, n, split=True)), dg.last_config()
     if out_dtype == torch.float:
         assert_close_fp32(case.d, want, 'per-column SFB, K split')
     else:
@@ -868,7 +912,7 @@ def test_repeatability_other_kernels():
             d = c0.clone()
             dg.fp8_gemm_nt(pc.a, pc.b, d, c=d, recipe=(1, 1, 128))
             outs.append(d)
-        assert dg.last_config() == ('pipe_pc_256x256' if k_major else 'pipe_pc_mn_256x256')
+        assert dg.last_config() == (per_col_tile_name(2048, 2304) if k_major else 'pipe_pc_mn_256x256')
         assert all(torch.equal(o, outs[0]) for o in outs[1:]), dg.last_config()
     for k_major in (True, False):
         kg = gen.generate_k_grouped_contiguous(3, 1024, 1280, [1024, 512, 1536], k_major)
@@ -1025,8 +1069,10 @@ def test_packed_ue8m0_m_grouped_contiguous(use_psum):
         a = gen.packed_ue8m0_operand(*case.a)
         b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
         cfgs = ['auto', 'e8_quad_128x256'] + (E8_QUAD_256 if not use_psum and k % 512 == 0 else [])
+        # round 5: the nn form's MN-major weights read in place by the 8-wave kernel (two-pass 256-row tiles; contiguous layout without psum)
+        cfgs += ['e8_duo_bmn_256x256'] if not use_psum and n % 16 == 0 else []
         for cfg in cfgs:
-            for nn in (False, True):
+            for nn in ((True,) if cfg == 'e8_duo_bmn_256x256' else (False, True)):
                 dg.set_forced_config(cfg)
                 case.d.fill_(float('nan'))
                 if nn:
@@ -1034,7 +1080,7 @@ def test_packed_ue8m0_m_grouped_contiguous(use_psum):
                     dg.m_grouped_fp8_gemm_nn_contiguous(a, (b_nn[0], b_nn[1].mT), case.d, case.grouped_layout, use_psum_layout=use_psum)
                 else:
                     dg.m_grouped_fp8_gemm_nt_contiguous(a, b, case.d, case.grouped_layout, use_psum_layout=use_psum)
-                assert dg.last_config().startswith('e8_quad'), dg.last_config()
+                assert dg.last_config() == cfg if cfg == 'e8_duo_bmn_256x256' else dg.last_config().startswith('e8_quad'), dg.last_config()
                 start = 0
                 for actual, aligned in zip(case.actual_ms, case.aligned_ms):
                     rows = slice(start, start + actual)
@@ -1042,6 +1088,35 @@ def test_packed_ue8m0_m_grouped_contiguous(use_psum):
                     assert bool((case.d[start + actual:start + aligned] == 0).all()), f'{cfg}: padding rows must be zeros'
                     start += aligned
                 assert calc_diff(torch.nan_to_num(case.d), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
+
+
+def test_packed_ue8m0_m_grouped_nn_weights_in_place():
+    """m_grouped_fp8_gemm_nn_contiguous with packed scales at a size where a pass over every group's weights costs more than the 8-wave
+    kernel's slower K loop (dg_ue8m0_grouped_operand_plan answers 0): the automatic selection reads B [G, K, N] in place
+    (csrc/apis/gemm.hpp:234-248: the SM100 path takes either majorness through its descriptors) -- same bits as the K-major call,
+    padding rows zero, rows of every group against the oracle."""
+    gen.reset_seed(23)
+    actual_ms, n, k = [500, 384, 130, 640, 0, 256], 4096, 1024
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, False, actual_ms=actual_ms, use_ue8m0=True)
+    a = gen.packed_ue8m0_operand(*case.a)
+    b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+    dg.m_grouped_fp8_gemm_nt_contiguous(a, b, case.d, case.grouped_layout)
+    assert dg.last_config().startswith('e8_quad'), dg.last_config()
+    k_major = case.d.clone()
+    b_nn = b[0].mT.contiguous()                                    # [G, K, N] storage
+    d = torch.full_like(case.d, float('nan'))
+    dg.m_grouped_fp8_gemm_nn_contiguous(a, (b_nn, b[1].mT), d, case.grouped_layout)
+    assert dg.last_config() == 'e8_duo_bmn_256x256', dg.last_config()
+    want = torch.full(case.d.shape, float('nan'), dtype=torch.bfloat16)
+    oracle.m_grouped_fp8_gemm_nt_contiguous(*cpu_pair(case.a), *cpu_pair(case.b), want, case.grouped_layout.cpu(), False)
+    start = 0
+    for actual, aligned in zip(case.actual_ms, case.aligned_ms):
+        rows = slice(start, start + actual)
+        assert torch.equal(d[rows], k_major[rows]), f'rows {rows}: in place vs K-major'
+        if actual:
+            assert_close_to_oracle(d[rows], want[rows], f'nn in place, rows {rows}')
+        assert bool((d[start + actual:start + aligned] == 0).all()), 'padding rows must be zeros'
+        start += aligned
 
 
 @pytest.mark.parametrize('m,n,k', [(256, 384, 576), (130, 264, 2112), (1040, 784, 2112), (512, 1024, 144), (300, 520, 656)])
@@ -1198,7 +1273,7 @@ def test_k_grouped_tn_psum_layout(num_groups, m, n, real_ks):
         a_off.copy_(case.a[0])
         d3 = case.c.clone()
         dg.k_grouped_fp8_gemm_tn_contiguous((a_off, case.a[1]), case.b, d3, None, case.grouped_layout, c=d3, use_psum_layout=True)
-        assert dg.last_config() == 'pipe_pc_256x256' and torch.equal(d3, d)
+        assert dg.last_config() in ('pipe_pc_256x256', per_col_tile_name(m, n)) and torch.equal(d3, d)
 
 
 def test_k_grouped_argument_checks():
@@ -1396,7 +1471,7 @@ def test_skinny_two_subtile_form(m, n, k):
     wide = torch.full((m, n + 40), float('nan'), device='cuda', dtype=torch.bfloat16)
     d = wide[:, :n]
     dg.fp8_gemm_nt(case.a, case.b, d)
-    assert dg.last_config() == 'skinny_16w', dg.last_config()
+    assert dg.last_config() in ('skinny_16w', 'skinny_16wc'), dg.last_config()
     assert_close_to_oracle(d, want, 'skinny_16w')
     assert bool(torch.isnan(wide[:, n:]).all())
     dg.set_forced_config('skinny_16')
@@ -1409,7 +1484,7 @@ def test_skinny_two_subtile_form(m, n, k):
         assert torch.equal(again, case.d)
     acc_case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float)
     dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
-    assert dg.last_config() == 'skinny_16'
+    assert dg.last_config() in ('skinny_16', 'skinny_16c')
     dg.set_forced_config('skinny_16w')
     with pytest.raises(RuntimeError):
         dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
