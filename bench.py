@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -36,9 +36,11 @@ PEAK_HBM_GBS = 8000.0
 # own 32: the arithmetic roof of that recipe on this part is 32 / 62 of the matrix rate.  Reported beside the MFMA fraction.
 RECIPE_1_1_128_ROOF = 32.0 / 62.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
-             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0']
+             'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
+             'contiguous_ue8m0']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
-             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0']
+             'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
+             'contiguous_ue8m0']
 GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
@@ -312,19 +314,25 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         desc = {'workload': f'k_grouped_fp8_gemm_nt_contiguous G={g} M={m} N={n} sum_k={sum(ks)} (reference sweep entry, tests/generators.py:200-202)',
                 'm': m, 'n': n, 'sum_k': sum(ks), 'groups': g, 'recipe_roof': RECIPE_1_1_128_ROOF}
         check = lambda: float('nan')                               # noqa: E731
-    elif name == 'contiguous':
+    elif name in ('contiguous', 'contiguous_ue8m0'):
+        # (contiguous_ue8m0, round 5: C4 with packed UE8M0 scales -- the group-relative tiling of the hardware-scaled kernels)
         groups, expected, n, k = 8, 512, 4096, 7168
+        packed = name == 'contiguous_ue8m0'
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_m_grouped_contiguous(groups, expected, n, k)
-            case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            case = gen.generate_m_grouped_contiguous(groups, expected, n, k, use_ue8m0=packed)
             cases.append(case)
-            calls.append(lambda c=case: dg.m_grouped_fp8_gemm_nt_contiguous(c.a, c.b, c.d, c.grouped_layout))
+            if packed:
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+                calls.append(lambda a=a, b=b, c=case: dg.m_grouped_fp8_gemm_nt_contiguous(a, b, c.d, c.grouped_layout))
+            else:
+                case.a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+                calls.append(lambda c=case: dg.m_grouped_fp8_gemm_nt_contiguous(c.a, c.b, c.d, c.grouped_layout))
         m = cases[0].m
         flops = 2.0 * m * n * k                                     # the reference's own count: padded M (tests/test_fp8_fp4.py:124)
         nbytes = count_bytes(cases[0].a, cases[0].b, cases[0].d)
         valid_rows = int((cases[0].grouped_layout >= 0).sum().item())      # rows that belong to a group (the rest is alignment padding)
-        desc = {'workload': f'm_grouped_fp8_gemm_nt_contiguous G={groups} M_total={m} N={n} K={k} (BASELINE configs[3])',
+        desc = {'workload': f'm_grouped_fp8_gemm_nt_contiguous G={groups} M_total={m} N={n} K={k} (BASELINE configs[3])' + (', packed UE8M0 scales' if packed else ''),
                 'm': m, 'n': n, 'k': k, 'groups': groups, 'valid_rows': valid_rows, 'useful_flops': 2.0 * valid_rows * n * k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     else:
@@ -562,7 +570,7 @@ def run(rank: int, world: int, local_rank: int, args):
                                         ([_sig(rec['roofline']['frac_of_recipe_roof'])] if 'frac_of_recipe_roof' in rec['roofline'] else [])
                                         if 'roofline' in rec else rec.get('error', '?')[:40])
                                  for name, rec in zip(SECONDARY, detail)}
-            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us/call, bound, 4th: frac on data rows (contiguous) | of the (1,1,128) recipe roof]'
+            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us/call, bound, 4th: frac on data rows | of the (1,1,128) roof]'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
         if 'secondary' in line:         # keep the whole headline line inside the driver's 2000-character tail

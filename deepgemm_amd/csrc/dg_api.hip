@@ -1011,9 +1011,56 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
     return cfg;
 }
 
+// Packed scales on the contiguous layout at the M alignment of 128 (round 5): the group-relative tiling of launch_contiguous_tabled for the
+// hardware-scaled kernels -- launch 1: e8_quad_256x256 over the 256-row tiles of the in-kernel tile list (two 128-row blocks of ONE group: no
+// tile is walked twice), launch 2: e8_quad_128x256 over the remainders (at most one per group) and padding blocks.  No K split (the quad
+// kernels accumulate in AGPRs and have no partial-tile form), so no workspace.  Against 128-row tiles everywhere: C4 with packed scales
+// (8 x ~512 rows, N 4096, K 7168) 576 tiles = 2.25 rounds -> 256 big tiles + 80 remainder tiles.
+bool e8_contiguous_tabled(const dg::GemmParams& p) {
+    // (K >= 4096: with a short K loop the second launch costs what the taller tiles save -- profiles/r05_probe/packed_contiguous_group_relative_tiles_ab.jsonl:
+    //  8 x ~512 rows, N 4096, K 7168 202.9 -> 153.2 us; K 2048: 78.6 -> 82.3 and 84.9 -> 83.9)
+    if (p.gemm_type != dg::kContiguous || p.m_alignment != 128 || p.k % 512 != 0 || p.k < 4096 || !fast_eligible(p))
+        return false;
+    const int nb = ceil_div(p.m, 128);
+    return nb <= 64 && static_cast<long>(nb) * ceil_div(p.n, 256) >= num_cus();
+}
+
+int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream) {
+    const int nb = ceil_div(base.m, 128), n_tiles = ceil_div(base.n, 256);
+    for (int mode = 1; mode <= 2; ++mode) {
+        dg::GemmParams q = base;
+        const int bm = mode == 1 ? 256 : 128;
+        q.tile_table = nullptr; q.table_mode = mode;
+        q.num_m_tiles = ceil_div(q.m, bm);          // upper bound (grouping, grid); the in-kernel list holds the real count
+        q.num_n_tiles = n_tiles;
+        q.group_m = q.num_m_tiles >= 2 ? 2 : 1;
+        q.d_vec_ok = aligned16(q.d) && (q.d_sm * 2) % 16 == 0;
+        q.d_nt = output_streams_past_l2(q);
+        q.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+        const long items = static_cast<long>(mode == 1 ? nb / 2 : nb) * n_tiles;
+        const long grid = std::min<long>(items, num_cus());
+        if (grid <= 0)
+            continue;
+        if (mode == 1)
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), q);
+        else
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), q);
+        DG_HIP_CHECK(hipGetLastError());
+    }
+    g_last_config = "e8_quad_tab_256x256";
+    if (env_knobs().print_configs)
+        fprintf(stderr, "[deepgemm_amd] ue8m0 contiguous m=%d n=%d k=%d groups=%d -> e8_quad_256x256 + e8_quad_128x256 over the group-relative tile list\n",
+                base.m, base.n, base.k, base.num_groups);
+    return 0;
+}
+
 int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
     const bool k_tail = p.k % 128 != 0;
     const bool mn_form = e8_mn_eligible(p);           // an MN-major operand read in place
+    if (!mn_form && forced_config() == "auto" && e8_contiguous_tabled(p))
+        return launch_e8_contiguous_tabled(p, stream);
     if (!mn_form && (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal))) {
         g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0 (dense: or k % 16 == 0 and k > 128)";
         return 3;
@@ -1904,8 +1951,9 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
             name = e8_mn_config_name(p);
         else {
             p.a_sm = k; p.a_sk = 1; p.b_sn = k; p.b_sk = 1;
-            name = fast_eligible(p) ? select_e8_config(p, expected_m)->name
-                                    : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
+            name = e8_contiguous_tabled(p) ? "e8_quad_tab_256x256"
+                 : fast_eligible(p)        ? select_e8_config(p, expected_m)->name
+                                           : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
         }
     } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
         name = per_col_eligible(p) ? (per_col_bm(p, true) == 192 ? "pipe_pc_ks_192x256" : "pipe_pc_ks_256x256") : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)

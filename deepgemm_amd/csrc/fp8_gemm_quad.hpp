@@ -218,6 +218,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
     MaskedWalk walk;
+    if (p.table_mode != 0)          // (round 5: the group-relative tiling of the contiguous layout, launch_e8_contiguous_tabled; every lane is active here)
+        walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
     const int num_launched = gridDim.x;
     auto uniform_ptr = [](const uint8_t* ptr) {
         const uint64_t v = reinterpret_cast<uint64_t>(ptr);

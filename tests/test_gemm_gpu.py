@@ -819,14 +819,14 @@ def test_import_is_fork_safe_and_bench_runs():
     # the full records on a prefixed (non-JSON) line before it
     assert len(out.stdout.splitlines()[-1]) < 2000, len(out.stdout.splitlines()[-1])
     secondary = line['secondary']
-    assert len(secondary) == 21 and not [v for v in secondary.values() if isinstance(v, str)], secondary
+    assert len(secondary) == 22 and not [v for v in secondary.values() if isinstance(v, str)], secondary
     for name, rec in secondary.items():
         assert 0 < rec[0] < 1 and rec[1] > 0 and rec[2] in ('m', 'h'), (name, rec)
     assert {rec[2] for rec in secondary.values()} == {'m', 'h'} and len(secondary['contiguous']) == 4
     detail = [ln for ln in out.stdout.splitlines() if ln.startswith('secondary_detail: ')]
     assert len(detail) == 1
     detail = json.loads(detail[0][len('secondary_detail: '):])
-    assert len(detail) == 21 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
+    assert len(detail) == 22 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
     # --gpus N without a launcher must not silently run one rank
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '2', '--warmup', '1'],
                          capture_output=True, text=True, timeout=600)
@@ -1428,6 +1428,42 @@ def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
     fixed = torch.empty_like(case.d)
     dg.m_grouped_fp8_gemm_nt_contiguous(case.a, case.b, fixed, case.grouped_layout)
     assert calc_diff(outs[0], fixed) < 2e-6           # (K pieces are summed in piece order: not the same bits as an unsplit K loop)
+
+
+@pytest.mark.parametrize('actual_ms,n,k', [
+    ([617, 591, 487, 437, 515, 482, 599, 451], 4096, 4096),      # C4's layout
+    ([128, 1, 0, 256, 129, 1000, 384, 3000, 77, 640], 2304, 4096),  # odd / even runs, empty group, one-block groups
+    ([4000, 4050], 2048, 4608),                                  # two long groups (64 blocks: the largest in-kernel tile list)
+])
+def test_packed_ue8m0_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
+    """Round 5: the group-relative tiling for packed UE8M0 scales (launch_e8_contiguous_tabled: e8_quad_256x256 over the 256-row tiles of the
+    in-kernel tile list, e8_quad_128x256 over the remainders and padding blocks): same bits as the 128-row quad kernel on the fixed grid (the
+    scaled MFMA accumulates in K-block order whatever the tile), every group against the oracle, padding rows zero, nothing outside D."""
+    gen.reset_seed(29)
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, False, actual_ms=actual_ms, use_ue8m0=True)
+    a = gen.packed_ue8m0_operand(*case.a)
+    b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+    m = case.d.size(0)
+    guarded = torch.full((m + 256, n), 777.0, device='cuda', dtype=torch.bfloat16)
+    d = guarded[128:128 + m]
+    d.fill_(float('nan'))
+    dg.m_grouped_fp8_gemm_nt_contiguous(a, b, d, case.grouped_layout)
+    assert dg.last_config() == 'e8_quad_tab_256x256', dg.last_config()
+    assert bool((guarded[:128] == 777.0).all()) and bool((guarded[128 + m:] == 777.0).all()), 'wrote outside D'
+    dg.set_forced_config('e8_quad_128x256')
+    fixed = torch.full_like(case.d, float('nan'))
+    dg.m_grouped_fp8_gemm_nt_contiguous(a, b, fixed, case.grouped_layout)
+    dg.set_forced_config('auto')
+    assert dg.last_config() == 'e8_quad_128x256'
+    start = 0
+    for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+        rows = slice(start, start + actual)
+        assert torch.equal(d[rows], fixed[rows]), f'group {g}: tabled vs fixed grid'
+        if actual:
+            want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows], case.a[1][rows], case.b[0][g], case.b[1][g])
+            assert_close_to_oracle(d[rows], want, f'group {g}')
+        assert bool((d[start + actual:start + aligned] == 0).all()), f'group {g}: padding rows must be zeros'
+        start += aligned
 
 
 def test_stream_kernels_need_aligned_scale_rows():

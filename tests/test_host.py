@@ -450,7 +450,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 576, 4096, 7168, gran_n=1) == 'pipe_pc_ks_192x256' and pick(dense, 576, 4096, 7168, a_mn=1, b_mn=1, gran_n=1) == 'pipe_pc_mn_ks_256x256'
     assert pick(dense, 576, 4096, 7168, gran_n=1, workspace=0) == 'pipe_pc_192x256' and pick(dense, 2112, 4096, 7168, gran_n=1) == 'pipe_pc_192x256'
     assert pick(dense, 3264, 4096, 7168, gran_n=1) == 'pipe_pc_256x256' and pick(dense, 640, 4096, 2048, gran_n=1) == 'pipe_pc_192x256'
-    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128, packed=1) == 'e8_quad_128x256'
+    assert pick(contiguous, 4608, 4096, 7168, groups=8, alignment=128, packed=1) == 'e8_quad_tab_256x256'       # (round 5: group-relative 256-row tiles + 128-row remainders)
     # recipe (1, 1, 128)
     assert pick(dense, 4096, 4096, 7168, gran_n=1) == 'pipe_pc_256x256'
     assert pick(dense, 4096, 4096, 7168, gran_n=1, a_mn=1, b_mn=1) == 'pipe_pc_mn_256x256'
@@ -530,7 +530,7 @@ def test_bench_workload_tables_are_consistent():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert set(bench.SECONDARY) <= set(bench.WORKLOADS) and 'dense' in bench.WORKLOADS and 'dense' not in bench.SECONDARY
-    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 21 and bench.GRAPHED <= set(bench.WORKLOADS)
+    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 22 and bench.GRAPHED <= set(bench.WORKLOADS)
     assert bench.PEAK_FP8_TFLOPS == 5000.0
 
 

@@ -146,7 +146,43 @@ def grouped_nn():
         print(json.dumps({'kernels': names}), flush=True)
 
 
+def packed_c4():
+    """Packed scales on the contiguous layout: the group-relative tiling (auto) against 128-row tiles on the fixed grid (forced)."""
+    for groups, m_per, n, k in ((8, 512, 4096, 7168), (4, 1024, 7168, 2048), (8, 512, 7168, 2048)):
+        calls = []
+        for i in range(2):
+            gen.reset_seed(i)
+            case = gen.generate_m_grouped_contiguous(groups, m_per, n, k, True, False, use_ue8m0=True)
+            a = gen.packed_ue8m0_operand(*case.a)
+            b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+            calls.append(lambda a=a, b=b, c=case: dg.m_grouped_fp8_gemm_nt_contiguous(a, b, c.d, c.grouped_layout))
+        names = {}
+
+        def note(tag, setup):
+            def f():
+                setup()
+                calls[0]()
+                names[tag] = dg.last_config()
+            return f
+        ab(f'grouped contiguous nt, packed scales, {groups} x ~{m_per} rows, n={n} k={k}',
+           [('auto', note('auto', lambda: None), calls), ('e8_quad_128x256', note('forced', forced('e8_quad_128x256')), calls)], replays=20)
+        print(json.dumps({'kernels': names}), flush=True)
+
+
+def skinny_w():
+    """One N-subtile per workgroup (1.x rounds) against two (one round) with the coalesced loads, where n / 16 lies between one and two rounds."""
+    for m, n, k in ((1, 7168, 4096), (16, 8192, 2048), (1, 6144, 7168), (4, 7168, 16384)):
+        calls = []
+        for i in range(4):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        calls = calls * 5
+        ab(f'decode {m}x{n}x{k}', [('skinny_16c', forced('skinny_16c'), calls), ('skinny_16wc', forced('skinny_16wc'), calls)])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['pc192', 'skinny', 'grouped_nn']
     for w in which:
-        {'pc192': pc192, 'skinny': skinny, 'grouped_nn': grouped_nn}[w]()
+        {'pc192': pc192, 'skinny': skinny, 'grouped_nn': grouped_nn, 'packed_c4': packed_c4, 'skinny_w': skinny_w}[w]()
