@@ -331,7 +331,7 @@ int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols
 int dg_set_num_cus(int num_cus);
 int dg_get_num_cus(void);
 
-/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_KS_PIECES, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE, DG_TEST_HOOKS,
+/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_KS_PIECES, DG_PC_BM, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE, DG_TEST_HOOKS,
  * DG_SFA_ROWMAJOR_IN_PLACE, DG_SWIGLU_ONE_PER_CU) are read once, at the first launch; a process that changes them afterwards calls this to have them read again
  * (tests, tuning scripts).  No reference counterpart (its knobs are read per call, csrc/utils/system.hpp get_env). */
 void dg_reload_env(void);
