@@ -240,7 +240,11 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                                 g = fminf(g, o.clamp);
                                 u = fminf(fmaxf(u, -o.clamp), o.clamp);
                             }
+#if defined(DG_SWIGLU_ABL) && (DG_SWIGLU_ABL & 1)         // timing ablation (tuning builds only): no exponential, no division -- wrong values
+                            float y = g * u;
+#else
                             float y = (g / (1.0f + expf(-g))) * u;                       // silu(g.float()) * u.float()
+#endif
                             // without a routing weight the operator stands for "... -> BF16 intermediate -> per_token_cast_to_fp8": round to
                             // BF16 as the unfused pipeline stores it; with one it is the reference kernel's epilogue, which keeps
                             // silu(gate) * up * weight in FP32 up to the amax and the FP8 cast (sm100_fp8_fp4_mega_moe.cuh:1001-1020)
@@ -271,6 +275,10 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                 uint32_t v;
                 const long long t_wait = __builtin_amdgcn_s_memrealtime();
                 bool timed_out = false;
+#if defined(DG_SWIGLU_ABL) && (DG_SWIGLU_ABL & 2)         // timing ablation (tuning builds only): nobody waits for a partner -- wrong scales
+                v = 0x80000000u | __float_as_uint(mine);
+                if (false)
+#endif
                 do {
                     v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!(v & 0x80000000u)) {
