@@ -159,16 +159,21 @@ __device__ __forceinline__ int table_pieces(const GemmParams& p, int tiles) {
 
 // Maps a linear tile id to a tile for every GEMM type (reference scheduler semantics:
 // deep_gemm/include/deep_gemm/scheduler/gemm.cuh:156-237, :311-319).  `state` carries the masked-layout walk.
-struct MaskedWalk { int group = 0; int cum_m_tiles = 0; unsigned long long table_mask = 0; };
+// block_group (round 5): lane b holds the group id of the layout's 128-row block b (the very load the tile mask is built from), so that a table
+// tile's group is a lane read instead of a SECOND global load that depends on the first (a tile's first LDS-DMA piece waits for its group id:
+// the B base; tools/prologue_stamps.py put 12.4 k ticks in front of the first load of a table launch against 7 k of a dense one).
+struct MaskedWalk { int group = 0; int cum_m_tiles = 0; unsigned long long table_mask = 0; int block_group = 0; bool have_block_groups = false; };
 
 __device__ __forceinline__ bool table_launch(const GemmParams& p) { return p.tile_table != nullptr || p.table_mode != 0; }
 
 // The tile list of dg_build_contiguous_tile_table_kernel as a bit mask over the layout's (at most 64) blocks of 128 rows, computed by a
 // whole wave: a run of blocks of one group is cut into 256-row tiles from ITS first block (mode 1: bit = first block of such a tile); an odd
 // run leaves its last block, and every block of padding rows (-1) stands alone (mode 2).  Call with all 64 lanes active.
-__device__ __forceinline__ unsigned long long contiguous_tile_mask(const int32_t* __restrict__ layout, int m, int mode) {
+__device__ __forceinline__ unsigned long long contiguous_tile_mask(const int32_t* __restrict__ layout, int m, int mode, int* block_group = nullptr) {
     const int lane = threadIdx.x & 63, nb = (m + 127) / 128;
     const int g = lane < nb ? layout[lane * 128] : -2;
+    if (block_group != nullptr)
+        *block_group = g;
     const int g_prev = __shfl_up(g, 1, 64);
     const bool starts = lane == 0 || g != g_prev || g < 0;
     const unsigned long long start_mask = __ballot(starts);
@@ -229,7 +234,7 @@ __device__ __forceinline__ Tile get_tile(const GemmParams& p, int tile_id, Maske
         t.m_begin = t.m0;
         t.m_end = imin(t.m0 + BM, p.m);
         t.zero_from = t.zero_to = t.m_end;
-        const int g = p.layout[t.m0];
+        const int g = walk.have_block_groups ? __builtin_amdgcn_readlane(walk.block_group, __builtin_amdgcn_readfirstlane(t.m0 >> 7)) : p.layout[t.m0];
         if (g < 0) { t.m_end = t.m0; t.zero_from = t.m0; t.zero_to = imin(t.m0 + BM, p.m); }
         t.group = imax(g, 0);
         return t;
@@ -1754,8 +1759,10 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
     MaskedWalk walk;
 #ifndef DG_NO_TABLE_MASK
     if constexpr (PERSIST && !A_MN && !B_MN && !K_TAIL)         // (the launches of launch_contiguous_tabled)
-        if (p.table_mode != 0)
-            walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
+        if (p.table_mode != 0) {
+            walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode, &walk.block_group);
+            walk.have_block_groups = true;
+        }
 #endif
     const int num_launched = gridDim.x;
     const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
@@ -2574,8 +2581,10 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
     const int tail = blockIdx.x / MS, ms_mine = blockIdx.x % MS;
     MaskedWalk walk;
     int sk_first = p.sk_first_tile, sk_factor = p.sk_factor;
-    if (p.table_mode != 0)
-        walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
+    if (p.table_mode != 0) {
+        walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode, &walk.block_group);
+        walk.have_block_groups = true;
+    }
     if (p.sk_exchange != 0)
         return;                                 // (the two pieces were summed inside the first kernel)
     if (table_launch(p)) {                      // table launch: the grid is an upper bound, tile count and pieces live on the device

@@ -219,7 +219,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     long long t_loop0 = 0, t_loop1 = 0;
     MaskedWalk walk;
     if (p.table_mode != 0)          // (round 5: the group-relative tiling of the contiguous layout, launch_e8_contiguous_tabled; every lane is active here)
-        walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode);
+        walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode, &walk.block_group), walk.have_block_groups = true;
     const int num_launched = gridDim.x;
     auto uniform_ptr = [](const uint8_t* ptr) {
         const uint64_t v = reinterpret_cast<uint64_t>(ptr);
