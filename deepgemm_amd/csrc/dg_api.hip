@@ -304,12 +304,13 @@ const E8Config kE8Configs[] = {
 struct EnvKnobs {
     bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks, swiglu_one_per_cu;
     int group_m, ks_pieces, pc_bm;
+    bool e8_tab_unsplit;
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
           sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
           group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0),
-          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0) {}
+          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr) {}
 };
 EnvKnobs& env_knobs() {
     static EnvKnobs knobs;
@@ -1027,6 +1028,11 @@ bool e8_contiguous_tabled(const dg::GemmParams& p) {
 
 int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream) {
     const int nb = ceil_div(base.m, 128), n_tiles = ceil_div(base.n, 256);
+    // With the caller's workspace the remainder walk is cut along K (TABSK: one work item per (tile, piece), FP32 partial tiles, a second kernel
+    // sums them): 64 .. 96 remainder tiles of C4 are a quarter of a round, each streaming its group's whole weight panel -- 58 us for a ninth of
+    // the work.  Pieces: whole K quads, at most 8; how many a launch really uses is decided on the device from the tile count (table_pieces).
+    const size_t slab_bytes = 128 * 256 * sizeof(float);
+    const bool split = base.sk_workspace != nullptr && g_workspace_bytes >= 4096 + 64 * slab_bytes && !env_knobs().e8_tab_unsplit;
     for (int mode = 1; mode <= 2; ++mode) {
         dg::GemmParams q = base;
         const int bm = mode == 1 ? 256 : 128;
@@ -1037,16 +1043,33 @@ int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         q.d_vec_ok = aligned16(q.d) && (q.d_sm * 2) % 16 == 0;
         q.d_nt = output_streams_past_l2(q);
         q.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+        q.sk_first_tile = 0; q.sk_tiles = 0; q.sk_factor = 1; q.sk_capacity = 0;
+        if (mode == 1 || !split)
+            q.sk_workspace = nullptr;
         const long items = static_cast<long>(mode == 1 ? nb / 2 : nb) * n_tiles;
-        const long grid = std::min<long>(items, num_cus());
+        long grid = std::min<long>(items, num_cus());
         if (grid <= 0)
             continue;
-        if (mode == 1)
+        if (mode == 1) {
             hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
                                static_cast<hipStream_t>(stream), q);
-        else
+        } else if (!split) {
             hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
                                static_cast<hipStream_t>(stream), q);
+        } else {
+            q.sk_factor = static_cast<int>(std::min<long>(8, base.k / 512));
+            q.sk_tiles = num_cus();                 // (table launch: the slot count; the kernels read the tile count from the tile list)
+            q.sk_capacity = static_cast<int>(std::min<size_t>((g_workspace_bytes - 4096) / slab_bytes, 1u << 20));
+            grid = std::min<long>(items * q.sk_factor, num_cus());
+            hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), q);
+            DG_HIP_CHECK(hipGetLastError());
+            // grid: an upper bound on the tiles that can be split at all (capacity / 2 pieces) x 4 row quarters; surplus workgroups return at once
+            const long max_split_tiles = std::min<long>(items, q.sk_capacity / 2);
+            if (q.sk_factor >= 2 && max_split_tiles > 0)
+                hipLaunchKernelGGL(dg::dg_e8_tab_reduce_kernel, dim3(static_cast<unsigned>(max_split_tiles * 4)), dim3(256), 0,
+                                   static_cast<hipStream_t>(stream), q);
+        }
         DG_HIP_CHECK(hipGetLastError());
     }
     g_last_config = "e8_quad_tab_256x256";
@@ -1273,7 +1296,21 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
                                               int64_t sfa_stride_m, int64_t sfa_stride_kq,
                                               int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                                               int64_t d_stride_m, int use_psum, int m_alignment, void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(a, sfa_packed, b, sfb_packed, d, grouped_layout, num_groups, m, n, k, a_stride_m, a_stride_k,
+                                                        b_stride_g, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq, sfb_stride_g, sfb_stride_n,
+                                                        sfb_stride_kq, d_stride_m, use_psum, m_alignment, nullptr, 0, stream);
+}
+
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                                 void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                                 int64_t a_stride_m, int64_t a_stride_k,
+                                                 int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                                 int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                                 int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                                 int64_t d_stride_m, int use_psum, int m_alignment,
+                                                 void* workspace, int64_t workspace_bytes, void* stream) {
     DG_CHECK(m >= 0 && n > 0 && k > 0 && num_groups > 0);
+    DG_CHECK(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 4096));
     if (m == 0)
         return 0;
     DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr && grouped_layout != nullptr);
@@ -1296,6 +1333,8 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
     p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
     p.gemm_type = use_psum ? dg::kContiguousPsum : dg::kContiguous;
     p.m_alignment = m_alignment;
+    p.sk_workspace = workspace;
+    g_workspace_bytes = workspace != nullptr ? static_cast<size_t>(workspace_bytes) : 0;
     if (b_stride_k != 1 && !e8_mn_eligible(p)) {
         g_last_error = "dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0: MN-major B is read in place only in the contiguous layout without psum, with "
                        "k % 128 == 0, n % 16 == 0, 16-byte aligned k-rows and an M alignment of 128 or a multiple of 256 (dg_ue8m0_grouped_operand_plan)";

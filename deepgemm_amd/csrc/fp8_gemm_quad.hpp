@@ -149,8 +149,14 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // last block is an ordinary block of the loop whose pieces carry a per-lane offset bias that pushes the chunks at and beyond K out of the
 // descriptor's range: an out-of-range LDS-DMA lane writes ZEROS into the LDS (the duo kernels' tail mechanism; tools/ubench/lds_dma_oob_probe.hip),
 // so neither the row padding nor the next row's bytes reach the matrix core.  Its scale byte is the block's own, picked as for any block.
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0>
+// TABSK (round 5): the remainder walk of the packed-scale contiguous tiling (table_mode 2) with every tile cut along K into table_pieces()
+// ranges of whole K quads, one work item per (tile, piece) -- 64 .. 96 remainder tiles do not fill 256 CUs and each would stream its group's whole
+// weight panel alone.  A piece accumulates its range in place as always and writes its FP32 partial tile, row-major [BM][BN], to the caller's
+// workspace (slab (tile * pieces + piece)); dg_e8_tab_reduce_kernel adds the pieces in piece order and stores BF16.  Fewer than two pieces (no
+// workspace, many tiles): whole tiles, stored directly.
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
+    static_assert(!TABSK || (BM == 128 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0), "TABSK: the 128-row production form");
     static_assert(!K_TAIL || (BM == 128 && !STAGED && QV == 0 && WAVES_N == 2), "K tail: the 128-row production form");
     static_assert(HS == 0 || (BM == 256 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL), "HS: the 256 x 256 four-wave form");
     constexpr int NW = 2 * WAVES_N;
@@ -173,7 +179,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = K_TAIL ? (p.k + 127) / 128 : p.k / 128, num_kq = (num_kb + 3) / 4;
+    int num_kb = K_TAIL ? (p.k + 127) / 128 : p.k / 128, num_kq = (num_kb + 3) / 4;      // (TABSK: of the work item's K range)
     const int k_tail = K_TAIL ? (p.k & 127) : 0;
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
@@ -233,9 +239,25 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                    __builtin_amdgcn_readfirstlane(extent), 0x00020000};
     };
 
+    [[maybe_unused]] int sk_tiles = 0, sk_pieces = 1, sk_piece = 0, sk_kq0 = 0;
+    if constexpr (TABSK) {
+        sk_tiles = table_count(p, walk) * p.num_n_tiles;
+        sk_pieces = table_pieces(p, sk_tiles);
+    }
     int tile_id = blockIdx.x, pass = 0;
     while (true) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk, pass);
+        int tile = tile_id;
+        if constexpr (TABSK) {
+            if (tile_id >= sk_tiles * sk_pieces)
+                break;
+            tile = tile_id % sk_tiles;
+            sk_piece = tile_id / sk_tiles;
+            const int total_kq = p.k / 512;                       // (host: k % 512 == 0)
+            sk_kq0 = sk_piece * total_kq / sk_pieces;
+            num_kq = (sk_piece + 1) * total_kq / sk_pieces - sk_kq0;
+            num_kb = 4 * num_kq;
+        }
+        const Tile t = get_tile<BM, BN>(p, tile, walk, pass);
         if (!t.valid)
             break;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
@@ -252,15 +274,17 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // nothing to compute (padding rows of a contiguous layout): zero rows only.  Kept apart from the main path so that
             // the accumulators there have ONE definition chain (a join with this path would be resolved by copying all of them
             // out of the AGPRs, spills included).
-            v4f zero[MS][4];
-            #pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
+            if (!TABSK || sk_piece == 0) {              // (TABSK: the zero rows of a padding block are written once, by its first piece)
+                v4f zero[MS][4];
                 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    zero[ms][j] = v4f{0.f, 0.f, 0.f, 0.f};
-            store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base);
-            if constexpr (NS == 8)
-                store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base + 64);
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        zero[ms][j] = v4f{0.f, 0.f, 0.f, 0.f};
+                store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base);
+                if constexpr (NS == 8)
+                    store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, zero, m_base, n_base + 64);
+            }
             advance();
             continue;
         }
@@ -268,15 +292,18 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
         v4f acc[MS][NS];        // (zeroed below, AFTER the prologue's loads have been issued: the 128 accumulator writes fly under the memory latency)
 
         {
-            const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm);
-            const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn);
-            const int a_bytes = __builtin_amdgcn_readfirstlane((imin(t.m_end - t.m0, BM) - 1) * lda + p.k);
-            const int b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - t.n0, BN) - 1) * ldb + p.k);
+            // (TABSK: the piece's K range starts at K quad sk_kq0 -- operand bases, scale bases and extents move, every index below is relative)
+            const int k_ext = TABSK ? num_kb * 128 : p.k;
+            const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm + (TABSK ? sk_kq0 * 512 : 0));
+            const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn + (TABSK ? sk_kq0 * 512 : 0));
+            const int a_bytes = __builtin_amdgcn_readfirstlane((imin(t.m_end - t.m0, BM) - 1) * lda + k_ext);
+            const int b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - t.n0, BN) - 1) * ldb + k_ext);
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base) - (M0S ? M0_SHARE_BIAS : 0), 0, a_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base) - (M0S ? M0_SHARE_BIAS : 0), 0, b_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             // packed scale words: element (row, kq) at base[kq * stride + row] (int32); rows of the whole A (masked: of the group)
-            const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg), (num_kq - 1) * sfa_kq_stride + p.m * 4);
-            const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg),
+            const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg + (TABSK ? sk_kq0 * p.sfa_sk : 0)),
+                                            (num_kq - 1) * sfa_kq_stride + p.m * 4);
+            const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + (TABSK ? sk_kq0 * p.sfb_sk : 0)),
                                             (num_kq - 1) * sfb_kq_stride + p.n * 4);
             const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
             // B row of N-subtile ns, MFMA row slot i = lane & 15: wave_n0 + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)
@@ -619,7 +646,25 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             __syncthreads();
             }   // (default schedule)
         }
-        if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
+        if (TABSK && sk_pieces >= 2) {
+            // the piece's FP32 partial tile, row-major [BM][BN], into its workspace slab (accumulator -> (row, column) as store_tile's interleaved
+            // rows and permuted columns); one M-subtile at a time, as below
+            float* slab = reinterpret_cast<float*>(static_cast<uint8_t*>(p.sk_workspace) + 4096) +
+                          (static_cast<int64_t>(tile) * sk_pieces + sk_piece) * (BM * BN);
+            const int lg = lane >> 4;
+            #pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    asm volatile("" : "+a"(acc[ms][ns]));
+                    const v4f v = acc[ms][ns];
+                    const int row = wm * WM + (lane & 15) * MS + ms;
+                    const int col = wn * WN + (ns >> 2) * 64 + lg * 8 + ((ns & 3) >> 1) * 32 + (ns & 1) * 4;
+                    *reinterpret_cast<v4f*>(slab + row * BN + col) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
             // BF16 full-line stores, one M-subtile at a time: 32 accumulator registers leave the AGPRs, are packed, exchanged and
             // stored before the next 32 are touched (left alone hipcc reads all of them up front and spills half).
             #pragma unroll
@@ -664,10 +709,49 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK>(p);
+}
+
+// Second phase of the TABSK remainder walk: one workgroup per (remainder tile, 32-row quarter) adds the tile's partial slabs in piece order
+// (bit-repeatable) and stores the rows that belong to the group as BF16.  The grid is an upper bound; tile count and pieces come from the same
+// device-side tile list as in the first phase.  Padding blocks were zero-filled by the first phase.
+__global__ __launch_bounds__(256)
+void dg_e8_tab_reduce_kernel(const GemmParams p) {
+    constexpr int BM = 128, BN = 256;
+    MaskedWalk walk;
+    walk.table_mask = contiguous_tile_mask(p.layout, p.m, p.table_mode, &walk.block_group), walk.have_block_groups = true;
+    const int tiles = table_count(p, walk) * p.num_n_tiles, pieces = table_pieces(p, tiles);
+    const int tile = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    if (pieces < 2 || tile >= tiles)
+        return;
+    const Tile t = get_tile<BM, BN>(p, tile, walk, 0);
+    if (!t.valid || t.m_end <= t.m0)
+        return;
+    const float* slab = reinterpret_cast<const float*>(static_cast<const uint8_t*>(p.sk_workspace) + 4096) + static_cast<int64_t>(tile) * pieces * (BM * BN);
+    const int c4 = threadIdx.x & 63, r0 = quarter * 32 + (threadIdx.x >> 6);
+    const int col = t.n0 + c4 * 4;
+    uint16_t* d = reinterpret_cast<uint16_t*>(p.d);
+    #pragma unroll 2
+    for (int r = r0; r < quarter * 32 + 32; r += 4) {
+        const int row = t.m0 + r;
+        if (row >= t.m_end)
+            break;
+        v4f sum = *reinterpret_cast<const v4f*>(slab + r * BN + c4 * 4);
+        for (int s = 1; s < pieces; ++s)
+            sum += *reinterpret_cast<const v4f*>(slab + static_cast<int64_t>(s) * (BM * BN) + r * BN + c4 * 4);
+        uint16_t* dst = d + static_cast<int64_t>(row) * p.d_sm + col;
+        if (col + 4 <= p.n && p.d_vec_ok) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(sum[0], sum[1]), pack_bf16(sum[2], sum[3]));
+        } else {
+            #pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.n)
+                    dst[e] = static_cast<uint16_t>(pack_bf16(sum[e], 0.f) & 0xffffu);
+        }
+    }
 }
 
 }  // namespace dg

@@ -388,11 +388,18 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
                 a_data.data_ptr(), b_data.data_ptr(), num_groups, m, n, k, a_data.stride(0), b_data.stride(0), b_data.stride(1),
                 b_data.stride(2), int(use_psum_layout), runtime.get_mk_alignment_for_contiguous_layout()):
             b_km = _remajor(b_data)
-        check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(
+        # the K-split scratch buffer only where the library's group-relative tiling would cut its remainder tiles along K (it answers without
+        # launching: dg_select_config) -- other packed-scale grouped calls neither create nor pass it
+        stream = current_stream_ptr()
+        picked = lib.dg_select_config(2 if use_psum_layout else 1, m, n, k, num_groups, 0, 0, int(b_km.stride(-1) != 1), 128,
+                                      runtime.get_mk_alignment_for_contiguous_layout(), 1, 1)
+        workspace = _split_k_workspace(d.device, stream) if b'_tab_' in picked and lib.dg_get_forced_config() == b'auto' else None
+        check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(
             a_data.data_ptr(), sfa.data_ptr(), b_km.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
             num_groups, m, n, k, a_data.stride(0), a_data.stride(1), b_km.stride(0), b_km.stride(1), b_km.stride(2),
             sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), sfb.stride(2), d.stride(0), int(use_psum_layout),
-            runtime.get_mk_alignment_for_contiguous_layout(), current_stream_ptr()))
+            runtime.get_mk_alignment_for_contiguous_layout(), workspace.data_ptr() if workspace is not None else 0,
+            workspace.numel() if workspace is not None else 0, stream))
         return
     if _casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast):
         # 'sm100' mode with a K tail: the FP32-scale kernels on TRUNCATED scales -- the values the cast branch keeps -- as the dense entry does

@@ -92,6 +92,17 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
                                               int64_t sfa_stride_m, int64_t sfa_stride_kq,
                                               int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                                               int64_t d_stride_m, int use_psum, int m_alignment, void* stream);
+/* The same with a caller-owned scratch buffer (as dg_m_grouped_fp8_gemm_nt_contiguous_ws: 16-byte aligned, >= dg_split_k_workspace_bytes(), its
+ * first 4096 bytes zero, one buffer per stream): the group-relative tiling of the contiguous layout (K >= 4096, M alignment 128, <= 64 row
+ * blocks) then cuts its 128-row remainder tiles along K over the idle CUs.  workspace == NULL: whole remainder tiles. */
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                                 void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                                 int64_t a_stride_m, int64_t a_stride_k,
+                                                 int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                                 int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                                 int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                                 int64_t d_stride_m, int use_psum, int m_alignment,
+                                                 void* workspace, int64_t workspace_bytes, void* stream);
 /* 2 = re-major the MN-major B of a dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0 call into K-major scratch first, 0 = hand it over as it is (the
  * grouped twin of dg_ue8m0_dense_operand_plan: eligibility of the in-place kernel + the model of when the pass over all groups' weights costs
  * more than the slower K loop).  Pointers are only tested for alignment. */
@@ -331,7 +342,7 @@ int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols
 int dg_set_num_cus(int num_cus);
 int dg_get_num_cus(void);
 
-/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_KS_PIECES, DG_PC_BM, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE, DG_TEST_HOOKS,
+/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_KS_PIECES, DG_PC_BM, DG_E8_TAB_UNSPLIT, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE, DG_TEST_HOOKS,
  * DG_SFA_ROWMAJOR_IN_PLACE, DG_SWIGLU_ONE_PER_CU) are read once, at the first launch; a process that changes them afterwards calls this to have them read again
  * (tests, tuning scripts).  No reference counterpart (its knobs are read per call, csrc/utils/system.hpp get_env). */
 void dg_reload_env(void);

@@ -1437,8 +1437,10 @@ def test_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
 ])
 def test_packed_ue8m0_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k):
     """Round 5: the group-relative tiling for packed UE8M0 scales (launch_e8_contiguous_tabled: e8_quad_256x256 over the 256-row tiles of the
-    in-kernel tile list, e8_quad_128x256 over the remainders and padding blocks): same bits as the 128-row quad kernel on the fixed grid (the
-    scaled MFMA accumulates in K-block order whatever the tile), every group against the oracle, padding rows zero, nothing outside D."""
+    in-kernel tile list, e8_quad_128x256 over the remainders and padding blocks, the remainders cut along K into whole-quad pieces whose FP32
+    partial tiles a second kernel sums in piece order): every group against the oracle, padding rows zero, nothing outside D, bit-repeatable;
+    with whole remainder tiles (DG_E8_TAB_UNSPLIT) the same bits as the 128-row quad kernel on the fixed grid (the scaled MFMA accumulates in
+    K-block order whatever the tile), with K pieces equal up to the FP32 association of the piece sums."""
     gen.reset_seed(29)
     case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, False, actual_ms=actual_ms, use_ue8m0=True)
     a = gen.packed_ue8m0_operand(*case.a)
@@ -1450,15 +1452,30 @@ def test_packed_ue8m0_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k)
     dg.m_grouped_fp8_gemm_nt_contiguous(a, b, d, case.grouped_layout)
     assert dg.last_config() == 'e8_quad_tab_256x256', dg.last_config()
     assert bool((guarded[:128] == 777.0).all()) and bool((guarded[128 + m:] == 777.0).all()), 'wrote outside D'
+    first = d.clone()
+    d.fill_(float('nan'))
+    dg.m_grouped_fp8_gemm_nt_contiguous(a, b, d, case.grouped_layout)
+    assert torch.equal(torch.nan_to_num(d), torch.nan_to_num(first)), 'not bit-repeatable'
     dg.set_forced_config('e8_quad_128x256')
     fixed = torch.full_like(case.d, float('nan'))
     dg.m_grouped_fp8_gemm_nt_contiguous(a, b, fixed, case.grouped_layout)
     dg.set_forced_config('auto')
     assert dg.last_config() == 'e8_quad_128x256'
+    os.environ['DG_E8_TAB_UNSPLIT'] = '1'
+    dg_lib.dg_reload_env()
+    try:
+        whole = torch.full_like(case.d, float('nan'))
+        dg.m_grouped_fp8_gemm_nt_contiguous(a, b, whole, case.grouped_layout)
+        assert dg.last_config() == 'e8_quad_tab_256x256'
+    finally:
+        del os.environ['DG_E8_TAB_UNSPLIT']
+        dg_lib.dg_reload_env()
     start = 0
     for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
         rows = slice(start, start + actual)
-        assert torch.equal(d[rows], fixed[rows]), f'group {g}: tabled vs fixed grid'
+        assert torch.equal(whole[rows], fixed[rows]), f'group {g}: whole group-relative tiles vs fixed grid'
+        if actual:
+            assert calc_diff(d[rows], fixed[rows]) < 2e-6, f'group {g}: K pieces vs fixed grid'
         if actual:
             want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][rows], case.a[1][rows], case.b[0][g], case.b[1][g])
             assert_close_to_oracle(d[rows], want, f'group {g}')
