@@ -1483,6 +1483,70 @@ def test_packed_ue8m0_m_grouped_contiguous_group_relative_tiles(actual_ms, n, k)
         start += aligned
 
 
+def test_packed_ue8m0_m_grouped_nn_in_place_alignment_256():
+    """The in-place grouped nn form at an M alignment of 256 (every 256-row tile belongs to ONE group: a single pass per tile) -- same bits as
+    the K-major call, padding rows zero."""
+    gen.reset_seed(31)
+    dg.set_mk_alignment_for_contiguous_layout(256)
+    try:
+        actual_ms, n, k = [300, 256, 0, 513, 100, 700], 2048, 1024
+        case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, False, actual_ms=actual_ms, use_ue8m0=True)
+        a = gen.packed_ue8m0_operand(*case.a)
+        b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+        ref = torch.full_like(case.d, float('nan'))
+        dg.m_grouped_fp8_gemm_nt_contiguous(a, b, ref, case.grouped_layout)
+        dg.set_forced_config('e8_duo_bmn_256x256')
+        d = torch.full_like(case.d, float('nan'))
+        dg.m_grouped_fp8_gemm_nn_contiguous(a, (b[0].mT.contiguous(), b[1].mT), d, case.grouped_layout)
+        dg.set_forced_config('auto')
+        assert dg.last_config() == 'e8_duo_bmn_256x256', dg.last_config()
+        start = 0
+        for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+            assert torch.equal(d[start:start + actual], ref[start:start + actual]), f'group {g}'
+            if actual:
+                want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0][start:start + actual], case.a[1][start:start + actual], case.b[0][g], case.b[1][g])
+                assert_close_to_oracle(d[start:start + actual], want, f'group {g}')
+            assert bool((d[start + actual:start + aligned] == 0).all()), f'group {g}: padding rows must be zeros'
+            start += aligned
+    finally:
+        dg.set_forced_config('auto')
+        dg.set_mk_alignment_for_contiguous_layout(128)
+
+
+def test_packed_ue8m0_m_grouped_contiguous_in_a_hip_graph():
+    """The group-relative tiling with packed scales inside a hipGraph: captured on a stream that already owns its K-split workspace it keeps
+    the K pieces (three launches per call), captured on a fresh stream it falls back to whole remainder tiles (no allocation during capture);
+    both replay to the eager result's bits / tolerance."""
+    gen.reset_seed(37)
+    actual_ms, n, k = [617, 591, 487, 437, 515, 482, 599, 451], 4096, 4096
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, False, actual_ms=actual_ms, use_ue8m0=True)
+    a = gen.packed_ue8m0_operand(*case.a)
+    b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+    warm = torch.cuda.Stream()
+    with torch.cuda.stream(warm):
+        dg.m_grouped_fp8_gemm_nt_contiguous(a, b, case.d, case.grouped_layout)
+        assert dg.last_config() == 'e8_quad_tab_256x256'
+    warm.synchronize()
+    want = case.d.clone()
+    for stream, exact in ((warm, True), (torch.cuda.Stream(), False)):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            dg.m_grouped_fp8_gemm_nt_contiguous(a, b, case.d, case.grouped_layout)
+        for _ in range(2):
+            case.d.fill_(float('nan'))
+            graph.replay()
+            torch.cuda.synchronize()
+            start = 0
+            for actual, aligned in zip(case.actual_ms, case.aligned_ms):
+                rows = slice(start, start + actual)
+                if exact:
+                    assert torch.equal(case.d[rows], want[rows])
+                else:
+                    assert calc_diff(case.d[rows], want[rows]) < 2e-6
+                assert bool((case.d[start + actual:start + aligned] == 0).all())
+                start += aligned
+
+
 def test_stream_kernels_need_aligned_scale_rows():
     """The stream kernels fetch the row scales of four K blocks with 16-byte requests (round 3): an MN-major SFA whose K-block rows do
     not start on 16-byte boundaries (a direct C-ABI caller: the host layer always produces the padded layout) takes another kernel --
