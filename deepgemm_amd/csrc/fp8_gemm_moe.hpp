@@ -25,8 +25,9 @@
 // stream_kernel_body (fp8_gemm_kernels.hpp): promotion by FMA in K-block order, bit-identical to the plain masked kernel.  Epilogue,
 // after the K loop has released the LDS:
 //   1. every accumulator is rounded to BF16 (the value the unfused pipeline stores and reloads);
-//   2. the up waves park their values in LDS, the gate waves read them at the same (lane, register) position: y = silu(g) * u in FP32
-//      (optionally clamped: g <= c, |u| <= c), rounded to BF16;
+//   2. gate and up waves swap halves through the LDS (a gate wave finishes M-subtiles 0, 1 of its columns, the up wave of the same columns
+//      subtiles 2, 3 -- round 5: the arithmetic on all four SIMDs) and read them at the same (lane, register) position: y = silu(g) * u in
+//      FP32 (optionally clamped: g <= c, |u| <= c), rounded to BF16;
 //   3. amax over the row's 64 values of this tile: 8 in a lane, 4 lanes of a row (lane bits 4, 5), 2 gate waves (LDS); then the
 //      exchange with the partner tile (wave 0, one lane per row): amax over the 128-wide block;
 //   4. scale = max(amax, 1e-4) * (1 / 448) (optionally rounded up to a power of two), q = e4m3(y * (1 / scale)) -- the arithmetic of
@@ -200,9 +201,9 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                        // the ring is free: the epilogue exchange lives in its first 17 KiB
 
-            // ---- 1. BF16 rounding; 2. up waves -> LDS ----
-            float* xch = reinterpret_cast<float*>(lds);                 // [2 up waves][MS * NS * 4 registers][64 lanes]
-            float* row_max = reinterpret_cast<float*>(lds + 2 * (MS * NS * 4) * 64 * 4);    // [2 gate waves][64 rows], then [64] block amax
+            // ---- 1. BF16 rounding; 2. every wave hands the half of its values that its partner wave finishes to the LDS ----
+            float* xch = reinterpret_cast<float*>(lds);                 // [4 waves][MS / 2 * NS * 4 registers][64 lanes]
+            float* row_max = reinterpret_cast<float*>(lds + 2 * (MS * NS * 4) * 64 * 4);    // [2 column halves][64 rows], then [64] block amax
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms)
                 #pragma unroll
@@ -210,32 +211,43 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                     #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc[ms][ns][e] = round_bf16(acc[ms][ns][e]);
-            if (wn >= 2) {
+            // round 5: the SiLU arithmetic is shared by all four waves (it used to run on the two gate waves alone -- two of a CU's four SIMDs,
+            // with both co-resident workgroups' gate waves on the same two: 1.7 us of the call, profiles/r05_probe/swiglu_epilogue_ablation.log).
+            // A gate wave keeps M-subtiles 0, 1 and hands its g of subtiles 2, 3 to the up wave of the same columns; the up wave hands over its u
+            // of subtiles 0, 1 and keeps 2, 3: every (row, column) is still computed once, by the same expression.
+            constexpr int HALF = MS / 2;
+            const bool gate_wave = wn < 2;
+            const int my_ms0 = gate_wave ? 0 : HALF;                 // the M-subtiles this wave finishes: my_ms0, my_ms0 + 1
+            {
+                float* mine_out = xch + wn * (HALF * NS * 4) * 64;   // [4 waves][HALF * NS * 4 registers][64 lanes]
                 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
+                for (int h = 0; h < HALF; ++h)                       // (the subtiles the partner wave finishes: gate -> HALF + h, up -> h)
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
                         #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            xch[((wn - 2) * (MS * NS * 4) + (ms * NS + ns) * 4 + e) * 64 + lane] = acc[ms][ns][e];
+                            mine_out[((h * NS + ns) * 4 + e) * 64 + lane] = gate_wave ? acc[HALF + h][ns][e] : acc[h][ns][e];
             }
             __syncthreads();
-            float amax[MS] = {0.f, 0.f, 0.f, 0.f};
-            if (wn < 2) {
-                float rw[MS] = {1.f, 1.f, 1.f, 1.f};
+            float amax[HALF] = {0.f, 0.f};
+            float y_out[HALF][NS][4];
+            {
+                const float* partner = xch + (wn ^ 2) * (HALF * NS * 4) * 64;
+                float rw[HALF] = {1.f, 1.f};
                 if (o.row_weight != nullptr) {
                     // (rows past m_end: whatever the buffer holds -- they are never stored and never meet another row's amax)
                     const v4f w4 = *reinterpret_cast<const v4f*>(o.row_weight + group * o.rw_sg + t.m0 + (lane & 15) * MS);
-                    rw[0] = w4[0]; rw[1] = w4[1]; rw[2] = w4[2]; rw[3] = w4[3];
+                    rw[0] = gate_wave ? w4[0] : w4[2]; rw[1] = gate_wave ? w4[1] : w4[3];
                 }
                 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
+                for (int h = 0; h < HALF; ++h)
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
                         #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float g = acc[ms][ns][e];
-                            float u = xch[(wn * (MS * NS * 4) + (ms * NS + ns) * 4 + e) * 64 + lane];
+                            const float other = partner[((h * NS + ns) * 4 + e) * 64 + lane];
+                            float g = gate_wave ? acc[h][ns][e] : other;
+                            float u = gate_wave ? other : acc[HALF + h][ns][e];
                             if (o.clamp > 0.f) {
                                 g = fminf(g, o.clamp);
                                 u = fminf(fmaxf(u, -o.clamp), o.clamp);
@@ -248,17 +260,17 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                             // without a routing weight the operator stands for "... -> BF16 intermediate -> per_token_cast_to_fp8": round to
                             // BF16 as the unfused pipeline stores it; with one it is the reference kernel's epilogue, which keeps
                             // silu(gate) * up * weight in FP32 up to the amax and the FP8 cast (sm100_fp8_fp4_mega_moe.cuh:1001-1020)
-                            y = o.row_weight != nullptr ? y * rw[ms] : round_bf16(y);
-                            acc[ms][ns][e] = y;
-                            amax[ms] = fmaxf(amax[ms], fabsf(y));
+                            y = o.row_weight != nullptr ? y * rw[h] : round_bf16(y);
+                            y_out[h][ns][e] = y;
+                            amax[h] = fmaxf(amax[h], fabsf(y));
                         }
-                // 3. the row's 4 lanes (lane bits 4, 5), then the two gate waves
+                // 3. the row's 4 lanes (lane bits 4, 5), then the two waves that hold the row's two column halves
                 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    amax[ms] = fmaxf(amax[ms], __shfl_xor(amax[ms], 16, 64));
-                    amax[ms] = fmaxf(amax[ms], __shfl_xor(amax[ms], 32, 64));
+                for (int h = 0; h < HALF; ++h) {
+                    amax[h] = fmaxf(amax[h], __shfl_xor(amax[h], 16, 64));
+                    amax[h] = fmaxf(amax[h], __shfl_xor(amax[h], 32, 64));
                     if (lg == 0)
-                        row_max[wn * 64 + (lane & 15) * MS + ms] = amax[ms];         // tile row of (lane, ms): interleaved rows
+                        row_max[(wn & 1) * 64 + (lane & 15) * MS + my_ms0 + h] = amax[h];     // tile row of (lane, ms): interleaved rows
                 }
             }
             __syncthreads();
@@ -299,11 +311,11 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                 }
             }
             __syncthreads();
-            if (wn < 2) {
+            {
                 const int kb2 = t.n0 / (2 * BN);                         // the intermediate's 128-block = GEMM2's K block
                 #pragma unroll
-                for (int ms = 0; ms < MS; ++ms) {
-                    const int row_in_tile = (lane & 15) * MS + ms;
+                for (int h = 0; h < HALF; ++h) {
+                    const int row_in_tile = (lane & 15) * MS + my_ms0 + h;
                     const int row = t.m0 + row_in_tile;
                     const float row_amax = row_max[128 + row_in_tile];
                     float scale = fmaxf(row_amax, 1e-4f) * (1.0f / 448.0f);     // the reference kernel (math.cuh:93) and torch's `/ 448.0` on a device both multiply
@@ -318,14 +330,14 @@ __device__ __forceinline__ void stream_swiglu_kernel_body(const GemmParams& p, c
                     const float inv = 1.0f / scale;
                     if (row >= t.m_end)
                         continue;
-                    uint8_t* qrow = o.q + group * o.q_sg + static_cast<int64_t>(row) * o.q_sm + (t.n0 / BN) * 64 + wn * 32 + lg * 8;
+                    uint8_t* qrow = o.q + group * o.q_sg + static_cast<int64_t>(row) * o.q_sm + (t.n0 / BN) * 64 + (wn & 1) * 32 + lg * 8;
                     int w0 = 0, w1 = 0;                                  // N-subtiles 0 and 1: 8 consecutive intermediate columns
-                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][0][0] * inv, acc[ms][0][1] * inv, w0, false);
-                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][0][2] * inv, acc[ms][0][3] * inv, w0, true);
-                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][1][0] * inv, acc[ms][1][1] * inv, w1, false);
-                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[ms][1][2] * inv, acc[ms][1][3] * inv, w1, true);
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y_out[h][0][0] * inv, y_out[h][0][1] * inv, w0, false);
+                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y_out[h][0][2] * inv, y_out[h][0][3] * inv, w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y_out[h][1][0] * inv, y_out[h][1][1] * inv, w1, false);
+                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y_out[h][1][2] * inv, y_out[h][1][3] * inv, w1, true);
                     *reinterpret_cast<uint2*>(qrow) = make_uint2(static_cast<uint32_t>(w0), static_cast<uint32_t>(w1));
-                    if (wn == 0 && lg == 0 && (tile_id & 1) == 0)
+                    if ((wn & 1) == 0 && lg == 0 && (tile_id & 1) == 0)
                         o.sf[group * o.sf_sg + static_cast<int64_t>(kb2) * o.sf_sk + row] = scale;
                 }
             }
