@@ -1522,12 +1522,14 @@ def test_packed_ue8m0_m_grouped_contiguous_in_a_hip_graph():
     case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, False, actual_ms=actual_ms, use_ue8m0=True)
     a = gen.packed_ue8m0_operand(*case.a)
     b = gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+    torch.cuda.synchronize()                    # (the operands were produced on the default stream; the side stream does not wait for it)
     warm = torch.cuda.Stream()
     with torch.cuda.stream(warm):
         dg.m_grouped_fp8_gemm_nt_contiguous(a, b, case.d, case.grouped_layout)
         assert dg.last_config() == 'e8_quad_tab_256x256'
     warm.synchronize()
     want = case.d.clone()
+    assert calc_diff(torch.nan_to_num(want), torch.nan_to_num(case.ref_d)) < gen.FP8_MAX_DIFF
     for stream, exact in ((warm, True), (torch.cuda.Stream(), False)):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
