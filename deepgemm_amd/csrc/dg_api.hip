@@ -158,6 +158,10 @@ const Config kConfigs[] = {
     {"skinny_16c", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true>},
     {"skinny_32c", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2, 4, 1, true>},
     {"skinny_16wc", 16, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 2, true>},
+    // ... and coalesced activation loads as well (m > 1: A is up to as many bytes per workgroup as the weights)
+    {"skinny_16ca", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true>},
+    // (the 32-row form with coalesced activation loads spills inside its K loop -- 24 VGPRs -- and loses at 32 x 4096 x 7168: 15.7 against 13.6 us;
+    //  not instantiated)
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>, true, false,
      false, true},
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
@@ -548,9 +552,11 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // round 5: the coalesced-load forms ('c': 8 weight rows x 128 bytes per load instruction, operands through wave-private LDS) -- same
         // bits, 10-18 % faster on every shape measured (profiles/r05_probe/skinny_coalesced_ab.jsonl: m = 1, 4096 x 7168 9.2 -> 8.3 us,
         // 7168 x 16384 27.8 -> 24.4 / 23.7, m = 16 11.9 -> 10.0, m = 32 15.8 -> 13.4)
+        // ... and, up to 16 rows, the activation loads too ('ca': m = 1, 4096 x 7168 8.4 -> 7.7 us, m = 16 10.0 -> 9.0; skinny_coalesced_activations_ab.jsonl)
         if (m_for_tiling <= 16 && num_kb >= 16)
-            pick = (p.n > 16 * num_cus() && p.n <= 32 * num_cus() && !p.accumulate && p.n % 4 == 0) ? "skinny_16wc" : "skinny_16c";
-        // (m = 1, 7168 x 16384: 448 column tiles = 1.75 rounds of skinny_16 -> 256 tiles of 28 columns)
+            pick = (p.n > 16 * num_cus() && p.n <= 32 * num_cus() && !p.accumulate && p.n % 4 == 0 && num_kb < 32) ? "skinny_16wc" : "skinny_16ca";
+        // (two N-subtiles per workgroup -- one round instead of 1.x -- only pay with short K loops now: 16 x 8192 x 2048 7.4 against 8.0 us, but
+        //  1 x 7168 x 4096 8.7 against 8.6, 1 x 6144 x 7168 13.3 against 12.8, 4 x 7168 x 16384 25.0 against 24.7)
         else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608)
             pick = "skinny_32c";
         if (pick != nullptr)

@@ -3823,13 +3823,17 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
 // g and g + 4) through 2 KiB of wave-private LDS at the moment they are consumed: two ds_write_b128 + two ds_read_b128 per K block in the
 // chunk-swizzled image of the tile kernels (lds_chunk_offset), no barrier (a wave's LDS operations complete in order).  Same operands, same
 // bits as the register-direct form.
-template <int MS, int CH = 4, int NSUB = 1, bool COAL = false>
+// ACOAL: the same for the activation rows (they come from the L2, but their load instructions were as scattered: at m = 16 A is as many bytes
+// per workgroup as the weights).
+template <int MS, int CH = 4, int NSUB = 1, bool COAL = false, bool ACOAL = false>
 __global__ __launch_bounds__(512)
 void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
+    static_assert(!ACOAL || COAL, "ACOAL shares the staging buffers' geometry with COAL");
     constexpr int NW = 8;                                       // CH: K blocks per software-pipeline chunk (two chunks in flight)
     static_assert(MS * NSUB <= NW, "one wave per (M-subtile, N-subtile) sums the partial tiles");
     __shared__ float red[NW][MS * NSUB][256];
     __shared__ __attribute__((aligned(16))) uint8_t staging[COAL ? NW : 1][COAL ? 2 : 1][COAL ? 2048 : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t staging_a[ACOAL ? NW : 1][ACOAL ? 2 : 1][ACOAL ? 2048 : 16];
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * (NSUB == 1 || p.skinny_cols == 0 ? 16 * NSUB : p.skinny_cols);
@@ -3853,11 +3857,17 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
         sfb_ptr[s] = p.sfb + static_cast<int64_t>(imin(n0 + s * 16 + 4 * g, p.n - 1) / 128) * p.sfb_sn;
     }
     const uint8_t* a_ptr[MS];
+    [[maybe_unused]] const uint8_t* a_ptr_hi[MS];               // ACOAL: rows (l >> 3) and (l >> 3) + 8 of the subtile, chunk l & 7
     const float* sfa_ptr[MS];
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
         const int row = imin(ms * 16 + r, p.m - 1);             // rows past m: a valid row's bytes, the result is never stored
-        a_ptr[ms] = p.a + static_cast<int64_t>(row) * p.a_sm + g * 16;
+        if constexpr (ACOAL) {
+            a_ptr[ms] = p.a + static_cast<int64_t>(imin(ms * 16 + (lane >> 3), p.m - 1)) * p.a_sm + (lane & 7) * 16;
+            a_ptr_hi[ms] = p.a + static_cast<int64_t>(imin(ms * 16 + 8 + (lane >> 3), p.m - 1)) * p.a_sm + (lane & 7) * 16;
+        } else {
+            a_ptr[ms] = p.a + static_cast<int64_t>(row) * p.a_sm + g * 16;
+        }
         sfa_ptr[ms] = p.sfa + static_cast<int64_t>(row) * p.sfa_sm;
     }
 
@@ -3877,7 +3887,8 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
                 c.a[ms][j][0] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off);
-                c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off + 64);
+                if constexpr (ACOAL) c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr_hi[ms] + off);
+                else c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off + 64);
                 c.sa[ms][j] = sfa_ptr[ms][static_cast<int64_t>(kb) * p.sfa_sk];
             }
         }
@@ -3892,6 +3903,22 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
         #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (kb0 + j < kb_end) {                             // wave-uniform
+                v8i afs[MS];
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    v4i a_lo = c.a[ms][j][0], a_hi = c.a[ms][j][1];
+                    if constexpr (ACOAL) {
+                        uint8_t* st = staging_a[wave][(j * MS + ms) & 1];
+                        *reinterpret_cast<v4i*>(st + st_write) = a_lo;
+                        *reinterpret_cast<v4i*>(st + st_write + 1024) = a_hi;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        a_lo = *reinterpret_cast<const v4i*>(st + st_read_lo);
+                        a_hi = *reinterpret_cast<const v4i*>(st + st_read_hi);
+                    }
+                    afs[ms] = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
                 #pragma unroll
                 for (int s = 0; s < NSUB; ++s) {
                     v4i b_lo = c.b[j][s][0], b_hi = c.b[j][s][1];
@@ -3908,8 +3935,7 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
                     const v8i bf = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     #pragma unroll
                     for (int ms = 0; ms < MS; ++ms) {
-                        const v8i af = __builtin_shufflevector(c.a[ms][j][0], c.a[ms][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        const v4f part = mfma_fp8_k128(bf, af);
+                        const v4f part = mfma_fp8_k128(bf, afs[ms]);
                         const float scale = c.sa[ms][j] * c.sb[j][s];
                         #pragma unroll
                         for (int e = 0; e < 4; ++e)

@@ -64,7 +64,7 @@ def test_skinny_decode_kernel(m, n, k):
     dg.fp8_gemm_nt(case.a, case.b, case.d)                        # automatic pick first (short K loops stay on the stream tiles)
     assert_close_to_oracle(case.d, want, f'auto: {dg.last_config()}')
     if k >= 2048 and (m <= 16 or (4096 <= k <= 8192 and n <= 4608)):
-        assert dg.last_config() in (cfg, cfg + 'c'), dg.last_config()          # ('c': the coalesced-load form, round 5)
+        assert dg.last_config() in (cfg, cfg + 'c', cfg + 'ca'), dg.last_config()          # ('c' / 'ca': the coalesced-load forms, round 5)
     dg.set_forced_config(cfg)
     wide = torch.full((m, n + 24), float('nan'), device='cuda', dtype=torch.bfloat16)
     d = wide[:, :n]
@@ -93,8 +93,8 @@ def test_skinny_coalesced_weight_loads_same_bits(m, n, k):
     gen.reset_seed(m + n + k)
     case = gen.generate_normal(m, n, k)
     want = oracle_dense(case)
-    pairs = [('skinny_16', 'skinny_16c')] if m <= 16 else []
-    pairs += [('skinny_32', 'skinny_32c')]
+    pairs = [('skinny_16', 'skinny_16c'), ('skinny_16', 'skinny_16ca')] if m <= 16 else []
+    pairs += [('skinny_32', 'skinny_32c')]                                        # ('ca': coalesced activation loads as well)
     pairs += [('skinny_16w', 'skinny_16wc')] if m <= 16 and n % 4 == 0 else []
     for plain, coal in pairs:
         outs = []
@@ -1590,7 +1590,7 @@ def test_skinny_two_subtile_form(m, n, k):
     wide = torch.full((m, n + 40), float('nan'), device='cuda', dtype=torch.bfloat16)
     d = wide[:, :n]
     dg.fp8_gemm_nt(case.a, case.b, d)
-    assert dg.last_config() in ('skinny_16w', 'skinny_16wc'), dg.last_config()
+    assert dg.last_config() in ('skinny_16w', 'skinny_16wc', 'skinny_16ca'), dg.last_config()      # (round 5: two subtiles only with short K loops)
     assert_close_to_oracle(d, want, 'skinny_16w')
     assert bool(torch.isnan(wide[:, n:]).all())
     dg.set_forced_config('skinny_16')
@@ -1603,7 +1603,7 @@ def test_skinny_two_subtile_form(m, n, k):
         assert torch.equal(again, case.d)
     acc_case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float)
     dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)
-    assert dg.last_config() in ('skinny_16', 'skinny_16c')
+    assert dg.last_config() in ('skinny_16', 'skinny_16c', 'skinny_16ca')
     dg.set_forced_config('skinny_16w')
     with pytest.raises(RuntimeError):
         dg.fp8_gemm_nt(acc_case.a, acc_case.b, acc_case.d, c=acc_case.c)

@@ -54,7 +54,7 @@ def skinnyc(seed):
     gen.reset_seed(seed)
     case = gen.generate_normal(m, n, k)
     want = oracle.fp8_gemm_nt_blockwise_torch(case.a[0], case.a[1], case.b[0], case.b[1])
-    pairs = ([('skinny_16', 'skinny_16c'), ('skinny_16w', 'skinny_16wc')] if m <= 16 else []) + [('skinny_32', 'skinny_32c')]
+    pairs = ([('skinny_16', 'skinny_16c'), ('skinny_16', 'skinny_16ca'), ('skinny_16w', 'skinny_16wc')] if m <= 16 else []) + [('skinny_32', 'skinny_32c')]
     for plain, coal in pairs:
         outs = []
         for cfg in (plain, coal):

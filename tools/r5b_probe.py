@@ -179,10 +179,27 @@ def skinny_w():
             a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
         calls = calls * 5
-        ab(f'decode {m}x{n}x{k}', [('skinny_16c', forced('skinny_16c'), calls), ('skinny_16wc', forced('skinny_16wc'), calls)])
+        ab(f'decode {m}x{n}x{k}', [('skinny_16c', forced('skinny_16c'), calls), ('skinny_16wc', forced('skinny_16wc'), calls),
+                                   ('skinny_16ca', forced('skinny_16ca'), calls)])
+
+
+def skinny_a():
+    """Coalesced activation loads on top of the coalesced weight loads."""
+    for (m, n, k), pair in (((1, 4096, 7168), ('skinny_16c', 'skinny_16ca')), ((4, 4096, 7168), ('skinny_16c', 'skinny_16ca')),
+                            ((8, 4096, 7168), ('skinny_16c', 'skinny_16ca')), ((16, 4096, 7168), ('skinny_16c', 'skinny_16ca')),
+                            ((16, 2112, 7168), ('skinny_16c', 'skinny_16ca')), ((32, 4096, 7168), ('skinny_32c', 'skinny_32ca')),
+                            ((24, 4096, 4096), ('skinny_32c', 'skinny_32ca'))):
+        calls = []
+        for i in range(4):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        calls = calls * 5
+        ab(f'decode {m}x{n}x{k}', [(pair[0], forced(pair[0]), calls), (pair[1], forced(pair[1]), calls)])
 
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['pc192', 'skinny', 'grouped_nn']
     for w in which:
-        {'pc192': pc192, 'skinny': skinny, 'grouped_nn': grouped_nn, 'packed_c4': packed_c4, 'skinny_w': skinny_w}[w]()
+        {'pc192': pc192, 'skinny': skinny, 'grouped_nn': grouped_nn, 'packed_c4': packed_c4, 'skinny_w': skinny_w, 'skinny_a': skinny_a}[w]()
