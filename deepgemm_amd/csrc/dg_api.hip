@@ -160,8 +160,9 @@ const Config kConfigs[] = {
     {"skinny_16wc", 16, 32, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 2, true>},
     // ... and coalesced activation loads as well (m > 1: A is up to as many bytes per workgroup as the weights)
     {"skinny_16ca", 16, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true>},
-    // (the 32-row form with coalesced activation loads spills inside its K loop -- 24 VGPRs -- and loses at 32 x 4096 x 7168: 15.7 against 13.6 us;
-    //  not instantiated)
+    // (the 32-row form with coalesced activation loads and four K blocks per chunk spills inside its K loop -- 24 VGPRs -- and loses at
+    //  32 x 4096 x 7168: 15.7 against 13.6 us; with three K blocks per chunk it fits)
+    {"skinny_32ca", 32, 16, 512, 1, 0.0f, true, dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true>},
     {"pipe_pc_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, false>, true, false,
      false, true},
     {"pipe_pc_mn_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 1, true>, true,
@@ -557,8 +558,10 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
             pick = (p.n > 16 * num_cus() && p.n <= 32 * num_cus() && !p.accumulate && p.n % 4 == 0 && num_kb < 32) ? "skinny_16wc" : "skinny_16ca";
         // (two N-subtiles per workgroup -- one round instead of 1.x -- only pay with short K loops now: 16 x 8192 x 2048 7.4 against 8.0 us, but
         //  1 x 7168 x 4096 8.7 against 8.6, 1 x 6144 x 7168 13.3 against 12.8, 4 x 7168 x 16384 25.0 against 24.7)
+        // (17 .. 32 rows: coalesced activation loads with three K blocks per chunk from K = 6144 -- 32 x 4096 x 7168 13.3 -> 12.1 us, 32 x 4608 x 8192
+        //  23.6 -> 21.1; four K blocks per wave (K = 4096) want the four-block chunks: 7.6 against 8.3; skinny_32_coalesced_activations_ab.jsonl)
         else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608)
-            pick = "skinny_32c";
+            pick = num_kb >= 48 ? "skinny_32ca" : "skinny_32c";
         if (pick != nullptr)
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, pick) == 0)

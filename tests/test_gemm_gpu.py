@@ -94,7 +94,7 @@ def test_skinny_coalesced_weight_loads_same_bits(m, n, k):
     case = gen.generate_normal(m, n, k)
     want = oracle_dense(case)
     pairs = [('skinny_16', 'skinny_16c'), ('skinny_16', 'skinny_16ca')] if m <= 16 else []
-    pairs += [('skinny_32', 'skinny_32c')]                                        # ('ca': coalesced activation loads as well)
+    pairs += [('skinny_32', 'skinny_32c'), ('skinny_32', 'skinny_32ca')]          # ('ca': coalesced activation loads as well)
     pairs += [('skinny_16w', 'skinny_16wc')] if m <= 16 and n % 4 == 0 else []
     for plain, coal in pairs:
         outs = []

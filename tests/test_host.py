@@ -457,7 +457,7 @@ def test_automatic_kernel_selection_is_pinned():
     # the reference's dense sweep: small M, K tails, few tiles with long K loops, tile-count quantisation
     assert pick(dense, 1, 7168, 16384) == 'skinny_16ca' and pick(dense, 16, 8192, 2048) == 'skinny_16wc' and pick(dense, 1, 4096, 16384) == 'skinny_16ca' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32'
     # decode batches: the skinny weight-stream kernel for long K loops, the stream tiles for short ones / wide N
-    assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_l8_64x32'
+    assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32ca' and pick(dense, 24, 4096, 4096) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_l8_64x32'
     assert pick(dense, 1, 24576, 1536) == 'stream2_64x128' and pick(dense, 1, 32768, 512) == 'stream2_64x128'
     assert pick(dense, 32, 7168, 16384) == 'stream_l8_64x32' and not pick(dense, 1, 4104, 7168).startswith('skinny_16')
     assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_l8_64x32'

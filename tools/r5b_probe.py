@@ -199,7 +199,19 @@ def skinny_a():
         ab(f'decode {m}x{n}x{k}', [(pair[0], forced(pair[0]), calls), (pair[1], forced(pair[1]), calls)])
 
 
+def skinny_32():
+    for m, n, k in ((32, 4096, 7168), (24, 4096, 4096), (17, 2112, 7168), (32, 4608, 8192)):
+        calls = []
+        for i in range(4):
+            gen.reset_seed(i)
+            case = gen.generate_normal(m, n, k)
+            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+        calls = calls * 5
+        ab(f'decode {m}x{n}x{k}', [('skinny_32c', forced('skinny_32c'), calls), ('skinny_32ca', forced('skinny_32ca'), calls)])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['pc192', 'skinny', 'grouped_nn']
     for w in which:
-        {'pc192': pc192, 'skinny': skinny, 'grouped_nn': grouped_nn, 'packed_c4': packed_c4, 'skinny_w': skinny_w, 'skinny_a': skinny_a}[w]()
+        {'pc192': pc192, 'skinny': skinny, 'grouped_nn': grouped_nn, 'packed_c4': packed_c4, 'skinny_w': skinny_w, 'skinny_a': skinny_a, 'skinny_32': skinny_32}[w]()
