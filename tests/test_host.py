@@ -420,6 +420,23 @@ def test_packed_ue8m0_words_expand_to_exact_powers_of_two():
     assert back.shape == (37, 17) and torch.equal(back, sf[:, :17])
 
 
+def test_grouped_operand_plan_of_packed_scales():
+    """dg_ue8m0_grouped_operand_plan (round 5): MN-major weights [G][K][N] of a packed-scale contiguous call stay in place where the in-place
+    kernel is eligible (no psum, n % 16 == 0, M alignment 128 or a multiple of 256) and a pass over every group's weights costs more than its
+    slower K loop; 2 = re-major first.  Answers without a device."""
+    from deepgemm_amd._lib import lib
+    a, b = 1 << 20, 1 << 21
+
+    def plan(groups, m, n, k, psum=0, alignment=128, b_sn=1, b_sk=None):
+        return lib.dg_ue8m0_grouped_operand_plan(a, b, groups, m, n, k, k, n * k, b_sn, n if b_sk is None else b_sk, psum, alignment)
+    assert plan(8, 4608, 4096, 7168) == 0                               # C4's shape in the nn form: 235 MB of weights would be re-majored
+    assert plan(8, 4608, 4096, 7168, psum=1) == 2                       # the psum walk is written for tiles that divide the alignment
+    assert plan(4, 32768, 4096, 7168) == 2                              # long groups: the pass is cheap next to the faster quad kernel
+    assert plan(8, 4608, 4104, 7168) == 2 and plan(8, 4608, 4096, 7168, alignment=384) == 2
+    assert plan(8, 4608, 4096, 7168, alignment=256) == 0 and plan(2, 256, 4096, 7168) == 2      # (decode-sized M: the stream tiles want K-major weights)
+    assert plan(8, 4608, 4096, 7168, b_sn=7168, b_sk=1) == 0            # K-major weights: nothing to decide
+
+
 def test_automatic_kernel_selection_is_pinned():
     """The tile-selection heuristics (dg_api.hip: select_config / select_e8_config, the analogue of get_best_config,
     csrc/jit_kernels/heuristics/common.hpp:14-52) on BASELINE's configurations and on the entries of the reference's sweeps that each
