@@ -41,20 +41,33 @@ WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt'
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
              'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
              'contiguous_ue8m0']
+# HBM-bound workloads whose per-call weight stream is smaller than the 256 MiB Infinity Cache (MALL): the rotation must cover more than the
+# cache, or the "fraction of 8 TB/s" is a cache-read rate (the reference flushes 8 GB between timed iterations: deep_gemm/testing/bench.py:93,108).
+# sets x (bytes not re-used across calls) >= COLD_ROTATION_BYTES; the other HBM-bound lines stream >= 235 MB of weights per call x >= 2 sets.
+COLD_ROTATION_BYTES = 320e6
+
+
+def cold_sets(weight_bytes: float, at_least: int) -> int:
+    return max(at_least, int(-(-COLD_ROTATION_BYTES // weight_bytes)))
+
+
 GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
-def measured_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/<round>/traffic.json,
-    FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes); None if no committed
-    profile is of this kernel."""
+def measured_counters(kernel: str) -> dict:
+    """Counter-derived figures of `kernel` from the newest committed rocprofv3 PMC passes (profiles/<round>/traffic_<kernel>.json, written
+    by tools/make_traffic_json.py): `traffic` = HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
+    MI355X_MICROARCH.md prescribes), `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (shader cycles x 1024 SIMDs), `clock_ghz` = shader cycles of
+    a launch / its kernel-trace duration, `counters_git` = the commit the passes were measured on.  They are properties of the kernel, measured
+    once per round on its own profiling runs -- not of this run; empty if no committed profile is of this kernel."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic*.json')), reverse=True):
         with open(path) as f:
             rec = json.load(f)
         if rec.get('kernel') == kernel:
-            return rec['traffic_bytes']
-    return None
+            return {'traffic': rec['traffic_bytes'], 'mfma_busy': rec.get('mfma_busy'), 'clock_ghz': rec.get('clock_ghz'),
+                    'counters_git': rec.get('git'), 'counters_from': os.path.relpath(path, ROOT)}
+    return {}
 
 
 def parse_args():
@@ -180,9 +193,12 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         # batch-1 decode entries of the reference's dense sweep (tests/generators.py:119-121, m = 1): a weight stream, HBM-bound
         bound = 'hbm'
         m, n, k = (1, 4096, 7168) if name == 'decode_m1' else (1, 7168, 16384)
+        sets = cold_sets(n * k, sets)           # 29 MB of weights a call: 11 sets; 117 MB: 3 (cold: see COLD_ROTATION_BYTES)
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_normal(m, n, k)
+            if i:
+                case.a_bf16 = case.b_bf16 = None        # (only case 0 is checked against the reference expression)
             a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
             calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
@@ -250,9 +266,12 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         # with too few 64-row tiles for 256 CUs -- the 64 x 32 stream tile with loader waves (round 4)
         bound = 'hbm'
         m, n, k = 128, 4096, 7168
+        sets = cold_sets(n * k, sets)           # 29 MB of weights a call: 11 sets (cold: see COLD_ROTATION_BYTES)
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_normal(m, n, k)
+            if i:
+                case.a_bf16 = case.b_bf16 = None
             a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
             calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
@@ -361,11 +380,13 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
     return calls, flops, float(nbytes), desc, check, bound
 
 
-def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, traffic=None, useful_flops=None, recipe_roof=None):
+def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, kernel: str, counters=None, useful_flops=None, recipe_roof=None):
     tflops, gbs = flops / kernel_s / 1e12, nbytes / kernel_s / 1e9
     rec = ({'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / PEAK_FP8_TFLOPS} if bound == 'mfma' else
            {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
-    rec.update({'traffic': traffic, 'kernel': kernel, 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
+    counters = counters or {}
+    rec.update({'traffic': counters.get('traffic'), 'mfma_busy': counters.get('mfma_busy'), 'clock_ghz': counters.get('clock_ghz'),
+                'counters_git': counters.get('counters_git'), 'kernel': kernel, 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
                 'algorithmic_bytes': nbytes, 'tflops': tflops, 'gbs': gbs})
     if useful_flops is not None:        # layouts with padding rows: the fraction on the rows that carry data, beside the reference-style count
         rec.update({'useful_flops': useful_flops, 'frac_useful': useful_flops / kernel_s / 1e12 / PEAK_FP8_TFLOPS})
@@ -446,8 +467,9 @@ def run_secondary(sets: int):
                 extra['fused_us'] = call_s * 1e6
                 other = None
             rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
-                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), useful_flops=desc.get('useful_flops'),
-                                               recipe_roof=desc.get('recipe_roof')), **extra}
+                   'input_sets': len(calls),
+                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), measured_counters(dg.last_config()),
+                                               useful_flops=desc.get('useful_flops'), recipe_roof=desc.get('recipe_roof')), **extra}
             out.append(rec)
         except Exception as e:                                       # noqa: BLE001  (a secondary line must not take the headline down)
             out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'[:200]})
@@ -538,8 +560,7 @@ def run(rank: int, world: int, local_rank: int, args):
     if rank == 0:
         total_flops = flops * args.steps * world
         value = total_flops / elapsed / 1e12
-        traffic = measured_traffic(dg.last_config()) if args.workload.startswith('dense') else None
-        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), traffic, useful_flops=desc.get('useful_flops'),
+        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), measured_counters(dg.last_config()), useful_flops=desc.get('useful_flops'),
                                    recipe_roof=desc.get('recipe_roof'))
         if split is not None:
             # the roofline of the EP step is that of its local GEMM (HBM-bound on the expert weights)

@@ -24,7 +24,6 @@ SIGNATURES = {
     'dg_m_grouped_fp8_gemm_nt_masked_swiglu': (_i32, [_vp] * 7 + [_i32] * 5 + [_i64] * 13 + [ctypes.c_float, _i32, _vp, _i64, _vp]),
     'dg_swiglu_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'dg_set_swiglu_exchange_timeout_us': (None, [_i64]),
-    'dg_set_swiglu_fault_injection': (None, [_i32]),
     'dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted': (_i32, [_vp] * 7 + [_i32] * 5 + [_i64] * 13 + [ctypes.c_float, _i32, _vp, _i64, _vp, _i64, _vp]),
     'dg_moe_scatter_to_masked': (_i32, [_vp, _vp, _vp, _i32, _vp] + [_i32] * 5 + [_i64, _i64] + [_vp] * 6 + [_i64] * 5 + [_vp]),
     'dg_moe_combine_from_masked': (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _i64, _vp]),

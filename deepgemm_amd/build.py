@@ -1,22 +1,35 @@
 """Ahead-of-time build of the HIP extension (`libdeepgemm_amd.so`) for gfx950.
 
-There is no JIT: the reference's NVCC/NVRTC runtime (csrc/jit/) is replaced by one `hipcc` invocation whose output is
+There is no JIT: the reference's NVCC/NVRTC runtime (csrc/jit/) is replaced by an ahead-of-time `hipcc` build whose output is
 kept in-tree next to the sources, so that it travels with the repository snapshot to the GPU box.
+
+The build is sharded (round 6): `dg_api.hip` (host code + the plain kernels) and `NUM_SHARDS` instantiation units
+(`dg_shard.hip -DDG_SHARD=n`, the template kernels listed in `csrc/kernel_instances.inc`) are compiled in parallel from a private
+snapshot of the sources and linked into one library -- one device pass over all instantiations took six minutes on this container.
+`DG_MONOLITHIC=1` restores the single translation unit.
 """
+import concurrent.futures
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libdeepgemm_amd.so')
-SOURCES = ['dg_api.hip']
-HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_moe.hpp', 'fp8_gemm_experiments.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
+SOURCES = ['dg_api.hip', 'dg_shard.hip', 'kernel_instances.inc']
+NUM_SHARDS = 8                          # shard ids 0 .. NUM_SHARDS - 1 of kernel_instances.inc
+MONOLITHIC = os.environ.get('DG_MONOLITHIC', '') not in ('', '0')
+HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_moe.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize'] + (['-DDG_MONOLITHIC'] if MONOLITHIC else [])
 # DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that HISTORY.md quotes (tools/cycles.py,
 # tools/sustained.py, tools/trace*.py take their names); they roughly triple the compile time and are never selected.
+# Their sources live outside the product: tools/experiments/ (no product build reads them).
 if os.environ.get('DG_EXPERIMENTS', '') not in ('', '0'):
-    FLAGS.append('-DDG_EXPERIMENTS')
+    _EXPERIMENTS = os.path.join('..', '..', 'tools', 'experiments')
+    FLAGS += ['-DDG_EXPERIMENTS', '-I', _EXPERIMENTS, '-I', '.']
+    HEADERS += [os.path.join(_EXPERIMENTS, 'fp8_gemm_experiments.hpp'), os.path.join(_EXPERIMENTS, 'experiment_configs.inc')]
 
 
 # Tuning aid (tools/ A/B runs of two builds in one GPU session): DG_VARIANT=<tag> builds csrc/libdeepgemm_amd_<tag>.so with the extra
@@ -63,20 +76,54 @@ def is_stale() -> bool:
         return '-DDG_EXPERIMENTS' in FLAGS
 
 
+def _snapshot(root: str) -> str:
+    """A private copy of everything the compiler reads (same relative layout), so that the sources may be edited while a build runs."""
+    repo = os.path.dirname(os.path.dirname(CSRC))
+    dst_csrc = os.path.join(root, 'deepgemm_amd', 'csrc')
+    os.makedirs(dst_csrc)
+    for name in os.listdir(CSRC):
+        if name.endswith(('.hip', '.hpp', '.inc', '.h')):
+            shutil.copy2(os.path.join(CSRC, name), dst_csrc)
+    shutil.copytree(os.path.join(repo, 'include'), os.path.join(root, 'include'))
+    experiments = os.path.join(repo, 'tools', 'experiments')
+    if os.path.isdir(experiments):
+        shutil.copytree(experiments, os.path.join(root, 'tools', 'experiments'))
+    return dst_csrc
+
+
 def build_extension(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
-        tmp = LIB_PATH + f'.{os.getpid()}.tmp'
-        cmd = [HIPCC, *FLAGS, *SOURCES, '-o', tmp]
         version = _hipcc_version()
         if not version.startswith(VALIDATED_HIP_VERSIONS):
             print(f'deepgemm_amd: building with HIP {version}; the kernels\' code-generation assumptions were validated with '
                   f'{", ".join(VALIDATED_HIP_VERSIONS)} -- run tests/test_codegen.py on the result', file=sys.stderr)
-        if verbose:
-            print(' '.join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd, cwd=CSRC)
-        os.replace(tmp, LIB_PATH)
+        stamp = _stamp()
+        with tempfile.TemporaryDirectory(prefix='dg_build_') as root:
+            cwd = _snapshot(root)
+            units = [('dg_api.o', ['dg_api.hip'])]
+            if not MONOLITHIC:
+                units += [(f'dg_shard{n}.o', [f'-DDG_SHARD={n}', 'dg_shard.hip']) for n in range(NUM_SHARDS)]
+
+            def compile_unit(unit):
+                cmd = [HIPCC, *FLAGS, '-c', *unit[1], '-o', unit[0]]
+                if verbose:
+                    print(' '.join(cmd), file=sys.stderr)
+                subprocess.check_call(cmd, cwd=cwd)
+                return unit[0]
+
+            jobs = int(os.environ.get('DG_BUILD_JOBS', '0')) or min(len(units), os.cpu_count() or 1)
+            with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+                objects = list(pool.map(compile_unit, units))
+            tmp = os.path.join(cwd, 'libdeepgemm_amd.so')
+            link = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objects, '-o', tmp]
+            if verbose:
+                print(' '.join(link), file=sys.stderr)
+            subprocess.check_call(link, cwd=cwd)
+            staged = LIB_PATH + f'.{os.getpid()}.tmp'
+            shutil.copy2(tmp, staged)
+            os.replace(staged, LIB_PATH)
         with open(STAMP_PATH, 'w') as f:
-            f.write(_stamp())
+            f.write(stamp)
     return LIB_PATH
 
 

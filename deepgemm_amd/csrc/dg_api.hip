@@ -15,7 +15,15 @@
 #include "fp8_gemm_kernels.hpp"
 #include "fp8_gemm_quad.hpp"
 #include "fp8_gemm_moe.hpp"
-#ifdef DG_EXPERIMENTS
+#ifndef DG_MONOLITHIC   // (the default build: the template kernels are compiled by the dg_shard.hip units, see kernel_instances.inc)
+namespace dg {
+#define DG_HAVE_MOE_HPP 1
+#define DG_KERNEL_INSTANCE(...) extern template __global__ __VA_ARGS__;
+#include "kernel_instances.inc"
+#undef DG_KERNEL_INSTANCE
+}  // namespace dg
+#endif
+#ifdef DG_EXPERIMENTS   // the lab notebook lives outside the product sources: tools/experiments/ (build.py adds the include path)
 #include "fp8_gemm_experiments.hpp"
 #endif
 
@@ -172,87 +180,10 @@ const Config kConfigs[] = {
     {"pipe_pc_192x256", 192, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<192, 256, 2, 4, 1, false>, true, false,
      false, true},
     {"generic_128x128", 128, 128, 256, 4, 0.15f, false, dg::dg_fp8_gemm_generic_kernel},
-#ifdef DG_EXPERIMENTS   // fp8_gemm_experiments.hpp: superseded forms, timing ablations, rejected variants (HISTORY.md);
-                        // only reachable through dg_set_forced_config (efficiency 0 keeps them out of the heuristic)
-    // round 4: the other loader-wave forms that were measured (12 loader waves: no better than 4; the 64 x 128 tile: 39.8 us against 38.4 at
-    // m = 128, C5 43.7 against 43.6; cache policies nt / sc on the weight pieces of the 64 x 32 tile: no difference -- profiles/r04_probe/)
-    {"stream_l16_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 12>, true},
-    {"stream_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 4>, true},
-    {"stream_nt_l8_64x128", 64, 128, 512, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2, 1, false, 4>, true},
-    // round 4, negative: split rings (stream2_kernel_body: activation pieces on a short ring, weight pieces on a deep one, issued by separate
-    // wave groups because a wave's vector-memory operations retire in order; bit-identical, 12-16 waves): m = 128, 4096 x 7168 22.4 us
-    // against 18.2 (stream_l8_64x32), C5 49.8 against 44.2 (profiles/r04_probe/sweep_stream2_negative.log) -- bytes in flight per stream
-    // are NOT what holds the stream tiles at ~40 GB/s per CU
-    {"stream2_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 32, 4, 1, 2, 4, 10, 8, 8>, true},
-    {"stream2b_64x32", 64, 32, 1024, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 32, 4, 1, 2, 3, 12, 8, 8>, true},
-    {"stream2_64x128", 64, 128, 768, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 128, 1, 4, 1, 4, 7, 4, 8>, true},
-    {"stream2_nt_64x128", 64, 128, 768, 1, 0.0f, true, dg::dg_fp8_gemm_stream2_kernel<64, 128, 1, 4, 1, 4, 7, 4, 8, 2>, true},
-    // round 4, negative: duo_p_256x256 reading a ROW-major SFA in place (eight strided dword loads per lane and K block -- 16 distinct
-    // rows per instruction -- instead of two dwordx4; bit-identical): C2 141.3 us against 92.2-92.9 with the MN-major hand-over, i.e. far
-    // worse than the transpose launch it was meant to save (~7 us; profiles/r04_probe/sfa_rowmajor_in_place_negative.log): the scattered
-    // loads sit in the same in-order return queue as the LDS-DMA pieces.  With the config out of the production table the selection's
-    // row-major branch finds nothing, dg_dense_rowmajor_sfa_native answers 0 and the host layer transposes as before.
-    {"duo_p_rm_256x256", 256, 256, 512, 1, 0.0f, true,
-     dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, false, false, false, false, true>, true, false, true, false, false, false, true},
-    // round 4, negative: recipe (1, 1, 128) on the two-segment 128 x 256 duo tile (persistent walk, the 20 scale values of a K block landing
-    // in two alternating register sets, MFMA + 4 v_mul + 4 v_fmac per step in the matrix segment; bit-identical to pipe_pc_256x256, 393 GPU
-    // tests green with it selected): wgrad 4096 x 4096 x 7168 146.4-147.1 us against 141.1 (profiles/r04_probe/wgrad_duo_pc_ab.log).  A step
-    // with EIGHT VALU operations costs ~62 matrix-pipe cycles in either schedule (2.05 k cycles per 16-step K block here, 4.0 k per 64
-    // steps of a SIMD there): the recipe is VALU-issue bound, not schedule bound -- the role split has nothing to hide behind.
-    {"duo_pc_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<128, 256, 2, 4, true, false, false, false, false, true, false, true>,
-     true, false, true, true},
-    // round 3, negative: two segments per K block with the A fragments streamed through the matrix segment (STREAM_A: half the barrier
-    // round trips, bit-identical) -- 2.65 k cycles per K block against 2.55 k, C2 96.2 us against 93.1 (fragment reads between the MFMAs
-    // of a wave that shares its SIMD cost more than the two barriers they save)
-    {"duo_s_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_kernel<256, 256, 2, 4, true, false, false, false, false, false, true>, true, true, true},
-    {"naive_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_fast_kernel<256, 256, 2, 4, 0>},
-    {"pipe_pc_s2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 2, false>, true, false, false, true},
-    {"pipe_pc_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 3, false>, true, false, false, true},
-    {"pipe_pc_s4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_pc_kernel<256, 256, 2, 4, 4, false>, true, false, false, true},
-    {"pipe_s0_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 0>},
-    {"pipe_s1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 1>},
-    {"pipe_s3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_pipe_kernel<256, 256, 2, 4, 3>},
-    {"ring_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4>, true},
-    {"rabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 1>, true},
-    {"rabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 2>, true},
-    {"rabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 3>, true},
-    {"rabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 4>, true},
-    {"rabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 5>, true},
-    {"ring_p2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 2>, true},
-    {"ring_p4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 4>, true},
-    {"ring_p8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_ring_kernel<256, 256, 2, 4, 0, 8>, true},
-    {"dabl1_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 1>, true},
-    {"dabl2_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 2>, true},
-    {"dabl3_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 3>, true},
-    {"dabl4_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 4>, true},
-    {"dabl5_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 5>, true},
-    {"dabl6_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 6>, true},
-    {"dabl7_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 7>, true},
-    {"dabl8_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 8>, true},
-    {"dabl9_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 9>, true},
-    {"dabl10_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 10>, true},
-    {"dabl11_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 11>, true},
-    {"dabl12_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 12>, true},
-    {"dabl13_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 13>, true},
-    {"dabl14_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 14>, true},
-    {"dabl15_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 15>, true},
-    {"dabl16_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 16>, true},
-    {"dabl17_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 17>, true},
-    {"dabl18_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 18>, true},
-    {"dabl21_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 21>, true},
-    {"dabl30_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 30>, true},
-    {"dabl31_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 31>, true},
-    {"dabl32_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 32>, true},
-    {"duo_pprio_256x256", 256, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<256, 256, 2, 4, 26>, true, true, true},
-    {"duo_prio_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<128, 256, 2, 4, 28>, true},
-    {"duo_load_128x256", 128, 256, 512, 1, 0.0f, true, dg::dg_fp8_gemm_duo_abl_kernel<128, 256, 2, 4, 29>, true},
-    {"stream_noa_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 64>, true},
-    // FP32-scale kernels in the one-wave-per-SIMD schedule of the UE8M0 quad kernel: bit-identical to the duo kernels and 1.4x
-    // SLOWER -- a lone wave pays ~51 cycles per MFMA + 4 FMA step and ~60 more per LDS-DMA piece
-    {"quad_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2>, true, false, true},
-    {"quad_256x128", 256, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<256, 128, 2, 2>, true, true, true},
-    {"quad_v1_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 1>, true, false, true},
-    {"quad_v5_128x256", 128, 256, 256, 1, 0.0f, true, dg::dg_fp8_gemm_quad_kernel<128, 256, 2, 2, 5>, true, false, true},
+#ifdef DG_EXPERIMENTS   // (tools/experiments/, on the include path of DG_EXPERIMENTS builds only)
+#define DG_EXPERIMENT_ROWS_FP32
+#include "experiment_configs.inc"
+#undef DG_EXPERIMENT_ROWS_FP32
 #endif
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
@@ -287,39 +218,39 @@ const E8Config kE8Configs[] = {
     {"e8_stream2_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 0, 1, true>, 64, 128, 256, false, true, true, 2},
     {"e8_stream_nt2_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2, 1, true>, 64, 128, 256, false, true, true, 2},
 #ifdef DG_EXPERIMENTS
-    {"e8_ring_256x256", dg::dg_fp8_gemm_e8_kernel<256, 256, 2, 4>, 256, 256, 512, false, false, false},
-    {"e8_quad_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1>, 256, 256, 256, true, false, false},
-    {"e8_quad_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2>, 256, 256, 256, true, false, false},
-    {"e8_quad_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3>, 256, 256, 256, true, false, false},
-    {"e8_quad_v5", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 5>, 256, 256, 256, true, false, false},
-    {"e8_octo_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 4>, 256, 256, 512, true, true, false},
-    {"e8_quad_v7", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 7>, 256, 256, 256, true, false, false},
-    {"e8_octo_v7", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 7, false, 4>, 256, 256, 512, true, false, false},
-    {"e8_octo_v1", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 1, false, 4>, 256, 256, 512, true, false, false},
-    {"e8_octo_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2, false, 4>, 256, 256, 512, true, false, false},
-    {"e8_octo_v3", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 3, false, 4>, 256, 256, 512, true, false, false},
-    {"e8_quad_s_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, true>, 256, 256, 256, true, true, false},
-    {"e8_quad_s_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, true>, 128, 256, 256, false, true, false},
-    {"e8_quad_s_v6", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 6, true>, 256, 256, 256, true, false, false},
-    {"e8_quad_s_v2", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 2, true>, 256, 256, 256, true, false, false},
+#define DG_EXPERIMENT_ROWS_E8
+#include "experiment_configs.inc"
+#undef DG_EXPERIMENT_ROWS_E8
 #endif
 };
 
 // Tuning / diagnostic environment variables are read ONCE (first use): the launch paths are hot (a cached dense call is ~8 us of host time).
+// A launch reads them through an immutable snapshot behind an atomic pointer; dg_reload_env publishes a fresh snapshot (the old one is
+// leaked on purpose: a launch on another thread may still be reading it, and a reload is a tools / tests event, a few dozen bytes each).
+// Variables set after the first launch are therefore ignored until dg_reload_env() is called (README, "Environment").
 struct EnvKnobs {
-    bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, test_hooks, swiglu_one_per_cu;
+    bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, swiglu_one_per_cu;
     int group_m, ks_pieces, pc_bm;
     bool e8_tab_unsplit;
+    int swiglu_fault;       // DG_TEST_SWIGLU_FAULT (tests only): 1 = odd tiles of the fused SwiGLU kernel never publish their amax
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
-          sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), test_hooks(getenv("DG_TEST_HOOKS") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
+          sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
           group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0),
-          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr) {}
+          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr),
+          swiglu_fault(getenv("DG_TEST_SWIGLU_FAULT") ? atoi(getenv("DG_TEST_SWIGLU_FAULT")) : 0) {}
 };
-EnvKnobs& env_knobs() {
-    static EnvKnobs knobs;
-    return knobs;
+std::atomic<const EnvKnobs*> g_env_knobs{nullptr};
+const EnvKnobs& env_knobs() {
+    const EnvKnobs* k = g_env_knobs.load(std::memory_order_acquire);
+    if (k == nullptr) {
+        const EnvKnobs* fresh = new EnvKnobs();
+        if (g_env_knobs.compare_exchange_strong(k, fresh, std::memory_order_acq_rel))
+            return *fresh;
+        delete fresh;           // another thread published first
+    }
+    return *k;
 }
 
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
@@ -1484,10 +1415,8 @@ int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n) {
 
 namespace {
 std::atomic<long long> g_swiglu_timeout_us{10LL * 1000 * 1000};     // 10 s; the reference's grid / NVLink barriers give up after 60 s
-std::atomic<int> g_swiglu_fault{0};
 }
 void dg_set_swiglu_exchange_timeout_us(int64_t us) { g_swiglu_timeout_us.store(us > 0 ? us : 1, std::memory_order_relaxed); }
-void dg_set_swiglu_fault_injection(int mode) { g_swiglu_fault.store(mode, std::memory_order_relaxed); }
 
 int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, const void* b_interleaved, const float* sfb, void* out_fp8,
                                            float* out_sf, const int32_t* masked_m, int num_groups, int m_max, int n, int k, int expected_m,
@@ -1544,7 +1473,7 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu_weighted(const void* a, const float* 
     o.errors = static_cast<uint32_t*>(workspace);
     o.amax_ws = static_cast<uint32_t*>(workspace) + 64;
     o.timeout_ticks = g_swiglu_timeout_us.load(std::memory_order_relaxed) * 100;       // s_memrealtime: 100 MHz
-    o.fault = env_knobs().test_hooks ? g_swiglu_fault.load(std::memory_order_relaxed) : 0;     // (honoured only under DG_TEST_HOOKS)
+    o.fault = env_knobs().swiglu_fault;          // (tests only: DG_TEST_SWIGLU_FAULT + dg_reload_env; no entry point arms it)
     o.q = static_cast<uint8_t*>(out_fp8); o.sf = out_sf;
     o.q_sg = out_stride_g; o.q_sm = out_stride_m; o.sf_sg = out_sf_stride_g; o.sf_sk = out_sf_stride_k;
     o.clamp = activation_clamp; o.use_ue8m0 = use_ue8m0 ? 1 : 0;
@@ -1934,7 +1863,7 @@ int dg_set_num_cus(int n) {
 
 int dg_get_num_cus(void) { return num_cus(); }
 
-void dg_reload_env(void) { env_knobs() = EnvKnobs(); }
+void dg_reload_env(void) { g_env_knobs.store(new EnvKnobs(), std::memory_order_release); }
 
 int dg_set_forced_config(const char* name) {
     if (name == nullptr)

@@ -1669,7 +1669,7 @@ __device__ __forceinline__ void promote_only_v(float (&c)[4], const float (&s)[4
 // Same piece / transpose-read geometry as B_MN; A rows keep their natural order (subtile ms of a wave = rows 16 ms .. 16 ms + 15),
 // so a lane's row scales come as MS dword loads (ScaleLandingN) and the epilogue runs with INTERLEAVED_ROWS = false.
 // (The timing ablations this kernel was tuned with -- no stagger, priorities, early barriers, pieces between MFMAs, per-step
-// traces ... -- live in fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
+// traces ... -- live in tools/experiments/fp8_gemm_experiments.hpp, DG_EXPERIMENTS builds only.)
 // K_TAIL: K need not be a multiple of 128 (whole 16-byte chunks, K > 128): the partial last K block is computed once per tile after
 // the loop (separate instantiations: the stage costs registers that the tuned whole-block kernels do not have to spare).
 // MERGED (128-row tiles): TWO segments per K block instead of four -- L: scales, every piece of block kb+2, every fragment of block
@@ -3580,6 +3580,7 @@ void dg_fp8_gemm_duo_e8_kernel(const GemmParams p) {
 // `pieces` FP32 partial matrices [m][n] (dense, piece_stride floats apart), added in piece order (bit-repeatable), then the
 // operator's own output step -- FP32 or BF16, plain or reduce-add in D's dtype.  Four columns per thread, grid-stride.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_sum_partials_kernel(const float* __restrict__ parts, int pieces, int64_t piece_stride, void* d, int m, int n, int64_t d_sm,
                             int d_dtype, int accumulate, int vec_ok) {
@@ -3620,6 +3621,7 @@ void dg_sum_partials_kernel(const float* __restrict__ parts, int pieces, int64_t
         }
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Generic path: any operand majorness / alignment / K tail, both SFB granularities.  128 x 128 tile, 4 waves,
@@ -3694,6 +3696,7 @@ __device__ __forceinline__ void stage_store(uint8_t* tile, const StagedTile& s, 
     }
 }
 
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_fp8_gemm_generic_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MS = 4, NS = 4;
@@ -3797,6 +3800,7 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
         store_tile<MS, NS>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Skinny kernel: dense GEMMs with M <= 16 * MS rows (batch-1 ... batch-32 decode: the m = 1 rows of the reference's dense sweep,
@@ -3981,6 +3985,7 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
 // rows.  One workgroup; the block ids pass through LDS so that the serial scan does not chain dependent global loads.  Runs on the
 // GEMM's stream in front of it: the 256-row tiles then never straddle two groups (the fixed grid walked such tiles twice), and the
 // remainders -- too few to fill the chip -- are cut along K (launch_contiguous_tabled in dg_api.hip).
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_build_contiguous_tile_table_kernel(const int32_t* __restrict__ layout, int m, int32_t* __restrict__ big, int32_t* __restrict__ rem) {
     __shared__ int group_of[512];
@@ -4010,10 +4015,12 @@ void dg_build_contiguous_tile_table_kernel(const int32_t* __restrict__ layout, i
     big[0] = big_n;
     rem[0] = rem_n;
 }
+#endif
 
 // SF layout kernel: [batches, mn, sf_k] row-major FP32 -> MN-major with mn padded to a multiple of 4 floats
 // (semantics of transpose_fp32, deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:12-50).  One block moves a
 // 64 (mn) x 64 (sf_k) patch through LDS so that both the read (along sf_k) and the write (along mn) are coalesced.
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_transpose_sf_fp32_kernel(const float* __restrict__ sf, float* __restrict__ out, int mn, int sf_k, int aligned_mn) {
     __shared__ float patch[64][65];
@@ -4034,11 +4041,13 @@ void dg_transpose_sf_fp32_kernel(const float* __restrict__ sf, float* __restrict
             dst[static_cast<int64_t>(col) * aligned_mn + row] = patch[tx][j];
     }
 }
+#endif
 
 // The same transpose for the common case sf_k % 4 == 0 with 16-byte aligned rows (K a multiple of 512: every DeepSeek-V3 shape): one
 // thread takes FOUR consecutive K blocks of one row with a single 16-byte load and writes them to four MN-major rows -- every load of the
 // launch is independent (the patch kernel above walks 16 dependent iterations per thread and took ~7 us for 0.9 MB in front of a 90 us
 // GEMM: this launch is pure latency), the writes run along mn (coalesced).  Round 5.
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_transpose_sf_fp32_vec4_kernel(const float* __restrict__ sf, float* __restrict__ out, int mn, int sf_k, int aligned_mn) {
     const int batch = blockIdx.z;
@@ -4053,6 +4062,7 @@ void dg_transpose_sf_fp32_vec4_kernel(const float* __restrict__ sf, float* __res
     dst[2 * static_cast<int64_t>(aligned_mn)] = v[2];
     dst[3 * static_cast<int64_t>(aligned_mn)] = v[3];
 }
+#endif
 
 // SF packing kernel: FP32 power-of-two scales [batches, ceil(mn / gran_mn), sf_k] (any strides) -> packed UE8M0 words, MN-major:
 // word (row, kq) = exponent bytes of K blocks 4 kq .. 4 kq + 3 of source row `row / gran_mn` (byte j = bits 30..23 of
@@ -4103,6 +4113,7 @@ __device__ __forceinline__ void pack_sf_ue8m0_words(const PackSfArgs& a, int blo
 
 // One launch packs up to two scale tensors (the SFA / SFB pair of a GEMM call in the 'sm100' scaling-factor mode: one kernel boundary in
 // front of the GEMM instead of two): block ids [0, work items of a) belong to `a`, the rest to `b`.
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_pack_sf_ue8m0_kernel(const PackSfArgs a, const PackSfArgs b) {
     const int items_a = a.blocks_mn * ((a.sf_k + 3) / 4) * a.batches;
@@ -4114,6 +4125,7 @@ void dg_pack_sf_ue8m0_kernel(const PackSfArgs a, const PackSfArgs b) {
     const int packed_k = (t.sf_k + 3) / 4;
     pack_sf_ue8m0_words(t, bx, id % packed_k, id / packed_k);
 }
+#endif
 
 // Fused per-token quantiser (the producer side of operand A): BF16 [m, n] -> e4m3fn [m, n] + one FP32 scale per
 // 1 x 128 block, the arithmetic of per_token_cast_to_fp8 (deep_gemm/utils/math.py:26-38): amax over the block (ragged
@@ -4125,6 +4137,7 @@ void dg_pack_sf_ue8m0_kernel(const PackSfArgs a, const PackSfArgs b) {
 // 16384 x 7168: FETCH 229 MB = the input; WRITE 142 MB vs 121 MB of payload -- the 4-byte MN-major scale writes cost
 // partial lines; walking down K-block columns instead to make them adjacent was slower, 79 vs 68 us: the reads lose
 // their row locality).
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_per_token_cast_to_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ q, float* __restrict__ sf,
                                      int m, int n, int64_t x_sm, int64_t q_sm, int64_t sf_sm, int64_t sf_sk, int use_ue8m0) {
@@ -4193,6 +4206,7 @@ void dg_per_token_cast_to_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __
             sf[row * sf_sm + kb * sf_sk] = scale;
     }
 }
+#endif
 
 // Fused block quantisers of the weight / wgrad side: one 256-thread workgroup casts a 128 x 128 patch of a BF16 matrix in
 // one pass (each thread holds 8 rows x 8 columns).  PER_CHANNEL = false: one scale per 128 x 128 block
@@ -4311,6 +4325,7 @@ void dg_block_cast_to_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __rest
 // Operand re-majoring: dst[c][r] = src[r][c] for 1-byte elements (an MN-major FP8 operand -> the K-major form the
 // LDS-DMA kernels consume).  64 x 64 byte patches through LDS; both the global read (16 bytes along c per lane) and the
 // global write (16 bytes along r per lane) are coalesced 16-byte vectors.  HBM-bound: 2 bytes of traffic per element.
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_transpose_bytes_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols,
                                int64_t src_ld, int64_t dst_ld, int64_t src_batch, int64_t dst_batch) {
@@ -4356,5 +4371,6 @@ void dg_transpose_bytes_kernel(const uint8_t* __restrict__ src, uint8_t* __restr
         }
     }
 }
+#endif
 
 }  // namespace dg

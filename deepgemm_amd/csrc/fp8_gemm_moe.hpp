@@ -54,7 +54,7 @@ struct SwigluOut {
     long long timeout_ticks;    // bound of the partner wait in s_memrealtime ticks (100 MHz); reference: comm/barrier.cuh:12,36-40 (60 s)
     const float* row_weight;    // optional [G, m_max] FP32 (element (g, m) at row_weight[g * rw_sg + m]): the row's top-k routing weight, applied
     int64_t rw_sg;              // to the SwiGLU output before the re-quantisation as the reference kernel does (sm100_fp8_fp4_mega_moe.cuh:1019)
-    int fault;              // test hook (dg_set_swiglu_fault_injection): 1 = odd tiles never publish their amax -> their partners time out
+    int fault;              // test hook (environment DG_TEST_SWIGLU_FAULT, tests only): 1 = odd tiles never publish their amax -> their partners time out
 };
 
 template <int STAGES>
@@ -370,6 +370,7 @@ struct MoeRoute {
     int64_t a_sg, a_sm, sfa_sg, sfa_sk, rw_sg;
 };
 
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_moe_scatter_kernel(const MoeRoute r) {
     __shared__ int s_pos;
@@ -407,8 +408,10 @@ void dg_moe_scatter_kernel(const MoeRoute r) {
             r.rw[e * r.rw_sg + pos] = r.topk_w[static_cast<int64_t>(t) * r.topk + j];
     }
 }
+#endif
 
 // y[t, :] = bf16( sum_j float(y2[slot(t, j), :]) ), j in top-k order, FP32 accumulation, entries without a slot skipped.
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_moe_combine_kernel(const uint16_t* y2, const int32_t* slot, int tokens, int topk, int hidden, int64_t y2_row_stride, uint16_t* y,
                            int64_t y_sm) {
@@ -433,5 +436,6 @@ void dg_moe_combine_kernel(const uint16_t* y2, const int32_t* slot, int tokens, 
         *reinterpret_cast<uint4*>(y + static_cast<int64_t>(t) * y_sm + c) = out;
     }
 }
+#endif
 
 }  // namespace dg

@@ -437,7 +437,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                             else if (step < 12) af[step - 4] = load_fragment(a_tile + (step - 4) * 2048, frag_off);
                         } else {
                             if (step % 2 == 0) issue_b_piece(b_cur, kb + 2, step / 2);
-                            else if (step >= 7) af[4 + (step - 7) / 2] = load_fragment(a_tile + (4 + (step - 7) / 2) * 2048, frag_off);
+                            else if (step >= 7 && step < 15) {          // steps 7, 9, 11, 13: exactly the four fragments of rows 4 .. 7
+                                static_assert(MS == 8, "af[4 .. 7] are the fragments read here");
+                                af[4 + (step - 7) / 2] = load_fragment(a_tile + (4 + (step - 7) / 2) * 2048, frag_off);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -718,6 +721,7 @@ void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
 // Second phase of the TABSK remainder walk: one workgroup per (remainder tile, 32-row quarter) adds the tile's partial slabs in piece order
 // (bit-repeatable) and stores the rows that belong to the group as BF16.  The grid is an upper bound; tile count and pieces come from the same
 // device-side tile list as in the first phase.  Padding blocks were zero-filled by the first phase.
+#ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_e8_tab_reduce_kernel(const GemmParams p) {
     constexpr int BM = 128, BN = 256;
@@ -753,5 +757,6 @@ void dg_e8_tab_reduce_kernel(const GemmParams p) {
         }
     }
 }
+#endif
 
 }  // namespace dg

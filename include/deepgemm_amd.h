@@ -169,11 +169,9 @@ int dg_pack_sf_pair_ue8m0(const float* sfa, int32_t* out_a, int batches_a, int m
  *   The partner wait is BOUNDED (dg_set_swiglu_exchange_timeout_us, default 10 s; reference: comm/barrier.cuh:12,36-40): a wait that
  *   times out -- a workspace that was not all-zero, a lost partner -- increments the uint32 at workspace[0] and gives the rows involved
  *   NaN scales and bytes and takes its own slot back; the caller re-zeroes the workspace all the same before the next launch on it.
- *   dg_set_swiglu_fault_injection(1) makes every odd tile skip its publish so that the path can be exercised: a TEST hook, honoured only
- *   when the process runs with DG_TEST_HOOKS set (dg_reload_env); ignored otherwise. */
+ *   (No entry point injects a fault: the test of this bound sets DG_TEST_SWIGLU_FAULT=1 in its own environment + dg_reload_env.) */
 int64_t dg_swiglu_workspace_bytes(int num_groups, int m_max, int n);
 void dg_set_swiglu_exchange_timeout_us(int64_t us);
-void dg_set_swiglu_fault_injection(int mode);
 /* The same with the row's routing weight applied to the SwiGLU output BEFORE the re-quantisation, as the reference's fused kernel does
  * (deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:1001-1020): gate and up rounded to BF16 (and clamped there), then
  * y = silu(g) * u * row_weight[g, m] in FP32 -- no BF16 rounding of the product -- into the row amax and the FP8 cast;
@@ -342,9 +340,9 @@ int dg_transpose_fp8(const void* src, void* dst, int batches, int rows, int cols
 int dg_set_num_cus(int num_cus);
 int dg_get_num_cus(void);
 
-/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_KS_PIECES, DG_PC_BM, DG_E8_TAB_UNSPLIT, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE, DG_TEST_HOOKS,
+/* The tuning / diagnostic environment variables (DG_PRINT_CONFIGS, DG_GROUP_M, DG_KS_PIECES, DG_PC_BM, DG_E8_TAB_UNSPLIT, DG_TAB_UNFUSED, DG_TABLE_KERNEL, DG_SK_EXCHANGE, DG_TEST_SWIGLU_FAULT,
  * DG_SFA_ROWMAJOR_IN_PLACE, DG_SWIGLU_ONE_PER_CU) are read once, at the first launch; a process that changes them afterwards calls this to have them read again
- * (tests, tuning scripts).  No reference counterpart (its knobs are read per call, csrc/utils/system.hpp get_env). */
+ * (tests, tuning scripts); launches in flight on other threads keep the snapshot they started with.  No reference counterpart (its knobs are read per call, csrc/utils/system.hpp get_env). */
 void dg_reload_env(void);
 
 /* Tuning / test hook: force a kernel configuration by name for subsequent calls of the process ("auto" restores the

@@ -35,6 +35,25 @@
 
 #define DGO_BLOCK_K 128
 
+/* Scale granularity along K: 128 (the SM90 recipes) or 32 (the reference's SM100 MX recipe for FP8 x FP8: csrc/apis/gemm.hpp:311-312,
+ * csrc/apis/layout.hpp:48-58, per_token_cast_to_fp8(..., gran_k=32) in deep_gemm/utils/math.py:26-38).  The arithmetic is the same statement
+ * with 32-K blocks: D = cast( sum_kb (sfa[m,kb] * sfb[n,kb]) * sum_{k in 32-block kb} Aq Bq ); the scale tensors then hold ceil(K / 32) columns.
+ * A process-wide setting of the checker (test infrastructure), set around a call by oracle.py. */
+static int g_gran_k = DGO_BLOCK_K;
+static int g_grouped_gran_n = 128;        /* rows of B per SFB row in the grouped entries: 128 (block scales) or 1 (per-row scales: the packed-UE8M0 input format) */
+int dgo_set_gran_k(int gran_k) {
+    if (gran_k != 32 && gran_k != 128)
+        return 1;
+    g_gran_k = gran_k;
+    return 0;
+}
+int dgo_set_grouped_gran_n(int gran_n) {
+    if (gran_n != 1 && gran_n != 32 && gran_n != 128)
+        return 1;
+    g_grouped_gran_n = gran_n;
+    return 0;
+}
+
 static float g_e4m3_lut[256];
 static int g_lut_ready = 0;
 
@@ -104,7 +123,8 @@ static void dgo_rows(const uint8_t* a, int64_t a_sm, int64_t a_sk,
                      void* d, int64_t d_sm, int d_dtype, int accumulate,
                      int m_begin, int m_end, int n, int k, int zero_rows) {
     dgo_init_lut();
-    const int num_kb = (k + DGO_BLOCK_K - 1) / DGO_BLOCK_K;
+    const int block_k = g_gran_k;
+    const int num_kb = (k + block_k - 1) / block_k;
     if (zero_rows) {
         for (int m = m_begin; m < m_end; ++m)
             for (int j = 0; j < n; ++j)
@@ -129,8 +149,8 @@ static void dgo_rows(const uint8_t* a, int64_t a_sm, int64_t a_sk,
                 const float* brow = bf + (size_t) j * k;
                 float total = 0.0f;
                 for (int kb = 0; kb < num_kb; ++kb) {
-                    const int k0 = kb * DGO_BLOCK_K;
-                    const int k1 = (k0 + DGO_BLOCK_K < k) ? k0 + DGO_BLOCK_K : k;
+                    const int k0 = kb * block_k;
+                    const int k1 = (k0 + block_k < k) ? k0 + block_k : k;
                     double block = 0.0;
                     for (int kk = k0; kk < k1; ++kk)
                         block += (double) af[kk] * (double) brow[kk];
@@ -149,7 +169,7 @@ static void dgo_rows(const uint8_t* a, int64_t a_sm, int64_t a_sk,
 int dgo_fp8_gemm(const uint8_t* a, int64_t a_sm, int64_t a_sk, const float* sfa, int64_t sfa_sm, int64_t sfa_sk,
                  const uint8_t* b, int64_t b_sn, int64_t b_sk, const float* sfb, int64_t sfb_sn, int64_t sfb_sk,
                  int gran_n, void* d, int64_t d_sm, int d_dtype, int accumulate, int m, int n, int k) {
-    if (gran_n != 1 && gran_n != 128)
+    if (gran_n != 1 && gran_n != 32 && gran_n != 128)
         return 1;
     if (m == 0 || n == 0)
         return 0;
@@ -181,7 +201,7 @@ int dgo_fp8_gemm_m_grouped_contiguous(const uint8_t* a, int64_t a_sm, int64_t a_
                 return 2;
             if (end > start)
                 dgo_rows(a, a_sm, a_sk, sfa, sfa_sm, sfa_sk, b + g * b_sg, b_sn, b_sk,
-                         sfb + g * sfb_sg, sfb_sn, sfb_sk, 128, d, d_sm, 0, 0, start, end, n, k, 0);
+                         sfb + g * sfb_sg, sfb_sn, sfb_sk, g_grouped_gran_n, d, d_sm, 0, 0, start, end, n, k, 0);
             start = (end + m_alignment - 1) / m_alignment * m_alignment;
         }
         return 0;
@@ -193,7 +213,7 @@ int dgo_fp8_gemm_m_grouped_contiguous(const uint8_t* a, int64_t a_sm, int64_t a_
             return 2;
         const int gg = g < 0 ? 0 : g;
         dgo_rows(a, a_sm, a_sk, sfa, sfa_sm, sfa_sk, b + gg * b_sg, b_sn, b_sk,
-                 sfb + gg * sfb_sg, sfb_sn, sfb_sk, 128, d, d_sm, 0, 0, m0, m1, n, k, g < 0);
+                 sfb + gg * sfb_sg, sfb_sn, sfb_sk, g_grouped_gran_n, d, d_sm, 0, 0, m0, m1, n, k, g < 0);
     }
     return 0;
 }
@@ -215,7 +235,7 @@ int dgo_fp8_gemm_m_grouped_masked(const uint8_t* a, int64_t a_sg, int64_t a_sm, 
         if (rows == 0)
             continue;
         dgo_rows(a + g * a_sg, a_sm, a_sk, sfa + g * sfa_sg, sfa_sm, sfa_sk, b + g * b_sg, b_sn, b_sk,
-                 sfb + g * sfb_sg, sfb_sn, sfb_sk, 128, d + g * d_sg, d_sm, 0, 0, 0, rows, n, k, 0);
+                 sfb + g * sfb_sg, sfb_sn, sfb_sk, g_grouped_gran_n, d + g * d_sg, d_sm, 0, 0, 0, rows, n, k, 0);
     }
     return 0;
 }

@@ -85,8 +85,26 @@ def _d_dtype(d: torch.Tensor) -> int:
     return 0 if d.dtype == torch.bfloat16 else 1
 
 
-def fp8_gemm_nt(a, sfa, b, sfb, d, c=None, gran_n: int = 128) -> torch.Tensor:
-    """D = (C +) A @ B^T.  a:[M,K] e4m3, sfa:[M,ceil(K/128)], b:[N,K], sfb:[ceil(N/gran_n),ceil(K/128)]."""
+class _gran_k:
+    """Scale granularity along K of the calls inside the block (32: the SM100 MX recipe; default 128)."""
+
+    def __init__(self, gran_k: int, grouped_gran_n: int = 128):
+        self.gran_k, self.grouped_gran_n = gran_k, grouped_gran_n
+
+    def __enter__(self):
+        assert lib().dgo_set_gran_k(self.gran_k) == 0, f'gran_k {self.gran_k}'
+        assert lib().dgo_set_grouped_gran_n(self.grouped_gran_n) == 0, f'gran_n {self.grouped_gran_n}'
+
+    def __exit__(self, *exc):
+        lib().dgo_set_gran_k(128)
+        lib().dgo_set_grouped_gran_n(128)
+
+
+def fp8_gemm_nt(a, sfa, b, sfb, d, c=None, gran_n: int = 128, gran_k: int = 128) -> torch.Tensor:
+    """D = (C +) A @ B^T.  a:[M,K] e4m3, sfa:[M,ceil(K/gran_k)], b:[N,K], sfb:[ceil(N/gran_n),ceil(K/gran_k)]."""
+    if gran_k != 128:
+        with _gran_k(gran_k):
+            return fp8_gemm_nt(a, sfa, b, sfb, d, c, gran_n)
     a, b, sfa, sfb = _cpu(a, torch.float8_e4m3fn), _cpu(b, torch.float8_e4m3fn), _sf(sfa), _sf(sfb)
     m, k = a.shape
     n, k_ = b.shape
@@ -108,8 +126,11 @@ def fp8_gemm_nt(a, sfa, b, sfb, d, c=None, gran_n: int = 128) -> torch.Tensor:
 
 
 def m_grouped_fp8_gemm_nt_contiguous(a, sfa, b, sfb, d, grouped_layout, use_psum_layout=False,
-                                     m_alignment: int = 128) -> torch.Tensor:
-    """a:[M,K], b:[G,N,K], sfb:[G,ceil(N/128),ceil(K/128)], d:[M,N] bf16, grouped_layout int32 [M] or [G]."""
+                                     m_alignment: int = 128, gran_k: int = 128, gran_n: int = 128) -> torch.Tensor:
+    """a:[M,K], b:[G,N,K], sfb:[G,ceil(N/gran_n),ceil(K/gran_k)], d:[M,N] bf16, grouped_layout int32 [M] or [G]."""
+    if gran_k != 128 or gran_n != 128:
+        with _gran_k(gran_k, gran_n):
+            return m_grouped_fp8_gemm_nt_contiguous(a, sfa, b, sfb, d, grouped_layout, use_psum_layout, m_alignment)
     a, b, sfa, sfb = _cpu(a, torch.float8_e4m3fn), _cpu(b, torch.float8_e4m3fn), _sf(sfa), _sf(sfb)
     layout = _cpu(grouped_layout, torch.int32).contiguous()
     m, k = a.shape
@@ -126,8 +147,12 @@ def m_grouped_fp8_gemm_nt_contiguous(a, sfa, b, sfb, d, grouped_layout, use_psum
     return d
 
 
-def m_grouped_fp8_gemm_nt_masked(a, sfa, b, sfb, d, masked_m) -> torch.Tensor:
-    """a:[G,Mmax,K], sfa:[G,Mmax,ceil(K/128)], b:[G,N,K], d:[G,Mmax,N] bf16; rows >= masked_m[g] left untouched."""
+def m_grouped_fp8_gemm_nt_masked(a, sfa, b, sfb, d, masked_m, gran_k: int = 128, gran_n: int = 128) -> torch.Tensor:
+    """a:[G,Mmax,K], sfa:[G,Mmax,ceil(K/gran_k)], b:[G,N,K], sfb:[G,ceil(N/gran_n),ceil(K/gran_k)], d:[G,Mmax,N] bf16; rows >= masked_m[g]
+    left untouched."""
+    if gran_k != 128 or gran_n != 128:
+        with _gran_k(gran_k, gran_n):
+            return m_grouped_fp8_gemm_nt_masked(a, sfa, b, sfb, d, masked_m)
     a, b, sfa, sfb = _cpu(a, torch.float8_e4m3fn), _cpu(b, torch.float8_e4m3fn), _sf(sfa), _sf(sfb)
     masked = _cpu(masked_m, torch.int32).contiguous()
     g, m_max, k = a.shape

@@ -253,20 +253,18 @@ def test_exchange_wait_is_bounded_and_loud():
     dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, good, masked, 40, workspace=ws)
     assert mega.exchange_timeouts(ws) == 0 and bool(torch.isfinite(good[1][0, :64]).all())
     mega.set_exchange_timeout_us(20000)
-    lib.dg_set_swiglu_fault_injection(1)                               # without DG_TEST_HOOKS the hook is ignored: a production process cannot arm it
+    os.environ['DG_TEST_SWIGLU_FAULT'] = '1'                            # read at dg_reload_env only: no entry point arms the fault
     ignored = dg.empty_intermediate(groups, m_max, inter, 'cuda')
     dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, ignored, masked, 40, workspace=ws)
     assert mega.exchange_timeouts(ws) == 0 and torch.equal(ignored[1][0, :64], good[1][0, :64])
-    os.environ['DG_TEST_HOOKS'] = '1'
     lib.dg_reload_env()
     try:
         bad = dg.empty_intermediate(groups, m_max, inter, 'cuda')
         dg.m_grouped_fp8_gemm_nt_masked_swiglu(x, w1_t, bad, masked, 40, workspace=ws)
         torch.cuda.synchronize()                                    # returns: every wait gave up after 20 ms
     finally:
-        lib.dg_set_swiglu_fault_injection(0)
         mega.set_exchange_timeout_us(10_000_000)
-        del os.environ['DG_TEST_HOOKS']
+        del os.environ['DG_TEST_SWIGLU_FAULT']
         lib.dg_reload_env()
     assert bool(torch.isnan(bad[1][0, :64]).any()), 'rows whose partner never published must carry NaN scales'
     assert mega.exchange_timeouts(ws, reset=False) > 0

@@ -126,11 +126,14 @@ def report():
             dst.write(src.read())
         subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '--offloading', local], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        device = [f for f in os.listdir(tmp) if 'amdgcn' in f]
+        # one device code object per translation unit of the (sharded) build: deepgemm_amd/build.py
+        device = sorted(f for f in os.listdir(tmp) if 'amdgcn' in f)
         assert device, 'no device code object found in the library'
-        obj = os.path.join(tmp, device[0])
-        notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', obj], check=True, capture_output=True, text=True).stdout
-        asm = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', obj], check=True, capture_output=True, text=True).stdout
+        notes, asm = '', ''
+        for f in device:
+            obj = os.path.join(tmp, f)
+            notes += subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', obj], check=True, capture_output=True, text=True).stdout
+            asm += subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', obj], check=True, capture_output=True, text=True).stdout
     meta = {}
     name = None
     for line in notes.splitlines():
