@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0|dense_ue8m0_g32]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -37,10 +37,10 @@ PEAK_HBM_GBS = 8000.0
 RECIPE_1_1_128_ROOF = 32.0 / 62.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
              'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
-             'contiguous_ue8m0']
+             'contiguous_ue8m0', 'dense_ue8m0_g32']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
              'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
-             'contiguous_ue8m0']
+             'contiguous_ue8m0', 'dense_ue8m0_g32']
 # HBM-bound workloads whose per-call weight stream is smaller than the 256 MiB Infinity Cache (MALL): the rotation must cover more than the
 # cache, or the "fraction of 8 TB/s" is a cache-read rate (the reference flushes 8 GB between timed iterations: deep_gemm/testing/bench.py:93,108).
 # sets x (bytes not re-used across calls) >= COLD_ROTATION_BYTES; the other HBM-bound lines stream >= 235 MB of weights per call x >= 2 sets.
@@ -144,12 +144,23 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k}, FP32 power-of-two scales, sf cast mode sm100: whole call (cast branch + GEMM)',
                 'm': m, 'n': n, 'k': k, 'sfa_layout': 'FP32 row-major (as per_token_cast_to_fp8 returns it); cast to packed UE8M0 inside the call'}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
-    elif name in ('dense', 'dense_ue8m0', 'dense_sfa_rowmajor'):
+    elif name in ('dense', 'dense_ue8m0', 'dense_sfa_rowmajor', 'dense_ue8m0_g32'):
         m, n, k = 4096, 4096, 7168
         packed = name == 'dense_ue8m0'
         for i in range(sets):
             gen.reset_seed(i)
             case = gen.generate_normal(m, n, k, use_ue8m0=packed)
+            if name == 'dense_ue8m0_g32':
+                # C2 with scales of granularity 32 along K (round 6: the reference's SM100 MX recipe (1, 1, 32), csrc/apis/gemm.hpp:311-312): the
+                # reference's quantiser at gran_k = 32, packed words of one 128-K block each, the scaled MFMA's native block size
+                from deepgemm_amd.utils.math import pack_ue8m0_to_int, per_token_cast_to_fp8
+                qa, qb = per_token_cast_to_fp8(case.a_bf16, True, 32), per_token_cast_to_fp8(case.b_bf16, True, 32)
+                a = (qa[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, 32)))
+                b = (qb[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, 32)))
+                case.a_bf16 = case.b_bf16 = None
+                cases.append(case)
+                calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d, recipe=(1, 1, 32)))
+                continue
             if packed:
                 # power-of-two scales handed over as packed UE8M0 words (the reference's SM100 input format): hardware-scaled MFMA
                 a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
@@ -165,11 +176,14 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
             calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d))
         flops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        if name == 'dense_ue8m0_g32':
+            nbytes = m * k + n * k + 4 * (m + n) * (k // 128) + 2 * m * n           # one packed word per row and 128-K block, both operands
         desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (DeepSeek-V3 dense shape, BASELINE configs[1])' +
                             (', packed UE8M0 scales (power-of-two scales, recipe (1, 1, 128))' if packed else '') +
+                            (', packed UE8M0 scales of granularity 32 along K (recipe (1, 1, 32))' if name == 'dense_ue8m0_g32' else '') +
                             (', SFA row-major as the cast returns it: whole call = layout step (transpose launch) + GEMM' if name == 'dense_sfa_rowmajor' else ''),
                 'm': m, 'n': n, 'k': k,
-                'sfa_layout': 'packed UE8M0 words, MN-major' if packed else 'FP32 row-major [M, K/128]: transposed inside the call' if name == 'dense_sfa_rowmajor' else 'FP32 MN-major (zero-copy branch)'}
+                'sfa_layout': 'packed UE8M0 words, MN-major' if packed or name == 'dense_ue8m0_g32' else 'FP32 row-major [M, K/128]: transposed inside the call' if name == 'dense_sfa_rowmajor' else 'FP32 MN-major (zero-copy branch)'}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
     elif name.startswith('c3_'):
         layout, packed = name[3:5], name.endswith('_ue8m0')
@@ -494,8 +508,7 @@ def cpu_baseline(workload: str):
         if i:
             best = min(best, dt)
     return {'value': 2.0 * m * n * k / best / 1e12, 'unit': 'TFLOPS', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'full {m}x{n}x{k}, reference test expr (a.float() @ b.float().t()).to(bf16), min of 2 runs, {best:.2f} s each, '
-                      f'os.cpu_count()={os.cpu_count()}'}
+            'sample': f'full {m}x{n}x{k}, reference test expr (generators.py:312), min of 2 runs, {best:.2f} s each, cpu_count {os.cpu_count()}'}
 
 
 def run(rank: int, world: int, local_rank: int, args):
@@ -591,7 +604,7 @@ def run(rank: int, world: int, local_rank: int, args):
                                         ([_sig(rec['roofline']['frac_of_recipe_roof'])] if 'frac_of_recipe_roof' in rec['roofline'] else [])
                                         if 'roofline' in rec else rec.get('error', '?')[:40])
                                  for name, rec in zip(SECONDARY, detail)}
-            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us/call, bound, 4th: frac on data rows | of the (1,1,128) roof]'
+            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us/call, bound, 4th: frac on data rows | of (1,1,128) roof]'
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
         if 'secondary' in line:         # keep the whole headline line inside the driver's 2000-character tail

@@ -189,7 +189,7 @@ const Config kConfigs[] = {
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 // Kernels of the packed-UE8M0 entry points (hardware-scaled MFMA); selected by launch_e8, forced by name for A/B runs.
-struct E8Config { const char* name; KernelFn fn; int bm, bn, threads; bool whole_quads; bool grouped_ok; bool stream; int per_cu = 1; };
+struct E8Config { const char* name; KernelFn fn; int bm, bn, threads; bool whole_quads; bool grouped_ok; bool stream; int per_cu = 1; bool g32 = false; };
 const E8Config kE8Configs[] = {
     {"e8_quad_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>, 256, 256, 256, true, true, false},
     {"e8_quad_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0>, 128, 256, 256, false, true, false},
@@ -217,6 +217,10 @@ const E8Config kE8Configs[] = {
     // round 5: the stream tile on a 3-stage ring (74 KiB of LDS), two workgroups per CU (stream2_64x128 above)
     {"e8_stream2_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 0, 1, true>, 64, 128, 256, false, true, true, 2},
     {"e8_stream_nt2_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2, 1, true>, 64, 128, 256, false, true, true, 2},
+    // round 6: scale granularity 32 along K (the reference's SM100 MX recipe; one packed word per row and 128-K block, every lane group of the
+    // scaled MFMA takes its own byte): the two four-wave forms, selected by the *_g32 entry points only (E8Config::g32)
+    {"e8_quad_g32_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true>, 256, 256, 256, false, true, false, 1, true},
+    {"e8_quad_g32_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true>, 128, 256, 256, false, true, false, 1, true},
 #ifdef DG_EXPERIMENTS
 #define DG_EXPERIMENT_ROWS_E8
 #include "experiment_configs.inc"
@@ -957,22 +961,26 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
 // tile is walked twice), launch 2: e8_quad_128x256 over the remainders (at most one per group) and padding blocks.  No K split (the quad
 // kernels accumulate in AGPRs and have no partial-tile form), so no workspace.  Against 128-row tiles everywhere: C4 with packed scales
 // (8 x ~512 rows, N 4096, K 7168) 576 tiles = 2.25 rounds -> 256 big tiles + 80 remainder tiles.
-bool e8_contiguous_tabled(const dg::GemmParams& p) {
+bool e8_contiguous_tabled(const dg::GemmParams& p, int gran_k = 128) {
+    // (granularity 32: one word per K block -- no whole-quad condition)
+    if (gran_k == 32 && p.k % 128 != 0)
+        return false;
     // (K >= 4096: with a short K loop the second launch costs what the taller tiles save -- profiles/r05_probe/packed_contiguous_group_relative_tiles_ab.jsonl:
     //  8 x ~512 rows, N 4096, K 7168 202.9 -> 153.2 us; K 2048: 78.6 -> 82.3 and 84.9 -> 83.9)
-    if (p.gemm_type != dg::kContiguous || p.m_alignment != 128 || p.k % 512 != 0 || p.k < 4096 || !fast_eligible(p))
+    if (p.gemm_type != dg::kContiguous || p.m_alignment != 128 || (gran_k != 32 && p.k % 512 != 0) || p.k < 4096 || !fast_eligible(p))
         return false;
     const int nb = ceil_div(p.m, 128);
     return nb <= 64 && static_cast<long>(nb) * ceil_div(p.n, 256) >= num_cus();
 }
 
-int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream) {
+int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream, int gran_k = 128) {
     const int nb = ceil_div(base.m, 128), n_tiles = ceil_div(base.n, 256);
     // With the caller's workspace the remainder walk is cut along K (TABSK: one work item per (tile, piece), FP32 partial tiles, a second kernel
     // sums them): 64 .. 96 remainder tiles of C4 are a quarter of a round, each streaming its group's whole weight panel -- 58 us for a ninth of
     // the work.  Pieces: whole K quads, at most 8; how many a launch really uses is decided on the device from the tile count (table_pieces).
     const size_t slab_bytes = 128 * 256 * sizeof(float);
-    const bool split = base.sk_workspace != nullptr && g_workspace_bytes >= 4096 + 64 * slab_bytes && !env_knobs().e8_tab_unsplit;
+    // (granularity 32: whole remainder tiles -- the K-split form cuts at K quads of the gran-128 words)
+    const bool split = gran_k != 32 && base.sk_workspace != nullptr && g_workspace_bytes >= 4096 + 64 * slab_bytes && !env_knobs().e8_tab_unsplit;
     for (int mode = 1; mode <= 2; ++mode) {
         dg::GemmParams q = base;
         const int bm = mode == 1 ? 256 : 128;
@@ -990,7 +998,14 @@ int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         long grid = std::min<long>(items, num_cus());
         if (grid <= 0)
             continue;
-        if (mode == 1) {
+        if (gran_k == 32) {
+            if (mode == 1)
+                hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                                   static_cast<hipStream_t>(stream), q);
+            else
+                hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                                   static_cast<hipStream_t>(stream), q);
+        } else if (mode == 1) {
             hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
                                static_cast<hipStream_t>(stream), q);
         } else if (!split) {
@@ -1012,18 +1027,36 @@ int launch_e8_contiguous_tabled(const dg::GemmParams& base, void* stream) {
         }
         DG_HIP_CHECK(hipGetLastError());
     }
-    g_last_config = "e8_quad_tab_256x256";
+    g_last_config = gran_k == 32 ? "e8_quad_g32_tab_256x256" : "e8_quad_tab_256x256";
     if (env_knobs().print_configs)
         fprintf(stderr, "[deepgemm_amd] ue8m0 contiguous m=%d n=%d k=%d groups=%d -> e8_quad_256x256 + e8_quad_128x256 over the group-relative tile list\n",
                 base.m, base.n, base.k, base.num_groups);
     return 0;
 }
 
-int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
+// The granularity-32 launch (round 6): K-major operands, k % 128 == 0; the two four-wave G32 forms by the tile rule of the gran-128 selection
+// (256 x 256 when the problem fills the chip with them, 128 x 256 otherwise and for every grouped layout but the group-relative tiling).
+const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
+    const int m_hint = expected_m > 0 ? expected_m : p.m;
+    const long groups = p.gemm_type == dg::kMasked ? p.num_groups : 1;
+    const long tiles256 = groups * ceil_div(m_hint, 256) * ceil_div(p.n, 256);
+    bool big = m_hint > 128 && 2 * tiles256 >= num_cus();
+    if (p.gemm_type == dg::kContiguous)
+        big = big && p.m_alignment == 128 && tiles256 >= 4L * num_cus();
+    if (p.gemm_type == dg::kContiguousPsum)
+        big = false;
+    return e8_config_by_name(big ? "e8_quad_g32_256x256" : "e8_quad_g32_128x256");
+}
+
+int launch_e8(dg::GemmParams& p, int expected_m, void* stream, int gran_k = 128) {
     const bool k_tail = p.k % 128 != 0;
-    const bool mn_form = e8_mn_eligible(p);           // an MN-major operand read in place
-    if (!mn_form && forced_config() == "auto" && e8_contiguous_tabled(p))
-        return launch_e8_contiguous_tabled(p, stream);
+    const bool mn_form = gran_k != 32 && e8_mn_eligible(p);           // an MN-major operand read in place
+    if (gran_k == 32 && (k_tail || !fast_eligible(p))) {
+        g_last_error = "packed-UE8M0 GEMMs with scale granularity 32 need K-major, 16-byte aligned FP8 operands and k % 128 == 0";
+        return 3;
+    }
+    if (!mn_form && forced_config() == "auto" && e8_contiguous_tabled(p, gran_k))
+        return launch_e8_contiguous_tabled(p, stream, gran_k);
     if (!mn_form && (!fast_eligible(p, !k_tail) || (k_tail && p.gemm_type != dg::kNormal))) {
         g_last_error = "packed-UE8M0 GEMMs need K-major, 16-byte aligned FP8 operands and k % 128 == 0 (dense: or k % 16 == 0 and k > 128)";
         return 3;
@@ -1060,8 +1093,14 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream) {
         g_last_error = std::string("config '") + cfg->name + "' reads MN-major operands";
         return 3;
     }
+    if (gran_k == 32 && (cfg == nullptr || !cfg->g32))
+        cfg = select_e8_g32_config(p, expected_m);          // (a forced name of a gran-128 kernel does not apply to these entries)
     if (cfg == nullptr)
         cfg = select_e8_config(p, expected_m);
+    if (cfg->g32 != (gran_k == 32)) {
+        g_last_error = std::string("config '") + cfg->name + "' reads scale words of granularity " + (cfg->g32 ? "32" : "128");
+        return 3;
+    }
     if (cfg->stream && (p.gemm_type == dg::kContiguous || p.gemm_type == dg::kContiguousPsum)) {
         g_last_error = std::string("config '") + cfg->name + "' does not implement the contiguous layouts";
         return 3;
@@ -1177,11 +1216,11 @@ int dg_fp8_gemm_nt_skip_head_mid(const void* a, const float* sfa, const void* b,
     return launch_gemm(p, 0, stream);
 }
 
-int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+static int dg_fp8_gemm_nt_ue8m0_impl(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
                          int m, int n, int k,
                          int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
-                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
+                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream, int gran_k) {
     DG_CHECK(m >= 0 && n >= 0 && k > 0);
     if (m == 0 || n == 0)
         return 0;
@@ -1205,7 +1244,23 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
                        "k % 128 == 0, MN-major (m resp. n % 16 == 0)";
         return 3;
     }
-    return launch_e8(p, 0, stream);
+    return launch_e8(p, 0, stream, gran_k);
+}
+
+int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                         int m, int n, int k,
+                         int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                         int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
+    return dg_fp8_gemm_nt_ue8m0_impl(a, sfa_packed, b, sfb_packed, d, m, n, k, a_stride_m, a_stride_k, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq, sfb_stride_n, sfb_stride_kq, d_stride_m, d_dtype, accumulate, stream, 128);
+}
+
+int dg_fp8_gemm_nt_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                         int m, int n, int k,
+                         int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                         int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
+    return dg_fp8_gemm_nt_ue8m0_impl(a, sfa_packed, b, sfb_packed, d, m, n, k, a_stride_m, a_stride_k, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq, sfb_stride_n, sfb_stride_kq, d_stride_m, d_dtype, accumulate, stream, 32);
 }
 
 int dg_ue8m0_dense_operand_plan(const void* a, const void* b, int m, int n, int k, int64_t a_stride_m, int64_t a_stride_k,
@@ -1241,14 +1296,14 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0(const void* a, const int32_t* sfa_
                                                         sfb_stride_kq, d_stride_m, use_psum, m_alignment, nullptr, 0, stream);
 }
 
-int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+static int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws_impl(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
                                                  void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
                                                  int64_t a_stride_m, int64_t a_stride_k,
                                                  int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
                                                  int64_t sfa_stride_m, int64_t sfa_stride_kq,
                                                  int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                                                  int64_t d_stride_m, int use_psum, int m_alignment,
-                                                 void* workspace, int64_t workspace_bytes, void* stream) {
+                                                 void* workspace, int64_t workspace_bytes, void* stream, int gran_k) {
     DG_CHECK(m >= 0 && n > 0 && k > 0 && num_groups > 0);
     DG_CHECK(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 4096));
     if (m == 0)
@@ -1280,7 +1335,29 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* s
                        "k % 128 == 0, n % 16 == 0, 16-byte aligned k-rows and an M alignment of 128 or a multiple of 256 (dg_ue8m0_grouped_operand_plan)";
         return 3;
     }
-    return launch_e8(p, 0, stream);
+    return launch_e8(p, 0, stream, gran_k);
+}
+
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                                 void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                                 int64_t a_stride_m, int64_t a_stride_k,
+                                                 int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                                 int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                                 int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                                 int64_t d_stride_m, int use_psum, int m_alignment,
+                                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws_impl(a, sfa_packed, b, sfb_packed, d, grouped_layout, num_groups, m, n, k, a_stride_m, a_stride_k, b_stride_g, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq, sfb_stride_g, sfb_stride_n, sfb_stride_kq, d_stride_m, use_psum, m_alignment, workspace, workspace_bytes, stream, 128);
+}
+
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                                 void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                                 int64_t a_stride_m, int64_t a_stride_k,
+                                                 int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                                 int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                                 int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                                 int64_t d_stride_m, int use_psum, int m_alignment,
+                                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws_impl(a, sfa_packed, b, sfb_packed, d, grouped_layout, num_groups, m, n, k, a_stride_m, a_stride_k, b_stride_g, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq, sfb_stride_g, sfb_stride_n, sfb_stride_kq, d_stride_m, use_psum, m_alignment, workspace, workspace_bytes, stream, 32);
 }
 
 int dg_ue8m0_grouped_operand_plan(const void* a, const void* b, int num_groups, int m, int n, int k, int64_t a_stride_m,
@@ -1301,14 +1378,14 @@ int dg_ue8m0_grouped_operand_plan(const void* a, const void* b, int num_groups, 
     return forced == "auto" && e8_mn_pays(p) ? 0 : 2;
 }
 
-int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+static int dg_m_grouped_fp8_gemm_nt_masked_ue8m0_impl(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
                                           void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
                                           int expected_m,
                                           int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
                                           int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
                                           int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_kq,
                                           int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
-                                          int64_t d_stride_g, int64_t d_stride_m, void* stream) {
+                                          int64_t d_stride_g, int64_t d_stride_m, void* stream, int gran_k) {
     DG_CHECK(expected_m > 0 && m_max > 0 && n > 0 && k > 0 && num_groups > 0);   // reference gemm.hpp:274
     DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr && masked_m != nullptr);
     DG_CHECK(a_stride_k == 1 && b_stride_k == 1);       // reference gemm.hpp:263
@@ -1326,7 +1403,29 @@ int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_pack
     p.d_sg = d_stride_g; p.d_sm = d_stride_m;
     p.sfb_gran_n = 128; p.d_dtype = DG_BF16; p.accumulate = 0;
     p.gemm_type = dg::kMasked; p.m_alignment = 0;
-    return launch_e8(p, expected_m < m_max ? expected_m : m_max, stream);
+    return launch_e8(p, expected_m < m_max ? expected_m : m_max, stream, gran_k);
+}
+
+int dg_m_grouped_fp8_gemm_nt_masked_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                          void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
+                                          int expected_m,
+                                          int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                          int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                          int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                          int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                          int64_t d_stride_g, int64_t d_stride_m, void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_masked_ue8m0_impl(a, sfa_packed, b, sfb_packed, d, masked_m, num_groups, m_max, n, k, expected_m, a_stride_g, a_stride_m, a_stride_k, b_stride_g, b_stride_n, b_stride_k, sfa_stride_g, sfa_stride_m, sfa_stride_kq, sfb_stride_g, sfb_stride_n, sfb_stride_kq, d_stride_g, d_stride_m, stream, 128);
+}
+
+int dg_m_grouped_fp8_gemm_nt_masked_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                          void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
+                                          int expected_m,
+                                          int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                          int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                          int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                          int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                          int64_t d_stride_g, int64_t d_stride_m, void* stream) {
+    return dg_m_grouped_fp8_gemm_nt_masked_ue8m0_impl(a, sfa_packed, b, sfb_packed, d, masked_m, num_groups, m_max, n, k, expected_m, a_stride_g, a_stride_m, a_stride_k, b_stride_g, b_stride_n, b_stride_k, sfa_stride_g, sfa_stride_m, sfa_stride_kq, sfb_stride_g, sfb_stride_n, sfb_stride_kq, d_stride_g, d_stride_m, stream, 32);
 }
 
 int dg_m_grouped_fp8_gemm_nt_contiguous_ws(const void* a, const float* sfa, const void* b, const float* sfb, void* d,

@@ -154,8 +154,17 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // weight panel alone.  A piece accumulates its range in place as always and writes its FP32 partial tile, row-major [BM][BN], to the caller's
 // workspace (slab (tile * pieces + piece)); dg_e8_tab_reduce_kernel adds the pieces in piece order and stores BF16.  Fewer than two pieces (no
 // workspace, many tiles): whole tiles, stored directly.
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false>
+// G32 (round 6): scale granularity 32 along K -- the reference's SM100 MX recipe for FP8 x FP8 (csrc/apis/gemm.hpp:311-312,
+// csrc/apis/layout.hpp:48-58; per_token_cast_to_fp8(..., gran_k = 32), deep_gemm/utils/math.py:26-38) and the NATIVE block size of
+// v_mfma_scale_f32_16x16x128_f8f6f4: lane group g = lane >> 4 of an operand supplies the scale of ITS 32 K-bytes.  A packed word then holds the four
+// exponents of ONE 128-K block (byte j = K bytes [32 j, 32 j + 32)), one word per row and K block: element (row, kb) at base[kb * stride + row].
+// Two changes against the gran-128 kernel: (1) a fragment lane (r, g) reads the 16-byte chunks 2 g and 2 g + 1 of its row (K bytes [32 g, 32 g + 32))
+// instead of g and g + 4 -- the same XOR swizzle, conflict-free for the same reason, and still one K permutation shared by both operands;
+// (2) the words of block kb + 1 are loaded at the top of block kb (older than its pieces: landed by barrier Z's counted wait) and, behind the
+// block's last MFMA, shifted down by 8 g per lane (16 VALU operations per K block) so that every lane's byte sits in byte 0: op_sel stays 0.
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
+    static_assert(!G32 || (QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0 && !TABSK), "G32: the two production four-wave forms");
     static_assert(!TABSK || (BM == 128 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0), "TABSK: the 128-row production form");
     static_assert(!K_TAIL || (BM == 128 && !STAGED && QV == 0 && WAVES_N == 2), "K tail: the 128-row production form");
     static_assert(HS == 0 || (BM == 256 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL), "HS: the 256 x 256 four-wave form");
@@ -183,7 +192,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int k_tail = K_TAIL ? (p.k & 127) : 0;
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
-    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const int frag_off = (lane & 15) * 128 + ((((G32 ? 2 * (lane >> 4) : (lane >> 4)) ^ (lane & 7))) << 4);
+    [[maybe_unused]] const int g32_shift = (lane >> 4) * 8;         // G32: the lane group's byte of a scale word
+    // (the second half of a fragment: chunk g + 4 = offset ^ 64; G32: chunk 2 g + 1 = offset ^ 16)
+    auto read_fragment = [&](const uint8_t* tile_rows) { return load_fragment_x<G32 ? 16 : 64>(tile_rows, frag_off); };
     const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
     // A rows interleaved inside a wave's WM rows (LDS row position ms * 16 + i holds tile row i * MS + ms): a lane's MS row
     // scales are MS consecutive words of the MN-major scale tensor.  See duo_kernel_body.
@@ -301,10 +313,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base) - (M0S ? M0_SHARE_BIAS : 0), 0, a_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base) - (M0S ? M0_SHARE_BIAS : 0), 0, b_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             // packed scale words: element (row, kq) at base[kq * stride + row] (int32); rows of the whole A (masked: of the group)
+            const int num_sf = G32 ? num_kb : num_kq;       // rows of the scale tensors along K: one per K quad (G32: per K block)
             const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg + (TABSK ? sk_kq0 * p.sfa_sk : 0)),
-                                            (num_kq - 1) * sfa_kq_stride + p.m * 4);
+                                            (num_sf - 1) * sfa_kq_stride + p.m * 4);
             const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + (TABSK ? sk_kq0 * p.sfb_sk : 0)),
-                                            (num_kq - 1) * sfb_kq_stride + p.n * 4);
+                                            (num_sf - 1) * sfb_kq_stride + p.n * 4);
             const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
             // B row of N-subtile ns, MFMA row slot i = lane & 15: wave_n0 + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)
             const int sfb_voff = (t.n0 + wn * WN + ((lane & 15) >> 2) * 8 + (lane & 3)) * 4;
@@ -360,8 +373,19 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             };
             E8LandingQ cur, nxt;
             auto issue_scales = [&](E8LandingQ& l, int kq) {
-                const int q = imin(kq, num_kq - 1);
+                const int q = imin(kq, num_sf - 1);
                 issue_e8q_scale_loads<MS, NS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
+            };
+            // G32: every lane's own byte of the landed words into byte 0 (lane group g: bits [8 g, 8 g + 8))
+            [[maybe_unused]] auto shift_down = [&](E8LandingQ& dst, const E8LandingQ& src) {
+                #pragma unroll
+                for (int q = 0; q < MS / 4; ++q)
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dst.sa[q][e] = static_cast<int>(static_cast<unsigned>(src.sa[q][e]) >> g32_shift);
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    dst.sb[ns] = static_cast<int>(static_cast<unsigned>(src.sb[ns]) >> g32_shift);
             };
 
             if constexpr (HS != 0) {
@@ -513,6 +537,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
             tie_e8q_landing<MS, NS>(cur);
+            if constexpr (G32)
+                shift_down(cur, cur);
             raw_barrier();
             if constexpr (STAGED) {
                 #pragma unroll
@@ -525,9 +551,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             v8i bf[NS], af[4];
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
-                bf[ns] = load_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128, frag_off);
-            af[0] = load_fragment(lds + (wm * WM) * 128, frag_off);
-            af[1] = load_fragment(lds + (wm * WM + 16) * 128, frag_off);
+                bf[ns] = read_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128);
+            af[0] = read_fragment(lds + (wm * WM) * 128);
+            af[1] = read_fragment(lds + (wm * WM + 16) * 128);
 
             if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
             asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
@@ -539,6 +565,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
                 const uint8_t* b_next_tile = lds + B_BASE + (b_cur ^ B_BYTES) + (wn * WN) * 128;
+                if constexpr (G32)
+                    issue_scales(nxt, kb + 1);      // block kb + 1's words: older than every piece of this block, in by barrier Z's counted wait
                 // ---- rows 0 .. MS-3 ----
                 #pragma unroll
                 for (int step = 0; step < PRE; ++step) {
@@ -547,7 +575,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     // the accumulators are independent: same bits
                     const int ms = step / NS, ns = (ms & 1) ? NS - 1 - step % NS : step % NS;
                     if (step % NS == 0 && !NO_READS)
-                        af[(ms + 2) & 3] = load_fragment(a_tile + (ms + 2) * 2048, frag_off);
+                        af[(ms + 2) & 3] = read_fragment(a_tile + (ms + 2) * 2048);
                     mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
                     // pieces: one per PRE_STRIDE steps: second half of B(kb+1), then A(kb+2)
                     if (step % PRE_STRIDE == 1) {
@@ -580,7 +608,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 } else {
                     __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
                 }
-                if (TIE_NEXT) tie_e8q_landing<MS, NS>(nxt);         // the next K quad's words (issued one block earlier) are in
+                if (TIE_NEXT || G32) tie_e8q_landing<MS, NS>(nxt);  // the next K quad's words (issued one block earlier; G32: the next block's, issued at the top) are in
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
@@ -590,9 +618,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     const int ns = step >> 1, ms = MS - 2 + ((step & 1) ^ (ns & 1));
                     mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
                     if ((step & 1) && !NO_READS)
-                        bf[ns] = load_fragment(b_next_tile + ns * 2048, frag_off);
-                    if (step == POST / 4 && !NO_READS) af[0] = load_fragment(a_next_tile, frag_off);
-                    if (step == (POST * 5) / 8 && !NO_READS) af[1] = load_fragment(a_next_tile + 2048, frag_off);
+                        bf[ns] = read_fragment(b_next_tile + ns * 2048);
+                    if (step == POST / 4 && !NO_READS) af[0] = read_fragment(a_next_tile);
+                    if (step == (POST * 5) / 8 && !NO_READS) af[1] = read_fragment(a_next_tile + 2048);
                     if (step % POST_STRIDE == 1) {
                         if constexpr (STAGED) {
                             const int pos = N_PRE + step / POST_STRIDE;
@@ -618,6 +646,13 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
             using Yes = std::true_type; using No = std::false_type;
             int kb = 0;
+            if constexpr (G32) {
+                for (; kb < num_kb; ++kb) {                     // one word per row and K block, every lane's byte shifted into byte 0
+                    block(I0{}, No{}, No{}, cur, kb);
+                    shift_down(cur, nxt);
+                    asm volatile("s_nop 3" ::: "memory");       // VALU-written scale registers -> MFMA
+                }
+            } else {
             for (; kb + 4 <= num_kb; kb += 4) {                 // whole K quads: byte select by op_sel, no shifts
                 block(I0{}, No{}, No{}, cur, kb);
                 block(I1{}, Yes{}, No{}, cur, kb + 1);
@@ -644,6 +679,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 asm volatile("s_nop 3" ::: "memory");
                 block(I0{}, No{}, No{}, w, kb);
             }
+            }   // (!G32)
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA -> accumulator reads; the tail's re-read pieces
             __syncthreads();
@@ -712,10 +748,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK, G32>(p);
 }
 
 // Second phase of the TABSK remainder walk: one workgroup per (remainder tile, 32-row quarter) adds the tile's partial slabs in piece order

@@ -105,13 +105,27 @@ def _early_return(m: int, n: int, k: int, d: torch.Tensor, c: Optional[torch.Ten
     return False
 
 
-def _packed_sf_mn_major(sf: torch.Tensor, mn: int, k: int) -> torch.Tensor:
-    """Packed UE8M0 scale words [mn, ceil(k / 512)] int32 -> the MN-major, 16-byte aligned layout (zero-copy if already
+def _packed_sf_mn_major(sf: torch.Tensor, mn: int, k: int, gran_k: int = 128) -> torch.Tensor:
+    """Packed UE8M0 scale words [mn, ceil(k / (4 gran_k))] int32 -> the MN-major, 16-byte aligned layout (zero-copy if already
     there): the int32 twin of get_mn_major_tma_aligned_tensor (csrc/jit_kernels/impls/smxx_layout.hpp:120-153)."""
     host_assert(sf.dtype == torch.int, 'sf.scalar_type() == torch::kInt')
     host_assert(sf.dim() == 2, 'sf.dim() == 2')
-    host_assert(sf.size(0) == mn and sf.size(1) == -(-k // 512), 'sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4)')
+    host_assert(sf.size(0) == mn and sf.size(1) == -(-k // (4 * gran_k)), 'sf.size(-2) == mn and sf.size(-1) == ceil_div(k, gran_k * 4)')
     return get_mn_major_tma_aligned_tensor(sf.view(torch.float)).view(torch.int)
+
+
+def _packed_gran_k(recipe, recipe_a, recipe_b) -> int:
+    """Scale granularity along K of a packed-UE8M0 call: 128 (default recipe of int scales, csrc/utils/layout.hpp:64-77) or 32 (the SM100 MX
+    recipe, csrc/apis/gemm.hpp:311-312); one granularity for both operands (the reference's mixed case, 128 / 32, is its FP8 x FP4 form)."""
+    if recipe is not None:
+        recipe = tuple(recipe)
+        host_assert(len(recipe) == 3 and recipe[0] == 1 and recipe[2] in (32, 128), 'recipe == (1, gran_n, gran_k) with gran_k == 32 or gran_k == 128')
+        return recipe[2]
+    if recipe_a is not None and recipe_b is not None:
+        host_assert(tuple(recipe_a)[1] == tuple(recipe_b)[1] and tuple(recipe_a)[1] in (32, 128),
+                    'gran_k_a == gran_k_b and (gran_k == 32 or gran_k == 128): FP8 x FP8 operands share one K granularity')
+        return tuple(recipe_a)[1]
+    return 128
 
 
 def _unpack_ue8m0(sf_packed: torch.Tensor, k: int) -> torch.Tensor:
@@ -140,10 +154,12 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
     the ``'sm100'`` mode, which the layout step casts to that format (csrc/apis/layout.hpp:48-54): hardware-scaled MFMA path, no FP32
     promotion."""
     fp32_in = a_sf.dtype == torch.float and b_sf.dtype == torch.float
+    gran_k = _packed_gran_k(recipe, recipe_a, recipe_b)
     if not fp32_in:
         host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
-        host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
-        host_assert(recipe_a is None and recipe_b is None, 'not recipe_a.has_value() and not recipe_b.has_value()')
+        host_assert(recipe is None or tuple(recipe) == (1, 1, gran_k), 'recipe == (1, 1, gran_k) for packed UE8M0 scaling factors')
+        host_assert((recipe_a is None) == (recipe_b is None) and (recipe_a is None or (tuple(recipe_a) == (1, gran_k) and tuple(recipe_b) == (1, gran_k))),
+                    'recipe_a == (1, gran_k) and recipe_b == (1, gran_k) for packed UE8M0 scaling factors')
     major_check(a_data), major_check(b_data)
     check_major_type_cd(d)
     m, k = _check_ab_fp8(a_data, 2)
@@ -155,6 +171,8 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
     def _tail_operand_ok(t):        # K-major: 16-byte aligned rows; MN-major: re-majored into aligned scratch below
         return t.stride(-1) != 1 or (t.stride(0) % 16 == 0 and t.data_ptr() % 16 == 0)
     packed_tail_ok = not fp32_in and k % 16 == 0 and k > 128 and _tail_operand_ok(a_data) and _tail_operand_ok(b_data)
+    # (granularity 32: whole 128-K blocks -- a packed word is one block's four exponents; the reference takes any K through TMA zero-fill)
+    host_assert(gran_k == 128 or k % 128 == 0, 'k % 128 == 0 for scaling factors of granularity 32 along K')
     if k % 128 != 0 and not packed_tail_ok:
         # A partial last K block (the reference's SM100 kernels take any K: TMA zero-fills).  Packed words with K-major operands and whole
         # 16-byte chunks stay on the hardware-scaled path (e8_quad_kt_128x256: the partial block is zero-filled by the buffer range check).
@@ -174,17 +192,18 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
     if fp32_in:
         sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, None, False)
     else:
-        sfa, sfb = _packed_sf_mn_major(a_sf, m, k), _packed_sf_mn_major(b_sf, n, k)
+        sfa, sfb = _packed_sf_mn_major(a_sf, m, k, gran_k), _packed_sf_mn_major(b_sf, n, k, gran_k)
     require_device(a_data, b_data, sfa, sfb, d)
     # MN-major operands (nn / tn / tt): read in place by the 8-wave hardware-scaled kernels where the library says that beats a re-majoring pass
+    # (granularity 32: the four-wave kernels only -- every MN-major operand is re-majored)
     if a_data.stride(-1) != 1 or b_data.stride(-1) != 1:
-        plan = lib.dg_ue8m0_dense_operand_plan(a_data.data_ptr(), b_data.data_ptr(), m, n, k, a_data.stride(0), a_data.stride(1),
-                                               b_data.stride(0), b_data.stride(1))
-        if plan & 1:
+        plan = 3 if gran_k == 32 else lib.dg_ue8m0_dense_operand_plan(a_data.data_ptr(), b_data.data_ptr(), m, n, k, a_data.stride(0), a_data.stride(1),
+                                                                       b_data.stride(0), b_data.stride(1))
+        if plan & 1 and a_data.stride(-1) != 1:
             a_data = _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
-        if plan & 2:
+        if plan & 2 and b_data.stride(-1) != 1:
             b_data = _as_k_major(b_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
-    check(lib.dg_fp8_gemm_nt_ue8m0(
+    check((lib.dg_fp8_gemm_nt_ue8m0_g32 if gran_k == 32 else lib.dg_fp8_gemm_nt_ue8m0)(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
         sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1),
@@ -237,17 +256,18 @@ def _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_
     transform_sf_into_required_layout; default recipe for int scales is (1, 1, 128), csrc/utils/layout.hpp:64-77) -- or, for FP32
     scales in the 'sm100' mode, the cast branch (:48-54; ``psum_layout`` lets the SFA pack zero the psum layout's gap rows)."""
     host_assert(k % 128 == 0, 'k % 128 == 0')
+    gran_k = _packed_gran_k(recipe, recipe_a, recipe_b)
     if a_sf.dtype == torch.float and b_sf.dtype == torch.float:
         sfa, sfb, _ = transform_sf_pair_into_required_layout(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups_a, num_groups_b,
                                                              False, psum_layout)
-        return sfa, sfb
+        return sfa, sfb, gran_k
     host_assert(a_sf.dtype == torch.int and b_sf.dtype == torch.int, 'sfa.scalar_type() == torch::kInt and sfb.scalar_type() == torch::kInt')
-    host_assert(recipe is None or tuple(recipe) == (1, 1, 128), 'recipe == (1, 1, 128) for packed UE8M0 scaling factors')
+    host_assert(recipe is None or tuple(recipe) == (1, 1, gran_k), 'recipe == (1, 1, gran_k) for packed UE8M0 scaling factors')
     host_assert((recipe_a is None) == (recipe_b is None), 'recipe_a.has_value() == recipe_b.has_value()')
-    host_assert(recipe_a is None or (tuple(recipe_a) == (1, 128) and tuple(recipe_b) == (1, 128)),
-                'recipe_a == (1, 128) and recipe_b == (1, 128) for packed UE8M0 scaling factors')
-    return (transform_sf_into_required_layout(a_sf, m, k, (1, 128), num_groups_a),
-            transform_sf_into_required_layout(b_sf, n, k, (1, 128), num_groups_b))
+    host_assert(recipe_a is None or (tuple(recipe_a) == (1, gran_k) and tuple(recipe_b) == (1, gran_k)),
+                'recipe_a == (1, gran_k) and recipe_b == (1, gran_k) for packed UE8M0 scaling factors')
+    return (transform_sf_into_required_layout(a_sf, m, k, (1, gran_k), num_groups_a),
+            transform_sf_into_required_layout(b_sf, n, k, (1, gran_k), num_groups_b), gran_k)
 
 
 def _m_grouped_masked_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, masked_m, expected_m, recipe, recipe_a, recipe_b) -> None:
@@ -265,9 +285,9 @@ def _m_grouped_masked_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, masked_m, expe
     host_assert(d.dtype == torch.bfloat16, 'd.scalar_type() == torch::kBFloat16')
     host_assert(masked_m.dtype == torch.int, 'masked_m.scalar_type() == torch::kInt')
     check_major_type_cd(d)
-    sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups, num_groups)
+    sfa, sfb, gran_k = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, num_groups, num_groups)
     require_device(a_data, b_data, sfa, sfb, d, masked_m)
-    check(lib.dg_m_grouped_fp8_gemm_nt_masked_ue8m0(
+    check((lib.dg_m_grouped_fp8_gemm_nt_masked_ue8m0_g32 if gran_k == 32 else lib.dg_m_grouped_fp8_gemm_nt_masked_ue8m0)(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), masked_m.data_ptr(),
         num_groups, m, n, k, int(expected_m),
         a_data.stride(0), a_data.stride(1), a_data.stride(2), b_data.stride(0), b_data.stride(1), b_data.stride(2),
@@ -378,9 +398,18 @@ def m_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     if a_sf.dtype == torch.int or b_sf.dtype == torch.int or (_casts_to_ue8m0(a_sf, b_sf, disable_ue8m0_cast) and k % 128 == 0):
         # packed UE8M0 scales (SM100 format, recipe (1, 1, 128)) or FP32 scales cast to them ('sm100' mode): hardware-scaled MFMA kernels
         # (csrc/apis/gemm.hpp:213-216: the psum layout goes to the SFA pack so that it skips the gap rows)
-        sfa, sfb = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, num_groups,
-                                   grouped_layout if use_psum_layout and a_sf.dtype == torch.float else None)
+        sfa, sfb, gran_k = _packed_sf_pair(a_sf, b_sf, m, n, k, recipe, recipe_a, recipe_b, None, num_groups,
+                                           grouped_layout if use_psum_layout and a_sf.dtype == torch.float else None)
         require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
+        if gran_k == 32:
+            # granularity 32 (the SM100 MX recipe): the four-wave G32 kernels, K-major weights (MN-major ones are re-majored), no K split
+            b_km = _remajor(b_data) if b_data.stride(-1) != 1 else b_data
+            check(lib.dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_g32(
+                a_data.data_ptr(), sfa.data_ptr(), b_km.data_ptr(), sfb.data_ptr(), d.data_ptr(), grouped_layout.data_ptr(),
+                num_groups, m, n, k, a_data.stride(0), a_data.stride(1), b_km.stride(0), b_km.stride(1), b_km.stride(2),
+                sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), sfb.stride(2), d.stride(0), int(use_psum_layout),
+                runtime.get_mk_alignment_for_contiguous_layout(), 0, 0, current_stream_ptr()))
+            return
         # MN-major weights ([G, K, N]: the nn form) stay as they are where the library reads them in place and that beats a pass over every
         # group's weights (dg_ue8m0_grouped_operand_plan: its predicates and model, no copy here)
         b_km = b_data

@@ -203,29 +203,29 @@ def transform_sf_into_required_layout(sf: torch.Tensor, mn: int, k: int, recipe:
     # (FP32, 128, 128) consumed as FP32: only checked -- csrc/apis/layout.hpp:44-46
     if sf.dtype == torch.float and gran_mn == 128 and gran_k == 128 and fp32_as_is:
         return check_sf_layout(sf, mn, k, gran_mn, gran_k, num_groups, False, True, torch.float)
-    # (FP32, x, 128) in 'sm100' mode: cast to (INT, 1, 128) -- broadcast to rows, packed, MN-major -- csrc/apis/layout.hpp:48-54.
-    # One fused kernel (dg_pack_sf_ue8m0_ex): no index_select temporary.
-    if sf.dtype == torch.float and gran_k == 128 and runtime.get_sf_cast_mode() == 'sm100':
+    # (FP32, x, gran_k) in 'sm100' mode, gran_k 32 or 128: cast to (INT, 1, gran_k) -- broadcast to rows, packed (four consecutive scales along K
+    # per word, whatever the granularity), MN-major -- csrc/apis/layout.hpp:48-54.  One fused kernel (dg_pack_sf_ue8m0_ex): no index_select temporary.
+    if sf.dtype == torch.float and gran_k in (32, 128) and runtime.get_sf_cast_mode() == 'sm100':
         host_assert(not disable_ue8m0_cast, 'not disable_ue8m0_cast')
         return get_mn_major_tma_aligned_packed_ue8m0_tensor(sf, psum_layout, _gran_mn=gran_mn, _mn=mn)
-    # (INT, 1, 128): packed UE8M0 words, only checked and brought to the MN-major layout -- csrc/apis/layout.hpp:56-58
-    if sf.dtype == torch.int and gran_mn == 1 and gran_k == 128:
+    # (INT, 1, gran_k): packed UE8M0 words, only checked and brought to the MN-major layout -- csrc/apis/layout.hpp:56-58
+    if sf.dtype == torch.int and gran_mn == 1 and gran_k in (32, 128):
         host_assert(sf.dim() == (2 if num_groups is None else 3), 'sf.dim() == static_cast<int>(num_groups.has_value()) + 2')
-        host_assert(sf.size(-2) == mn and sf.size(-1) == ceil_div(k, 128 * 4),
+        host_assert(sf.size(-2) == mn and sf.size(-1) == ceil_div(k, gran_k * 4),
                     'sf.size(-2) == ceil_div(mn, gran_mn) and sf.size(-1) == ceil_div(k, gran_k * 4)')
         return get_mn_major_tma_aligned_tensor(sf.view(torch.float)).view(torch.int)
     raise RuntimeError('Assertion error (layout.py): Unknown SF transformation '
-                       '(gran_k = 32 scales are not supported on gfx950)')
+                       '(FP32 scales of granularity 32 along K are consumed as packed UE8M0 only: sf cast mode \'sm100\' or int scale tensors)')
 
 
-def _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, gran_m, gran_n, num_groups_a, num_groups_b, psum_layout):
+def _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, gran_m, gran_n, num_groups_a, num_groups_b, psum_layout, gran_k: int = 128):
     """The cast branch (csrc/apis/layout.hpp:48-54) for BOTH scale tensors of a call in one launch (dg_pack_sf_pair_ue8m0): checks as
     transform_sf_into_required_layout makes them for each tensor, one kernel boundary in front of the GEMM instead of two."""
-    check_sf_layout(sfa, m, k, gran_m, 128, num_groups_a)
-    check_sf_layout(sfb, n, k, gran_n, 128, num_groups_b)
+    check_sf_layout(sfa, m, k, gran_m, gran_k, num_groups_a)
+    check_sf_layout(sfb, n, k, gran_n, gran_k, num_groups_b)
     require_device(sfa, sfb)
     ba, bb = (sfa.unsqueeze(0) if sfa.dim() == 2 else sfa), (sfb.unsqueeze(0) if sfb.dim() == 2 else sfb)
-    sf_k, packed_k = ceil_div(k, 128), ceil_div(ceil_div(k, 128), 4)
+    sf_k, packed_k = ceil_div(k, gran_k), ceil_div(ceil_div(k, gran_k), 4)
     host_assert(ba.size(0) <= 65535 and bb.size(0) <= 65535, 'num_sf_batches <= 65535')
     layout_ptr, num_psum_groups, m_alignment = None, 0, 0
     if psum_layout is not None:
@@ -257,18 +257,27 @@ def transform_sf_pair_into_required_layout(sfa, sfb, m, n, k, recipe, recipe_a, 
     if recipe is not None:
         recipe = tuple(recipe)
         host_assert(len(recipe) == 3, 'recipe must be (gran_m, gran_n, gran_k)')
-        host_assert(recipe[0] == 1 and recipe[2] == 128 and recipe[1] in (1, 128),
-                    'supported recipes: (1, 128, 128) and (1, 1, 128)')
+        host_assert(recipe[0] == 1 and recipe[2] in (32, 128) and recipe[1] in (1, 32, 128),
+                    'supported recipes: (1, 128, 128), (1, 1, 128) and -- packed UE8M0 only -- (1, 1, 32) / (1, 32, 32)')
         from . import runtime
         if (sfa.dtype == torch.float and sfb.dtype == torch.float and not disable_ue8m0_cast and runtime.get_sf_cast_mode() == 'sm100'):
-            return _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, recipe[0], recipe[1], num_groups_a, num_groups_b, psum_layout) + (recipe[1],)
+            return _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, recipe[0], recipe[1], num_groups_a, num_groups_b, psum_layout, recipe[2]) + (recipe[1],)
+        host_assert(recipe[2] == 128 or (sfa.dtype == torch.int and sfb.dtype == torch.int),
+                    "gran_k == 128 for FP32 scaling factors consumed as FP32 (gran_k == 32: packed UE8M0 words or sf cast mode 'sm100')")
+        host_assert(recipe[1] in (1, 128) or recipe[2] == 32, 'gran_n in (1, 128)')
         t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe, num_groups_a, True, disable_ue8m0_cast, psum_layout, keep_sfa_row_major)
         t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe, num_groups_b, False, disable_ue8m0_cast)
         gran_n = recipe[1]
     else:
         recipe_a, recipe_b = tuple(recipe_a), tuple(recipe_b)
-        host_assert(recipe_a == (1, 128) and recipe_b[1] == 128 and recipe_b[0] in (1, 128),
-                    'supported recipes: recipe_a = (1, 128), recipe_b in ((1, 128), (128, 128))')
+        host_assert(recipe_a[0] == 1 and recipe_a[1] in (32, 128) and recipe_b[1] == recipe_a[1] and recipe_b[0] in (1, recipe_b[1]),
+                    'supported recipes: recipe_a = (1, gran_k), recipe_b in ((1, gran_k), (gran_k, gran_k)), gran_k 128 or -- packed UE8M0 only -- 32')
+        from . import runtime
+        if (recipe_a[1] == 32 and sfa.dtype == torch.float and sfb.dtype == torch.float and not disable_ue8m0_cast and
+                runtime.get_sf_cast_mode() == 'sm100'):
+            return _cast_sf_pair_to_ue8m0(sfa, sfb, m, n, k, 1, recipe_b[0], num_groups_a, num_groups_b, psum_layout, 32) + (recipe_b[0],)
+        host_assert(recipe_a[1] == 128 or (sfa.dtype == torch.int and sfb.dtype == torch.int),
+                    "gran_k == 128 for FP32 scaling factors consumed as FP32 (gran_k == 32: packed UE8M0 words or sf cast mode 'sm100')")
         t_sfa = transform_sf_into_required_layout(sfa, m, k, recipe_a, num_groups_a, None, disable_ue8m0_cast, psum_layout, keep_sfa_row_major)
         t_sfb = transform_sf_into_required_layout(sfb, n, k, recipe_b, num_groups_b, None, disable_ue8m0_cast)
         gran_n = recipe_b[0]

@@ -103,6 +103,37 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* s
                                                  int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                                                  int64_t d_stride_m, int use_psum, int m_alignment,
                                                  void* workspace, int64_t workspace_bytes, void* stream);
+/* Scale granularity 32 along K (round 6) -- the reference's SM100 MX recipe for FP8 x FP8 operands: recipe (1, 1, 32) / recipe_a = (1, 32)
+ * (csrc/apis/gemm.hpp:311-312 gran_k == 32 or gran_k == 128; csrc/apis/layout.hpp:48-58 the (INT, 1, gran_k) and the FP32 cast branches;
+ * per_token_cast_to_fp8(..., gran_k = 32, use_packed_ue8m0 = True), deep_gemm/utils/math.py:26-38; sweep tests/generators.py:192-194,230).
+ * The packed words keep their meaning -- four consecutive exponents along K per int32 -- so a word now covers ONE 128-K block: byte j of
+ * element (row, kb) = biased exponent of the scale of K bytes [128 kb + 32 j, 128 kb + 32 j + 32) of that row; element (row, kb) at
+ * ptr[row * stride_mn + kb * stride_kq] (the *_stride_kq arguments: words per step of 128 along K), stride_mn must be 1.  It is the native block
+ * size of v_mfma_scale_f32_16x16x128_f8f6f4 (one scale byte per lane group of 32 K-bytes).  Arguments otherwise as the gran-128 entries of the
+ * same name; operands K-major with 16-byte aligned rows and k % 128 == 0 (MN-major operands: re-majored by the caller, dg_transpose_fp8);
+ * the contiguous entry takes the workspace arguments of its _ws twin (unused by these kernels: NULL / 0 is fine). */
+int dg_fp8_gemm_nt_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                             int m, int n, int k,
+                             int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                             int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                             int64_t d_stride_m, int d_dtype, int accumulate, void* stream);
+int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                                  void* d, const int32_t* grouped_layout, int num_groups, int m, int n, int k,
+                                                  int64_t a_stride_m, int64_t a_stride_k,
+                                                  int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                                  int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                                  int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                                  int64_t d_stride_m, int use_psum, int m_alignment,
+                                                  void* workspace, int64_t workspace_bytes, void* stream);
+int dg_m_grouped_fp8_gemm_nt_masked_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed,
+                                              void* d, const int32_t* masked_m, int num_groups, int m_max, int n, int k,
+                                              int expected_m,
+                                              int64_t a_stride_g, int64_t a_stride_m, int64_t a_stride_k,
+                                              int64_t b_stride_g, int64_t b_stride_n, int64_t b_stride_k,
+                                              int64_t sfa_stride_g, int64_t sfa_stride_m, int64_t sfa_stride_kq,
+                                              int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                                              int64_t d_stride_g, int64_t d_stride_m, void* stream);
+
 /* 2 = re-major the MN-major B of a dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0 call into K-major scratch first, 0 = hand it over as it is (the
  * grouped twin of dg_ue8m0_dense_operand_plan: eligibility of the in-place kernel + the model of when the pass over all groups' weights costs
  * more than the slower K loop).  Pointers are only tested for alignment. */

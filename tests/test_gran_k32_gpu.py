@@ -1,0 +1,236 @@
+"""Scale granularity 32 along K -- the reference's SM100 MX recipe for FP8 x FP8 operands (csrc/apis/gemm.hpp:311-312 ``gran_k == 32 or
+gran_k == 128``; csrc/apis/layout.hpp:48-58; ``per_token_cast_to_fp8(..., gran_k=32, use_ue8m0=True, use_packed_ue8m0=True)``,
+deep_gemm/utils/math.py:26-38; sweep tests/generators.py:192-194,230): packed UE8M0 words hold the four exponents of ONE 128-K block, the scaled
+MFMA takes one byte per lane group natively (csrc/fp8_gemm_quad.hpp, G32).  Every result is checked against the C oracle evaluated with 32-K blocks
+on the same bytes and the same scales as FP32 (tolerance of the packed gran-128 tests: the only freedom is the matrix core's summation order;
+products with power-of-two scales are exact) and against the reference's own gate vs the unquantised matmul."""
+import pytest
+import torch
+
+import deepgemm_amd as dg
+import oracle
+from deepgemm_amd.testing import calc_diff, generators as gen
+from deepgemm_amd.utils.math import pack_ue8m0_to_int, per_token_cast_to_fp8
+from gpu_helpers import assert_close_to_oracle, assert_close_fp32
+
+pytestmark = pytest.mark.gpu
+
+
+def _cast32(x: torch.Tensor):
+    """(fp8, FP32 power-of-two scales [rows, k / 32], packed words [rows, k / 128]) with the reference's quantiser at gran_k = 32."""
+    q, sf = per_token_cast_to_fp8(x, use_ue8m0=True, gran_k=32)
+    return q, sf, pack_ue8m0_to_int(sf)
+
+
+def _device_oracle32(a, sfa, b, sfb, out_dtype=torch.bfloat16, chunk=512):
+    """The oracle's statement on the device for full-size outputs: per 32-K block the exactly scaled partial product (power-of-two scales: exact in
+    FP32), summed in FP64 and rounded once -- within the tolerance below of any FP32 summation order."""
+    m, k = a.shape
+    out = torch.empty((m, b.size(0)), dtype=out_dtype, device=a.device)
+    bd = (b.float().view(b.size(0), k // 32, 32) * sfb.unsqueeze(-1)).view(b.size(0), k).double()
+    for r0 in range(0, m, chunk):
+        ad = (a[r0:r0 + chunk].float().view(-1, k // 32, 32) * sfa[r0:r0 + chunk].unsqueeze(-1)).view(-1, k).double()
+        out[r0:r0 + chunk] = (ad @ bd.t()).to(out_dtype)
+    return out
+
+
+@pytest.mark.parametrize('m,n,k', [(256, 512, 1024), (300, 520, 1536), (64, 136, 512), (129, 4096, 384), (1024, 2048, 7168)])
+def test_dense_packed_gran_k_32(m, n, k):
+    gen.reset_seed(m + n + k)
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    ref = (a.float() @ b.float().t()).to(torch.bfloat16)
+    (a_q, sfa, pa), (b_q, sfb, pb) = _cast32(a), _cast32(b)
+    assert pa.shape == (m, k // 128) and pb.shape == (n, k // 128)
+    d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d, recipe=(1, 1, 32))
+    assert dg.last_config().startswith('e8_quad_g32'), dg.last_config()
+    want = torch.empty((m, n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, gran_n=1, gran_k=32)
+    assert_close_to_oracle(d, want, 'packed ue8m0, gran_k 32')
+    assert calc_diff(d, ref) < gen.FP8_MAX_DIFF
+    # recipe_a / recipe_b spelling of the same call; both tile forms agree bit for bit (in-place accumulation in K order in both)
+    d2 = torch.empty_like(d)
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d2, recipe_a=(1, 32), recipe_b=(1, 32))
+    assert torch.equal(d.view(torch.int16), d2.view(torch.int16))
+    for name in ('e8_quad_g32_256x256', 'e8_quad_g32_128x256'):
+        dg.set_forced_config(name)
+        try:
+            d3 = torch.full_like(d, float('nan'))
+            dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d3, recipe=(1, 1, 32))
+            assert dg.last_config() == name
+        finally:
+            dg.set_forced_config('auto')
+        assert torch.equal(d.view(torch.int16), d3.view(torch.int16)), name
+    # FP32 output with accumulation
+    c32 = torch.randn((m, n), device='cuda', dtype=torch.float)
+    d32 = c32.clone()
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d32, c=d32, recipe=(1, 1, 32))
+    want32 = torch.empty((m, n), dtype=torch.float)
+    oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want32, c=c32.cpu(), gran_n=1, gran_k=32)
+    assert_close_fp32(d32, want32, 'packed ue8m0 gran_k 32, fp32 accumulate')
+
+
+def test_gran_k_32_differs_from_gran_k_128_scales():
+    """Guards against a kernel that ignores three of the four bytes: scales that differ between the 32-K groups of a block."""
+    gen.reset_seed(7)
+    m, n, k = 128, 256, 512
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    a[:, 32:64] *= 64.0                     # the second 32-K group of every row gets a much larger scale
+    a[:, 448:480] *= 1.0 / 64.0
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    b[:, 96:128] *= 32.0
+    (a_q, sfa, pa), (b_q, sfb, pb) = _cast32(a), _cast32(b)
+    assert int((sfa[:, 0] != sfa[:, 1]).sum()) > m // 2
+    d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d, recipe=(1, 1, 32))
+    want = torch.empty((m, n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, gran_n=1, gran_k=32)
+    assert_close_to_oracle(d, want, 'gran_k 32, uneven groups')
+
+
+@pytest.mark.parametrize('layout', ['nn', 'tn', 'tt'])
+def test_gran_k_32_mn_major_operands(layout):
+    """MN-major operands are re-majored by the host layer in front of the G32 kernels (csrc/apis/gemm.hpp:126-164 semantics)."""
+    gen.reset_seed(11)
+    m, n, k = 384, 512, 1024
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    (a_q, sfa, pa), (b_q, sfb, pb) = _cast32(a), _cast32(b)
+    a_in = a_q if layout[0] == 'n' else a_q.t().contiguous().t()
+    b_in = b_q if layout[1] == 't' else b_q.t().contiguous().t()
+    d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_in, pa), (b_in, pb), d, recipe=(1, 1, 32))
+    want = torch.empty((m, n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, gran_n=1, gran_k=32)
+    assert_close_to_oracle(d, want, f'gran_k 32 {layout}')
+
+
+def test_gran_k_32_fp32_scales_in_sm100_mode():
+    """FP32 power-of-two scales with recipe (1, 32, 32) in the 'sm100' cast mode: the layout step packs them (csrc/apis/layout.hpp:48-54, the
+    row broadcast of the 32 x 32 weight blocks fused into the pack kernel) -- same bits as handing over the packed words."""
+    from deepgemm_amd.utils.math import per_block_cast_to_fp8
+    gen.reset_seed(3)
+    m, n, k = 256, 384, 1024
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    a_q, sfa, pa = _cast32(a)
+    b_q, sfb_blocks = per_block_cast_to_fp8(b, use_ue8m0=True, gran_k=32)                # [n / 32, k / 32]
+    sfb_rows = sfb_blocks.repeat_interleave(32, dim=0)[:n].contiguous()
+    d_packed = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pack_ue8m0_to_int(sfb_rows)), d_packed, recipe=(1, 1, 32))
+    dg.set_sf_cast_mode('sm100')
+    try:
+        d = torch.empty_like(d_packed)
+        dg.fp8_gemm_nt((a_q, sfa), (b_q, sfb_blocks), d, recipe=(1, 32, 32))
+        assert dg.last_config().startswith('e8_quad_g32')
+    finally:
+        dg.set_sf_cast_mode('sm90')
+    assert torch.equal(d.view(torch.int16), d_packed.view(torch.int16))
+    with pytest.raises(RuntimeError):                   # FP32 scales of granularity 32 consumed as FP32: no such arithmetic (reference: SM100 only)
+        dg.fp8_gemm_nt((a_q, sfa), (b_q, sfb_blocks), d, recipe=(1, 32, 32))
+
+
+@pytest.mark.parametrize('use_psum', [False, True])
+def test_m_grouped_contiguous_gran_k_32(use_psum):
+    gen.reset_seed(5)
+    n, k = 512, 1024
+    actual_ms = [100, 256, 0, 130]
+    case = gen.generate_m_grouped_contiguous(len(actual_ms), 0, n, k, True, use_psum, actual_ms=actual_ms)
+    m = case.m
+    # the generator's layout with fresh BF16 operands quantised at granularity 32 (its own casts are gran-128); padding rows of A are zero as
+    # the reference's generator leaves them (tests/generators.py:343-355)
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    if not use_psum:
+        a[case.grouped_layout < 0] = 0
+    b = torch.randn((len(actual_ms), n, k), device='cuda', dtype=torch.bfloat16)
+    a_q, sfa, pa = _cast32(a)
+    bq = [_cast32(b[g]) for g in range(len(actual_ms))]
+    b_q, sfb, pb = torch.stack([x[0] for x in bq]), torch.stack([x[1] for x in bq]), torch.stack([x[2] for x in bq])
+    d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.m_grouped_fp8_gemm_nt_contiguous((a_q, pa), (b_q, pb), d, case.grouped_layout, recipe=(1, 1, 32), use_psum_layout=use_psum)
+    assert 'g32' in dg.last_config(), dg.last_config()
+    want = torch.full((m, n), float('nan'), dtype=torch.bfloat16)
+    oracle.m_grouped_fp8_gemm_nt_contiguous(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, case.grouped_layout.cpu(), use_psum,
+                                            gran_k=32, gran_n=1)
+    written = ~torch.isnan(want.float())
+    assert bool(written.any())
+    assert_close_to_oracle(torch.where(written.cuda(), d, torch.zeros_like(d)), torch.where(written, want, torch.zeros_like(want)), 'contiguous gran_k 32')
+    if not use_psum:        # padding rows (-1) are exact zeros (tests/test_fp8_fp4.py:22-29)
+        pad = (case.grouped_layout < 0)
+        assert bool((d[pad] == 0).all())
+
+
+@pytest.mark.parametrize('masked_ms,max_m', [([5, 0, 64, 33], 64), ([200, 17, 256], 256)])
+def test_m_grouped_masked_gran_k_32(masked_ms, max_m):
+    gen.reset_seed(9)
+    n, k = 512, 768
+    g = len(masked_ms)
+    a = torch.randn((g, max_m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((g, n, k), device='cuda', dtype=torch.bfloat16)
+    aq, bq = [_cast32(a[i]) for i in range(g)], [_cast32(b[i]) for i in range(g)]
+    a_q, sfa, pa = (torch.stack([x[j] for x in aq]) for j in range(3))
+    b_q, sfb, pb = (torch.stack([x[j] for x in bq]) for j in range(3))
+    masked = torch.tensor(masked_ms, dtype=torch.int, device='cuda')
+    d = torch.full((g, max_m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.m_grouped_fp8_gemm_nt_masked((a_q, pa), (b_q, pb), d, masked, max(1, sum(masked_ms) // g), recipe=(1, 1, 32))
+    assert 'g32' in dg.last_config(), dg.last_config()
+    want = torch.full((g, max_m, n), float('nan'), dtype=torch.bfloat16)
+    oracle.m_grouped_fp8_gemm_nt_masked(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, masked.cpu(), gran_k=32, gran_n=1)
+    for i, rows in enumerate(masked_ms):
+        if rows:
+            assert_close_to_oracle(d[i, :rows], want[i, :rows], f'masked gran_k 32, group {i}')
+        assert bool(torch.isnan(d[i, rows:]).all()), 'rows >= masked_m stay untouched'
+
+
+def test_full_size_c2_c4_c5_gran_k_32():
+    """BASELINE configs[1], [3], [4] (one rank) at size with granularity-32 scales, every element against the device statement of the oracle
+    (sampled rows of which are pinned to the C oracle)."""
+    # C2
+    gen.reset_seed(0)
+    m, n, k = 4096, 4096, 7168
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    (a_q, sfa, pa), (b_q, sfb, pb) = _cast32(a), _cast32(b)
+    d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d, recipe=(1, 1, 32))
+    assert dg.last_config() == 'e8_quad_g32_256x256'
+    want = _device_oracle32(a_q, sfa, b_q, sfb)
+    assert calc_diff(d, want) < 2e-6
+    rows = [0, 1, 255, 256, 2047, 4095]
+    pin = torch.empty((len(rows), n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(a_q[rows].cpu(), sfa[rows].cpu(), b_q.cpu(), sfb.cpu(), pin, gran_n=1, gran_k=32)
+    assert calc_diff(want[rows].cpu(), pin) < 2e-6 and calc_diff(d[rows].cpu(), pin) < 2e-6
+    del a, b, want
+    # C4: 8 groups x ~512 rows (the group-relative tiling of the contiguous layout)
+    import random
+    random.seed(0)
+    actual_ms = [int(512 * random.uniform(0.7, 1.3)) for _ in range(8)]
+    case = gen.generate_m_grouped_contiguous(8, 512, 4096, 7168, actual_ms=actual_ms)
+    mm = case.m
+    a = torch.randn((mm, k), device='cuda', dtype=torch.bfloat16)
+    a[case.grouped_layout < 0] = 0
+    a_q, sfa, pa = _cast32(a)
+    wq = [_cast32(torch.randn((n, k), device='cuda', dtype=torch.bfloat16)) for _ in range(8)]
+    w_q, sfw, pw = (torch.stack([x[j] for x in wq]) for j in range(3))
+    d = torch.full((mm, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.m_grouped_fp8_gemm_nt_contiguous((a_q, pa), (w_q, pw), d, case.grouped_layout, recipe=(1, 1, 32))
+    assert dg.last_config() == 'e8_quad_g32_tab_256x256', dg.last_config()
+    start = 0
+    for g, (actual, aligned) in enumerate(zip(case.actual_ms, case.aligned_ms)):
+        want = _device_oracle32(a_q[start:start + actual], sfa[start:start + actual], w_q[g], sfw[g])
+        assert calc_diff(d[start:start + actual], want) < 2e-6, g
+        assert bool((d[start + actual:start + aligned] == 0).all()), 'padding rows are exact zeros'
+        start += aligned
+    del a, wq, case
+    # C5: 8 local experts, M <= 64
+    masked_ms = [int(48 * random.uniform(0.7, 1.3)) for _ in range(8)]
+    aq = [_cast32(torch.randn((64, k), device='cuda', dtype=torch.bfloat16)) for _ in range(8)]
+    a_q, sfa, pa = (torch.stack([x[j] for x in aq]) for j in range(3))
+    masked = torch.tensor(masked_ms, dtype=torch.int, device='cuda')
+    d = torch.full((8, 64, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.m_grouped_fp8_gemm_nt_masked((a_q, pa), (w_q, pw), d, masked, 48, recipe=(1, 1, 32))
+    for g, rows in enumerate(masked_ms):
+        want = _device_oracle32(a_q[g, :rows], sfa[g, :rows], w_q[g], sfw[g])
+        assert calc_diff(d[g, :rows], want) < 2e-6, g
+        assert bool(torch.isnan(d[g, rows:]).all())

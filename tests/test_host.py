@@ -193,8 +193,15 @@ def test_sf_layout_helpers_on_host():
     assert packed.dtype == torch.int and packed.shape == (64, 2) and packed.stride() == (1, 64)
     with pytest.raises(RuntimeError, match='ceil_div'):
         dg.transform_sf_into_required_layout(torch.zeros(64, 3, dtype=torch.int), 64, 1024, (1, 128))
+    # ... and at granularity 32 (round 6: the SM100 MX recipe, csrc/apis/layout.hpp:56-58 with gran_k == 32): a word per 128-K block
+    packed32 = dg.transform_sf_into_required_layout(torch.zeros(64, 8, dtype=torch.int), 64, 1024, (1, 32))
+    assert packed32.dtype == torch.int and packed32.shape == (64, 8) and packed32.stride() == (1, 64)
+    with pytest.raises(RuntimeError, match='ceil_div'):
+        dg.transform_sf_into_required_layout(torch.zeros(64, 2, dtype=torch.int), 64, 1024, (1, 32))
+    with pytest.raises(RuntimeError, match='Unknown SF transformation'):      # FP32 scales of granularity 32 consumed as FP32: no such arithmetic
+        dg.transform_sf_into_required_layout(torch.ones(64, 32), 64, 1024, (1, 32))
     with pytest.raises(RuntimeError, match='Unknown SF transformation'):
-        dg.transform_sf_into_required_layout(torch.zeros(64, 8, dtype=torch.int), 64, 1024, (1, 32))
+        dg.transform_sf_into_required_layout(torch.zeros(64, 4, dtype=torch.int), 64, 1024, (1, 64))
 
 
 def test_generators_follow_reference_conventions():
@@ -320,7 +327,7 @@ def test_every_reference_keyword_by_name():
     pa, pb = (c.a[0], torch.zeros(128, 1, dtype=torch.int)), (c.b[0], torch.zeros(256, 1, dtype=torch.int))
     with pytest.raises(RuntimeError, match='no CPU path'):
         dg.fp8_gemm_nt(pa, pb, c.d)
-    with pytest.raises(RuntimeError, match='recipe == .1, 1, 128.'):
+    with pytest.raises(RuntimeError, match='recipe == .1, 1, gran_k.'):
         dg.fp8_gemm_nt(pa, pb, c.d, recipe=(1, 128, 128))
     with pytest.raises(RuntimeError, match='no CPU path'):
         dg.m_grouped_fp8_gemm_nt_contiguous((g.a[0], torch.zeros(g.m, 1, dtype=torch.int)), (g.b[0], torch.zeros(2, 128, 1, dtype=torch.int)),
