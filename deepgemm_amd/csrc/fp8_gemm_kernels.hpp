@@ -329,15 +329,6 @@ __device__ __forceinline__ v8i load_fragment(const uint8_t* tile_rows, int frag_
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// The same with the second 16-byte chunk at byte offset frag_off ^ X: X = 64 is load_fragment (chunks g, g + 4), X = 16 the pair (2 g, 2 g + 1) of
-// the granularity-32 hardware-scaled kernels, whose frag_off holds chunk 2 g (fp8_gemm_quad.hpp, G32).
-template <int X>
-__device__ __forceinline__ v8i load_fragment_x(const uint8_t* tile_rows, int frag_off) {
-    const v4i lo = *reinterpret_cast<const v4i*>(tile_rows + frag_off);
-    const v4i hi = *reinterpret_cast<const v4i*>(tile_rows + (frag_off ^ X));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
 // B-tile row permutation: LDS row position p (within the BN-row tile) holds global column n0 + perm(p), chosen so that
 // the MFMA row slot i = 4 * lg + r of N-subtile ns lands on column wave_n0 + (ns >> 1) * 32 + lg * 8 + (ns & 1) * 4 + r:
 // a lane then holds 8 consecutive BF16 outputs (16 bytes) per pair of N-subtiles, and the four lanes lg = 0..3 of a row

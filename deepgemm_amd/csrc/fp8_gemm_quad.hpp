@@ -98,6 +98,27 @@ __device__ __forceinline__ void tie_e8q_landing(E8LandingQ& l) {
                           "+v"(l.sb[5]), "+v"(l.sb[6]), "+v"(l.sb[7]) :: "memory");
 }
 
+// ONE of the loads of issue_e8q_scale_loads (MS == 8, NS == 8: index 0, 1 = the two dwordx4 of the A rows, 2 .. 9 = the word of N-subtile
+// index - 2), for the granularity-32 loop, which spreads a K block's ten scale loads over the MFMA gaps of the block in front of it.
+// `index` is a constant after unrolling; the immediates must be literals.
+__device__ __forceinline__ void issue_e8q_scale_load_one(E8LandingQ& l, int index, const v4i& sfa_rsrc, int sfa_voff, int sfa_soff,
+                                                         const v4i& sfb_rsrc, int sfb_voff, int sfb_soff) {
+#define DG_E8Q_SB(i, off) asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:" #off : "=&v"(l.sb[i]) : "v"(sfb_voff), "s"(sfb_rsrc), "s"(sfb_soff) : "memory")
+    switch (index) {
+    case 0: asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(l.sa[0]) : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff) : "memory"); break;
+    case 1: asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=&v"(l.sa[1]) : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff) : "memory"); break;
+    case 2: DG_E8Q_SB(0, 0); break;
+    case 3: DG_E8Q_SB(1, 16); break;
+    case 4: DG_E8Q_SB(2, 128); break;
+    case 5: DG_E8Q_SB(3, 144); break;
+    case 6: DG_E8Q_SB(4, 256); break;
+    case 7: DG_E8Q_SB(5, 272); break;
+    case 8: DG_E8Q_SB(6, 384); break;
+    default: DG_E8Q_SB(7, 400); break;
+    }
+#undef DG_E8Q_SB
+}
+
 // The scaled MFMA accumulating in place, as inline asm: with the builtin hipcc treats every accumulator update as a new
 // value, gives results and inputs different registers and rotates 256 registers back at the loop end through thousands of
 // v_accvgpr moves and scratch spills.  "+a" pins each accumulator to one AGPR quad for the whole K loop.  J = byte of the
@@ -156,12 +177,15 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // workspace, many tiles): whole tiles, stored directly.
 // G32 (round 6): scale granularity 32 along K -- the reference's SM100 MX recipe for FP8 x FP8 (csrc/apis/gemm.hpp:311-312,
 // csrc/apis/layout.hpp:48-58; per_token_cast_to_fp8(..., gran_k = 32), deep_gemm/utils/math.py:26-38) and the NATIVE block size of
-// v_mfma_scale_f32_16x16x128_f8f6f4: lane group g = lane >> 4 of an operand supplies the scale of ITS 32 K-bytes.  A packed word then holds the four
-// exponents of ONE 128-K block (byte j = K bytes [32 j, 32 j + 32)), one word per row and K block: element (row, kb) at base[kb * stride + row].
-// Two changes against the gran-128 kernel: (1) a fragment lane (r, g) reads the 16-byte chunks 2 g and 2 g + 1 of its row (K bytes [32 g, 32 g + 32))
-// instead of g and g + 4 -- the same XOR swizzle, conflict-free for the same reason, and still one K permutation shared by both operands;
-// (2) the words of block kb + 1 are loaded at the top of block kb (older than its pieces: landed by barrier Z's counted wait) and, behind the
-// block's last MFMA, shifted down by 8 g per lane (16 VALU operations per K block) so that every lane's byte sits in byte 0: op_sel stays 0.
+// v_mfma_scale_f32_16x16x128_f8f6f4.  A packed word then holds the four exponents of ONE 128-K block (byte j = K bytes [32 j, 32 j + 32)), one word
+// per row and K block: element (row, kb) at base[kb * stride + row].  What the hardware does with the scale operand, measured (tools/g32_probe.py,
+// profiles/r06_probe/g32_scale_byte_mapping.log): lane (r, g) holds the K bytes 16 g .. 16 g + 15 (registers 0-3) and 64 + 16 g .. (registers 4-7)
+// of row r -- the chunk pair (g, g + 4) the fragment reads of every kernel here already use is the matrix core's NATURAL K order, not a
+// permutation -- and the scale supplied by lane group g applies to MX block g of the row, K bytes [32 g, 32 g + 32): the first (g < 2) or second
+// register half of lane groups 2 (g & 1) and 2 (g & 1) + 1, NOT to the lane's own 32 bytes.  So the fragments stay as they are and lane group g
+// takes byte g of the row's word.  One change against the gran-128 kernel: the words of block kb + 1 are loaded at the top of block kb (older than
+// its pieces: landed by barrier Z's counted wait) and, behind the block's last MFMA, shifted down by 8 g per lane (16 VALU operations per K block)
+// so that every lane's byte sits in byte 0: op_sel stays 0.
 template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     static_assert(!G32 || (QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0 && !TABSK), "G32: the two production four-wave forms");
@@ -192,10 +216,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int k_tail = K_TAIL ? (p.k & 127) : 0;
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
-    const int frag_off = (lane & 15) * 128 + ((((G32 ? 2 * (lane >> 4) : (lane >> 4)) ^ (lane & 7))) << 4);
-    [[maybe_unused]] const int g32_shift = (lane >> 4) * 8;         // G32: the lane group's byte of a scale word
-    // (the second half of a fragment: chunk g + 4 = offset ^ 64; G32: chunk 2 g + 1 = offset ^ 16)
-    auto read_fragment = [&](const uint8_t* tile_rows) { return load_fragment_x<G32 ? 16 : 64>(tile_rows, frag_off); };
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    [[maybe_unused]] const int g32_shift = (lane >> 4) * 8;         // G32: lane group g supplies the scale of MX block g = byte g of the row's word
+    auto read_fragment = [&](const uint8_t* tile_rows) { return load_fragment(tile_rows, frag_off); };
     const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
     // A rows interleaved inside a wave's WM rows (LDS row position ms * 16 + i holds tile row i * MS + ms): a lane's MS row
     // scales are MS consecutive words of the MN-major scale tensor.  See duo_kernel_body.
@@ -559,14 +582,19 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
             // One K block with byte J of the scale words `w`.  LOAD_NEXT: this block issues the loads of the next K quad's
             // words (block J == 1 of a whole quad); TIE_NEXT: they are waited for at this block's barrier (J == 2).
-            auto block = [&](auto jc, auto load_next, auto tie_next, const E8LandingQ& w, int kb) {
+            // G32, 256-row form: `land` receives block kb + 1's words -- one load per MFMA gap in steps 2 .. 15 (all of them older than the A pieces,
+            // the only operations barrier Z's counted wait leaves in flight), tied at barrier Z, shifted IN PLACE in the gaps of the last two rows
+            // (one word per step) -- and is the next block's `w`: the loop alternates the two register sets, nothing is copied.
+            auto block = [&](auto jc, auto load_next, auto tie_next, const E8LandingQ& w, int kb, E8LandingQ& land) {
                 constexpr int J = decltype(jc)::value;
+                constexpr bool G32_SPREAD = G32 && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
                 constexpr bool LOAD_NEXT = decltype(load_next)::value, TIE_NEXT = decltype(tie_next)::value;
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
                 const uint8_t* b_next_tile = lds + B_BASE + (b_cur ^ B_BYTES) + (wn * WN) * 128;
-                if constexpr (G32)
-                    issue_scales(nxt, kb + 1);      // block kb + 1's words: older than every piece of this block, in by barrier Z's counted wait
+                [[maybe_unused]] const int g32_q = imin(kb + 1, num_sf - 1);
+                if constexpr (G32 && !G32_SPREAD)
+                    issue_scales(land, kb + 1);     // block kb + 1's words: older than every piece of this block, in by barrier Z's counted wait
                 // ---- rows 0 .. MS-3 ----
                 #pragma unroll
                 for (int step = 0; step < PRE; ++step) {
@@ -596,6 +624,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     if constexpr (STAGED && PRE_STRIDE >= 4)        // the refill of the staging register two MFMA gaps behind its write:
                         if (step % PRE_STRIDE == 3)                 // one filler per gap (both in one gap held up the next MFMA)
                             stage_load((step / PRE_STRIDE) % DEPTH, step / PRE_STRIDE + DEPTH, kb);
+                    if constexpr (G32_SPREAD) {
+                        // gaps 2, 3, 4, 6, 7, 10, 11, 12, 14, 15 (pieces sit in gaps 1, 5, 9, 13, ...; fragment reads in gaps 0, 8, ...)
+                        constexpr int kSlots[10] = {2, 3, 4, 6, 7, 10, 11, 12, 14, 15};
+                        #pragma unroll
+                        for (int i = 0; i < 10; ++i)
+                            if (step == kSlots[i])
+                                issue_e8q_scale_load_one(land, i, sfa_rsrc, sfa_voff, g32_q * sfa_kq_stride, sfb_rsrc, sfb_voff, g32_q * sfb_kq_stride);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- barrier Z ----
@@ -608,7 +644,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 } else {
                     __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
                 }
-                if (TIE_NEXT || G32) tie_e8q_landing<MS, NS>(nxt);  // the next K quad's words (issued one block earlier; G32: the next block's, issued at the top) are in
+                if (TIE_NEXT) tie_e8q_landing<MS, NS>(nxt);         // the next K quad's words (issued one block earlier) are in
+                if (G32) tie_e8q_landing<MS, NS>(land);             // G32: the next block's words, issued in this block
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
@@ -634,8 +671,18 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     if constexpr (STAGED && POST_STRIDE >= 4)
                         if (step % POST_STRIDE == 3)
                             stage_load((N_PRE + step / POST_STRIDE) % DEPTH, N_PRE + step / POST_STRIDE + DEPTH, kb);
+                    if constexpr (G32_SPREAD) {         // one landed word per gap: its lane group's byte into byte 0
+                        if (step < 8)
+                            land.sa[step / 4][step % 4] = static_cast<int>(static_cast<unsigned>(land.sa[step / 4][step % 4]) >> g32_shift);
+                        else
+                            land.sb[step - 8] = static_cast<int>(static_cast<unsigned>(land.sb[step - 8]) >> g32_shift);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (G32 && !G32_SPREAD)
+                    shift_down(land, land);
+                if constexpr (G32)
+                    asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> the next block's MFMAs
                 const int a_free = a_cur;
                 a_cur = a_nxt;
                 a_nxt = a_fill;
@@ -647,17 +694,19 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             using Yes = std::true_type; using No = std::false_type;
             int kb = 0;
             if constexpr (G32) {
-                for (; kb < num_kb; ++kb) {                     // one word per row and K block, every lane's byte shifted into byte 0
-                    block(I0{}, No{}, No{}, cur, kb);
-                    shift_down(cur, nxt);
-                    asm volatile("s_nop 3" ::: "memory");       // VALU-written scale registers -> MFMA
+                // one word per row and K block, every lane's byte shifted into byte 0; the two register sets alternate
+                for (; kb + 2 <= num_kb; kb += 2) {
+                    block(I0{}, No{}, No{}, cur, kb, nxt);
+                    block(I0{}, No{}, No{}, nxt, kb + 1, cur);
                 }
+                if (kb < num_kb)
+                    block(I0{}, No{}, No{}, cur, kb++, nxt);
             } else {
             for (; kb + 4 <= num_kb; kb += 4) {                 // whole K quads: byte select by op_sel, no shifts
-                block(I0{}, No{}, No{}, cur, kb);
-                block(I1{}, Yes{}, No{}, cur, kb + 1);
-                block(I2{}, No{}, Yes{}, cur, kb + 2);
-                block(I3{}, No{}, No{}, cur, kb + 3);
+                block(I0{}, No{}, No{}, cur, kb, nxt);
+                block(I1{}, Yes{}, No{}, cur, kb + 1, nxt);
+                block(I2{}, No{}, Yes{}, cur, kb + 2, nxt);
+                block(I3{}, No{}, No{}, cur, kb + 3, nxt);
                 cur = nxt;
                 asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> MFMA
             }
@@ -677,7 +726,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 for (int ns = 0; ns < NS; ++ns)
                     w.sb[ns] = static_cast<int>(static_cast<unsigned>(cur.sb[ns]) >> shift);
                 asm volatile("s_nop 3" ::: "memory");
-                block(I0{}, No{}, No{}, w, kb);
+                block(I0{}, No{}, No{}, w, kb, nxt);
             }
             }   // (!G32)
             if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();

@@ -109,7 +109,7 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* s
  * The packed words keep their meaning -- four consecutive exponents along K per int32 -- so a word now covers ONE 128-K block: byte j of
  * element (row, kb) = biased exponent of the scale of K bytes [128 kb + 32 j, 128 kb + 32 j + 32) of that row; element (row, kb) at
  * ptr[row * stride_mn + kb * stride_kq] (the *_stride_kq arguments: words per step of 128 along K), stride_mn must be 1.  It is the native block
- * size of v_mfma_scale_f32_16x16x128_f8f6f4 (one scale byte per lane group of 32 K-bytes).  Arguments otherwise as the gran-128 entries of the
+ * size of v_mfma_scale_f32_16x16x128_f8f6f4 (one scale byte per MX block of 32 K-bytes, supplied by lane group j for block j).  Arguments otherwise as the gran-128 entries of the
  * same name; operands K-major with 16-byte aligned rows and k % 128 == 0 (MN-major operands: re-majored by the caller, dg_transpose_fp8);
  * the contiguous entry takes the workspace arguments of its _ws twin (unused by these kernels: NULL / 0 is fine). */
 int dg_fp8_gemm_nt_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
