@@ -8,7 +8,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so the extensi
 
 from .build import LIB_PATH
 
-_i32, _i64, _vp, _cp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
+_i32, _i64, _vp, _cp, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32
 
 # name -> (restype, argtypes); must list every symbol declared in include/deepgemm_amd.h
 SIGNATURES = {
@@ -48,6 +48,16 @@ SIGNATURES = {
     'dg_get_num_cus': (_i32, []),
     'dg_set_forced_config': (_i32, [_cp]),
     'dg_reload_env': (None, []),
+    'dg_set_moe_p2p_timeout_us': (None, [_i64]),
+    'dg_symm_alloc': (_i32, [_i64, _vp, _vp]),
+    'dg_symm_free': (_i32, [_vp]),
+    'dg_ipc_get_handle': (_i32, [_vp, _vp]),
+    'dg_ipc_open_handle': (_i32, [_vp, _vp]),
+    'dg_ipc_close_handle': (_i32, [_vp]),
+    'dg_moe_p2p_layout': (_i32, [_i32] * 6 + [_vp]),
+    'dg_moe_p2p_dispatch': (_i32, [_vp] + [_i32] * 7 + [_vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _u32, _vp, _vp, _vp, _vp]),
+    'dg_moe_p2p_combine': (_i32, [_vp] + [_i32] * 7 + [_vp, _i64, _i64, _vp, _u32, _vp, _vp]),
+    'dg_moe_p2p_reduce': (_i32, [_vp] + [_i32] * 7 + [_vp, _i32, _vp, _i64, _vp, _u32, _vp, _vp]),
     'dg_get_forced_config': (_cp, []),
     'dg_set_debug_buffer': (_i32, [_vp]),
     'dg_list_configs': (_cp, []),

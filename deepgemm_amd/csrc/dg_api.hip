@@ -1627,6 +1627,156 @@ int dg_moe_combine_from_masked(const void* y2_bf16, const int32_t* slot, int tok
     return 0;
 }
 
+// ---- in-kernel dispatch / combine over peer-mapped memory (fp8_gemm_moe.hpp, "In-kernel dispatch / combine") ----
+namespace {
+std::atomic<long long> g_p2p_timeout_us{10LL * 1000 * 1000};        // 10 s, as the fused L1 kernel's partner wait
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+dg::P2pLayout p2p_layout(int local_experts, int cap, int hidden, int max_tokens, int topk, int world) {
+    dg::P2pLayout l{};
+    int64_t off = 0;
+    l.counts = off;   off += align_up(4LL * local_experts, 256);
+    l.arrived = off;  off += align_up(4LL * world, 256);
+    l.combined = off; off += align_up(4LL * world, 256);
+    l.done = off;     off += 256;
+    off = align_up(off, 4096);
+    l.l1_acts = off;  off += align_up(static_cast<int64_t>(local_experts) * cap * hidden, 256);
+    l.l1_sf = off;    off += align_up(4LL * local_experts * (hidden / 128) * cap, 256);
+    l.row_w = off;    off += align_up(4LL * local_experts * cap, 256);
+    l.src_info = off; off += align_up(4LL * local_experts * cap, 256);
+    l.y_rows = off;   off += align_up(2LL * max_tokens * topk * hidden, 256);
+    l.bytes = off;
+    return l;
+}
+
+int fill_p2p_args(dg::P2pArgs& a, const void* const* peer_regions, int world, int rank, int local_experts, int cap, int hidden, int max_tokens,
+                  int topk, int tokens, unsigned epoch, void* errors) {
+    DG_CHECK(peer_regions != nullptr && world >= 1 && world <= dg::kMaxPeers && rank >= 0 && rank < world);
+    DG_CHECK(local_experts >= 1 && cap >= 1 && cap % 4 == 0 && hidden > 0 && hidden % 128 == 0 && topk >= 1 && max_tokens >= 1);
+    DG_CHECK(tokens >= 0 && tokens <= max_tokens && static_cast<int64_t>(max_tokens) * topk < (1 << 24) && epoch != 0 && errors != nullptr);
+    for (int r = 0; r < world; ++r) {
+        DG_CHECK(peer_regions[r] != nullptr && aligned16(peer_regions[r]));
+        a.peer[r] = static_cast<uint8_t*>(const_cast<void*>(peer_regions[r]));
+    }
+    a.lay = p2p_layout(local_experts, cap, hidden, max_tokens, topk, world);
+    a.world = world; a.rank = rank; a.tokens = tokens; a.hidden = hidden; a.topk = topk; a.num_experts = local_experts * world;
+    a.local_experts = local_experts; a.cap = cap; a.epoch = epoch;
+    a.timeout_ticks = g_p2p_timeout_us.load(std::memory_order_relaxed) * 100;        // wall_clock64: 100 MHz
+    a.errors = static_cast<uint32_t*>(errors);
+    return 0;
+}
+}  // namespace
+
+void dg_set_moe_p2p_timeout_us(int64_t us) { g_p2p_timeout_us.store(us > 0 ? us : 1, std::memory_order_relaxed); }
+
+int dg_symm_alloc(int64_t bytes, void** out_ptr, int* out_fine_grained) {
+    DG_CHECK(bytes > 0 && out_ptr != nullptr);
+    void* ptr = nullptr;
+    int fine = 0;
+    // fine-grained device memory where the runtime grants it (coherent for peers without cache maintenance); ordinary device memory otherwise
+    // -- or when the caller asks for it: DG_SYMM_COARSE=1 (tests compare both)
+    if (getenv("DG_SYMM_COARSE") == nullptr && hipExtMallocWithFlags(&ptr, static_cast<size_t>(bytes), hipDeviceMallocFinegrained) == hipSuccess && ptr != nullptr)
+        fine = 1;
+    else {
+        (void)hipGetLastError();
+        ptr = nullptr;
+        DG_HIP_CHECK(hipMalloc(&ptr, static_cast<size_t>(bytes)));
+    }
+    DG_HIP_CHECK(hipMemset(ptr, 0, static_cast<size_t>(bytes)));
+    DG_HIP_CHECK(hipDeviceSynchronize());
+    *out_ptr = ptr;
+    if (out_fine_grained != nullptr)
+        *out_fine_grained = fine;
+    return 0;
+}
+
+int dg_symm_free(void* ptr) {
+    if (ptr != nullptr)
+        DG_HIP_CHECK(hipFree(ptr));
+    return 0;
+}
+
+int dg_ipc_get_handle(void* ptr, void* handle_out_64_bytes) {
+    DG_CHECK(ptr != nullptr && handle_out_64_bytes != nullptr);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle crosses the ABI as 64 opaque bytes");
+    hipIpcMemHandle_t h;
+    DG_HIP_CHECK(hipIpcGetMemHandle(&h, ptr));
+    std::memcpy(handle_out_64_bytes, &h, sizeof(h));
+    return 0;
+}
+
+int dg_ipc_open_handle(const void* handle_64_bytes, void** out_ptr) {
+    DG_CHECK(handle_64_bytes != nullptr && out_ptr != nullptr);
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle_64_bytes, sizeof(h));
+    void* ptr = nullptr;
+    DG_HIP_CHECK(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    *out_ptr = ptr;
+    return 0;
+}
+
+int dg_ipc_close_handle(void* ptr) {
+    if (ptr != nullptr)
+        DG_HIP_CHECK(hipIpcCloseMemHandle(ptr));
+    return 0;
+}
+
+int dg_moe_p2p_layout(int local_experts, int capacity, int hidden, int max_tokens, int topk, int world, int64_t* offsets_out_10) {
+    DG_CHECK(offsets_out_10 != nullptr && local_experts >= 1 && capacity >= 1 && hidden % 128 == 0 && hidden > 0 && max_tokens >= 1 && topk >= 1 && world >= 1);
+    const dg::P2pLayout l = p2p_layout(local_experts, capacity, hidden, max_tokens, topk, world);
+    const int64_t v[10] = {l.counts, l.arrived, l.combined, l.done, l.l1_acts, l.l1_sf, l.row_w, l.src_info, l.y_rows, l.bytes};
+    std::memcpy(offsets_out_10, v, sizeof(v));
+    return 0;
+}
+
+int dg_moe_p2p_dispatch(const void* const* peer_regions, int world, int rank, int local_experts, int capacity, int hidden, int max_tokens, int topk,
+                        const void* x_fp8, const float* x_sf, const void* topk_idx, int topk_idx_is_int64, const float* topk_weights, int tokens,
+                        int64_t x_stride_m, int64_t x_sf_stride_m, uint32_t epoch, int32_t* masked_m_out, void* pair_ok_out, void* errors,
+                        void* stream) {
+    dg::P2pArgs a{};
+    if (const int rc = fill_p2p_args(a, peer_regions, world, rank, local_experts, capacity, hidden, max_tokens, topk, tokens, epoch, errors))
+        return rc;
+    DG_CHECK(masked_m_out != nullptr && pair_ok_out != nullptr);
+    DG_CHECK(tokens == 0 || (x_fp8 != nullptr && x_sf != nullptr && topk_idx != nullptr && topk_weights != nullptr && aligned16(x_fp8) && x_stride_m % 16 == 0));
+    a.x = static_cast<const uint8_t*>(x_fp8); a.x_sf = x_sf; a.topk_idx = topk_idx; a.topk_w = topk_weights; a.idx64 = topk_idx_is_int64 ? 1 : 0;
+    a.x_sm = x_stride_m; a.xsf_sm = x_sf_stride_m; a.masked_m = masked_m_out; a.pair_ok = static_cast<uint8_t*>(pair_ok_out);
+    // (a rank without tokens still announces itself to every peer: one workgroup)
+    hipLaunchKernelGGL(dg::dg_moe_p2p_dispatch_kernel, dim3(static_cast<unsigned>(std::max(tokens, 1))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int dg_moe_p2p_combine(const void* const* peer_regions, int world, int rank, int local_experts, int capacity, int hidden, int max_tokens, int topk,
+                       const void* l2_out_bf16, int64_t l2_stride_g, int64_t l2_stride_m, const int32_t* masked_m, uint32_t epoch, void* errors,
+                       void* stream) {
+    dg::P2pArgs a{};
+    if (const int rc = fill_p2p_args(a, peer_regions, world, rank, local_experts, capacity, hidden, max_tokens, topk, 0, epoch, errors))
+        return rc;
+    DG_CHECK(l2_out_bf16 != nullptr && masked_m != nullptr && aligned16(l2_out_bf16) && l2_stride_m % 8 == 0 && l2_stride_g % 8 == 0);
+    a.l2_out = static_cast<const uint16_t*>(l2_out_bf16); a.l2_sg = l2_stride_g; a.l2_sm = l2_stride_m; a.masked_m = const_cast<int32_t*>(masked_m);
+    const long rows = static_cast<long>(local_experts) * capacity;
+    const long grid = std::max<long>(1, std::min<long>(rows, 4L * num_cus()));
+    hipLaunchKernelGGL(dg::dg_moe_p2p_combine_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int dg_moe_p2p_reduce(const void* const* peer_regions, int world, int rank, int local_experts, int capacity, int hidden, int max_tokens, int topk,
+                      const void* pair_ok, int tokens, void* y_bf16, int64_t y_stride_m, const void* swiglu_workspace, uint32_t epoch, void* errors,
+                      void* stream) {
+    dg::P2pArgs a{};
+    if (const int rc = fill_p2p_args(a, peer_regions, world, rank, local_experts, capacity, hidden, max_tokens, topk, tokens, epoch, errors))
+        return rc;
+    DG_CHECK(pair_ok != nullptr && (tokens == 0 || (y_bf16 != nullptr && aligned16(y_bf16) && y_stride_m % 8 == 0)));
+    a.pair_ok = static_cast<uint8_t*>(const_cast<void*>(pair_ok)); a.y = static_cast<uint16_t*>(y_bf16); a.y_sm = y_stride_m;
+    a.swiglu_errors = static_cast<const uint32_t*>(swiglu_workspace);
+    // (a rank without tokens still waits for -- and thereby orders itself behind -- every owner's combine: one workgroup)
+    hipLaunchKernelGGL(dg::dg_moe_p2p_reduce_kernel, dim3(static_cast<unsigned>(std::max(tokens, 1))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const void* b, const float* sfb, float* d,
                                         int m, int n, const int32_t* ks_host, int num_groups, int ab_layout,
                                         int64_t a_stride_m, int64_t b_stride_n,

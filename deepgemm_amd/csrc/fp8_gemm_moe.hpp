@@ -438,4 +438,229 @@ void dg_moe_combine_kernel(const uint16_t* y2, const int32_t* slot, int tokens, 
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// In-kernel dispatch / combine over peer-mapped memory (round 6): the communication half of the reference's Mega-MoE kernel -- token rows
+// pulled / pushed between GPUs from inside the kernel with system-scope acquire / release (impls/sm100_fp8_fp4_mega_moe.cuh:357-405 dispatch,
+// :523-595 remote pulls and write-back; comm/barrier.cuh:47-83 the NVLink barrier) -- rebuilt for peer-mapped HBM over xGMI.
+//
+// Every rank owns one SYMMETRIC REGION (same layout on every rank, P2pLayout) that all its peers map (hipIpcOpenMemHandle; on one node every
+// GPU pair is one xGMI hop).  Per call, rank s:
+//   1. dg_moe_p2p_dispatch_kernel: for every (token t, top-k entry j) with expert e owned by rank o = e / E_loc: claims the next row slot of
+//      that expert with ONE system-scope fetch-add on o's counter, then writes the FP8 row, its K / 128 scales (straight into the MN-major
+//      layout the grouped GEMM reads), its routing weight and its return address (rank, t, j) into o's masked-layout input -- PUSHED by the
+//      sender, where the reference's receivers pull (a push needs no request / response round trip over a point-to-point link).  The last
+//      workgroup to finish releases `arrived[s] = epoch` on every peer, then waits (bounded) for the epoch of every peer on its own flags
+//      and publishes masked_m[e] = min(counter, capacity) for the GEMMs that follow on the stream.
+//   2. fused L1 + L2 on the local experts (the kernels of the one-rank path, unchanged).
+//   3. dg_moe_p2p_combine_kernel: every valid output row goes back to its return address (a BF16 row write into the token owner's y_rows);
+//      the last workgroup zeroes the slot counters for the next call and releases `combined[o] = epoch` on every peer.
+//   4. dg_moe_p2p_reduce_kernel: waits (bounded) for `combined[*] == epoch`, then y[t] = bf16(sum_j float(y_rows[t, j])) in top-k order.
+// Five launches per step, no host round trip, no collective.  The epoch protocol needs no second buffer: a peer can only start dispatch
+// e + 1 after its reduce e has seen combined[o] == e from every owner o, and o releases that flag after its combine kernel has read the last
+// row of call e and zeroed its counters.  Slot order inside an expert depends on arrival order; no result does (every row of the grouped
+// GEMMs and of the per-token re-quantisation is computed independently, the reduce sums in top-k order).
+// Visibility: payload stores are written through (sc0 sc1) and fenced at system scope before the flag's release; the consumers of dispatched
+// rows are LATER KERNELS on the owner's stream (kernel-boundary acquire); the reduce kernel reads the returned rows in the kernel that waited,
+// with cache-bypassing loads behind a system-scope acquire.  The region is allocated fine-grained where the runtime allows it
+// (dg_symm_alloc).  Every wait is bounded (timeout_ticks of the 100 MHz wall clock) and counted in `errors`: a lost peer ends in a flagged,
+// wrong result -- never in a hung device (reference: comm/barrier.cuh:12,36-40).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxPeers = 16;
+
+struct P2pLayout {      // byte offsets inside a symmetric region (dg_moe_p2p_layout, the same on every rank)
+    int64_t counts;     // uint32 [E_loc]: rows claimed per local expert (system-scope fetch-add by every sender; zeroed by the owner's combine)
+    int64_t arrived;    // uint32 [R]: arrived[s] = epoch once rank s has pushed all its rows of that call
+    int64_t combined;   // uint32 [R]: combined[o] = epoch once owner o has returned all rows of that call
+    int64_t done;       // uint32 [2]: workgroup arrival counters of this rank's own dispatch / combine kernels
+    int64_t l1_acts;    // e4m3 [E_loc][cap][H]
+    int64_t l1_sf;      // float [E_loc][H / 128][cap]   (MN-major: what the grouped GEMM reads zero-copy)
+    int64_t row_w;      // float [E_loc][cap]
+    int64_t src_info;   // int32 [E_loc][cap]: (source rank << 24) | (token * topk + j)
+    int64_t y_rows;     // bf16 [T][topk][H]: combine landing zone of the token owner
+    int64_t bytes;
+};
+
+struct P2pArgs {
+    uint8_t* peer[kMaxPeers];       // region base of every rank as mapped into THIS process (peer[rank] = the own region)
+    P2pLayout lay;
+    int world, rank;
+    int tokens, hidden, topk, num_experts, local_experts, cap;
+    unsigned epoch;
+    long long timeout_ticks;
+    uint32_t* errors;               // local uint32 [4]: 0 rows dropped over a capacity (counted by their SENDER), 1 partner waits of the fused L1 kernel,
+                                    // 2 dispatch flag waits that timed out, 3 combine flag waits that timed out
+    // dispatch
+    const uint8_t* x; const float* x_sf; const void* topk_idx; const float* topk_w; int idx64;
+    int64_t x_sm, xsf_sm;
+    int32_t* masked_m;              // local int32 [E_loc]
+    uint8_t* pair_ok;               // local uint8 [T * topk]: 1 = the pair was delivered (a row will come back)
+    // combine
+    const uint16_t* l2_out; int64_t l2_sg, l2_sm;
+    // reduce
+    uint16_t* y; int64_t y_sm;
+    const uint32_t* swiglu_errors;  // optional: word 0 of the fused L1 kernel's workspace, copied into errors[1]
+};
+
+#ifndef DG_SHARD_TU   // (plain kernels: defined once, in the dg_api.hip translation unit)
+__device__ __forceinline__ void p2p_store16(uint8_t* dst, const uint4& v) {
+    // written through to memory (sc0 sc1): the line must not linger in this XCD's L2 when the flag goes out
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000), 0, 0, 17);
+}
+__device__ __forceinline__ uint4 p2p_load16(const uint8_t* src) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, 16, 0x00020000), 0, 0, 17));
+}
+// Bounded wait for `*flag == want` (system scope); false = timed out.
+__device__ __forceinline__ bool p2p_wait_flag(const uint32_t* flag, unsigned want, long long timeout_ticks) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+        if (wall_clock64() - t0 > timeout_ticks)
+            return false;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256)
+void dg_moe_p2p_dispatch_kernel(const P2pArgs a) {
+    __shared__ int s_pos, s_last;
+    const int t = blockIdx.x;
+    uint8_t* self = a.peer[a.rank];
+    if (t < a.tokens) {
+        for (int j = 0; j < a.topk; ++j) {
+            const int64_t e64 = a.idx64 ? static_cast<const int64_t*>(a.topk_idx)[static_cast<int64_t>(t) * a.topk + j]
+                                        : static_cast<int64_t>(static_cast<const int32_t*>(a.topk_idx)[static_cast<int64_t>(t) * a.topk + j]);
+            const bool valid = e64 >= 0 && e64 < a.num_experts;          // (-1 = no expert for this entry, as the reference's masked top-k)
+            const int e = valid ? static_cast<int>(e64) : 0;
+            const int owner = e / a.local_experts, le = e - owner * a.local_experts;
+            uint8_t* dst = a.peer[owner];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int pos = -1;
+                if (valid) {
+                    pos = static_cast<int>(__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(dst + a.lay.counts) + le, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                    if (pos >= a.cap) {                                  // more rows than the owner's buffer holds: dropped, counted HERE (by the sender)
+                        atomicAdd(a.errors, 1u);
+                        pos = -1;
+                    }
+                }
+                s_pos = pos;
+                a.pair_ok[static_cast<int64_t>(t) * a.topk + j] = pos >= 0 ? 1 : 0;
+            }
+            __syncthreads();
+            const int pos = s_pos;
+            if (pos < 0)
+                continue;
+            const int64_t row = static_cast<int64_t>(le) * a.cap + pos;
+            const uint4* src = reinterpret_cast<const uint4*>(a.x + static_cast<int64_t>(t) * a.x_sm);
+            uint8_t* drow = dst + a.lay.l1_acts + row * a.hidden;
+            for (int c = threadIdx.x; c < a.hidden / 16; c += 256)
+                p2p_store16(drow + c * 16, src[c]);
+            float* dsf = reinterpret_cast<float*>(dst + a.lay.l1_sf) + static_cast<int64_t>(le) * (a.hidden / 128) * a.cap + pos;
+            for (int kb = threadIdx.x; kb < a.hidden / 128; kb += 256)
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(dsf + static_cast<int64_t>(kb) * a.cap), __float_as_uint(a.x_sf[static_cast<int64_t>(t) * a.xsf_sm + kb]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(dst + a.lay.row_w) + row, __float_as_uint(a.topk_w[static_cast<int64_t>(t) * a.topk + j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(reinterpret_cast<int32_t*>(dst + a.lay.src_info) + row, (a.rank << 24) | (t * a.topk + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    // every store of this workgroup is out before it counts itself done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    uint32_t* done = reinterpret_cast<uint32_t*>(self + a.lay.done);
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last)
+        return;
+    // ---- the last workgroup of this rank's dispatch: announce, wait for everybody's rows, publish the counts ----
+    if (threadIdx.x == 0)
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (threadIdx.x < a.world)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[threadIdx.x] + a.lay.arrived) + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < a.world)
+        if (!p2p_wait_flag(reinterpret_cast<const uint32_t*>(self + a.lay.arrived) + threadIdx.x, a.epoch, a.timeout_ticks))
+            atomicAdd(a.errors + 2, 1u);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    for (int le = threadIdx.x; le < a.local_experts; le += 256) {
+        const unsigned c = __hip_atomic_load(reinterpret_cast<const uint32_t*>(self + a.lay.counts) + le, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.masked_m[le] = static_cast<int>(c < static_cast<unsigned>(a.cap) ? c : static_cast<unsigned>(a.cap));
+    }
+}
+
+__global__ __launch_bounds__(256)
+void dg_moe_p2p_combine_kernel(const P2pArgs a) {
+    __shared__ int s_last;
+    uint8_t* self = a.peer[a.rank];
+    const int total = a.local_experts * a.cap;
+    for (int r = blockIdx.x; r < total; r += gridDim.x) {
+        const int le = r / a.cap, slot = r - le * a.cap;
+        if (slot >= a.masked_m[le])
+            continue;
+        const int info = reinterpret_cast<const int32_t*>(self + a.lay.src_info)[r];
+        const int src_rank = (info >> 24) & 0xff, pair = info & 0xffffff;
+        const uint4* src = reinterpret_cast<const uint4*>(a.l2_out + le * a.l2_sg + static_cast<int64_t>(slot) * a.l2_sm);
+        uint8_t* drow = a.peer[src_rank] + a.lay.y_rows + static_cast<int64_t>(pair) * a.hidden * 2;
+        for (int c = threadIdx.x; c < a.hidden / 8; c += 256)
+            p2p_store16(drow + c * 16, src[c]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    uint32_t* done = reinterpret_cast<uint32_t*>(self + a.lay.done) + 1;
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last)
+        return;
+    // ---- the last workgroup: the slot counters are free for the next call, then everybody may know that this owner is done ----
+    if (threadIdx.x == 0)
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int le = threadIdx.x; le < a.local_experts; le += 256)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(self + a.lay.counts) + le, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x < a.world)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[threadIdx.x] + a.lay.combined) + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256)
+void dg_moe_p2p_reduce_kernel(const P2pArgs a) {
+    uint8_t* self = a.peer[a.rank];
+    if (threadIdx.x < a.world)
+        if (!p2p_wait_flag(reinterpret_cast<const uint32_t*>(self + a.lay.combined) + threadIdx.x, a.epoch, a.timeout_ticks) && blockIdx.x == 0)
+            atomicAdd(a.errors + 3, 1u);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.swiglu_errors != nullptr)
+        a.errors[1] = *a.swiglu_errors;
+    const int t = blockIdx.x;
+    if (t >= a.tokens)
+        return;
+    const uint8_t* rows = self + a.lay.y_rows + static_cast<int64_t>(t) * a.topk * a.hidden * 2;
+    for (int c = threadIdx.x * 8; c < a.hidden; c += 256 * 8) {
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // as dg_moe_combine_kernel: top-k order, FP32, absent entries skipped
+        for (int j = 0; j < a.topk; ++j) {
+            if (!a.pair_ok[static_cast<int64_t>(t) * a.topk + j])
+                continue;
+            const uint4 v = p2p_load16(rows + (static_cast<int64_t>(j) * a.hidden + c) * 2);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sum[2 * i] += bf16_lo(w[i]);
+                sum[2 * i + 1] += bf16_hi(w[i]);
+            }
+        }
+        uint4 out;
+        out.x = pack_bf16(sum[0], sum[1]); out.y = pack_bf16(sum[2], sum[3]);
+        out.z = pack_bf16(sum[4], sum[5]); out.w = pack_bf16(sum[6], sum[7]);
+        *reinterpret_cast<uint4*>(a.y + static_cast<int64_t>(t) * a.y_sm + c) = out;
+    }
+}
+#endif  // DG_SHARD_TU
+
 }  // namespace dg

@@ -5,10 +5,14 @@ Reference: ``deep_gemm/mega/__init__.py`` (``transform_weights_for_mega_moe`` :1
 ``deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh`` (the L1 -> L2 hand-off in GEMM1's epilogue), host driver
 ``csrc/apis/mega.hpp:30-159``.  What is here: the fused L1 operator (``m_grouped_fp8_gemm_nt_masked_swiglu``), the weight transform
 this library's kernel wants, ``fp8_mega_moe_local`` = fused L1 + masked L2 on the tokens already resident on this GPU, and the
-reference-shaped ``fp8_mega_moe(y, l1, l2, sym_buffer)`` for any group size: with more than one rank the dispatch / combine legs are
-fixed-shape RCCL all-to-alls (``deepgemm_amd/ep.py``: no host synchronisation, capturable), the routing weight travels with each row and
-is applied before the re-quantisation exactly as at world size 1.  What is NOT here: the reference kernel's IN-KERNEL dispatch / combine
-over NVLink symmetric memory -- that needs xGMI peer access inside the kernel and a multi-GPU node to measure it on.
+reference-shaped ``fp8_mega_moe(y, l1, l2, sym_buffer)`` for any group size.  With more than one rank the dispatch / combine legs are
+either (round 6, ``SymmBuffer(..., p2p=True)``) IN-KERNEL over peer-mapped memory -- every rank maps every peer's symmetric region
+(``hipIpcOpenMemHandle``), a dispatch kernel pushes each token row straight into the owner's masked layout, arrival flags with system-scope
+release / acquire and bounded waits, results return as remote BF16 row writes, a local top-k sum: five launches per step, no collective
+(csrc/fp8_gemm_moe.hpp; reference: sm100_fp8_fp4_mega_moe.cuh:357-405, 523-595, comm/barrier.cuh:47-83) -- or fixed-shape RCCL
+all-to-alls (``deepgemm_amd/ep.py``: no host synchronisation, capturable), the fallback where peers cannot be mapped.  The routing weight
+travels with each row and is applied before the re-quantisation exactly as at world size 1.  The protocol is exercised on ONE GPU by two
+processes that map each other's regions (tests/test_mega_p2p_gpu.py); its xGMI timing is unmeasured (no multi-GPU node in any round).
 """
 from typing import Optional, Tuple
 
@@ -197,9 +201,14 @@ class SymmBuffer:
 
     def __init__(self, group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
                  num_ring_tokens: int = 0, mma_type: str = 'fp8xfp8', activation: str = 'swiglu', device='cuda',
-                 expert_capacity: Optional[int] = None, exchange_capacity: Optional[int] = None, force_exchange: bool = False):
+                 expert_capacity: Optional[int] = None, exchange_capacity: Optional[int] = None, force_exchange: bool = False,
+                 p2p: bool = False):
         host_assert(activation == 'swiglu', "activation == 'swiglu'")
         self.world = 1 if group is None else group.size()
+        self.p2p = bool(p2p)
+        if self.p2p:
+            self._init_p2p(group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, mma_type, device, expert_capacity)
+            return
         # force_exchange: take the multi-rank path (fixed-shape all-to-alls around the two GEMMs) even with one rank -- how the 1-GPU test box
         # runs the HIP side of that path over RCCL (tests/test_ep_gpu.py); needs an initialised process group
         self.exchange = self.world > 1 or force_exchange
@@ -241,17 +250,136 @@ class SymmBuffer:
         else:
             self.l1_acts = self.l1_acts_sf = self.row_weight = self.slot = None     # (the exchange hands these over per call: ep.dispatch_fixed)
 
+    # ---- the in-kernel (peer-to-peer) form: csrc/fp8_gemm_moe.hpp, "In-kernel dispatch / combine" ----
+    def _init_p2p(self, group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, mma_type, device, expert_capacity):
+        """Every rank allocates one symmetric region (``dg_symm_alloc``), the ranks exchange its IPC handle (``all_gather_object`` over
+        ``group`` -- any backend: gloo on one GPU shared by two processes, RCCL on a node) and map each other's regions.  The masked-layout
+        input of the fused L1 kernel (``l1_acts``, ``l1_acts_sf``, ``row_weight``) are VIEWS of the own region: peers write straight into them."""
+        import ctypes
+        import torch.distributed as dist
+        if mma_type not in ('fp8xfp8', 'fp8'):
+            raise RuntimeError(f"SymmBuffer: mma_type '{mma_type}' is not supported on gfx950 (FP8 e4m3 activations x FP8 e4m3 weights only)")
+        host_assert(hidden % 128 == 0 and intermediate_hidden % 128 == 0, 'hidden % 128 == 0 and intermediate_hidden % 128 == 0')
+        host_assert(num_experts % self.world == 0 and self.world <= 16, 'num_experts % num_ranks == 0 and num_ranks <= 16')
+        host_assert(torch.device(device).type == 'cuda', 'the in-kernel dispatch / combine has no CPU path')
+        self.exchange = False
+        self.rank = 0 if group is None else dist.get_rank(group)
+        self.group, self.num_experts, self.num_topk = group, num_experts, num_topk
+        self.num_local_experts = e = num_experts // self.world
+        self.num_max_tokens_per_rank = t = -(-num_max_tokens_per_rank // 64) * 64
+        self.hidden, self.intermediate_hidden, self.num_ring_tokens = hidden, intermediate_hidden, 0
+        host_assert(t * num_topk < (1 << 24), 'num_max_tokens_per_rank * num_topk < 2^24 (return addresses are 24-bit)')
+        # rows per local expert: the worst case (every token of every rank names it) unless the caller sizes it for its routing; rows over it
+        # are dropped and counted in errors[0] ON THEIR SENDER
+        m = -(-min(self.world * t, expert_capacity or self.world * t) // 64) * 64
+        self.expert_capacity, self.exchange_capacity = m, 0
+        offs = (ctypes.c_int64 * 10)()
+        check(lib.dg_moe_p2p_layout(e, m, hidden, t, num_topk, self.world, offs))
+        self._offsets = dict(zip(('counts', 'arrived', 'combined', 'done', 'l1_acts', 'l1_sf', 'row_w', 'src_info', 'y_rows', 'bytes'), list(offs)))
+        local_bytes = e * m * (intermediate_hidden + intermediate_hidden // 32 + 2 * hidden) + t * (hidden + hidden // 32)
+        free_bytes = torch.cuda.mem_get_info(torch.device(device))[0]
+        if self._offsets['bytes'] + local_bytes > free_bytes:
+            raise RuntimeError(f'SymmBuffer(p2p=True): {(self._offsets["bytes"] + local_bytes) / 2 ** 30:.1f} GiB of staging for {e} local experts x {m} rows '
+                               f'(hidden {hidden}) exceed the {free_bytes / 2 ** 30:.1f} GiB free on the device; pass expert_capacity= sized for the '
+                               f'routing you have (rows over it are dropped and counted in errors[0])')
+        ptr, fine = ctypes.c_void_p(), ctypes.c_int()
+        with torch.cuda.device(torch.device(device)):
+            check(lib.dg_symm_alloc(self._offsets['bytes'], ctypes.byref(ptr), ctypes.byref(fine)))
+        self._region, self.fine_grained = ptr.value, bool(fine.value)
+        handle = (ctypes.c_char * 64)()
+        self._peer_ptrs = [None] * self.world
+        self._peer_ptrs[self.rank] = self._region
+        if self.world > 1:
+            # export, exchange, map -- and AGREE: a rank whose runtime cannot map a peer (another node, IPC disabled) must not leave the others
+            # waiting; every rank learns the outcome of every rank and all take the same path
+            problem = None
+            try:
+                check(lib.dg_ipc_get_handle(self._region, handle))
+            except RuntimeError as err:
+                problem = str(err)
+            handles = [None] * self.world
+            dist.all_gather_object(handles, None if problem else bytes(handle.raw), group=group)
+            for r, h in enumerate(handles):
+                if r == self.rank or problem or h is None:
+                    continue
+                opened = ctypes.c_void_p()
+                try:
+                    check(lib.dg_ipc_open_handle(ctypes.c_char_p(h), ctypes.byref(opened)))
+                    self._peer_ptrs[r] = opened.value
+                except RuntimeError as err:
+                    problem = str(err)
+            outcomes = [None] * self.world
+            dist.all_gather_object(outcomes, problem or (None if all(h is not None for h in handles) else 'a peer could not export its region'), group=group)
+            if any(o is not None for o in outcomes):
+                for r, ptr in enumerate(self._peer_ptrs):
+                    if r != self.rank and ptr:
+                        lib.dg_ipc_close_handle(ptr)
+                lib.dg_symm_free(self._region)
+                self._region = None
+                raise RuntimeError('HIP error: the ranks of this group cannot map each other\'s memory (' +
+                                   '; '.join(f'rank {r}: {o}' for r, o in enumerate(outcomes) if o is not None) + ')')
+        self._peers = (ctypes.c_void_p * self.world)(*self._peer_ptrs)
+        self._epoch = 0
+        dev = torch.device(device)
+        self.x = torch.zeros((t, hidden), dtype=torch.float8_e4m3fn, device=dev)
+        self.x_sf = torch.zeros((t, hidden // 128), dtype=torch.float, device=dev)
+        self.topk_idx = torch.full((t, num_topk), -1, dtype=torch.int64, device=dev)
+        self.topk_weights = torch.zeros((t, num_topk), dtype=torch.float, device=dev)
+        self.errors = torch.zeros((4,), dtype=torch.int32, device=dev)
+        self.buffer = self.x
+        self.masked_m = torch.zeros((e,), dtype=torch.int32, device=dev)
+        self.pair_ok = torch.zeros((t * num_topk,), dtype=torch.uint8, device=dev)
+        self.l2_out = torch.empty((e, m, hidden), dtype=torch.bfloat16, device=dev)
+        self.l2_acts, self.l2_acts_sf = empty_intermediate(e, m, intermediate_hidden, dev)
+        self.workspace = swiglu_workspace(e, m, 2 * intermediate_hidden, dev)
+        region = _raw_device_bytes(self._region, self._offsets['bytes'], dev)
+        o = self._offsets
+        self.l1_acts = region[o['l1_acts']:o['l1_acts'] + e * m * hidden].view(torch.float8_e4m3fn).view(e, m, hidden)
+        self.l1_acts_sf = region[o['l1_sf']:o['l1_sf'] + 4 * e * (hidden // 128) * m].view(torch.float).view(e, hidden // 128, m).transpose(1, 2)
+        self.row_weight = region[o['row_w']:o['row_w'] + 4 * e * m].view(torch.float).view(e, m)
+        self.slot = None
+        self._region_view = region
+        if self.world > 1:
+            dist.barrier(group=group)           # nobody dispatches into a region that is not zeroed and mapped everywhere yet
+
     def destroy(self):
+        if getattr(self, 'p2p', False) and getattr(self, '_region', None):
+            import torch.distributed as dist
+            torch.cuda.synchronize()
+            if self.world > 1:
+                dist.barrier(group=self.group)  # every rank is done with every region before any mapping goes away
+            for r, ptr in enumerate(self._peer_ptrs):
+                if r != self.rank and ptr:
+                    lib.dg_ipc_close_handle(ptr)
+            self.l1_acts = self.l1_acts_sf = self.row_weight = self._region_view = None
+            lib.dg_symm_free(self._region)
+            self._region = None
         for name in ('x', 'x_sf', 'topk_idx', 'topk_weights', 'l1_acts', 'l1_acts_sf', 'l2_acts', 'l2_acts_sf', 'l2_out', 'row_weight', 'slot',
                      'masked_m', 'errors', 'workspace', 'buffer', 'group'):
             setattr(self, name, None)
 
 
 def get_symm_buffer_for_mega_moe(group, num_experts: int, num_max_tokens_per_rank: int, num_topk: int, hidden: int, intermediate_hidden: int,
-                                 use_fp8_dispatch: Optional[bool] = None, mma_type: str = 'fp8xfp8', activation: str = 'swiglu') -> SymmBuffer:
-    """deep_gemm/mega/__init__.py:68-128 (the ring-token sizing of the reference belongs to its NVLink pull pipeline; the capacities of
-    the fixed-shape exchange are :class:`SymmBuffer` arguments)."""
-    return SymmBuffer(group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, 0, mma_type, activation)
+                                 use_fp8_dispatch: Optional[bool] = None, mma_type: str = 'fp8xfp8', activation: str = 'swiglu',
+                                 expert_capacity: Optional[int] = None, exchange_capacity: Optional[int] = None,
+                                 p2p: Optional[bool] = None) -> SymmBuffer:
+    """deep_gemm/mega/__init__.py:68-128 (the ring-token sizing of the reference belongs to its NVLink pull pipeline).  Beyond the
+    reference's arguments: ``expert_capacity`` / ``exchange_capacity`` size the staging for the routing the caller has (defaults: the worst
+    case, O(E / R * R * T * H) bytes -- a clear sizing error is raised when that exceeds the device's free memory); ``p2p``: the in-kernel
+    dispatch / combine over peer-mapped memory (default: taken when the group has more than one rank, its ranks share one node and peers can be
+    mapped -- i.e. the ``DG_MEGA_P2P`` environment variable is not ``0`` --, RCCL all-to-alls otherwise)."""
+    import os
+    if p2p is None:
+        p2p = group is not None and group.size() > 1 and os.environ.get('DG_MEGA_P2P', '1') != '0' and torch.cuda.is_available()
+    if p2p:
+        try:
+            return SymmBuffer(group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, 0, mma_type, activation,
+                              expert_capacity=expert_capacity, p2p=True)
+        except RuntimeError as e:
+            if 'HIP error' not in str(e):       # (sizing and argument errors are the caller's to see; a runtime that cannot map peers falls back)
+                raise
+    return SymmBuffer(group, num_experts, num_max_tokens_per_rank, num_topk, hidden, intermediate_hidden, 0, mma_type, activation,
+                      expert_capacity=expert_capacity, exchange_capacity=exchange_capacity)
 
 
 def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair, sym_buffer: SymmBuffer,
@@ -282,6 +410,9 @@ def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair
     host_assert(l2_weights[0].size(0) == b.num_local_experts and l2_weights[0].size(1) == b.hidden and l2_weights[0].size(2) == b.intermediate_hidden,
                 'l2_weights[0].shape == (num_experts / num_ranks, hidden, intermediate_hidden)')
     host_assert(l1_weights[0].size(0) == b.num_local_experts, 'l1_weights[0].size(0) == num_experts / num_ranks')
+    if getattr(b, 'p2p', False):
+        _mega_moe_p2p(y, l1_weights, l2_weights, b, cumulative_local_expert_recv_stats, activation_clamp)
+        return
     if b.exchange:
         _mega_moe_ep(y, l1_weights, l2_weights, b, cumulative_local_expert_recv_stats, activation_clamp, local_ops)
         return
@@ -302,6 +433,47 @@ def fp8_mega_moe(y: torch.Tensor, l1_weights: TensorPair, l2_weights: TensorPair
                                          y.data_ptr(), y.stride(0), stream))
     if cumulative_local_expert_recv_stats is not None:
         cumulative_local_expert_recv_stats.add_(b.masked_m.to(cumulative_local_expert_recv_stats.dtype))
+
+
+class _RawDeviceMemory:
+    """``__cuda_array_interface__`` over a raw device pointer (memory owned by the C side: dg_symm_alloc)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2, 'strides': None}
+
+
+def _raw_device_bytes(ptr: int, nbytes: int, device: torch.device) -> torch.Tensor:
+    return torch.as_tensor(_RawDeviceMemory(ptr, nbytes), device=device)
+
+
+def set_p2p_timeout_us(us: int) -> None:
+    """Bound of the flag waits of the in-kernel dispatch / combine (default 10 s; reference: comm/barrier.cuh:12, 60 s)."""
+    lib.dg_set_moe_p2p_timeout_us(int(us))
+
+
+def _mega_moe_p2p(y, l1_weights, l2_weights, b: SymmBuffer, stats, activation_clamp) -> None:
+    """``fp8_mega_moe`` with the in-kernel dispatch / combine (csrc/fp8_gemm_moe.hpp; reference: sm100_fp8_fp4_mega_moe.cuh:357-405, 523-595):
+    FIVE stream-ordered launches -- push dispatch (+ arrival wait + counts), fused L1, masked L2, push combine, wait + top-k sum -- no
+    collective, no host round trip.  Every rank of the group must make the call (the flags are an all-to-all), with the same epoch: one
+    ``fp8_mega_moe`` per rank per step on this buffer."""
+    require_device(y, b.x, l1_weights[0], l2_weights[0])
+    tokens = int(y.size(0))
+    stream = current_stream_ptr()
+    b._epoch += 1
+    geometry = (b.world, b.rank, b.num_local_experts, b.expert_capacity, b.hidden, b.num_max_tokens_per_rank, b.num_topk)
+    check(lib.dg_moe_p2p_dispatch(b._peers, *geometry, b.x.data_ptr(), b.x_sf.data_ptr(), b.topk_idx.data_ptr(),
+                                  int(b.topk_idx.dtype == torch.int64), b.topk_weights.data_ptr(), tokens, b.x.stride(0), b.x_sf.stride(0),
+                                  b._epoch, b.masked_m.data_ptr(), b.pair_ok.data_ptr(), b.errors.data_ptr(), stream))
+    expected_m = max(1, min(b.expert_capacity, -(-tokens * b.num_topk // b.num_local_experts)))     # (a tuning hint: this rank's share as a proxy)
+    m_grouped_fp8_gemm_nt_masked_swiglu((b.l1_acts, b.l1_acts_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m,
+                                        activation_clamp, workspace=b.workspace, row_weight=b.row_weight)
+    m_grouped_fp8_gemm_nt_masked((b.l2_acts, b.l2_acts_sf), l2_weights, b.l2_out, b.masked_m, expected_m)
+    check(lib.dg_moe_p2p_combine(b._peers, *geometry, b.l2_out.data_ptr(), b.l2_out.stride(0), b.l2_out.stride(1), b.masked_m.data_ptr(),
+                                 b._epoch, b.errors.data_ptr(), stream))
+    check(lib.dg_moe_p2p_reduce(b._peers, *geometry, b.pair_ok.data_ptr(), tokens, y.data_ptr(), y.stride(0) if tokens else 0,
+                                b.workspace.data_ptr(), b._epoch, b.errors.data_ptr(), stream))
+    if stats is not None:
+        stats.add_(b.masked_m.to(stats.dtype))
 
 
 def _mega_moe_ep(y, l1_weights, l2_weights, b: SymmBuffer, stats, activation_clamp, local_ops) -> None:

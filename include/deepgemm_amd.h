@@ -239,6 +239,47 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, cons
                                            int64_t out_sf_stride_k, float activation_clamp, int use_ue8m0, void* workspace, int64_t workspace_bytes,
                                            void* stream);
 
+/* In-kernel dispatch / combine of the fused MoE operator over peer-mapped memory (round 6) -- the communication half of the reference's
+ * Mega-MoE kernel, where tokens are pulled and results pushed between GPUs from inside the kernel with system-scope acquire / release
+ * (deep_gemm/include/deep_gemm/impls/sm100_fp8_fp4_mega_moe.cuh:357-405 dispatch, :523-595 remote pulls / write-back;
+ * deep_gemm/include/deep_gemm/comm/barrier.cuh:47-83 the NVLink barrier; host side csrc/apis/mega.hpp:30-159, buffer
+ * deep_gemm/mega/__init__.py:18-58).  Protocol, memory ordering and the bound on every wait: csrc/fp8_gemm_moe.hpp.
+ *
+ * dg_symm_alloc / dg_symm_free: the rank's symmetric region (zeroed; fine-grained device memory where the runtime grants it,
+ *   *out_fine_grained tells which; the environment variable DG_SYMM_COARSE forces ordinary device memory).
+ * dg_ipc_get_handle / dg_ipc_open_handle / dg_ipc_close_handle: hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle with the
+ *   handle as 64 opaque bytes -- how the ranks of one node map each other's regions (exchanged by the caller, e.g. all_gather_object).
+ * dg_moe_p2p_layout: byte offsets of {counts, arrived, combined, done, l1_acts [E_loc, cap, H] e4m3, l1_sf [E_loc, H / 128, cap] FP32
+ *   (MN-major), row_weight [E_loc, cap] FP32, src_info [E_loc, cap] int32, y_rows [T, topk, H] BF16, total bytes} inside a region.
+ * All three kernels take the region base of every rank AS MAPPED INTO THE CALLING PROCESS (peer_regions[rank] = the own region), the
+ * problem geometry (local_experts = E / world, capacity = rows per local expert, hidden, max_tokens, topk) and the call's epoch (1, 2, ...:
+ * the same on every rank, never 0).  errors: device uint32 [4] -- [0] += rows this rank sent that found their expert full (dropped: the pair
+ * contributes nothing to y), [1] = word 0 of the fused L1 kernel's workspace, [2] / [3] += dispatch / combine flag waits that timed out
+ * (dg_set_moe_p2p_timeout_us, default 10 s; reference: comm/barrier.cuh:12,36-40).
+ *   dg_moe_p2p_dispatch: every (token t < tokens, entry j) with 0 <= topk_idx[t, j] < E pushes x_fp8[t], x_sf[t, :], topk_weights[t, j] and its
+ *     return address into the next free row of expert e on rank e / local_experts; pair_ok_out[t * topk + j] = 1 if delivered.  Returns after
+ *     every rank's rows have arrived here: masked_m_out[e_local] = rows of the local expert (int32, what the masked GEMMs read).
+ *   dg_moe_p2p_combine: row slot (e, r < masked_m[e]) of l2_out_bf16 [E_loc, cap, H] goes back to y_rows[t, j] of its source rank.
+ *   dg_moe_p2p_reduce: y[t] = bf16( sum_j float(y_rows[t, j]) ) over the delivered pairs in top-k order, after every owner has returned.
+ * Stream-ordered, no host synchronisation, no allocation; one call of each per step on every rank of the group, in this order. */
+void dg_set_moe_p2p_timeout_us(int64_t us);
+int dg_symm_alloc(int64_t bytes, void** out_ptr, int* out_fine_grained);
+int dg_symm_free(void* ptr);
+int dg_ipc_get_handle(void* ptr, void* handle_out_64_bytes);
+int dg_ipc_open_handle(const void* handle_64_bytes, void** out_ptr);
+int dg_ipc_close_handle(void* ptr);
+int dg_moe_p2p_layout(int local_experts, int capacity, int hidden, int max_tokens, int topk, int world, int64_t* offsets_out_10);
+int dg_moe_p2p_dispatch(const void* const* peer_regions, int world, int rank, int local_experts, int capacity, int hidden, int max_tokens, int topk,
+                        const void* x_fp8, const float* x_sf, const void* topk_idx, int topk_idx_is_int64, const float* topk_weights, int tokens,
+                        int64_t x_stride_m, int64_t x_sf_stride_m, uint32_t epoch, int32_t* masked_m_out, void* pair_ok_out, void* errors,
+                        void* stream);
+int dg_moe_p2p_combine(const void* const* peer_regions, int world, int rank, int local_experts, int capacity, int hidden, int max_tokens, int topk,
+                       const void* l2_out_bf16, int64_t l2_stride_g, int64_t l2_stride_m, const int32_t* masked_m, uint32_t epoch, void* errors,
+                       void* stream);
+int dg_moe_p2p_reduce(const void* const* peer_regions, int world, int rank, int local_experts, int capacity, int hidden, int max_tokens, int topk,
+                      const void* pair_ok, int tokens, void* y_bf16, int64_t y_stride_m, const void* swiglu_workspace, uint32_t epoch, void* errors,
+                      void* stream);
+
 /* K-grouped contiguous GEMM (MoE weight gradients): D[g] += A_g * B_g^T for every group g, where group g owns the K range
  * [sum(ks[:g]), sum(ks[:g+1])) of both operands.  Replaces sm90_k_grouped_fp8_gemm_1d1d / sm100_k_grouped_fp8_gemm_1d1d as
  * called from k_grouped_fp8_gemm_nt_contiguous / k_grouped_fp8_gemm_tn_contiguous (csrc/apis/gemm.hpp:299-400).
