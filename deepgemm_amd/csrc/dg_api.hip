@@ -1907,22 +1907,32 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
 int dg_k_grouped_fp8_gemm_tn_psum(const void* a, const float* sfa, const void* b, const float* sfb, float* d, int m, int n, int total_k,
                                   const int32_t* psum_layout, int num_groups, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
                                   int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k, void* stream) {
+    return dg_k_grouped_fp8_gemm_tn_psum_aligned(a, sfa, b, sfb, d, m, n, total_k, psum_layout, num_groups, ab_layout, a_stride_m, b_stride_n,
+                                                 sfa_stride_m, sfa_stride_k, sfb_stride_n, sfb_stride_k, 128, stream);
+}
+
+int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const void* b, const float* sfb, float* d, int m, int n, int total_k,
+                                          const int32_t* psum_layout, int num_groups, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
+                                          int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                          int k_alignment, void* stream) {
     DG_CHECK(m >= 0 && n >= 0 && num_groups >= 0 && total_k >= 0);
     if (m == 0 || n == 0 || num_groups == 0 || total_k == 0)
         return 0;
     DG_CHECK(a != nullptr && b != nullptr && sfa != nullptr && sfb != nullptr && d != nullptr && psum_layout != nullptr);
     DG_CHECK(ab_layout == DG_KGROUPED_COLUMNS || ab_layout == DG_KGROUPED_ROWS);
-    DG_CHECK(total_k % 128 == 0);
+    DG_CHECK(k_alignment > 0 && k_alignment % 32 == 0 && total_k % k_alignment == 0);
     dg::GemmParams p{};
     p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.sfa = sfa; p.sfb = sfb; p.d = d;
     p.layout = psum_layout;
     p.m = m; p.n = n; p.k = total_k; p.num_groups = num_groups;
     p.sfa_sm = sfa_stride_m; p.sfa_sk = sfa_stride_k; p.sfb_sn = sfb_stride_n; p.sfb_sk = sfb_stride_k;
     p.d_sm = n; p.d_sg = static_cast<int64_t>(m) * n;
-    p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1; p.m_alignment = 0;
+    p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1;
+    p.m_alignment = k_alignment == 128 ? 0 : k_alignment;       // (kernel: the K alignment of the psum layout; 0 = whole 128-blocks)
     p.kg_blocks = 0; p.kg_psum = 1;
     const bool mn_major = ab_layout == DG_KGROUPED_ROWS;
-    bool ok = m > 64;
+    // (a K alignment other than 128 means partial last blocks: masked by the operand descriptors of the MN-major form only)
+    bool ok = m > 64 && (k_alignment == 128 || mn_major);
     if (mn_major) {
         ok = ok && aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= m && b_stride_n >= n &&
              a_stride_m <= (1 << 22) && b_stride_n <= (1 << 22) && static_cast<int64_t>(total_k) * a_stride_m < (1LL << 31) &&

@@ -1190,7 +1190,22 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
         int k_extent = p.k;
         if (p.gemm_type == kKGrouped) {
             int k_begin, k_stop;
-            if (p.kg_psum) {
+            if (p.kg_psum && p.m_alignment != 0 && p.m_alignment != 128) {
+                // K alignment A != 128 (round 6; the reference's SM100 sweep: 32 / 160 / 192 / 224, tests/generators.py:192-194,
+                // scheduler/gemm.cuh:74-85): a group starts at the previous end rounded up to A, its scale blocks count from ITS start (compact
+                // rows: ceil(extent / 128) per non-empty group, scheduler/gemm.cuh:247), its last block is partial -- the k-rows at and beyond
+                // the group's end lie outside the operand descriptors below and arrive in the LDS as zeros (MN-major operands only: host check)
+                int prev_end = 0, rows = 0;
+                for (int g = 0; g < t.group; ++g) {
+                    const int end = p.layout[g], start = (prev_end + p.m_alignment - 1) / p.m_alignment * p.m_alignment;
+                    if (end > start)
+                        rows += (end - start + 127) >> 7;
+                    prev_end = end;
+                }
+                k_begin = __builtin_amdgcn_readfirstlane((prev_end + p.m_alignment - 1) / p.m_alignment * p.m_alignment);
+                k_stop = __builtin_amdgcn_readfirstlane(imin(p.layout[t.group], p.k));
+                kg_sf_blocks = __builtin_amdgcn_readfirstlane(rows);
+            } else if (p.kg_psum) {
                 const int prev_end = t.group > 0 ? p.layout[t.group - 1] : 0;
                 k_begin = __builtin_amdgcn_readfirstlane((prev_end + 127) & ~127);
                 k_stop = __builtin_amdgcn_readfirstlane(imin((p.layout[t.group] + 127) & ~127, p.k));
@@ -1201,8 +1216,9 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             k_extent = k_stop - k_begin;
             if (k_extent <= 0)
                 continue;                                         // empty group: D[g] stays as it is
-            num_kb = k_extent / 128;
-            kg_sf_blocks = k_begin / 128;
+            num_kb = (k_extent + 127) / 128;                  // (a partial last block only in the psum form with a K alignment != 128)
+            if (!(p.kg_psum && p.m_alignment != 0 && p.m_alignment != 128))
+                kg_sf_blocks = k_begin / 128;
             if constexpr (MN) {
                 kg_a_off = static_cast<int64_t>(k_begin) * lda;
                 kg_b_off = static_cast<int64_t>(k_begin) * ldb;

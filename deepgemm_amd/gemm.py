@@ -559,12 +559,12 @@ def _k_grouped_launch(a_data, sfa, b_data, sfb, d, m, n, ks, layout, a_ld, b_ld,
     return True
 
 
-def _k_grouped_psum_launch(a_data, sfa, b_data, sfb, d, m, n, total_k, psum_layout, layout, a_ld, b_ld) -> bool:
-    """dg_k_grouped_fp8_gemm_tn_psum; False = the library has no kernel for this operand form and launched nothing."""
+def _k_grouped_psum_launch(a_data, sfa, b_data, sfb, d, m, n, total_k, psum_layout, layout, a_ld, b_ld, k_alignment: int = 128) -> bool:
+    """dg_k_grouped_fp8_gemm_tn_psum[_aligned]; False = the library has no kernel for this operand form and launched nothing."""
     require_device(a_data, b_data, sfa, sfb, d, psum_layout)
-    rc = lib.dg_k_grouped_fp8_gemm_tn_psum(
+    rc = lib.dg_k_grouped_fp8_gemm_tn_psum_aligned(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, total_k, psum_layout.data_ptr(),
-        psum_layout.numel(), layout, a_ld, b_ld, sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), current_stream_ptr())
+        psum_layout.numel(), layout, a_ld, b_ld, sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1), k_alignment, current_stream_ptr())
     if rc == _NO_NATIVE_KERNEL:
         return False
     check(rc)
@@ -609,9 +609,9 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
 
     ``use_psum_layout``: ``grouped_layout[g]`` is group g's END along K, groups start at the previous end rounded up to the K alignment,
     the rows in between hold zeros (tests/generators.py:480-530) and ``ks_cpu`` may be missing -- the K ranges are then read on the
-    device, no host copy of the group sizes exists.  Implemented for FP32 per-channel scales with ``gran_k`` = K alignment = 128 (the
-    reference: SM100 only, packed UE8M0 scales, also ``gran_k`` 32 and alignments that are not the scale granularity -- those end
-    where the reference ends on an architecture without them)."""
+    device, no host copy of the group sizes exists.  Implemented for FP32 per-channel scales with ``gran_k`` = 128 and any K alignment that
+    is a multiple of 32 (round 6: 32 / 160 / 192 / 224 of the reference's SM100 sweep -- compact scale rows counted from each group's start,
+    partial last blocks); ``gran_k`` 32 needs per-32 FP32 promotion, which no kernel here has."""
     (a_data, a_sf), (b_data, b_sf) = a, b
     ks = ks_cpu
     recipe = tuple(recipe)
@@ -622,11 +622,10 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     host_assert(d.dim() == 3, 'd.dim() == 3')
     num_groups, m, n = (int(x) for x in d.shape)
     host_assert(a_data.dim() == 2 and b_data.dim() == 2, 'a.first.dim() == 2 and b.first.dim() == 2')
-    # (K extents in whole scale blocks: the reference's `k % k_alignment == 0` with this path's one supported alignment)
-    sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, 128, int(a_data.size(0)))
-    if use_psum_layout and k_alignment != 128:
-        raise RuntimeError('Assertion error (gemm.py): Unsupported architecture (the psum layout of the K-grouped GEMM with a K '
-                           f'alignment of {k_alignment} != gran_k is implemented by the reference for SM100 packed UE8M0 scales only)')
+    # (K extents in whole scale blocks -- the reference's `k % k_alignment == 0` at 128 -- except in the psum form, whose ranges are read on the
+    #  device: any alignment that is a multiple of 32, round 6)
+    general = use_psum_layout and k_alignment != 128
+    sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, k_alignment if general else 128, int(a_data.size(0)))
     host_assert(a_data.dtype == torch.float8_e4m3fn and b_data.dtype == torch.float8_e4m3fn,
                 'ab.scalar_type() == torch::kFloat8_e4m3fn')
     host_assert(tuple(a_data.shape) == (sum_k, m) and tuple(b_data.shape) == (sum_k, n),
@@ -638,6 +637,23 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     if _early_return(m, n, sum_k, d, c):
         return
     host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
+    if general:
+        # K alignment != 128 (the reference's SM100 sweep: 32 / 160 / 192 / 224 at gran_k = 128, tests/generators.py:192-194): groups start at
+        # multiples of the alignment, their scale rows are compact and count from the group's own start (ceil(extent / 128) per non-empty group:
+        # scheduler/gemm.cuh:247), the last block of a group is partial.  The ranges live on the device: the scale-row count cannot be checked
+        # here beyond its upper bound.  MN-major operands in place only (the reference's own restriction, tests/generators.py:497).
+        host_assert(sum_k % k_alignment == 0, 'sum_k % k_alignment == 0')
+        for sf, mn in ((a_sf, m), (b_sf, n)):
+            host_assert(sf.dtype == torch.float and sf.size(1) == mn and sf.size(0) <= sum_k // 128 + num_groups,
+                        'sf.scalar_type() == torch::kFloat and sf.size(1) == mn and sf.size(0) <= sum over groups of ceil_div(k_g, gran_k)')
+        sfa, sfb = get_mn_major_tma_aligned_tensor(a_sf.transpose(0, 1)), get_mn_major_tma_aligned_tensor(b_sf.transpose(0, 1))
+        require_device(grouped_layout)
+        if not _k_grouped_psum_launch(a_data, sfa, b_data, sfb, d, m, n, sum_k, grouped_layout, _KGROUPED_ROWS, a_data.stride(0), b_data.stride(0),
+                                      k_alignment):
+            raise RuntimeError('Assertion error (gemm.py): Unsupported architecture (the psum layout of the K-grouped GEMM with a K alignment of '
+                               f'{k_alignment} needs m > 64 and MN-major operands and scales with 16-byte aligned rows: ' +
+                               lib.dg_last_error().decode() + ')')
+        return
     host_assert(sum_k % 128 == 0, 'sum_k % 128 == 0 (the operands end on a scale-block boundary)')
     sfa, sfb = _k_grouped_sf(a_sf.transpose(0, 1), m, sum_k), _k_grouped_sf(b_sf.transpose(0, 1), n, sum_k)
     if use_psum_layout:

@@ -212,18 +212,18 @@ def generate_k_grouped_contiguous_psum(num_groups: int, m: int, n: int, real_ks:
                                        device: str = 'cuda') -> KGroupedCase:
     """tests/generators.py:490-530 with FP32 scales and gran_k = 128: MN-major ``a [total_k, m]``, ``b [total_k, n]`` whose rows between
     a group's end and the next multiple of ``k_alignment`` are zeros, each group cast on its own padded copy (compact scale rows:
-    ceil(k / 128) per group); ``grouped_layout`` = the ends; ``ks`` = the aligned extents (what a caller may pass as ``ks_cpu``)."""
-    assert len(real_ks) == num_groups and k_alignment == 128
+    ceil(k / 128) per non-empty group, counted from the group's own start -- k_grouped_per_channel_cast_to_fp8, :411-433);
+    ``grouped_layout`` = the ends; ``ks`` = the aligned extents (what a caller may pass as ``ks_cpu``).  Any ``k_alignment`` that is a
+    multiple of 32 (the reference's SM100 sweep: 32 / 128 / 160 / 192 / 224)."""
+    assert len(real_ks) == num_groups and k_alignment % 32 == 0
     from ..utils.math import per_channel_cast_to_fp8
     ends = build_psum_layout_from_ks(real_ks, k_alignment)
     total_k = align(ends[-1] if ends else 0, k_alignment)
     a_q = torch.zeros((total_k, m), device=device, dtype=torch.float8_e4m3fn)
     b_q = torch.zeros((total_k, n), device=device, dtype=torch.float8_e4m3fn)
-    sfa = torch.ones((total_k // 128, m), device=device, dtype=torch.float)
-    sfb = torch.ones((total_k // 128, n), device=device, dtype=torch.float)
     c = torch.randn((num_groups, m, n), device=device, dtype=torch.float) * 32
     ref_d = torch.empty_like(c)
-    a_groups, b_groups = [], []
+    a_groups, b_groups, sfa_rows, sfb_rows = [], [], [], []
     for g, (k, end) in enumerate(zip(real_ks, ends)):
         if k == 0:
             ref_d[g] = c[g]
@@ -234,10 +234,22 @@ def generate_k_grouped_contiguous_psum(num_groups: int, m: int, n: int, real_ks:
         b_g = torch.zeros((k_pad, n), device=device, dtype=torch.bfloat16)
         a_g[:k], b_g[:k] = torch.randn((k, m), device=device, dtype=torch.bfloat16), torch.randn((k, n), device=device, dtype=torch.bfloat16)
         ref_d[g] = c[g] + a_g.float().t() @ b_g.float()
-        a_q[start:start + k_pad], sfa[start // 128:(start + k_pad) // 128] = per_channel_cast_to_fp8(a_g, use_ue8m0=False)
-        b_q[start:start + k_pad], sfb[start // 128:(start + k_pad) // 128] = per_channel_cast_to_fp8(b_g, use_ue8m0=False)
-        a_groups.append((a_q[start:start + k_pad].t().contiguous(), sfa[start // 128:(start + k_pad) // 128].t().contiguous()))
-        b_groups.append((b_q[start:start + k_pad].t().contiguous(), sfb[start // 128:(start + k_pad) // 128].t().contiguous()))
+        qa, sa = per_channel_cast_to_fp8(a_g, use_ue8m0=False)
+        qb, sb = per_channel_cast_to_fp8(b_g, use_ue8m0=False)
+        a_q[start:end], b_q[start:end] = qa[:k], qb[:k]
+        sfa_rows.append(sa), sfb_rows.append(sb)
+        a_groups.append((qa.t().contiguous(), sa.t().contiguous()))
+        b_groups.append((qb.t().contiguous(), sb.t().contiguous()))
+    if k_alignment == 128:
+        # (one scale row per 128-row block of the operands, empty groups included: what the whole-block form indexes by k / 128)
+        sfa = torch.ones((total_k // 128, m), device=device, dtype=torch.float)
+        sfb = torch.ones((total_k // 128, n), device=device, dtype=torch.float)
+        for (k, end), sa, sb in zip([(k, e) for k, e in zip(real_ks, ends) if k], sfa_rows, sfb_rows):
+            start = end - k
+            sfa[start // 128:start // 128 + sa.size(0)], sfb[start // 128:start // 128 + sb.size(0)] = sa, sb
+    else:
+        sfa = torch.cat(sfa_rows) if sfa_rows else torch.empty((0, m), device=device, dtype=torch.float)
+        sfb = torch.cat(sfb_rows) if sfb_rows else torch.empty((0, n), device=device, dtype=torch.float)
     layout = torch.tensor(ends, device=device, dtype=torch.int32)
     return KGroupedCase((a_q, sfa), (b_q, sfb), a_groups, b_groups, c, c.clone(), ref_d, [align(k, k_alignment) for k in real_ks], layout)
 

@@ -319,6 +319,15 @@ int dg_k_grouped_fp8_gemm_nt_contiguous(const void* a, const float* sfa, const v
 int dg_k_grouped_fp8_gemm_tn_psum(const void* a, const float* sfa, const void* b, const float* sfb, float* d, int m, int n, int total_k,
                                   const int32_t* psum_layout, int num_groups, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
                                   int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k, void* stream);
+/* The same for a K alignment other than 128 (round 6; the reference's SM100 sweep: 32 / 160 / 192 / 224 with gran_k = 128,
+ * tests/generators.py:192-194, scheduler/gemm.cuh:74-85, 238-261): group g covers K rows [align(end[g-1], k_alignment), end[g]), its scale rows
+ * are COMPACT and count from its own start (ceil(extent / 128) rows per non-empty group, in group order), its last 128-block may be partial (the
+ * rows at and beyond end[g] do not contribute, whatever they hold).  k_alignment % 32 == 0, total_k % k_alignment == 0; alignments != 128 take
+ * MN-major operands only (DG_KGROUPED_ROWS: the reference's own restriction, tests/generators.py:497). */
+int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const void* b, const float* sfb, float* d, int m, int n, int total_k,
+                                          const int32_t* psum_layout, int num_groups, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
+                                          int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
+                                          int k_alignment, void* stream);
 
 /* M-grouped contiguous GEMM.  Replaces sm90_m_grouped_fp8_gemm_contiguous_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:147) /
  * sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:161) as called from

@@ -1276,6 +1276,52 @@ def test_k_grouped_tn_psum_layout(num_groups, m, n, real_ks):
         assert dg.last_config() in ('pipe_pc_256x256', per_col_tile_name(m, n)) and torch.equal(d3, d)
 
 
+@pytest.mark.parametrize('k_alignment', [32, 160, 192, 224])
+@pytest.mark.parametrize('num_groups,m,n,real_ks', [(4, 256, 384, [300, 0, 129, 512]), (3, 512, 1024, [128, 1, 640]), (2, 304, 272, [1000, 77]),
+                                                    (70, 128, 256, [(37 * i) % 300 for i in range(70)])])
+def test_k_grouped_tn_psum_layout_at_other_k_alignments(num_groups, m, n, real_ks, k_alignment):
+    """The psum form with a K alignment that is not the scale granularity (round 6; the reference's SM100 sweep, tests/generators.py:192-194:
+    gran_k 128 with alignments 160 / 224, here also 32 / 192; scheduler/gemm.cuh:74-85, 238-261): groups start at multiples of the alignment,
+    scale rows are compact and count from each group's start, the last 128-block of a group is partial -- the rows behind a group's end belong
+    to the NEXT group (alignment 32) and must not contribute.  Every group against the oracle on its own operands."""
+    gen.reset_seed(sum(real_ks) + m + k_alignment)
+    dg.set_mk_alignment_for_contiguous_layout(k_alignment)
+    try:
+        case = gen.generate_k_grouped_contiguous_psum(num_groups, m, n, real_ks, k_alignment)
+        ends = case.grouped_layout.tolist()
+        a_q, b_q = case.a[0].clone(), case.b[0].clone()
+        results = []
+        for ks_cpu in (case.ks, None):
+            d = case.c.clone()
+            dg.k_grouped_fp8_gemm_tn_contiguous((a_q, case.a[1]), (b_q, case.b[1]), d, ks_cpu, case.grouped_layout, c=d, use_psum_layout=True)
+            assert dg.last_config() == 'pipe_pc_mn_256x256', dg.last_config()
+            results.append(d)
+        assert torch.equal(results[0], results[1])
+        d = results[0]
+        for g, k in enumerate(real_ks):
+            if k == 0:
+                assert torch.equal(d[g], case.c[g])
+                continue
+            (a_g, sfa_g), (b_g, sfb_g) = case.a_groups[g], case.b_groups[g]
+            want = torch.empty((m, n), dtype=torch.float)
+            oracle.fp8_gemm_nt(a_g.cpu(), sfa_g.cpu(), b_g.cpu(), sfb_g.cpu(), want, c=case.c[g].cpu(), gran_n=1)
+            assert_close_fp32(d[g], want, f'k-grouped psum, K alignment {k_alignment}, group {g}')
+        assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+        # garbage in the rows between a group's end and the next group's start must not reach any result (the reference zero-fills them through
+        # TMA; here the operand descriptors end at the group's end)
+        prev = 0
+        for e in ends:
+            start = -(-prev // k_alignment) * k_alignment
+            a_q[prev:start] = torch.full((1,), 448.0, device='cuda').to(torch.float8_e4m3fn)
+            b_q[prev:start] = torch.full((1,), -448.0, device='cuda').to(torch.float8_e4m3fn)
+            prev = e
+        d2 = case.c.clone()
+        dg.k_grouped_fp8_gemm_tn_contiguous((a_q, case.a[1]), (b_q, case.b[1]), d2, None, case.grouped_layout, c=d2, use_psum_layout=True)
+        assert torch.equal(d2, d)
+    finally:
+        dg.set_mk_alignment_for_contiguous_layout(128)
+
+
 def test_k_grouped_argument_checks():
     gen.reset_seed(1)
     case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)

@@ -306,15 +306,16 @@ def test_every_reference_keyword_by_name():
         dg.k_grouped_fp8_gemm_tn_contiguous(a=kt.a, b=kt.b, d=kt.d, ks_cpu=kt.ks, grouped_layout=kt.grouped_layout, c=kt.c,
                                             recipe=(1, 1, 128), compiled_dims='mn', use_psum_layout=False)
     # ks_cpu missing: legal only together with the psum layout (csrc/apis/gemm.hpp:66-68) -- the K ranges then come from the device
-    # tensor; implemented for a K alignment of 128 (= gran_k), other alignments end where the reference ends off SM100
+    # tensor
     for missing in (None, []):
         with pytest.raises(RuntimeError, match=r'\): use_psum_layout'):
             dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c)
         with pytest.raises(RuntimeError, match='no CPU path'):
             dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c, use_psum_layout=True)
+        # (round 6: any K alignment that is a multiple of 32 -- the reference's SM100 sweep 32 / 160 / 192 / 224 -- is taken by the psum form)
         dg.set_mk_alignment_for_contiguous_layout(64)
         try:
-            with pytest.raises(RuntimeError, match='Unsupported architecture'):
+            with pytest.raises(RuntimeError, match='no CPU path'):
                 dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, missing, kt.grouped_layout, c=kt.c, use_psum_layout=True)
         finally:
             dg.set_mk_alignment_for_contiguous_layout(128)
