@@ -145,6 +145,7 @@ class FixedPlan:
     recv_valid: torch.Tensor          # same shape, bool: the slot holds a row this rank kept (not padding, not over ``max_m``)
     masked_m: torch.Tensor            # [G_local] int32 rows per local expert
     overflow: torch.Tensor            # 0-dim bool: a block or an expert was over capacity (rows were dropped)
+    dropped: Optional[torch.Tensor] = None     # 0-dim int64: rows dropped -- over ``capacity`` on this rank as a sender + over ``max_m`` on this rank as a receiver
     row_extra: Optional[torch.Tensor] = None   # [G_local, max_m] FP32: the per-pair value that travelled with the rows (routing weight)
 
 
@@ -181,6 +182,7 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
     pos = torch.arange(sorted_key.numel(), device=device) - run_begin[sorted_key]
     per_expert = per_expert[:num_experts]
     overflow = (per_expert > capacity).any()
+    dropped = (per_expert - capacity).clamp(min=0).sum()
     dump = world * per_rank * capacity
     # flat slot of a pair: ((rank * per_rank + local expert) * capacity + position) = sorted_key * capacity + pos
     pair_dest = torch.where((sorted_key < num_experts) & (pos < capacity), sorted_key * capacity + pos, torch.full_like(pos, dump))
@@ -207,6 +209,7 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
     slot = offsets.unsqueeze(-1) + c
     valid = (c < recv_counts.unsqueeze(-1)) & (slot < max_m)
     overflow = overflow | (recv_counts.sum(dim=0) > max_m).any()
+    dropped = dropped + (recv_counts.sum(dim=0).to(torch.int64) - max_m).clamp(min=0).sum()
     recv_expert = torch.arange(per_rank, device=device).view(1, per_rank, 1).expand(world, per_rank, capacity).reshape(-1)
     recv_slot = slot.clamp(max=max_m - 1).reshape(-1).to(torch.int64)
     # row of the flat [per_rank * max_m (+ 1 dump row)] stores: invalid entries all land in the dump row behind the last block
@@ -223,7 +226,7 @@ def dispatch_fixed(x: TensorPair, expert_ids: torch.Tensor, num_experts: int, ma
         extra_store = torch.zeros((per_rank * max_m + 1,), dtype=torch.float, device=device)
         extra_store[flat_row] = flat[:, k + sf_bytes:].contiguous().view(torch.float).reshape(-1)
         extra = extra_store[:per_rank * max_m].view(per_rank, max_m)
-    plan = FixedPlan(order, pair_dest, recv_expert, recv_slot, valid.reshape(-1), masked_m, overflow, extra)
+    plan = FixedPlan(order, pair_dest, recv_expert, recv_slot, valid.reshape(-1), masked_m, overflow, dropped=dropped, row_extra=extra)
     a = a_store[:per_rank * max_m].view(torch.float8_e4m3fn).view(per_rank, max_m, k)
     return (a, sf_store[:per_rank * max_m].view(per_rank, max_m, x_sf.size(1))), plan
 

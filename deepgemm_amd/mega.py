@@ -493,7 +493,9 @@ def _mega_moe_ep(y, l1_weights, l2_weights, b: SymmBuffer, stats, activation_cla
     (a, a_sf), plan = ep.dispatch_fixed(x, b.topk_idx[:tokens], b.num_experts, b.expert_capacity, b.exchange_capacity, b.group,
                                         row_extra=b.topk_weights[:tokens])
     b.masked_m.copy_(plan.masked_m)
-    b.errors[0] += plan.overflow.to(torch.int32)
+    # word 0 counts ROWS, as at one rank: this rank's pairs over the exchange capacity + rows it received over an expert's capacity (the
+    # latter belong to other ranks' tokens: the count tells that rows were zeroed somewhere in the group, the sum over ranks how many)
+    b.errors[0] += plan.dropped.to(torch.int32)
     expected_m = max(1, min(b.expert_capacity, -(-tokens * b.num_topk // b.num_local_experts)))
     if local_ops is None:
         m_grouped_fp8_gemm_nt_masked_swiglu((a, a_sf), l1_weights, (b.l2_acts, b.l2_acts_sf), b.masked_m, expected_m, activation_clamp,
