@@ -88,8 +88,16 @@ struct GemmParams {
     // reduction kernel's), stores the tile and clears the flag.  0 = off.  The value is a NaN bit pattern that changes per launch: nothing
     // else that ever lands in the workspace header (tile tables, zeros) equals it.
     unsigned sk_exchange;
+    int tab_rem_first;              // dg_fp8_gemm_duo_tab_fused_kernel: see there
 };
 
+// The clock of the debug stamps: the shader-clock counter (s_memtime: per CU, NOT comparable between CUs -- good for durations inside a wave) or, in
+// -DDG_STAMP_REALTIME tuning builds, the chip-wide 100 MHz counter (s_memrealtime: comparable between workgroups, 10 ns resolution; tools/c2_end_time_histogram.py)
+#ifdef DG_STAMP_REALTIME
+#define DG_STAMP_CLOCK() static_cast<long long>(__builtin_amdgcn_s_memrealtime())
+#else
+#define DG_STAMP_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
 __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int waves_per_block, int slot, long long t) {
     if (p.dbg != nullptr && (threadIdx.x & 63) == 0)
         p.dbg[(static_cast<long long>(blockIdx.x) * waves_per_block + (threadIdx.x >> 6)) * 4 + slot] = t;
@@ -874,7 +882,7 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
     // the K block go into the (wave-uniform) soffset of the buffer instruction.
     const int a_voff = (wave * 8 + piece_row) * lda + src_chunk * 16;
     const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    const long long t_entry = p.dbg != nullptr ? DG_STAMP_CLOCK() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
 
     MaskedWalk walk;
@@ -957,7 +965,7 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
             __syncthreads();
 
             v8i bf[NS], af[2];
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
             for (int kb = 0; kb < num_kb; ++kb) {
                 const int cur = kb & 1;
                 const bool has_next = kb + 1 < num_kb;
@@ -1008,7 +1016,7 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
             // drain the ring: steps TOTAL-3 .. TOTAL-1 of the last K block
             #pragma unroll
             for (int i = 0; i < DEPTH; ++i) {
@@ -1029,7 +1037,7 @@ __device__ __forceinline__ void pipe_kernel_body(const GemmParams& p) {
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+            dbg_stamp(p, NW, 3, DG_STAMP_CLOCK());
         }
     }
 }
@@ -1176,7 +1184,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
     const int sa_lds_off = (wm * WM + (lane & 15)) * 4;                            // + ms * 64
     const int sb_lds_off = MN ? 1024 + (wn * WN + (lane >> 4) * 4) * 4               // + ns * 64 (natural column order)
                               : 1024 + (wn * WN + (lane >> 4) * 8) * 4;              // + (ns >> 1) * 128 + (ns & 1) * 16
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    const long long t_entry = p.dbg != nullptr ? DG_STAMP_CLOCK() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
 
     MaskedWalk walk;
@@ -1343,7 +1351,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             __syncthreads();
 
             v8i bf[NS], af[2];
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
             for (int kb = 0; kb < num_kb; ++kb) {
                 const int cur = kb & 1;
                 const bool has_next = kb + 1 < num_kb;
@@ -1421,7 +1429,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
             #pragma unroll
             for (int i = 0; i < DEPTH; ++i) {
                 const int j = TOTAL - DEPTH + i;
@@ -1443,7 +1451,7 @@ __device__ __forceinline__ void pipe_pc_kernel_body(const GemmParams& p) {
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+            dbg_stamp(p, NW, 3, DG_STAMP_CLOCK());
         }
     }
 }
@@ -1769,7 +1777,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
     auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
     const int a_voff = piece_row * MS * lda + src_chunk * 16;
     const int b_voff = b_row_perm<WN>(wave * 8 + piece_row) * ldb + src_chunk * 16;
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    const long long t_entry = p.dbg != nullptr ? DG_STAMP_CLOCK() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
 
     MaskedWalk walk;
@@ -1936,11 +1944,11 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
     };
     Piece piece, piece_next;
 #if defined(DG_STAMP_ISSUE) && DG_STAMP_ISSUE == 3
-    if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+    if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
 #endif
     Tile t = work_of(tile_id, pass, piece);
 #if defined(DG_STAMP_ISSUE) && DG_STAMP_ISSUE == 2
-    if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+    if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
 #endif
     while (t.valid) {
         kb0 = piece.kb0;
@@ -2027,7 +2035,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
 
             // ---- block 0 and its scales must land before the first segment ----
 #if defined(DG_STAMP_ISSUE) && DG_STAMP_ISSUE == 1     // (tuning builds: how long does a workgroup run before its first load goes out?  slot 2 = this stamp instead of the loop end)
-            if (p.dbg != nullptr && first_tile) t_loop1 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr && first_tile) t_loop1 = DG_STAMP_CLOCK();
 #endif
             if (!prefetched) {
                 // SF(0) first, then the pieces of blocks 0 and 1: the wait leaves block 1's pieces in flight (the first K block's
@@ -2051,7 +2059,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
             int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;     // slots of A(kb), A(kb+2) [= A(kb-1)'s], B(kb)
             [[maybe_unused]] int b_fill = 2 * B_BYTES;          // MERGED: slot of B(kb+2) [= B(kb-1)'s]
             v8i bf[NS], af[HS];
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
 
             [[maybe_unused]] float tailp[DEPTH][4];            // PC: scale products of the last DEPTH steps of the previous K block
             #pragma unroll
@@ -2376,7 +2384,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
             if (!upper_half)
                 raw_barrier();              // pairs with the barrier in front of the upper half's last segment
 #ifndef DG_STAMP_ISSUE
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's re-read pieces: the ring is about to be reused
             __syncthreads();                                    // every wave is done with the LDS
@@ -2547,7 +2555,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+            dbg_stamp(p, NW, 3, DG_STAMP_CLOCK());
         }
         t = tn;
         piece = piece_next;
@@ -2576,9 +2584,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_tab_fused_kernel(const GemmParams q, const GemmParams r) {
     static_assert(duo_lds_bytes(REM_BM, BN, true) <= duo_lds_bytes(BIG_BM, BN, false), "the remainder body fits in the 256-row body's LDS");
     __shared__ __attribute__((aligned(1024))) uint8_t lds[duo_lds_bytes(BIG_BM, BN, false)];
-    duo_kernel_body<BIG_BM, BN, WAVES_M, WAVES_N, true, false, false, false, false, false, false, false, false, 1>(q, lds);
-    __syncthreads();
-    duo_kernel_body<REM_BM, BN, WAVES_M, WAVES_N, true, false, true, false, false, true, false, false, false, 1>(r, lds);
+    // r.tab_rem_first (round 6): which workgroups walk their remainder pieces BEFORE their 256-row tiles -- 0 none, 1 every second workgroup of
+    // an XCD, 2 all.  The remainder walk is an HBM phase (it re-reads its groups' weights at the HBM rate while the matrix pipes idle) and the
+    // 256-row walk a compute phase with the HBM at a third of its rate: with half the chip in each at any time the two overlap instead of queueing.
+    const bool rem_first = r.tab_rem_first == 2 || (r.tab_rem_first == 1 && ((blockIdx.x >> 3) & 1) != 0);
+    #pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {       // (ONE call site per body specialization: see CALLER above)
+        if ((phase == 0) != rem_first)
+            duo_kernel_body<BIG_BM, BN, WAVES_M, WAVES_N, true, false, false, false, false, false, false, false, false, 1>(q, lds);
+        else
+            duo_kernel_body<REM_BM, BN, WAVES_M, WAVES_N, true, false, true, false, false, true, false, false, false, 1>(r, lds);
+        __syncthreads();
+    }
 }
 
 
@@ -3311,7 +3328,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
     [[maybe_unused]] const int bmn_voff = (lane >> 4) * ldb_mn + mn_chunk, amn_voff = (lane >> 4) * lda_mn + mn_chunk;
     [[maybe_unused]] const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
     [[maybe_unused]] const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    const long long t_entry = p.dbg != nullptr ? DG_STAMP_CLOCK() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
 
     MaskedWalk walk;
@@ -3409,7 +3426,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
 
             int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;
             v8i bf[NS], af[HS];
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
             for (int kb = 0; kb < num_kb; ++kb) {
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
@@ -3498,7 +3515,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             }
             if (!upper_half)
                 seg_barrier();              // pairs with the barrier in front of the upper half's last segment
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if constexpr (K_TAIL) {
@@ -3574,7 +3591,7 @@ __device__ __forceinline__ void duo_e8_kernel_body(const GemmParams& p) {
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+            dbg_stamp(p, NW, 3, DG_STAMP_CLOCK());
         }
         if (t.second_pass) {
             pass = 1;

@@ -256,7 +256,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     [[maybe_unused]] const int tail_bias = (K_TAIL && k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;   // bytes per K quad
 
-    const long long t_entry = p.dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0;
+    const long long t_entry = p.dbg != nullptr ? DG_STAMP_CLOCK() : 0;
     long long t_loop0 = 0, t_loop1 = 0;
     MaskedWalk walk;
     if (p.table_mode != 0)          // (round 5: the group-relative tiling of the contiguous layout, launch_e8_contiguous_tabled; every lane is active here)
@@ -451,7 +451,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     bf[i] = load_fragment(lds + B_BASE + (wn * WN + i * 16) * 128, frag_off);
                     af[i] = load_fragment(lds + (wm * WM + i * 16) * 128, frag_off);
                 }
-                if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+                if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
                 asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
                 auto block = [&](auto jc, auto load_next, const E8LandingQ& w, int kb) {
                     constexpr int J = decltype(jc)::value;
@@ -535,7 +535,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     cur = nxt;
                     asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> MFMA
                 }
-                if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+                if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             } else {
@@ -578,7 +578,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             af[0] = read_fragment(lds + (wm * WM) * 128);
             af[1] = read_fragment(lds + (wm * WM + 16) * 128);
 
-            if (p.dbg != nullptr) t_loop0 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
             asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
             // One K block with byte J of the scale words `w`.  LOAD_NEXT: this block issues the loads of the next K quad's
             // words (block J == 1 of a whole quad); TIE_NEXT: they are waited for at this block's barrier (J == 2).
@@ -729,7 +729,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 block(I0{}, No{}, No{}, w, kb, nxt);
             }
             }   // (!G32)
-            if (p.dbg != nullptr) t_loop1 = __builtin_amdgcn_s_memtime();
+            if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA -> accumulator reads; the tail's re-read pieces
             __syncthreads();
             }   // (default schedule)
@@ -791,7 +791,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             dbg_stamp(p, NW, 0, t_entry);
             dbg_stamp(p, NW, 1, t_loop0);
             dbg_stamp(p, NW, 2, t_loop1);
-            dbg_stamp(p, NW, 3, __builtin_amdgcn_s_memtime());
+            dbg_stamp(p, NW, 3, DG_STAMP_CLOCK());
         }
         advance();
     }
