@@ -234,7 +234,7 @@ const E8Config kE8Configs[] = {
 // Variables set after the first launch are therefore ignored until dg_reload_env() is called (README, "Environment").
 struct EnvKnobs {
     bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, swiglu_one_per_cu;
-    int group_m, ks_pieces, pc_bm, tab_rem_first;
+    int group_m, ks_pieces, pc_bm;
     bool e8_tab_unsplit;
     int swiglu_fault;       // DG_TEST_SWIGLU_FAULT (tests only): 1 = odd tiles of the fused SwiGLU kernel never publish their amax
     EnvKnobs()
@@ -242,8 +242,7 @@ struct EnvKnobs {
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
           sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
           group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0),
-          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), tab_rem_first(getenv("DG_TAB_REM_FIRST") ? atoi(getenv("DG_TAB_REM_FIRST")) : -1),
-          e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr),
+          pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr),
           swiglu_fault(getenv("DG_TEST_SWIGLU_FAULT") ? atoi(getenv("DG_TEST_SWIGLU_FAULT")) : 0) {}
 };
 std::atomic<const EnvKnobs*> g_env_knobs{nullptr};
@@ -886,7 +885,6 @@ int launch_contiguous_tabled(const dg::GemmParams& base, void* stream) {
             r.sk_exchange = 0x7fd00000u | (exchange_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu);
         }
         r.sk_factor = static_cast<int>(std::max<long>(pieces, 1));
-        r.tab_rem_first = env_knobs().tab_rem_first >= 0 ? env_knobs().tab_rem_first : 0;       // (tuning runs: DG_TAB_REM_FIRST)
         r.sk_first_tile = 0;
         r.sk_tiles = num_cus();              // (table launch: the slot count; the kernels read the tile count from the table)
         const long max_items = static_cast<long>(nb) * n_tiles * r.sk_factor;

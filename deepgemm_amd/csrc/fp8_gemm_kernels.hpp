@@ -88,7 +88,6 @@ struct GemmParams {
     // reduction kernel's), stores the tile and clears the flag.  0 = off.  The value is a NaN bit pattern that changes per launch: nothing
     // else that ever lands in the workspace header (tile tables, zeros) equals it.
     unsigned sk_exchange;
-    int tab_rem_first;              // dg_fp8_gemm_duo_tab_fused_kernel: see there
 };
 
 // The clock of the debug stamps: the shader-clock counter (s_memtime: per CU, NOT comparable between CUs -- good for durations inside a wave) or, in
@@ -345,6 +344,8 @@ __device__ __forceinline__ v8i load_fragment(const uint8_t* tile_rows, int frag_
 template <int WN>
 __device__ __forceinline__ int b_row_perm(int p) {
     const int w = p / WN, q = p % WN, ns = q >> 4, i = q & 15;
+    if (WN % 32 != 0 && ns == WN / 16 - 1)      // (WN = 112, the 256 x 224 tile: the unpaired seventh subtile keeps its natural column order)
+        return w * WN + ns * 16 + i;
     return w * WN + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3);
 }
 
@@ -1535,6 +1536,35 @@ __device__ __forceinline__ void issue_scale_loads_v(ScaleLandingV<MS>& l, const 
             : "memory");
 }
 
+// 256 x 224 tile (round 6): a wave tile of 112 columns may straddle ONE 128-column boundary of the SFB grid (reference: the two-value SFB of
+// sm90_fp8_gemm_1d2d.cuh:232-237, 290-291, 342-346): both candidate values land, `delta` = byte distance from the first block's scale to the
+// second's (0 when the wave tile lies in one block or the second would lie past N: the same value twice).
+template <int MS>
+struct ScaleLandingV2 { v4f q[MS / 4]; float sb, sb1; int delta; };
+
+template <int MS>
+__device__ __forceinline__ void issue_scale_loads_v2(ScaleLandingV2<MS>& l, const v4i& sfa_rsrc, int sfa_voff,
+                                                     const v4i& sfb_rsrc, int sfb_voff) {
+    static_assert(MS == 4, "unrolled by hand");
+    const int sfb_voff1 = sfb_voff + l.delta;
+    asm volatile(
+        "s_nop 4\n\t"      // SGPR operands written by VALU (v_readlane / v_readfirstlane) just before: 5 wait states, nothing pads an asm
+        "buffer_load_dwordx4 %0, %3, %4, 0 offen\n\t"
+        "buffer_load_dword %1, %5, %6, 0 offen\n\t"
+        "buffer_load_dword %2, %7, %6, 0 offen"
+        : "=&v"(l.q[0]), "=&v"(l.sb), "=&v"(l.sb1)
+        : "v"(sfa_voff), "s"(sfa_rsrc), "v"(sfb_voff), "s"(sfb_rsrc), "v"(sfb_voff1)
+        : "memory");
+}
+
+template <int ALLOWED, int MS>
+__device__ __forceinline__ void wait_landing_v2(ScaleLandingV2<MS>& l) {
+    static_assert(ALLOWED >= 0 && ALLOWED < 64, "vmcnt is a 6-bit counter");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(ALLOWED, 0));
+    asm volatile("" : "+v"(l.q[0]), "+v"(l.sb), "+v"(l.sb1) :: "memory");
+}
+
 // The wait goes through the builtin so that hipcc's own waitcnt pass sees the LDS counter drained and does not re-wait
 // for the fragment reads inside the following matrix segment; the empty asm ties the landing registers to this point.
 template <int ALLOWED, int MS>
@@ -1622,10 +1652,14 @@ template <int MS> __device__ __forceinline__ void issue_scale_loads_any(ScaleLan
 template <int MS> __device__ __forceinline__ void issue_scale_loads_any(ScaleLandingN<MS>& l, const v4i& ra, int va, const v4i& rb, int vb) { issue_scale_loads_n<MS>(l, ra, va, rb, vb); }
 template <int ALLOWED, int MS> __device__ __forceinline__ void wait_landing_any(ScaleLandingV<MS>& l) { wait_landing_v<ALLOWED, MS>(l); }
 template <int ALLOWED, int MS> __device__ __forceinline__ void wait_landing_any(ScaleLandingN<MS>& l) { wait_landing_n<ALLOWED, MS>(l); }
+template <int MS> __device__ __forceinline__ void issue_scale_loads_any(ScaleLandingV2<MS>& l, const v4i& ra, int va, const v4i& rb, int vb) { issue_scale_loads_v2<MS>(l, ra, va, rb, vb); }
+template <int ALLOWED, int MS> __device__ __forceinline__ void wait_landing_any(ScaleLandingV2<MS>& l) { wait_landing_v2<ALLOWED, MS>(l); }
+template <int MS> __device__ __forceinline__ float landed_sfa(const ScaleLandingV2<MS>& l, int ms) { return l.q[ms / 4][ms % 4]; }
 template <int MS> __device__ __forceinline__ float landed_sfa(const ScaleLandingV<MS>& l, int ms) { return l.q[ms / 4][ms % 4]; }
 template <int MS> __device__ __forceinline__ float landed_sfa(const ScaleLandingN<MS>& l, int ms) { return l.s[ms]; }
-template <int MS, bool NATURAL> struct ScaleLandingSel { typedef ScaleLandingV<MS> type; };
-template <int MS> struct ScaleLandingSel<MS, true> { typedef ScaleLandingN<MS> type; };
+template <int MS, bool NATURAL, bool TWO_SFB = false> struct ScaleLandingSel { typedef ScaleLandingV<MS> type; };
+template <int MS> struct ScaleLandingSel<MS, true, false> { typedef ScaleLandingN<MS> type; };
+template <int MS> struct ScaleLandingSel<MS, false, true> { typedef ScaleLandingV2<MS> type; };
 
 // Scale landing registers of the per-column form (PC: recipe (1, 1, 128), one SFB value per ROW of B): the lane's MS = 4 row scales (one
 // dwordx4 of the MN-major SFA, interleaved rows) and its 16 column scales -- N-subtile ns, accumulator register r sits on column
@@ -1720,7 +1754,7 @@ __device__ __forceinline__ void promote_only_v(float (&c)[4], const float (&s)[4
 #else
 #define DUO_NS(i) ((i) % NS)
 #endif
-constexpr int duo_lds_bytes(int bm, int bn, bool merged) { return 3 * bm * 128 + (merged ? 3 : 2) * bn * 128; }
+constexpr int duo_lds_bytes(int bm, int bn, bool merged) { return 3 * bm * 128 + (merged ? 3 : 2) * (bn == 224 ? 256 : bn) * 128; }   // (224: a 256-row slot)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PERSIST = false, bool B_MN = false, bool SPLITK = false, bool A_MN = false,
           bool K_TAIL = false, bool MERGED = false, bool STREAM_A = false, bool PC = false, bool SFA_RM = false, int CALLER = 0>
@@ -1729,13 +1763,22 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                   "SFA_RM: the dense persistent 256-row form reading a row-major SFA in place");
     static_assert(!PC || (MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK && !STREAM_A), "PC: the two-segment 128-row tile, K-major operands");
     constexpr int NW = WAVES_M * WAVES_N;
+    // N224 (round 6): 256 x 224 tiles, 4 x 2 waves, wave tile 64 x 112 (MS = 4, NS = 7) -- N = 7168 is 32 x 224: C3 (2048 x 7168 x 2048) becomes
+    // exactly 256 tiles instead of 224 of 256 x 256 on 256 CUs, 4096 x 7168 two full rounds instead of 1.75.  The B slot stays 256 rows (the 32 rows
+    // behind the tile are the next tile's, or out of range: never read); the seventh N-subtile keeps its natural column order (b_row_perm); a wave
+    // tile may straddle one 128-column boundary of the SFB grid: both values land (ScaleLandingV2), the scale product of a lane is formed per
+    // 32-column GROUP of its columns (the boundary is a multiple of 16: a group that straddles it splits between lane groups 0-1 and 2-3).
+    constexpr bool N224 = BN == 224;
+    static_assert(!N224 || (BM == 256 && WAVES_M == 4 && WAVES_N == 2 && PERSIST && !B_MN && !SPLITK && !A_MN && !K_TAIL && !MERGED && !STREAM_A && !PC && !SFA_RM),
+                  "N224: the dense persistent form with K-major operands");
+    constexpr int BN_LDS = N224 ? 256 : BN;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16, HS = MERGED ? MS : MS / 2;
     static_assert(!STREAM_A || (BM == 256 && !MERGED && !A_MN && !B_MN && !K_TAIL && !SPLITK), "STREAM_A: dense 256-row tiles, K-major operands");
     constexpr int TOTAL = MS * NS, SEG = HS * NS, DEPTH = 3;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, A_SLOTS = 3, B_SLOTS = MERGED ? 3 : 2;
-    constexpr int SCALE_LOADS = PC ? 5 : (A_MN || SFA_RM ? MS + 1 : MS / 4 + 1);    // vector-memory operations of one issue_scale_loads_any / _pc
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN_LDS * 128, A_SLOTS = 3, B_SLOTS = MERGED ? 3 : 2;
+    constexpr int SCALE_LOADS = PC ? 5 : (A_MN || SFA_RM ? MS + 1 : MS / 4 + 1 + (N224 ? 1 : 0));    // vector-memory operations of one issue_scale_loads_any / _pc
     constexpr int B_BASE = A_SLOTS * A_BYTES, LDS_BYTES = B_BASE + B_SLOTS * B_BYTES;
-    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
+    constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN_LDS / 8 / NW;
 #ifdef DG_A_EARLY                               // (tuning builds: DG_VARIANT_FLAGS=-DDG_A_EARLY=n)
     constexpr int A_EARLY = DG_A_EARLY < A_ITERS ? DG_A_EARLY : A_ITERS;
 #else
@@ -1751,13 +1794,13 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
     static_assert(!SPLITK || (PERSIST && !A_MN), "the K-split tail belongs to the persistent forms");
     static_assert(!K_TAIL || !SPLITK, "K tail and K split are not combined");
     static_assert(!MERGED || (BM == 128 && !A_MN), "the two-segment form needs all fragments of the wave tile in registers");
-    static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave issues the same number of pieces");
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile shape");
-    static_assert(WN <= 128 && 128 % WN == 0, "one SFB value per wave");
+    static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN_LDS % (8 * NW) == 0, "every wave issues the same number of pieces");
+    static_assert(WM % 32 == 0 && (WN % 32 == 0 || N224), "wave tile shape");
+    static_assert(N224 || (WN <= 128 && 128 % WN == 0), "one SFB value per wave");
     static_assert(SEG > DEPTH, "the promotion ring must fit in a segment");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0),
-                  "the row permutation of a B piece must be lane-independent");
+    static_assert((NW * 8) % 16 == 0 && ((NW * 8) % WN == 0 || WN % (NW * 8) == 0 || (N224 && M0S_B)),
+                  "the row permutation of a B piece must be lane-independent (N224: every piece has its own per-lane offset)");
 
     static_assert(LDS_BYTES == duo_lds_bytes(BM, BN, MERGED), "the kernel wrappers size the LDS array with duo_lds_bytes");
     // (`lds`: the calling kernel's __shared__ array -- a kernel that runs two bodies one after the other gives both the same bytes)
@@ -1796,7 +1839,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
     const int sfa_extent = SFA_RM ? (p.m - 1) * sfa_row_stride + (num_sf_kb - 1) * sfa_kb_stride + 4
                                   : (p.m - 1) * 4 + (num_sf_kb - 1) * sfa_kb_stride + 4;
     // (PC: the lane's 16 column scales of a K block; columns past N read the next block's head or fall out of range -- never stored)
-    const int sfb_extent = (num_sf_kb - 1) * sfb_kb_stride + (PC ? p.n * 4 : 4);
+    const int sfb_extent = (num_sf_kb - 1) * sfb_kb_stride + (PC ? p.n * 4 : 4) + (N224 ? static_cast<int>(p.sfb_sn) * 4 : 0);      // (N224: the next block's value too)
     [[maybe_unused]] const int sfb_lane_off = (lane >> 4) * 32;
 
     // Per-piece source offsets (rows + chunk: the bounds-checked part of the address) are kernel invariants held in
@@ -1845,7 +1888,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
         tm.a_base = uniform_ptr(p.a + adg * p.a_sg + static_cast<int64_t>(tt.m0) * (A_MN ? 1 : p.a_sm));
         tm.b_base = uniform_ptr(p.b + static_cast<int64_t>(tt.group) * p.b_sg + static_cast<int64_t>(tt.n0) * (B_MN ? 1 : p.b_sn));
         tm.a_bytes = __builtin_amdgcn_readfirstlane(A_MN ? (p.k - 1) * lda_mn + (p.m - tt.m0) : (imin(tt.m_end - tt.m0, BM) - 1) * lda + p.k);
-        tm.b_bytes = __builtin_amdgcn_readfirstlane(B_MN ? (p.k - 1) * ldb_mn + (p.n - tt.n0) : (imin(p.n - tt.n0, BN) - 1) * ldb + p.k);
+        tm.b_bytes = __builtin_amdgcn_readfirstlane(B_MN ? (p.k - 1) * ldb_mn + (p.n - tt.n0) : (imin(p.n - tt.n0, BN_LDS) - 1) * ldb + p.k);
         tm.sfa_addr = reinterpret_cast<uint64_t>(p.sfa + adg * p.sfa_sg);
         tm.sfb_addr = reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(tt.group) * p.sfb_sg +
                                                  (PC ? static_cast<int64_t>(tt.n0 + wn * WN)           // MN-major SFB: one value per column
@@ -1887,7 +1930,12 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
     // output stores, so that the cold-start latency of a tile and its predecessor's store tail overlap.  Only LDS-DMA
     // travels ahead: a VGPR-destination load (the scales) must reach its wait in straight-line code, because hipcc is
     // free to copy the destination registers at any control-flow join in between -- before the data has arrived.
-    typename ScaleLandingSel<MS, A_MN || SFA_RM>::type land;
+    typename ScaleLandingSel<MS, A_MN || SFA_RM, N224>::type land;
+    // N224: byte distance to the second SFB value of a tile's wave tile (0: one block, or the next block lies past N) and its boundary column
+    [[maybe_unused]] auto sfb_delta_of = [&](const Tile& tt) {
+        const int col0 = tt.n0 + wn * WN;
+        return __builtin_amdgcn_readfirstlane(((col0 >> 7) + 1) * 128 < p.n ? static_cast<int>(p.sfb_sn) * 4 : 0);
+    };
     [[maybe_unused]] ScaleLandingPC land_pc0, land_pc1;        // PC: block kb's scales in one, block kb+1's landing in the other
     // halves: 0 = block 0 only, 1 = block 1 only, 2 = both.  (Round 4: the FIRST tile of a workgroup issues block 0 the moment its
     // coordinates are known -- 1.6 k cycles of accumulator zeroing and descriptor set-up used to run in front of the first load:
@@ -1985,6 +2033,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                                              scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
                     wait_landing_any<0, MS>(land);
                 } else {
+                if constexpr (N224)
+                    land.delta = sfb_delta_of(tn);
                 issue_scale_loads_any<MS>(land, scale_rsrc(tmn.sfa_addr, sfa_extent), tmn.sfa_voff + kb0 * sfa_kb_stride,
                                           scale_rsrc(tmn.sfb_addr, sfb_extent), kb0 * sfb_kb_stride);
                 wait_landing_any<0, MS>(land);      // the landed values stay in `land` until the next tile's L_a(0) consumes them
@@ -2016,7 +2066,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
             const int sfa_voff = tm.sfa_voff;
             auto issue_a_piece = [&](int slot_off, int j, int q) { issue_a_piece_r(tm.a_base, tm.a_bytes, slot_off, j, q); };
             auto issue_b_piece = [&](int slot_off, int j, int q) { issue_b_piece_r(tm.b_base, tm.b_bytes, slot_off, j, q); };
-            auto issue_scales = [&](typename ScaleLandingSel<MS, A_MN || SFA_RM>::type& l, int j) {
+            auto issue_scales = [&](typename ScaleLandingSel<MS, A_MN || SFA_RM, N224>::type& l, int j) {
                 const int jj = kb0 + imin(j, nkb - 1);   // past the end: the last block's scales again (never consumed)
                 if constexpr (SFA_RM)
                     issue_scale_loads_rm<MS>(l, sfa_rsrc, sfa_voff + jj * sfa_kb_stride, sfa_row_stride, sfb_rsrc, jj * sfb_kb_stride);
@@ -2025,6 +2075,24 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
             };
 
             float scale[MS], scale_tail = 0.f;
+            // N224: scale product per M-subtile and 32-column GROUP of the lane's columns (groups 0 .. 2 = the subtile pairs, 3 = the seventh
+            // subtile); `second[g]`: this lane's columns of group g lie at or behind the wave tile's 128-column boundary (the second SFB value)
+            [[maybe_unused]] float scaleg[N224 ? MS : 1][4], tailg[4] = {0.f, 0.f, 0.f, 0.f};
+            [[maybe_unused]] bool second[4] = {false, false, false, false};
+            if constexpr (N224) {
+                const int col0 = t.n0 + wn * WN;
+                const int to_boundary = (128 - (col0 & 127)) & 127;                     // 0: col0 is itself a boundary, none inside before + 128
+                const int boundary = to_boundary == 0 ? 128 : to_boundary;              // first boundary strictly behind col0, relative to col0
+                #pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    second[g] = 32 * g + (lane >> 4) * 8 >= boundary;
+                second[3] = 96 >= boundary;
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        scaleg[ms][g] = 0.f;
+            }
             v4f part[DEPTH + 1];
             #pragma unroll
             for (int i = 0; i <= DEPTH; ++i)
@@ -2047,6 +2115,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                     issue_prologue(t, 1);
                     wait_landing_pc<A_ITERS + B_ITERS>(land_pc0);
                 } else {
+                if constexpr (N224)
+                    land.delta = sfb_delta_of(t);
                 issue_scales(land, 0);
                 issue_prologue(t, 1);
                 wait_landing_any<STREAM_A ? A_ITERS : A_ITERS + B_ITERS, MS>(land);
@@ -2058,7 +2128,7 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
 
             int a_cur = 0, a_fill = 2 * A_BYTES, b_cur = 0;     // slots of A(kb), A(kb+2) [= A(kb-1)'s], B(kb)
             [[maybe_unused]] int b_fill = 2 * B_BYTES;          // MERGED: slot of B(kb+2) [= B(kb-1)'s]
-            v8i bf[NS], af[HS];
+            v8i bf[N224 ? 4 : NS], af[N224 ? 1 : HS];
             if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
 
             [[maybe_unused]] float tailp[DEPTH][4];            // PC: scale products of the last DEPTH steps of the previous K block
@@ -2067,6 +2137,82 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     tailp[i][r] = 0.f;
+            if constexpr (N224) {
+                // The four-segment schedule of the 256-row tile (see below) on the 64 x 112 wave tile, cut along N instead of M so that the
+                // fragments fit the register file: M_a = all four A fragments x N-subtiles 0 .. 3 (16 steps), M_b = the same A fragments x
+                // subtiles 4 .. 6 (12 steps; their B fragments take the registers of subtiles 0 .. 2).  The scale of a step is the product of
+                // its M-subtile and its column GROUP.  Every accumulator still sees its K blocks in order: same bits as the 256 x 256 tile.
+                auto grp = [](int ns) { return ns >> 1; };                          // (ns = 6 -> group 3)
+                auto s_ms = [](int i) { return i < 16 ? i / 4 : (i - 16) / 3; };
+                auto s_ns = [](int i) { return i < 16 ? (((i / 4) & 1) ? 3 - i % 4 : i % 4) : 4 + ((((i - 16) / 3) & 1) ? 2 - (i - 16) % 3 : (i - 16) % 3); };
+                v8i af4[MS];
+                for (int kb = 0; kb < nkb; ++kb) {
+                    const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
+                    const uint8_t* b_tile = lds + B_BASE + b_cur + (wn * WN) * 128;
+                    // ---------------- L_a ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int ns = 0; ns < 4; ++ns)
+                        bf[ns] = load_fragment(b_tile + ns * 2048, frag_off);
+                    #pragma unroll
+                    for (int h = 0; h < MS; ++h)
+                        af4[h] = load_fragment(a_tile + h * 2048, frag_off);
+                    tailg[2] = scaleg[MS - 1][2];
+                    tailg[3] = scaleg[MS - 1][3];
+                    {
+                        float sbg[4];
+                        #pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            sbg[g] = second[g] ? land.sb1 : land.sb;
+                        #pragma unroll
+                        for (int ms = 0; ms < MS; ++ms)
+                            #pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                scaleg[ms][g] = landed_sfa<MS>(land, ms) * sbg[g];
+                                pin_vgpr(scaleg[ms][g]);
+                            }
+                    }
+                    issue_scales(land, kb + 1);
+                    #pragma unroll
+                    for (int q = 0; q < A_EARLY; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // ---------------- M_a ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int j = (i >= DEPTH) ? i - DEPTH : TOTAL - DEPTH + i;
+                        const float jscale = (i >= DEPTH) ? scaleg[s_ms(j)][grp(s_ns(j))] : tailg[grp(s_ns(j))];
+                        mfma_promote_step(part[i & DEPTH], bf[s_ns(i)], af4[s_ms(i)], acc[s_ms(j)][s_ns(j)], jscale, part[(i + 1) & DEPTH]);
+                    }
+                    // ---------------- L_b ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int ns = 0; ns < 3; ++ns)
+                        bf[ns] = load_fragment(b_tile + (4 + ns) * 2048, frag_off);
+                    #pragma unroll
+                    for (int q = A_EARLY; q < A_ITERS; ++q)
+                        issue_a_piece(a_fill, kb + 2, q);
+                    #pragma unroll
+                    for (int q = 0; q < B_ITERS; ++q)
+                        issue_b_piece(b_cur, kb + 2, q);
+                    wait_landing_any<A_ITERS + B_ITERS, MS>(land);
+                    #pragma unroll
+                    for (int ns = 0; ns < 3; ++ns)
+                        asm volatile("" : "+v"(bf[ns]) :: "memory");
+                    // ---------------- M_b ----------------
+                    raw_barrier();
+                    #pragma unroll
+                    for (int i = 16; i < TOTAL; ++i) {
+                        const int j = i - DEPTH;
+                        mfma_promote_step(part[i & DEPTH], bf[s_ns(i) - 4], af4[s_ms(i)], acc[s_ms(j)][s_ns(j)], scaleg[s_ms(j)][grp(s_ns(j))], part[(i + 1) & DEPTH]);
+                    }
+                    b_cur ^= B_BYTES;
+                    const int a_next = (a_cur == (A_SLOTS - 1) * A_BYTES) ? 0 : a_cur + A_BYTES;
+                    a_fill = a_cur;
+                    a_cur = a_next;
+                }
+            } else
             if constexpr (PC) {
                 // The MERGED schedule with one scale per row of A AND per row of B (reference: impls/sm90_fp8_gemm_1d1d.cuh:279-311): a step
                 // is MFMA + 4 v_mul (sfa x sfb) + 4 v_fmac.  The landing registers alternate between two sets (no copies): the loop body
@@ -2394,6 +2540,8 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                     const int j = TOTAL - DEPTH + i;
                     if constexpr (PC)
                         promote_only_v(acc[j / NS][j % NS], tailp[i], part[(TOTAL + i + 1) & DEPTH]);
+                    else if constexpr (N224)       // steps 25 .. 27 of the N-cut order: M-subtile 3, N-subtiles 6, 5, 4
+                        promote_only(acc[MS - 1][6 - i], scaleg[MS - 1][(6 - i) >> 1], part[(TOTAL + i + 1) & DEPTH]);
                     else
                         promote_only(acc[j / NS][STREAM_A ? j % NS : DUO_NS(j)], scale[MS - 1], part[(TOTAL + i + 1) & DEPTH]);
                 }
@@ -2548,6 +2696,46 @@ __device__ __forceinline__ void duo_kernel_body(const GemmParams& p, uint8_t* co
                 store = false;
             }
         }
+        if constexpr (N224) {
+            // subtiles 0 .. 3: the 64-column full-line stores; 4, 5: one permuted pair (32 columns: 16 bytes per lane); 6: natural order (16
+            // columns: 8 bytes per lane).  The common case -- BF16, no accumulation, aligned rows, the wave tile inside N -- inline and lean;
+            // everything else through the shared epilogue.
+            const int m_base = t.m0 + wm * WM, n_base = t.n0 + wn * WN;
+            if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n && p.head_lr == 0) {
+                const int lg = lane >> 4;
+                uint16_t* dbase = reinterpret_cast<uint16_t*>(p.d) + ad_group * p.d_sg;
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    const v4f quad4[4] = {out[ms][0], out[ms][1], out[ms][2], out[ms][3]};
+                    store_rows_full_line<MS, true>(p, t, ad_group * p.d_sg, quad4, ms, m_base, n_base);
+                    const int row = m_base + (lane & 15) * MS + ms;
+                    const bool compute_row = row >= t.m_begin && row < t.m_end, zero_row = row >= t.zero_from && row < t.zero_to;
+                    if (compute_row || zero_row) {
+                        uint16_t* drow = dbase + static_cast<int64_t>(row) * p.d_sm + n_base;
+                        const uint4 pair = zero_row ? make_uint4(0u, 0u, 0u, 0u)
+                                                    : make_uint4(pack_bf16(out[ms][4][0], out[ms][4][1]), pack_bf16(out[ms][4][2], out[ms][4][3]),
+                                                                 pack_bf16(out[ms][5][0], out[ms][5][1]), pack_bf16(out[ms][5][2], out[ms][5][3]));
+                        *reinterpret_cast<uint4*>(drow + 64 + lg * 8) = pair;
+                        *reinterpret_cast<uint2*>(drow + 96 + lg * 4) = zero_row ? make_uint2(0u, 0u)
+                                                                                 : make_uint2(pack_bf16(out[ms][6][0], out[ms][6][1]), pack_bf16(out[ms][6][2], out[ms][6][3]));
+                    }
+                }
+            } else {
+                v4f out4[MS][4], out2[MS][2], out1[MS][1];
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms) {
+                    #pragma unroll
+                    for (int ns = 0; ns < 4; ++ns)
+                        out4[ms][ns] = out[ms][ns];
+                    out2[ms][0] = out[ms][4];
+                    out2[ms][1] = out[ms][5];
+                    out1[ms][0] = out[ms][6];
+                }
+                store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, out4, m_base, n_base);
+                store_tile<MS, 2, true>(p, t, ad_group * p.d_sg, out2, m_base, n_base + 64);
+                store_tile<MS, 1, true, false, true>(p, t, ad_group * p.d_sg, out1, m_base, n_base + 96);
+            }
+        } else
         if (store)
             store_tile<MS, NS, !A_MN, false, B_MN, PC>(p, t, ad_group * p.d_sg, out, t.m0 + wm * WM, t.n0 + wn * WN);
         if (p.dbg != nullptr && first_tile && !next_prefetched) {
@@ -2584,18 +2772,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void dg_fp8_gemm_duo_tab_fused_kernel(const GemmParams q, const GemmParams r) {
     static_assert(duo_lds_bytes(REM_BM, BN, true) <= duo_lds_bytes(BIG_BM, BN, false), "the remainder body fits in the 256-row body's LDS");
     __shared__ __attribute__((aligned(1024))) uint8_t lds[duo_lds_bytes(BIG_BM, BN, false)];
-    // r.tab_rem_first (round 6): which workgroups walk their remainder pieces BEFORE their 256-row tiles -- 0 none, 1 every second workgroup of
-    // an XCD, 2 all.  The remainder walk is an HBM phase (it re-reads its groups' weights at the HBM rate while the matrix pipes idle) and the
-    // 256-row walk a compute phase with the HBM at a third of its rate: with half the chip in each at any time the two overlap instead of queueing.
-    const bool rem_first = r.tab_rem_first == 2 || (r.tab_rem_first == 1 && ((blockIdx.x >> 3) & 1) != 0);
-    #pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {       // (ONE call site per body specialization: see CALLER above)
-        if ((phase == 0) != rem_first)
-            duo_kernel_body<BIG_BM, BN, WAVES_M, WAVES_N, true, false, false, false, false, false, false, false, false, 1>(q, lds);
-        else
-            duo_kernel_body<REM_BM, BN, WAVES_M, WAVES_N, true, false, true, false, false, true, false, false, false, 1>(r, lds);
-        __syncthreads();
-    }
+    // (round 6, negative: letting every second workgroup of an XCD -- or all of them -- walk its remainder pieces FIRST, so that the HBM-bound remainder
+    //  phase and the compute-bound 256-row phase overlap across the chip: C4 155.6-157.1 / 153.4-154.9 us against 151.2-152.5 in this order,
+    //  profiles/r06_probe/c4_remainder_first_interleave_negative.log -- and the loop over the two bodies cost the kernel 40 spilled registers)
+    duo_kernel_body<BIG_BM, BN, WAVES_M, WAVES_N, true, false, false, false, false, false, false, false, false, 1>(q, lds);
+    __syncthreads();
+    duo_kernel_body<REM_BM, BN, WAVES_M, WAVES_N, true, false, true, false, false, true, false, false, false, 1>(r, lds);
 }
 
 

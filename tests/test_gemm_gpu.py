@@ -1322,6 +1322,46 @@ def test_k_grouped_tn_psum_layout_at_other_k_alignments(num_groups, m, n, real_k
         dg.set_mk_alignment_for_contiguous_layout(128)
 
 
+@pytest.mark.parametrize('m,n,k', [(256, 224, 256), (512, 448, 512), (300, 672, 384), (1024, 1568, 1024), (256, 7168, 512), (520, 500, 640)])
+def test_duo_256x224_tiles(m, n, k):
+    """The 256 x 224 tile family (round 6: wave tile 64 x 112, two SFB values per wave tile -- the reference's straddle logic,
+    sm90_fp8_gemm_1d2d.cuh:232-237, 290-291, 342-346 -- and a seventh N-subtile in natural column order): every wave-tile / SFB-boundary
+    alignment (n0 mod 128 takes 0, 96, 64, 32 over four consecutive tiles), ragged M, N that is not a multiple of 224, BF16 and FP32 outputs
+    with accumulation -- against the oracle, and bit-identical to the 256 x 256 kernel (same K-block order per accumulator)."""
+    if 'duo_p_256x224' not in dg.list_configs():
+        pytest.skip('a measured negative (profiles/r06_probe/n224_tile_family_negative.log): DG_EXPERIMENTS builds only')
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    dg.set_forced_config('duo_p_256x224')
+    try:
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(case.a, case.b, d)
+        assert dg.last_config() == 'duo_p_256x224'
+        c32 = torch.randn((m, n), device='cuda', dtype=torch.float)
+        d32 = c32.clone()
+        dg.fp8_gemm_nt(case.a, case.b, d32, c=d32)
+        cb = torch.randn((m, n), device='cuda', dtype=torch.bfloat16)
+        db = cb.clone()
+        dg.fp8_gemm_nt(case.a, case.b, db, c=db)
+    finally:
+        dg.set_forced_config('auto')
+    assert_close_to_oracle(d, want, '256 x 224 tiles')
+    assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+    dg.set_forced_config('duo_p_256x256')
+    try:
+        d256 = torch.empty_like(d)
+        dg.fp8_gemm_nt(case.a, case.b, d256)
+        e32 = c32.clone()
+        dg.fp8_gemm_nt(case.a, case.b, e32, c=e32)
+        eb = cb.clone()
+        dg.fp8_gemm_nt(case.a, case.b, eb, c=eb)
+    finally:
+        dg.set_forced_config('auto')
+    assert torch.equal(d.view(torch.int16), d256.view(torch.int16))
+    assert torch.equal(d32, e32) and torch.equal(db.view(torch.int16), eb.view(torch.int16))
+
+
 def test_k_grouped_argument_checks():
     gen.reset_seed(1)
     case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)
