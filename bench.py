@@ -54,17 +54,18 @@ def cold_sets(weight_bytes: float, at_least: int) -> int:
 GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
-def measured_counters(kernel: str) -> dict:
-    """Counter-derived figures of `kernel` from the newest committed rocprofv3 PMC passes (profiles/<round>/traffic_<kernel>.json, written
-    by tools/make_traffic_json.py): `traffic` = HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
-    MI355X_MICROARCH.md prescribes), `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (shader cycles x 1024 SIMDs), `clock_ghz` = shader cycles of
-    a launch / its kernel-trace duration, `counters_git` = the commit the passes were measured on.  They are properties of the kernel, measured
-    once per round on its own profiling runs -- not of this run; empty if no committed profile is of this kernel."""
+def measured_counters(kernel: str, workload: str) -> dict:
+    """Counter-derived figures of `kernel` ON `workload` from the newest committed rocprofv3 PMC passes (profiles/<round>/traffic_<workload>_<kernel>.json,
+    written by tools/make_traffic_json.py from tools/gpu_prof_r06.sh's passes): `traffic` = HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE,
+    separate passes, corrected as MI355X_MICROARCH.md prescribes), `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / (shader cycles x 1024 SIMDs),
+    `clock_ghz` = shader cycles of a launch / its kernel-trace duration, `counters_git` = the commit the passes were measured on.  They are
+    properties of the kernel on that workload, measured once per round on its own profiling runs -- not of this run; empty if no committed
+    profile matches (files of earlier rounds carry no workload: they describe the headline)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic*.json')), reverse=True):
         with open(path) as f:
             rec = json.load(f)
-        if rec.get('kernel') == kernel:
+        if rec.get('kernel') == kernel and rec.get('workload', 'dense') == workload:
             return {'traffic': rec['traffic_bytes'], 'mfma_busy': rec.get('mfma_busy'), 'clock_ghz': rec.get('clock_ghz'),
                     'counters_git': rec.get('git'), 'counters_from': os.path.relpath(path, ROOT)}
     return {}
@@ -399,7 +400,8 @@ def roofline_record(flops: float, nbytes: float, kernel_s: float, bound: str, ke
     rec = ({'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP8_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / PEAK_FP8_TFLOPS} if bound == 'mfma' else
            {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS})
     counters = counters or {}
-    rec.update({'traffic': counters.get('traffic'), 'mfma_busy': counters.get('mfma_busy'), 'clock_ghz': counters.get('clock_ghz'),
+    rec.update({'traffic': counters.get('traffic'), 'mfma_busy': counters.get('mfma_busy') and round(counters['mfma_busy'], 4),
+                'clock_ghz': counters.get('clock_ghz') and round(counters['clock_ghz'], 3),
                 'counters_git': counters.get('counters_git'), 'kernel': kernel, 'kernel_us': kernel_s * 1e6, 'algorithmic_flops': flops,
                 'algorithmic_bytes': nbytes, 'tflops': tflops, 'gbs': gbs})
     if useful_flops is not None:        # layouts with padding rows: the fraction on the rows that carry data, beside the reference-style count
@@ -482,7 +484,7 @@ def run_secondary(sets: int):
                 other = None
             rec = {'workload': desc['workload'], 'steps': steps, 'calc_diff_vs_reference_expr': diff,
                    'input_sets': len(calls),
-                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), measured_counters(dg.last_config()),
+                   'roofline': roofline_record(flops, nbytes, call_s, bound, dg.last_config(), measured_counters(dg.last_config(), name),
                                                useful_flops=desc.get('useful_flops'), recipe_roof=desc.get('recipe_roof')), **extra}
             out.append(rec)
         except Exception as e:                                       # noqa: BLE001  (a secondary line must not take the headline down)
@@ -573,7 +575,7 @@ def run(rank: int, world: int, local_rank: int, args):
     if rank == 0:
         total_flops = flops * args.steps * world
         value = total_flops / elapsed / 1e12
-        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), measured_counters(dg.last_config()), useful_flops=desc.get('useful_flops'),
+        roofline = roofline_record(flops, nbytes, kernel_s, bound, dg.last_config(), measured_counters(dg.last_config(), args.workload), useful_flops=desc.get('useful_flops'),
                                    recipe_roof=desc.get('recipe_roof'))
         if split is not None:
             # the roofline of the EP step is that of its local GEMM (HBM-bound on the expert weights)

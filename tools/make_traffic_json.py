@@ -43,7 +43,7 @@ rec = {'kernel': config, 'workload': workload, 'git': git,
        'fetch_bytes': fetch * 1024 * 2, 'write_bytes': write * 1024, 'traffic_bytes': fetch * 1024 * 2 + write * 1024,
        'shader_cycles': cycles, 'mfma_busy': mfma / (cycles * 1024.0), 'kernel_trace_us_of_the_counter_pass': trace_us,
        'clock_ghz': (cycles / trace_us / 1e3) if trace_us else None}
-out = os.path.join(root, f'traffic_{config}.json')
+out = os.path.join(root, f'traffic_{workload}_{config}.json')
 with open(out, 'w') as f:
     json.dump(rec, f, indent=1)
 print(out, round(rec['traffic_bytes'] / 1e6, 1), 'MB', 'mfma_busy', round(rec['mfma_busy'], 3), 'clock', rec['clock_ghz'])
