@@ -613,6 +613,9 @@ def run(rank: int, world: int, local_rank: int, args):
             line['roofline'] = {k: (_sig(v, 6) if isinstance(v, float) else v) for k, v in roofline.items()
                                 if k not in ('tflops', 'gbs', 'algorithmic_flops', 'algorithmic_bytes')}
             line['pct_of_mfma_peak'] = _sig(line['pct_of_mfma_peak'], 5)
+            line['value'], line['ms_per_step'] = _sig(line['value'], 7), _sig(line['ms_per_step'], 6)
+            if 'cpu_baseline' in line:
+                line['cpu_baseline']['value'] = _sig(line['cpu_baseline']['value'], 4)
             line['calc_diff_vs_reference_expr'] = _sig(diff, 3)
         print(json.dumps(line, separators=(',', ':')), flush=True)
     if distributed:

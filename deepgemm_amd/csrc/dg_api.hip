@@ -150,6 +150,11 @@ const Config kConfigs[] = {
     {"stream_nt_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 2>, true},
     // round 5: a 3-stage ring (77 KiB of LDS) so that TWO workgroups share a CU: 257 .. 512 tiles of 64 x 128 are then ONE resident round
     // instead of a full round and a mostly idle one (the masked GEMM2 of the expert MLP: 8 experts x 7168 x 2048 = 448 tiles)
+    // round 6: the 6-stage 64 x 128 stream tile with every tile cut along K into sk_factor pieces, one work item per (tile, piece), partials
+    // exchanged inside the kernel (stream_kernel_body, KSPLIT): dense mid-M problems whose tiles fill a quarter of the chip or less
+    // (m = 128, 4096 x 7168: 64 tiles x 4 pieces, 344 KB per CU instead of 688 KB on 64 x 32 tiles); needs the caller's workspace
+    {"stream_ks_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 0, true>, true, false, false,
+     false, true},
     {"stream2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3>, true},
     {"stream_nt2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
@@ -764,6 +769,29 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     p.sk_first_tile = static_cast<int>(total);
     p.sk_tiles = 0;
     p.sk_factor = 1;
+    const bool stream_ks = std::strcmp(cfg->name, "stream_ks_64x128") == 0;
+    if (stream_ks) {
+        // K pieces of the stream tile (see stream_kernel_body, KSPLIT): as many as keep tiles x pieces within one resident round, at most 8 and
+        // at least four K blocks each; flags and slabs live in the caller's workspace
+        static std::atomic<unsigned> ks_epoch{0};
+        const long slots = num_cus();
+        long pieces = std::min<long>(std::min<long>(8, total > 0 ? slots / total : 0), p.k / 128 / 4);
+        const size_t need = 4096 + 32768 + static_cast<size_t>(total) * 8 * 64 * 128 * sizeof(float);
+        if (p.gemm_type != dg::kNormal || p.sfb_gran_n != 128 || p.head_lr != 0 || !sfa_quads_ok(p) || total > 1024) {
+            g_last_error = "config 'stream_ks_64x128' implements dense problems with per-128 SFB and MN-major SFA with 16-byte aligned K-block rows";
+            return 3;
+        }
+        if (pieces < 2 || p.sk_workspace == nullptr || need > g_workspace_bytes)
+            pieces = 1;                             // whole tiles (no workspace, too many tiles): the plain 6-stage stream tile
+        p.sk_factor = static_cast<int>(pieces);
+        p.sk_exchange = 0x7fc00000u | (ks_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu) | 0x100000u;
+        const long items = total * pieces;
+        hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(std::min<long>(items, slots))), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
+        DG_HIP_CHECK(hipGetLastError());
+        if (env_knobs().print_configs)
+            fprintf(stderr, "[deepgemm_amd] type=%d m=%d n=%d k=%d -> %s pieces=%ld items=%ld\n", p.gemm_type, p.m, p.n, p.k, cfg->name, pieces, items);
+        return 0;
+    }
     if (cfg->split_k) {
         if (p.gemm_type == dg::kMasked) {
             g_last_error = std::string("config '") + cfg->name + "' does not implement the masked layout";
@@ -2238,6 +2266,11 @@ int dg_dense_wants_workspace(int m, int n, int k, int a_mn_major, int b_mn_major
     p.sk_workspace = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23);
     if (per_col_split_pieces(p, 0, true) >= 2)
         return 1;
+    {   // (a K-split form forced by name -- tuning runs, tests -- gets the buffer too)
+        const std::string forced = forced_config();
+        if (forced.find("_sk_") != std::string::npos || forced.find("_ks_") != std::string::npos)
+            return 1;
+    }
     const Config* cfg = select_config(p, p.m, 0, 0, true);
     return cfg != nullptr && cfg->split_k ? 1 : 0;
 }

@@ -2867,8 +2867,17 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
 // fill a CU at ~50 GB/s, 8 at ~80, 16 at ~96 whatever is in flight), not by its matrix work: the NW compute waves keep the tile's MFMA /
 // epilogue geometry, LW more waves do nothing but issue their share of every stage's pieces and join the barriers.  The pieces of a stage
 // (KBS blocks x (BM / 8 + BN / 8) units) are dealt round-robin over all NW + LW waves.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0>
+// KSPLIT (round 6): dense mid-M problems (64 < m <= 256) whose 64 x 128 tiles fill a quarter of the chip or less.  What bounds them is the
+// L2 -> LDS rate of a CU, i.e. the bytes ONE workgroup pulls (m = 128, 4096 x 7168 on 64 x 32 tiles: 688 KB per CU); here a work item is
+// (tile, K piece): p.sk_factor pieces per tile, piece q = K blocks [q kb / f, (q + 1) kb / f) -- 64 tiles x 4 pieces = 256 work items of
+// 344 KB each.  Pieces 0 .. f - 2 write their FP32 partial tile (lane-linear, written through) into the caller's workspace and raise a flag
+// (the launch's own epoch value, GemmParams::sk_exchange: nothing is ever reset); the LAST piece of a tile -- dispatched after all the
+// others, so they are resident or done: no deadlock whatever the residency -- waits for them (bounded) and adds the partials IN PIECE
+// ORDER (((p0 + p1) + ...) + own: bit-repeatable), then stores the tile through the shared epilogue.
+// Workspace: 4 KiB header | 32 KiB of flags ([tile][8]) | slabs [tile][8][BM * BN] FP32.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false>
 __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
+    static_assert(!KSPLIT || (!E8 && LW == 0 && B_AUX != 64), "KSPLIT: the FP32-scale stream tile");
     constexpr int NW = WAVES_M * WAVES_N, TW = NW + LW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int SFB_PIECES = E8 ? (BN + 63) / 64 : 1;
@@ -2908,7 +2917,8 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int num_kb = p.k / 128;
+    const int num_kb_total = p.k / 128;
+    int num_kb = num_kb_total, kb0 = 0;             // KSPLIT: the K blocks [kb0, kb0 + num_kb) of the work item's piece
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
@@ -2921,7 +2931,19 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     MaskedWalk walk;
     const int num_launched = gridDim.x;
     for (int tile_id = blockIdx.x;; tile_id += num_launched) {
-        const Tile t = get_tile<BM, BN>(p, tile_id, walk);
+        int tile = tile_id;
+        [[maybe_unused]] int ks_piece = 0, ks_pieces = 1;
+        if constexpr (KSPLIT) {
+            const int tiles = p.num_m_tiles * p.num_n_tiles;
+            ks_pieces = p.sk_factor;
+            if (tile_id >= tiles * ks_pieces)
+                break;
+            tile = tile_id % tiles;
+            ks_piece = tile_id / tiles;
+            kb0 = ks_piece * num_kb_total / ks_pieces;
+            num_kb = (ks_piece + 1) * num_kb_total / ks_pieces - kb0;
+        }
+        const Tile t = get_tile<BM, BN>(p, tile, walk);
         if (!t.valid)
             break;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
@@ -2945,7 +2967,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             // SFA of the tile's rows: MN-major, rows m0 .. m0+63 are 256 contiguous bytes per K block
             const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
             // (E8: the strides are per K quad and the "K block" index of a scale row is j >> 2)
-            const int num_sf_k = E8 ? (num_kb + 3) / 4 : num_kb;
+            const int num_sf_k = E8 ? (num_kb + 3) / 4 : num_kb_total;      // (KSPLIT: a piece's blocks are addressed from the operands' first block)
             float* sfa_tile = uniform_pointer(const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0);
             const int sfa_rows = uniform_int(imin(p.m - t.m0, BM));
             // (GSF: 16-byte requests -- the MN-major layout pads the rows to a multiple of four, so a request that starts below sfa_rows is whole)
@@ -2966,10 +2988,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
-                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
-                            static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), j * sfb_kb_stride, 0, 0);
+                            static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
                     }
                 }
                 #pragma unroll
@@ -2977,7 +2999,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     const int unit = wave + NW * q;
                     const int voff = static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob));
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        a_rsrc, (__attribute__((address_space(3))) void*)(stage + unit * 1024), 16, voff, j * 128, 0, 0);
+                        a_rsrc, (__attribute__((address_space(3))) void*)(stage + unit * 1024), 16, voff, (kb0 + j) * 128, 0, 0);
                 }
                 #pragma unroll
                 for (int q = 0; q < B_ITERS; ++q) {
@@ -2985,7 +3007,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     const int voff = static_cast<int>(static_cast<unsigned>(b_voff) +
                                                       (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | oob));
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, j * 128, 0, B_AUX & 3);
+                        b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, (kb0 + j) * 128, 0, B_AUX & 3);
                 }
                 if constexpr (GSF)
                     return;
@@ -3018,10 +3040,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                             uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
-                                static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                                static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
-                                static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), j * sfb_kb_stride, 0, 0);
+                                static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
                         }
                     }
                     #pragma unroll
@@ -3030,7 +3052,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         const unsigned oob = j < num_kb ? 0u : OOB;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + u * BLOCK_BYTES + unit * 1024), 16,
-                            static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob)), j * 128, 0, 0);
+                            static_cast<int>(static_cast<unsigned>(a_voff) + (static_cast<unsigned>(a_unit_row(unit) * lda) | oob)), (kb0 + j) * 128, 0, 0);
                     }
                     #pragma unroll
                     for (int q = 0; q < B_PER; ++q) {
@@ -3038,7 +3060,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         const unsigned oob = j < num_kb ? 0u : OOB;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             b_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + u * BLOCK_BYTES + A_BYTES + unit * 1024), 16,
-                            static_cast<int>(static_cast<unsigned>(b_row_perm<WN>(unit * 8 + piece_row) * ldb + src_chunk * 16) | oob), j * 128, 0,
+                            static_cast<int>(static_cast<unsigned>(b_row_perm<WN>(unit * 8 + piece_row) * ldb + src_chunk * 16) | oob), (kb0 + j) * 128, 0,
                             B_AUX & 3);
                     }
                     return;
@@ -3176,15 +3198,60 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if constexpr (KSPLIT) {
+            if (ks_pieces > 1) {
+                uint8_t* ws = static_cast<uint8_t*>(p.sk_workspace);
+                unsigned* flags = reinterpret_cast<unsigned*>(ws + 4096) + tile * 8;
+                uint8_t* slabs = ws + 4096 + 32768 + static_cast<int64_t>(tile) * 8 * (BM * BN * 4);
+                const int lane_off = (wave * 64 + lane) * 16;
+                if (ks_piece != ks_pieces - 1) {
+                    const auto slab = __builtin_amdgcn_make_buffer_rsrc(slabs + static_cast<int64_t>(ks_piece) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc[ms][ns]), slab, lane_off, (ms * NS + ns) * (NW * 1024), 17);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                    // every wave's partial is acknowledged (written through) before the flag goes out
+                    if (threadIdx.x == 0)
+                        __hip_atomic_store(flags + ks_piece, p.sk_exchange, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
+                }
+                if (threadIdx.x < ks_pieces - 1) {
+                    // the pieces in front of this one were dispatched earlier: resident or done.  Bounded all the same: a lost flag must end in a
+                    // wrong tile, not in a hung device
+                    int spins = 0;
+                    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_exchange && ++spins < (1 << 22))
+                        __builtin_amdgcn_s_sleep(4);
+                }
+                __syncthreads();
+                v4f total[MS][NS];
+                for (int q = 0; q < ks_pieces - 1; ++q) {
+                    const auto slab = __builtin_amdgcn_make_buffer_rsrc(slabs + static_cast<int64_t>(q) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
+                    #pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        #pragma unroll
+                        for (int ns = 0; ns < NS; ++ns) {
+                            const v4f part = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(slab, lane_off, (ms * NS + ns) * (NW * 1024), 17));
+                            total[ms][ns] = q == 0 ? part : total[ms][ns] + part;
+                        }
+                }
+                #pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        acc[ms][ns] = total[ms][ns] + acc[ms][ns];          // piece order: ((p0 + p1) + ...) + the last piece
+            }
+        }
         if (LW == 0 || wave < NW)
             store_tile<MS, NS, true>(p, t, ad_group * p.d_sg, acc, t.m0 + wm * WM, t.n0 + wn * WN);
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64)
 void dg_fp8_gemm_stream_kernel(const GemmParams p) {
-    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8, LW>(p);
+    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8, LW, KSPLIT>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -86,8 +86,12 @@ def get_theoretical_mk_alignment_for_contiguous_layout(expected_m: Optional[int]
 
 
 def set_forced_config(name: str) -> None:
-    """Tuning hook: force a kernel configuration ('auto' restores the heuristic).  Process-wide, like the knobs above."""
+    """Tuning hook: force a kernel configuration ('auto' restores the heuristic).  Process-wide, like the knobs above.  The cached call
+    plans of the dense / masked operators are dropped: whether a call gets the K-split workspace depends on the configuration."""
     check(lib.dg_set_forced_config(name.encode()))
+    from . import gemm
+    gemm._VALIDATED_DENSE.clear()
+    gemm._VALIDATED_MASKED.clear()
 
 
 def last_forced_config() -> str:

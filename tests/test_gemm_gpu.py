@@ -819,14 +819,14 @@ def test_import_is_fork_safe_and_bench_runs():
     # the full records on a prefixed (non-JSON) line before it
     assert len(out.stdout.splitlines()[-1]) < 2000, len(out.stdout.splitlines()[-1])
     secondary = line['secondary']
-    assert len(secondary) == 22 and not [v for v in secondary.values() if isinstance(v, str)], secondary
+    assert len(secondary) == 23 and not [v for v in secondary.values() if isinstance(v, str)], secondary
     for name, rec in secondary.items():
         assert 0 < rec[0] < 1 and rec[1] > 0 and rec[2] in ('m', 'h'), (name, rec)
     assert {rec[2] for rec in secondary.values()} == {'m', 'h'} and len(secondary['contiguous']) == 4
     detail = [ln for ln in out.stdout.splitlines() if ln.startswith('secondary_detail: ')]
     assert len(detail) == 1
     detail = json.loads(detail[0][len('secondary_detail: '):])
-    assert len(detail) == 22 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
+    assert len(detail) == 23 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
     # --gpus N without a launcher must not silently run one rank
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '2', '--warmup', '1'],
                          capture_output=True, text=True, timeout=600)
@@ -1360,6 +1360,34 @@ def test_duo_256x224_tiles(m, n, k):
         dg.set_forced_config('auto')
     assert torch.equal(d.view(torch.int16), d256.view(torch.int16))
     assert torch.equal(d32, e32) and torch.equal(db.view(torch.int16), eb.view(torch.int16))
+
+
+@pytest.mark.parametrize('m,n,k', [(128, 4096, 7168), (65, 512, 1024), (200, 1000, 2048), (256, 2112, 7168), (128, 7168, 2048), (96, 128, 512)])
+def test_stream_tile_with_in_kernel_k_split(m, n, k):
+    """`stream_ks_64x128` (round 6): the 64 x 128 stream tile with every tile cut along K into pieces that exchange their FP32 partials
+    inside the kernel (the last piece of a tile sums them in piece order): against the oracle, bit-repeatable, BF16 / FP32 outputs with
+    accumulation, ragged M and N, K ranges that do not divide evenly -- and without a workspace (whole tiles) the bits of the plain tile."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    dg.set_forced_config('stream_ks_64x128')
+    try:
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(case.a, case.b, d)
+        assert dg.last_config() == 'stream_ks_64x128'
+        again = torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt(case.a, case.b, again)
+        c32 = torch.randn((m, n), device='cuda', dtype=torch.float)
+        d32 = c32.clone()
+        dg.fp8_gemm_nt(case.a, case.b, d32, c=d32)
+    finally:
+        dg.set_forced_config('auto')
+    assert_close_to_oracle(d, want, 'stream tile, in-kernel K split')
+    assert torch.equal(d.view(torch.int16), again.view(torch.int16)), 'piece order is fixed: bit-repeatable'
+    assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+    want32 = torch.empty((m, n), dtype=torch.float)
+    oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want32, c=c32.cpu())
+    assert_close_fp32(d32, want32, 'stream tile, in-kernel K split, fp32 accumulate')
 
 
 def test_k_grouped_argument_checks():
