@@ -241,6 +241,7 @@ struct EnvKnobs {
     bool print_configs, table_kernel, tab_unfused, sk_exchange, sfa_rowmajor_in_place, swiglu_one_per_cu;
     int group_m, ks_pieces, pc_bm;
     bool e8_tab_unsplit;
+    int ks_max_pieces;      // DG_STREAM_KS_PIECES: upper bound of the K pieces of the stream_ks tile (tuning; default 8)
     int swiglu_fault;       // DG_TEST_SWIGLU_FAULT (tests only): 1 = odd tiles of the fused SwiGLU kernel never publish their amax
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
@@ -248,6 +249,7 @@ struct EnvKnobs {
           sfa_rowmajor_in_place(getenv("DG_SFA_ROWMAJOR_IN_PLACE") != nullptr), swiglu_one_per_cu(getenv("DG_SWIGLU_ONE_PER_CU") != nullptr),
           group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0),
           pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr),
+          ks_max_pieces(getenv("DG_STREAM_KS_PIECES") ? std::max(1, std::min(8, atoi(getenv("DG_STREAM_KS_PIECES")))) : 8),
           swiglu_fault(getenv("DG_TEST_SWIGLU_FAULT") ? atoi(getenv("DG_TEST_SWIGLU_FAULT")) : 0) {}
 };
 std::atomic<const EnvKnobs*> g_env_knobs{nullptr};
@@ -539,6 +541,19 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // (117 MB: 25.5 us against 28.3 with the default policy; 59 MB: 14.3 against 14.0).
         if (pick != nullptr && std::strcmp(pick, "stream_64x128") == 0)
             pick = static_cast<double>(groups) * p.n * p.k >= 80e6 ? "stream_nt2_64x128" : "stream2_64x128";
+        // round 6: 129 .. 256 rows whose 64 x 128 tiles fill at most half the chip: the same tile with every tile cut along K inside the kernel
+        // (stream_ks_64x128: one launch, pieces x tiles resident, FP32 partials through written-through slabs, the last piece of a tile sums
+        // them in piece order).  Cold inputs, us: 160 x 4096 x 7168 27.5 -> 23.4, 192 x .. 30.4 -> 23.7, 256 x .. 30.6 -> 24.5 (was duo_sk_128x256),
+        // 256 x 2112 x 7168 27.2 -> 19.4, 192 x 4096 x 4096 20.4 -> 17.3.  NOT up to 128 rows (128 x 4096 x 7168 16.7 -> 18.0, 128 x 2112 x 7168
+        // 16.3 -> 24.4: the 64 x 32 tiles with loader waves already cover the chip), not with short K loops (256 x 4096 x 2048 12.7 -> 13.4), not
+        // under 64 tiles (192 x 2112 x 7168 16.6 -> 16.8).  profiles/r06_probe/stream_ks_mid_m_ab.log
+        if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && p.head_lr == 0 &&
+            m_for_tiling > 128 && m_for_tiling <= 256 && p.k >= 4096 && tiles128 >= 64 && tiles128 * 2 <= num_cus() &&
+            4096 + 32768 + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes) {
+            for (int i = 0; i < kNumConfigs; ++i)
+                if (std::strcmp(kConfigs[i].name, "stream_ks_64x128") == 0)
+                    return &kConfigs[i];
+        }
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && m_hint > 64) {
             const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
             const long num_kb = p.k / 128;
@@ -769,16 +784,16 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     p.sk_first_tile = static_cast<int>(total);
     p.sk_tiles = 0;
     p.sk_factor = 1;
-    const bool stream_ks = std::strcmp(cfg->name, "stream_ks_64x128") == 0;
+    const bool stream_ks = std::strncmp(cfg->name, "stream_ks_", 10) == 0;
     if (stream_ks) {
         // K pieces of the stream tile (see stream_kernel_body, KSPLIT): as many as keep tiles x pieces within one resident round, at most 8 and
         // at least four K blocks each; flags and slabs live in the caller's workspace
         static std::atomic<unsigned> ks_epoch{0};
         const long slots = num_cus();
-        long pieces = std::min<long>(std::min<long>(8, total > 0 ? slots / total : 0), p.k / 128 / 4);
+        long pieces = std::min<long>(std::min<long>(env_knobs().ks_max_pieces, total > 0 ? slots / total : 0), p.k / 128 / 4);
         const size_t need = 4096 + 32768 + static_cast<size_t>(total) * 8 * 64 * 128 * sizeof(float);
         if (p.gemm_type != dg::kNormal || p.sfb_gran_n != 128 || p.head_lr != 0 || !sfa_quads_ok(p) || total > 1024) {
-            g_last_error = "config 'stream_ks_64x128' implements dense problems with per-128 SFB and MN-major SFA with 16-byte aligned K-block rows";
+            g_last_error = "the stream_ks configurations implement dense problems with per-128 SFB and MN-major SFA with 16-byte aligned K-block rows";
             return 3;
         }
         if (pieces < 2 || p.sk_workspace == nullptr || need > g_workspace_bytes)
@@ -2226,7 +2241,10 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
         name = "duo_tab_256x256";           // launch_contiguous_tabled: group-relative 256-row tiles + K-split remainders (_sk_: needs the workspace)
     } else {
         const int bm_must_divide = (gemm_type == dg::kContiguous || gemm_type == dg::kContiguousPsum) ? m_alignment : 0;
+        const size_t saved = g_workspace_bytes;     // (has_workspace: of the size the host layer creates)
+        g_workspace_bytes = has_workspace ? static_cast<size_t>(dg_split_k_workspace_bytes()) : 0;
         const Config* cfg = select_config(p, p.m, expected_m, bm_must_divide, true);
+        g_workspace_bytes = saved;
         name = cfg != nullptr ? cfg->name : "";
     }
     return name.c_str();
@@ -2271,7 +2289,10 @@ int dg_dense_wants_workspace(int m, int n, int k, int a_mn_major, int b_mn_major
         if (forced.find("_sk_") != std::string::npos || forced.find("_ks_") != std::string::npos)
             return 1;
     }
+    const size_t saved = g_workspace_bytes;         // (the question is asked BEFORE a workspace exists: assume the size the host layer creates)
+    g_workspace_bytes = static_cast<size_t>(dg_split_k_workspace_bytes());
     const Config* cfg = select_config(p, p.m, 0, 0, true);
+    g_workspace_bytes = saved;
     return cfg != nullptr && cfg->split_k ? 1 : 0;
 }
 

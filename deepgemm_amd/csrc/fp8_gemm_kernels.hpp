@@ -3206,11 +3206,13 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 const int lane_off = (wave * 64 + lane) * 16;
                 if (ks_piece != ks_pieces - 1) {
                     const auto slab = __builtin_amdgcn_make_buffer_rsrc(slabs + static_cast<int64_t>(ks_piece) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
-                    #pragma unroll
-                    for (int ms = 0; ms < MS; ++ms)
+                    if (LW == 0 || wave < NW) {
                         #pragma unroll
-                        for (int ns = 0; ns < NS; ++ns)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc[ms][ns]), slab, lane_off, (ms * NS + ns) * (NW * 1024), 17);
+                        for (int ms = 0; ms < MS; ++ms)
+                            #pragma unroll
+                            for (int ns = 0; ns < NS; ++ns)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc[ms][ns]), slab, lane_off, (ms * NS + ns) * (NW * 1024), 17);
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();                    // every wave's partial is acknowledged (written through) before the flag goes out
                     if (threadIdx.x == 0)
@@ -3225,22 +3227,39 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         __builtin_amdgcn_s_sleep(4);
                 }
                 __syncthreads();
+                // the partials of up to four pieces are in flight together (a written-through slab is a ~2 us round trip: one piece at a time
+                // made the exchange of a 4-piece tile ~8 us); the SUM keeps the piece order
                 v4f total[MS][NS];
-                for (int q = 0; q < ks_pieces - 1; ++q) {
-                    const auto slab = __builtin_amdgcn_make_buffer_rsrc(slabs + static_cast<int64_t>(q) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
+                if (LW == 0 || wave < NW)
+                for (int qb = 0; qb < ks_pieces - 1; qb += 4) {
+                    v4f part[4][MS][NS];
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (qb + u < ks_pieces - 1) {
+                            const auto slab = __builtin_amdgcn_make_buffer_rsrc(slabs + static_cast<int64_t>(qb + u) * (BM * BN * 4), 0, BM * BN * 4, 0x00020000);
+                            #pragma unroll
+                            for (int ms = 0; ms < MS; ++ms)
+                                #pragma unroll
+                                for (int ns = 0; ns < NS; ++ns)
+                                    part[u][ms][ns] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(slab, lane_off, (ms * NS + ns) * (NW * 1024), 17));
+                        }
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (qb + u < ks_pieces - 1) {
+                            #pragma unroll
+                            for (int ms = 0; ms < MS; ++ms)
+                                #pragma unroll
+                                for (int ns = 0; ns < NS; ++ns)
+                                    total[ms][ns] = qb + u == 0 ? part[u][ms][ns] : total[ms][ns] + part[u][ms][ns];
+                        }
+                }
+                if (LW == 0 || wave < NW) {
                     #pragma unroll
                     for (int ms = 0; ms < MS; ++ms)
                         #pragma unroll
-                        for (int ns = 0; ns < NS; ++ns) {
-                            const v4f part = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(slab, lane_off, (ms * NS + ns) * (NW * 1024), 17));
-                            total[ms][ns] = q == 0 ? part : total[ms][ns] + part;
-                        }
+                        for (int ns = 0; ns < NS; ++ns)
+                            acc[ms][ns] = total[ms][ns] + acc[ms][ns];      // piece order: ((p0 + p1) + ...) + the last piece
                 }
-                #pragma unroll
-                for (int ms = 0; ms < MS; ++ms)
-                    #pragma unroll
-                    for (int ns = 0; ns < NS; ++ns)
-                        acc[ms][ns] = total[ms][ns] + acc[ms][ns];          // piece order: ((p0 + p1) + ...) + the last piece
             }
         }
         if (LW == 0 || wave < NW)

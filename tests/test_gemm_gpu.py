@@ -1390,6 +1390,24 @@ def test_stream_tile_with_in_kernel_k_split(m, n, k):
     assert_close_fp32(d32, want32, 'stream tile, in-kernel K split, fp32 accumulate')
 
 
+@pytest.mark.parametrize('m,n,k', [(192, 4096, 7168), (256, 2112, 7168), (129, 4096, 4096)])
+def test_mid_m_dense_calls_take_the_k_split_stream_tile(m, n, k):
+    """The automatic selection (round 6): 129 .. 256 rows whose 64 x 128 tiles fill at most half the chip and K >= 4096 run `stream_ks_64x128`
+    through the plain entry (the host layer lends the workspace: dg_dense_wants_workspace), with the oracle's result; repeated calls (the
+    exchange epoch advances, the workspace is reused dirty) give the same bits."""
+    gen.reset_seed(3 * m + n + k)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    outs = []
+    for _ in range(4):
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(case.a, case.b, d)
+        assert dg.last_config() == 'stream_ks_64x128'
+        outs.append(d)
+    assert_close_to_oracle(outs[0], want, 'mid-M dense, automatic K-split stream tile')
+    assert all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:])
+
+
 def test_k_grouped_argument_checks():
     gen.reset_seed(1)
     case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)

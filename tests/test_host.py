@@ -487,6 +487,10 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 32, 7168, 16384) == 'stream_l8_64x32' and not pick(dense, 1, 4104, 7168).startswith('skinny_16')
     assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_l8_64x32'
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256'                                            # K split beats one stream tile per CU
+    # round 6: 129 .. 256 rows, 64 .. CUs / 2 tiles of 64 x 128, K >= 4096: the stream tile cut along K inside the kernel (profiles/r06_probe/stream_ks_mid_m_ab.log)
+    assert pick(dense, 192, 4096, 7168) == 'stream_ks_64x128' and pick(dense, 256, 4096, 7168) == 'stream_ks_64x128' and pick(dense, 256, 2112, 7168) == 'stream_ks_64x128'
+    assert pick(dense, 192, 4096, 7168, workspace=0) == 'stream_l8_64x32' and pick(dense, 192, 2112, 7168) == 'stream_l8_64x32' and pick(dense, 256, 4096, 2048) == 'stream2_64x128'
+    assert pick(dense, 192, 7168, 2048) == 'stream2_64x128' and pick(masked, 192, 4096, 7168, groups=1, expected_m=192) != 'stream_ks_64x128'
     assert pick(dense, 4096, 7168, 2112, b_mn=1) == 'duo_bmn_kt_256x256' and pick(dense, 4096, 7168, 2112) == 'duo_kt_256x256'
     assert pick(dense, 4096, 512, 32768, b_mn=1) == 'duo_sk_bmn_128x256' and pick(dense, 4096, 576, 7168) == 'duo_sk_128x256'
     assert pick(dense, 4096, 576, 7168, workspace=0) == 'duo_128x256'

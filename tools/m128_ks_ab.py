@@ -5,6 +5,7 @@ import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepgemm_amd as dg
+from deepgemm_amd import _lib
 from deepgemm_amd.testing import generators as gen
 
 shapes = [tuple(int(x) for x in s.split('x')) for s in sys.argv[1:]] or [(128, 4096, 7168), (128, 7168, 2048), (128, 2112, 7168), (256, 4096, 7168), (128, 24576, 1536), (128, 7168, 16384),
@@ -19,8 +20,10 @@ for m, n, k in shapes:
         cases.append(((c.a[0], dg.get_mn_major_tma_aligned_tensor(c.a[1])), c.b, c.d))
     out, names = {}, {}
     for rnd in range(3):
-        for cfg in ('auto', 'stream_ks_64x128'):
-            dg.set_forced_config(cfg)
+        for cfg in ('auto', 'stream_ks_64x128', 'stream_ks_64x128@2'):
+            os.environ['DG_STREAM_KS_PIECES'] = cfg.split('@')[1] if '@' in cfg else '8'
+            _lib.lib.dg_reload_env()
+            dg.set_forced_config(cfg.split('@')[0])
             for it in range(3 * sets):
                 a, b, d = cases[it % sets]
                 dg.fp8_gemm_nt(a, b, d)
