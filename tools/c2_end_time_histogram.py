@@ -21,18 +21,24 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--config', default='duo_p_256x256')
 ap.add_argument('--shape', default='4096x4096x7168')
 ap.add_argument('--reps', type=int, default=6)
+ap.add_argument('--wgrad', action='store_true', help='recipe (1, 1, 128) with FP32 accumulation into D (pipe_pc kernels); --config auto')
 args = ap.parse_args()
 m, n, k = (int(x) for x in args.shape.split('x'))
 e8 = args.config.startswith('e8_')
 cases = []
 for i in range(4):
     gen.reset_seed(i)
+    if args.wgrad:
+        c = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float, per_token_b=True)
+        cases.append((((c.a[0], dg.get_mn_major_tma_aligned_tensor(c.a[1])), (c.b[0], dg.get_mn_major_tma_aligned_tensor(c.b[1]))), c.d))
+        continue
     c = gen.generate_normal(m, n, k, use_ue8m0=e8)
     cases.append(((gen.packed_ue8m0_operand(*c.a), gen.packed_ue8m0_operand(*c.b, mn_rows=n)) if e8 else
                   ((c.a[0], dg.get_mn_major_tma_aligned_tensor(c.a[1])), c.b), c.d))
 dbg = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device='cuda')
 dg.set_forced_config(args.config)
-call = lambda i: dg.fp8_gemm_nt(cases[i % 4][0][0], cases[i % 4][0][1], cases[i % 4][1])       # noqa: E731
+call = (lambda i: dg.fp8_gemm_nt(cases[i % 4][0][0], cases[i % 4][0][1], cases[i % 4][1], c=cases[i % 4][1], recipe=(1, 1, 128))) if args.wgrad else \
+       (lambda i: dg.fp8_gemm_nt(cases[i % 4][0][0], cases[i % 4][0][1], cases[i % 4][1]))       # noqa: E731
 for it in range(60):                                                    # clocks up
     call(it)
 torch.cuda.synchronize()
