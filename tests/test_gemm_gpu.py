@@ -1408,6 +1408,32 @@ def test_mid_m_dense_calls_take_the_k_split_stream_tile(m, n, k):
     assert all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:])
 
 
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_mid_m_k_split_random_shapes(seed):
+    """Random problems inside the `stream_ks_64x128` rule (129 .. 256 rows, ragged N, K = 4096 .. 8192 in whole blocks), BF16 / FP32 outputs with
+    and without accumulation, each against the oracle."""
+    rng = random.Random(seed)
+    taken = 0
+    for _ in range(6):
+        m = rng.randrange(129, 257)
+        n = rng.choice([3000, 3584, 4096])          # 72 .. 128 tiles of 64 x 128: inside the rule
+        k = 128 * rng.randrange(32, 65)
+        accumulate = rng.random() < 0.4
+        out_dtype = torch.float if rng.random() < 0.4 else torch.bfloat16
+        gen.reset_seed(seed + m + n + k)
+        case = gen.generate_normal(m, n, k, accumulate=accumulate, out_dtype=out_dtype)
+        c_cpu = case.c.cpu().clone() if accumulate else None
+        want = oracle_dense(case, c_cpu=c_cpu)
+        dg.fp8_gemm_nt(case.a, case.b, case.d, c=case.c if accumulate else None)
+        label = f'm={m} n={n} k={k} acc={accumulate} {out_dtype} [{dg.last_config()}]'
+        taken += dg.last_config() == 'stream_ks_64x128'
+        if out_dtype == torch.float:
+            assert_close_fp32(case.d, want, label)
+        else:
+            assert_close_to_oracle(case.d, want, label, addend=c_cpu)
+    assert taken == 6, taken
+
+
 def test_k_grouped_argument_checks():
     gen.reset_seed(1)
     case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)
