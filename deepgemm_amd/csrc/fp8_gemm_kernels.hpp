@@ -2871,7 +2871,7 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
 // L2 -> LDS rate of a CU, i.e. the bytes ONE workgroup pulls (m = 128, 4096 x 7168 on 64 x 32 tiles: 688 KB per CU); here a work item is
 // (tile, K piece): p.sk_factor pieces per tile, piece q = K blocks [q kb / f, (q + 1) kb / f) -- 64 tiles x 4 pieces = 256 work items of
 // 344 KB each.  Pieces 0 .. f - 2 write their FP32 partial tile (lane-linear, written through) into the caller's workspace and raise a flag
-// (the launch's own epoch value, GemmParams::sk_exchange: nothing is ever reset); the LAST piece of a tile -- dispatched after all the
+// (the launch's own epoch value, GemmParams::sk_exchange; the last piece takes the flags back so that a hipGraph replay -- same epoch -- waits again); the LAST piece of a tile -- dispatched after all the
 // others, so they are resident or done: no deadlock whatever the residency -- waits for them (bounded) and adds the partials IN PIECE
 // ORDER (((p0 + p1) + ...) + own: bit-repeatable), then stores the tile through the shared epilogue.
 // Workspace: 4 KiB header | 32 KiB of flags ([tile][8]) | slabs [tile][8][BM * BN] FP32.
@@ -3260,6 +3260,11 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                         for (int ns = 0; ns < NS; ++ns)
                             acc[ms][ns] = total[ms][ns] + acc[ms][ns];      // piece order: ((p0 + p1) + ...) + the last piece
                 }
+                // the flags are taken back: a launch replayed from a hipGraph carries the SAME epoch value again, and flags left standing would
+                // let the next replay's last piece run ahead of its partials (every wave's loads have returned: their values were just used)
+                __syncthreads();
+                if (threadIdx.x < ks_pieces - 1)
+                    __hip_atomic_store(flags + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (LW == 0 || wave < NW)

@@ -459,6 +459,11 @@ def _mega_moe_p2p(y, l1_weights, l2_weights, b: SymmBuffer, stats, activation_cl
     require_device(y, b.x, l1_weights[0], l2_weights[0])
     tokens = int(y.size(0))
     stream = current_stream_ptr()
+    if torch.cuda.is_current_stream_capturing():
+        # the step's epoch is a host value in the kernels' arguments: a replayed graph would present the SAME epoch again and its waits would
+        # be satisfied by the previous step's flags
+        raise RuntimeError('fp8_mega_moe over peer-mapped memory cannot be captured in a hipGraph (the exchange epoch is a launch argument); '
+                           'capture the RCCL form (SymmBuffer(p2p=False) / DG_MEGA_P2P=0) or call it eagerly')
     b._epoch += 1
     geometry = (b.world, b.rank, b.num_local_experts, b.expert_capacity, b.hidden, b.num_max_tokens_per_rank, b.num_topk)
     check(lib.dg_moe_p2p_dispatch(b._peers, *geometry, b.x.data_ptr(), b.x_sf.data_ptr(), b.topk_idx.data_ptr(),

@@ -261,7 +261,8 @@ int dg_m_grouped_fp8_gemm_nt_masked_swiglu(const void* a, const float* sfa, cons
  *     every rank's rows have arrived here: masked_m_out[e_local] = rows of the local expert (int32, what the masked GEMMs read).
  *   dg_moe_p2p_combine: row slot (e, r < masked_m[e]) of l2_out_bf16 [E_loc, cap, H] goes back to y_rows[t, j] of its source rank.
  *   dg_moe_p2p_reduce: y[t] = bf16( sum_j float(y_rows[t, j]) ) over the delivered pairs in top-k order, after every owner has returned.
- * Stream-ordered, no host synchronisation, no allocation; one call of each per step on every rank of the group, in this order. */
+ * Stream-ordered, no host synchronisation, no allocation; one call of each per step on every rank of the group, in this order.  The epoch is
+ * a launch ARGUMENT: a step captured in a hipGraph would replay its epoch (its waits would see the previous step's flags) -- not capturable. */
 void dg_set_moe_p2p_timeout_us(int64_t us);
 int dg_symm_alloc(int64_t bytes, void** out_ptr, int* out_fine_grained);
 int dg_symm_free(void* ptr);

@@ -1408,6 +1408,39 @@ def test_mid_m_dense_calls_take_the_k_split_stream_tile(m, n, k):
     assert all(torch.equal(outs[0].view(torch.int16), o.view(torch.int16)) for o in outs[1:])
 
 
+def test_mid_m_k_split_in_a_hip_graph():
+    """A captured `stream_ks_64x128` launch carries ONE exchange epoch: every replay must wait for ITS partials (the last piece takes the flags
+    back) -- replays over changing inputs against eager calls, bit for bit."""
+    m, n, k = 192, 4096, 4096
+    cases = []
+    for i in range(3):
+        gen.reset_seed(40 + i)
+        cases.append(gen.generate_normal(m, n, k))
+    eager = []
+    for c in cases:
+        d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(c.a, c.b, d)
+        assert dg.last_config() == 'stream_ks_64x128'
+        eager.append(d)
+    a = (cases[0].a[0].clone(), dg.get_mn_major_tma_aligned_tensor(cases[0].a[1]).clone())
+    b = (cases[0].b[0].clone(), cases[0].b[1].clone())
+    d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dg.fp8_gemm_nt(a, b, d)                                     # (warm: plan caches, the stream's workspace)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        dg.fp8_gemm_nt(a, b, d)
+    for which in (1, 2, 0, 2, 1):
+        c = cases[which]
+        a[0].copy_(c.a[0]); a[1].copy_(dg.get_mn_major_tma_aligned_tensor(c.a[1])); b[0].copy_(c.b[0]); b[1].copy_(c.b[1])
+        d.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d.view(torch.int16), eager[which].view(torch.int16)), which
+
+
 @pytest.mark.parametrize('seed', [11, 12, 13])
 def test_mid_m_k_split_random_shapes(seed):
     """Random problems inside the `stream_ks_64x128` rule (129 .. 256 rows, ragged N, K = 4096 .. 8192 in whole blocks), BF16 / FP32 outputs with
