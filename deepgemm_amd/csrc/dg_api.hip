@@ -1696,7 +1696,7 @@ dg::P2pLayout p2p_layout(int local_experts, int cap, int hidden, int max_tokens,
 int fill_p2p_args(dg::P2pArgs& a, const void* const* peer_regions, int world, int rank, int local_experts, int cap, int hidden, int max_tokens,
                   int topk, int tokens, unsigned epoch, void* errors) {
     DG_CHECK(peer_regions != nullptr && world >= 1 && world <= dg::kMaxPeers && rank >= 0 && rank < world);
-    DG_CHECK(local_experts >= 1 && cap >= 1 && cap % 4 == 0 && hidden > 0 && hidden % 128 == 0 && topk >= 1 && max_tokens >= 1);
+    DG_CHECK(local_experts >= 1 && cap >= 1 && cap % 4 == 0 && hidden > 0 && hidden % 128 == 0 && topk >= 1 && topk <= dg::kP2pMaxTopk && max_tokens >= 1);
     DG_CHECK(tokens >= 0 && tokens <= max_tokens && static_cast<int64_t>(max_tokens) * topk < (1 << 24) && epoch != 0 && errors != nullptr);
     for (int r = 0; r < world; ++r) {
         DG_CHECK(peer_regions[r] != nullptr && aligned16(peer_regions[r]));
@@ -1705,6 +1705,8 @@ int fill_p2p_args(dg::P2pArgs& a, const void* const* peer_regions, int world, in
     a.lay = p2p_layout(local_experts, cap, hidden, max_tokens, topk, world);
     a.world = world; a.rank = rank; a.tokens = tokens; a.hidden = hidden; a.topk = topk; a.num_experts = local_experts * world;
     a.local_experts = local_experts; a.cap = cap; a.epoch = epoch;
+    a.stamps = g_debug_buffer.load(std::memory_order_relaxed);       // (tuning: the phase stamps live 65536 words into the debug buffer)
+    if (a.stamps != nullptr) a.stamps += 65536;
     a.timeout_ticks = g_p2p_timeout_us.load(std::memory_order_relaxed) * 100;        // wall_clock64: 100 MHz
     a.errors = static_cast<uint32_t*>(errors);
     return 0;
@@ -1815,7 +1817,8 @@ int dg_moe_p2p_reduce(const void* const* peer_regions, int world, int rank, int 
     a.pair_ok = static_cast<uint8_t*>(const_cast<void*>(pair_ok)); a.y = static_cast<uint16_t*>(y_bf16); a.y_sm = y_stride_m;
     a.swiglu_errors = static_cast<const uint32_t*>(swiglu_workspace);
     // (a rank without tokens still waits for -- and thereby orders itself behind -- every owner's combine: one workgroup)
-    hipLaunchKernelGGL(dg::dg_moe_p2p_reduce_kernel, dim3(static_cast<unsigned>(std::max(tokens, 1))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(dg::dg_moe_p2p_reduce_kernel, dim3(static_cast<unsigned>(std::max(tokens, 1)), static_cast<unsigned>((hidden + 2047) / 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
     DG_HIP_CHECK(hipGetLastError());
     return 0;
 }

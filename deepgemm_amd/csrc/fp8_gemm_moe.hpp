@@ -466,6 +466,7 @@ void dg_moe_combine_kernel(const uint16_t* y2, const int32_t* slot, int tokens, 
 // wrong result -- never in a hung device (reference: comm/barrier.cuh:12,36-40).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kMaxPeers = 16;
+constexpr int kP2pMaxTopk = 32;      // top-k entries per token of the in-kernel dispatch (their slot claims go out together, one per thread)
 
 struct P2pLayout {      // byte offsets inside a symmetric region (dg_moe_p2p_layout, the same on every rank)
     int64_t counts;     // uint32 [E_loc]: rows claimed per local expert (system-scope fetch-add by every sender; zeroed by the owner's combine)
@@ -499,96 +500,128 @@ struct P2pArgs {
     // reduce
     uint16_t* y; int64_t y_sm;
     const uint32_t* swiglu_errors;  // optional: word 0 of the fused L1 kernel's workspace, copied into errors[1]
+    long long* stamps;              // tuning aid (normally null; dg_set_debug_buffer): 100 MHz wall-clock stamps of the phases, [kernel 0..2][8]
 };
 
 #ifndef DG_SHARD_TU   // (plain kernels: defined once, in the dg_api.hip translation unit)
-__device__ __forceinline__ void p2p_store16(uint8_t* dst, const uint4& v) {
-    // written through to memory (sc0 sc1): the line must not linger in this XCD's L2 when the flag goes out
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000), 0, 0, 17);
+// 16 bytes at row + off, written through to memory (sc0 sc1): the line must not linger in this XCD's L2 when the flag goes out.  `row` is
+// WAVE-UNIFORM (a row of the peer's region), the lane's part travels as the offset: a descriptor built from a per-lane pointer makes hipcc wrap
+// the store in a 64-trip waterfall loop -- the first version of these kernels issued one lane per instruction (22 of the dispatch kernel's 28 us).
+__device__ __forceinline__ void p2p_store16(uint8_t* row, int off, const uint4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), __builtin_amdgcn_make_buffer_rsrc(uniform_pointer(row), 0, 0x7ffffff0, 0x00020000), off, 0, 17);
 }
-__device__ __forceinline__ uint4 p2p_load16(const uint8_t* src) {
-    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, 16, 0x00020000), 0, 0, 17));
+__device__ __forceinline__ uint4 p2p_load16(const uint8_t* row, int off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(uniform_pointer(const_cast<uint8_t*>(row)), 0, 0x7ffffff0, 0x00020000), off, 0, 17));
 }
-// Bounded wait for `*flag == want` (system scope); false = timed out.
+// Bounded wait for `*flag == want`; false = timed out.  RELAXED polls (an acquire load would put a cache invalidate behind every poll): what the
+// waiter reads afterwards is either read past the caches (p2p_load16, system-scope atomic loads) or behind the ONE acquire fence of its caller.
 __device__ __forceinline__ bool p2p_wait_flag(const uint32_t* flag, unsigned want, long long timeout_ticks) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want)
+        return true;
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
         if (wall_clock64() - t0 > timeout_ticks)
             return false;
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(2);
     }
     return true;
 }
+// "Every store this wave issued has reached memory": all payload stores of these kernels are written through (sc0 sc1) or system-scope atomic
+// stores, so once they are acknowledged nothing of theirs sits dirty in a cache -- the write-back of the whole L2 that a system-scope RELEASE
+// fence carries (buffer_wbl2: it also flushes every unrelated dirty line, e.g. the 3.7 MB the grouped GEMM just wrote) has nothing to add.
+// Round 6 measurement (one rank, 64 tokens, top-4, hidden 7168; tools/mega_step_latency.py): with release fences and one-at-a-time claims /
+// loads the three kernels took 34 + 38 + 51 us; in this form see profiles/r06_probe/mega_p2p_step_latency.log.
+__device__ __forceinline__ void p2p_stamp(const P2pArgs& a, int kernel, int slot) {
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        a.stamps[kernel * 8 + slot] = wall_clock64();
+}
+__device__ __forceinline__ void p2p_stores_done() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 
 __global__ __launch_bounds__(256)
 void dg_moe_p2p_dispatch_kernel(const P2pArgs a) {
-    __shared__ int s_pos, s_last;
+    __shared__ int s_pos[kP2pMaxTopk], s_owner[kP2pMaxTopk], s_le[kP2pMaxTopk], s_last;
     const int t = blockIdx.x;
     uint8_t* self = a.peer[a.rank];
+    if (blockIdx.x == 0) p2p_stamp(a, 0, 0);
     if (t < a.tokens) {
-        for (int j = 0; j < a.topk; ++j) {
+        // every entry of the token claims its row slot AT ONCE (one round trip to the owners' counters instead of top-k of them in a row)
+        if (threadIdx.x < a.topk) {
+            const int j = threadIdx.x;
             const int64_t e64 = a.idx64 ? static_cast<const int64_t*>(a.topk_idx)[static_cast<int64_t>(t) * a.topk + j]
                                         : static_cast<int64_t>(static_cast<const int32_t*>(a.topk_idx)[static_cast<int64_t>(t) * a.topk + j]);
             const bool valid = e64 >= 0 && e64 < a.num_experts;          // (-1 = no expert for this entry, as the reference's masked top-k)
             const int e = valid ? static_cast<int>(e64) : 0;
             const int owner = e / a.local_experts, le = e - owner * a.local_experts;
-            uint8_t* dst = a.peer[owner];
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int pos = -1;
-                if (valid) {
-                    pos = static_cast<int>(__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(dst + a.lay.counts) + le, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-                    if (pos >= a.cap) {                                  // more rows than the owner's buffer holds: dropped, counted HERE (by the sender)
-                        atomicAdd(a.errors, 1u);
-                        pos = -1;
-                    }
+            int pos = -1;
+            if (valid) {
+                pos = static_cast<int>(__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(a.peer[owner] + a.lay.counts) + le, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                if (pos >= a.cap) {                                      // more rows than the owner's buffer holds: dropped, counted HERE (by the sender)
+                    atomicAdd(a.errors, 1u);
+                    pos = -1;
                 }
-                s_pos = pos;
-                a.pair_ok[static_cast<int64_t>(t) * a.topk + j] = pos >= 0 ? 1 : 0;
             }
-            __syncthreads();
-            const int pos = s_pos;
-            if (pos < 0)
-                continue;
-            const int64_t row = static_cast<int64_t>(le) * a.cap + pos;
-            const uint4* src = reinterpret_cast<const uint4*>(a.x + static_cast<int64_t>(t) * a.x_sm);
-            uint8_t* drow = dst + a.lay.l1_acts + row * a.hidden;
-            for (int c = threadIdx.x; c < a.hidden / 16; c += 256)
-                p2p_store16(drow + c * 16, src[c]);
-            float* dsf = reinterpret_cast<float*>(dst + a.lay.l1_sf) + static_cast<int64_t>(le) * (a.hidden / 128) * a.cap + pos;
-            for (int kb = threadIdx.x; kb < a.hidden / 128; kb += 256)
-                __hip_atomic_store(reinterpret_cast<uint32_t*>(dsf + static_cast<int64_t>(kb) * a.cap), __float_as_uint(a.x_sf[static_cast<int64_t>(t) * a.xsf_sm + kb]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (threadIdx.x == 0) {
+            s_pos[j] = pos; s_owner[j] = owner; s_le[j] = le;
+            a.pair_ok[static_cast<int64_t>(t) * a.topk + j] = pos >= 0 ? 1 : 0;
+            if (pos >= 0) {
+                uint8_t* dst = a.peer[owner];
+                const int64_t row = static_cast<int64_t>(le) * a.cap + pos;
                 __hip_atomic_store(reinterpret_cast<uint32_t*>(dst + a.lay.row_w) + row, __float_as_uint(a.topk_w[static_cast<int64_t>(t) * a.topk + j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(reinterpret_cast<int32_t*>(dst + a.lay.src_info) + row, (a.rank << 24) | (t * a.topk + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        __syncthreads();
+        if (blockIdx.x == 0) p2p_stamp(a, 0, 1);                     // the claims are back
+        // the token's row is read ONCE and pushed to every owner that granted a slot
+        const uint4* src = reinterpret_cast<const uint4*>(a.x + static_cast<int64_t>(t) * a.x_sm);
+        for (int c = threadIdx.x; c < a.hidden / 16; c += 256) {
+            const uint4 v = src[c];
+            for (int j = 0; j < a.topk; ++j)
+                if (s_pos[j] >= 0)
+                    p2p_store16(a.peer[s_owner[j]] + a.lay.l1_acts + (static_cast<int64_t>(s_le[j]) * a.cap + s_pos[j]) * a.hidden, c * 16, v);
+        }
+        if (blockIdx.x == 0) p2p_stamp(a, 0, 7);                     // (row pieces issued; the scales follow)
+        for (int kb = threadIdx.x; kb < a.hidden / 128; kb += 256) {
+            const unsigned sf = __float_as_uint(a.x_sf[static_cast<int64_t>(t) * a.xsf_sm + kb]);
+            for (int j = 0; j < a.topk; ++j)
+                if (s_pos[j] >= 0) {
+                    float* dsf = reinterpret_cast<float*>(a.peer[s_owner[j]] + a.lay.l1_sf) + static_cast<int64_t>(s_le[j]) * (a.hidden / 128) * a.cap + s_pos[j];
+                    __hip_atomic_store(reinterpret_cast<uint32_t*>(dsf + static_cast<int64_t>(kb) * a.cap), sf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+        }
     }
-    // every store of this workgroup is out before it counts itself done
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    // every store of this workgroup has reached memory before it counts itself done
+    if (blockIdx.x == 0) p2p_stamp(a, 0, 2);                         // stores issued
+    p2p_stores_done();
     __syncthreads();
+    if (blockIdx.x == 0) p2p_stamp(a, 0, 3);                         // ... and acknowledged
     uint32_t* done = reinterpret_cast<uint32_t*>(self + a.lay.done);
     if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!s_last)
         return;
     // ---- the last workgroup of this rank's dispatch: announce, wait for everybody's rows, publish the counts ----
+    p2p_stamp(a, 0, 4);                                              // the last workgroup knows it is the last
     if (threadIdx.x == 0)
         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if (threadIdx.x < a.world)
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[threadIdx.x] + a.lay.arrived) + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x < a.world)
+    if (threadIdx.x < a.world) {
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[threadIdx.x] + a.lay.arrived) + a.rank, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!p2p_wait_flag(reinterpret_cast<const uint32_t*>(self + a.lay.arrived) + threadIdx.x, a.epoch, a.timeout_ticks))
             atomicAdd(a.errors + 2, 1u);
+    }
     __syncthreads();
+    p2p_stamp(a, 0, 5);                                              // every peer has arrived
+    // ONE system-scope acquire per call: lines of the region that an earlier step left in this GPU's caches (a coarse-grained region: the
+    // previous step's GEMM reads) must not answer for what the peers have just written; the kernels that read the rows start behind it
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     for (int le = threadIdx.x; le < a.local_experts; le += 256) {
         const unsigned c = __hip_atomic_load(reinterpret_cast<const uint32_t*>(self + a.lay.counts) + le, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         a.masked_m[le] = static_cast<int>(c < static_cast<unsigned>(a.cap) ? c : static_cast<unsigned>(a.cap));
     }
+    p2p_stamp(a, 0, 6);
 }
 
 __global__ __launch_bounds__(256)
@@ -596,70 +629,87 @@ void dg_moe_p2p_combine_kernel(const P2pArgs a) {
     __shared__ int s_last;
     uint8_t* self = a.peer[a.rank];
     const int total = a.local_experts * a.cap;
+    if (blockIdx.x == 0) p2p_stamp(a, 1, 0);
     for (int r = blockIdx.x; r < total; r += gridDim.x) {
         const int le = r / a.cap, slot = r - le * a.cap;
         if (slot >= a.masked_m[le])
             continue;
-        const int info = reinterpret_cast<const int32_t*>(self + a.lay.src_info)[r];
+        const int info = __hip_atomic_load(reinterpret_cast<const int32_t*>(self + a.lay.src_info) + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const int src_rank = (info >> 24) & 0xff, pair = info & 0xffffff;
         const uint4* src = reinterpret_cast<const uint4*>(a.l2_out + le * a.l2_sg + static_cast<int64_t>(slot) * a.l2_sm);
         uint8_t* drow = a.peer[src_rank] + a.lay.y_rows + static_cast<int64_t>(pair) * a.hidden * 2;
         for (int c = threadIdx.x; c < a.hidden / 8; c += 256)
-            p2p_store16(drow + c * 16, src[c]);
+            p2p_store16(drow, c * 16, src[c]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (blockIdx.x == 0) p2p_stamp(a, 1, 1);
+    p2p_stores_done();
     __syncthreads();
+    if (blockIdx.x == 0) p2p_stamp(a, 1, 2);
     uint32_t* done = reinterpret_cast<uint32_t*>(self + a.lay.done) + 1;
     if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!s_last)
         return;
     // ---- the last workgroup: the slot counters are free for the next call, then everybody may know that this owner is done ----
+    p2p_stamp(a, 1, 3);
     if (threadIdx.x == 0)
         __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int le = threadIdx.x; le < a.local_experts; le += 256)
         __hip_atomic_store(reinterpret_cast<uint32_t*>(self + a.lay.counts) + le, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    p2p_stores_done();
     __syncthreads();
     if (threadIdx.x < a.world)
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[threadIdx.x] + a.lay.combined) + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[threadIdx.x] + a.lay.combined) + a.rank, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    p2p_stamp(a, 1, 4);
 }
 
+// grid (tokens, ceil(hidden / 2048)): a thread owns 8 columns of one token and has the rows of ALL its top-k entries in flight together (the
+// returned rows are read past the caches: one at a time they were top-k x hidden / 2048 dependent ~2.5 us round trips per thread)
 __global__ __launch_bounds__(256)
 void dg_moe_p2p_reduce_kernel(const P2pArgs a) {
     uint8_t* self = a.peer[a.rank];
+    if (blockIdx.x == 0 && blockIdx.y == 0) p2p_stamp(a, 2, 0);
     if (threadIdx.x < a.world)
-        if (!p2p_wait_flag(reinterpret_cast<const uint32_t*>(self + a.lay.combined) + threadIdx.x, a.epoch, a.timeout_ticks) && blockIdx.x == 0)
+        if (!p2p_wait_flag(reinterpret_cast<const uint32_t*>(self + a.lay.combined) + threadIdx.x, a.epoch, a.timeout_ticks) && blockIdx.x == 0 && blockIdx.y == 0)
             atomicAdd(a.errors + 3, 1u);
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.swiglu_errors != nullptr)
+    if (blockIdx.x == 0 && blockIdx.y == 0) p2p_stamp(a, 2, 1);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.swiglu_errors != nullptr)
         a.errors[1] = *a.swiglu_errors;
     const int t = blockIdx.x;
-    if (t >= a.tokens)
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 8;
+    if (t >= a.tokens || c >= a.hidden)
         return;
     const uint8_t* rows = self + a.lay.y_rows + static_cast<int64_t>(t) * a.topk * a.hidden * 2;
-    for (int c = threadIdx.x * 8; c < a.hidden; c += 256 * 8) {
-        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // as dg_moe_combine_kernel: top-k order, FP32, absent entries skipped
-        for (int j = 0; j < a.topk; ++j) {
-            if (!a.pair_ok[static_cast<int64_t>(t) * a.topk + j])
+    const uint8_t* ok = a.pair_ok + static_cast<int64_t>(t) * a.topk;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              // as dg_moe_combine_kernel: top-k order, FP32, absent entries skipped
+    for (int j0 = 0; j0 < a.topk; j0 += 8) {
+        uint4 v[8];
+        bool have[8];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            have[u] = j0 + u < a.topk && ok[j0 + u] != 0;
+            if (have[u])
+                v[u] = p2p_load16(rows + static_cast<int64_t>(j0 + u) * a.hidden * 2, c * 2);
+        }
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (!have[u])
                 continue;
-            const uint4 v = p2p_load16(rows + (static_cast<int64_t>(j) * a.hidden + c) * 2);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 sum[2 * i] += bf16_lo(w[i]);
                 sum[2 * i + 1] += bf16_hi(w[i]);
             }
         }
-        uint4 out;
-        out.x = pack_bf16(sum[0], sum[1]); out.y = pack_bf16(sum[2], sum[3]);
-        out.z = pack_bf16(sum[4], sum[5]); out.w = pack_bf16(sum[6], sum[7]);
-        *reinterpret_cast<uint4*>(a.y + static_cast<int64_t>(t) * a.y_sm + c) = out;
     }
+    uint4 out;
+    out.x = pack_bf16(sum[0], sum[1]); out.y = pack_bf16(sum[2], sum[3]);
+    out.z = pack_bf16(sum[4], sum[5]); out.w = pack_bf16(sum[6], sum[7]);
+    *reinterpret_cast<uint4*>(a.y + static_cast<int64_t>(t) * a.y_sm + c) = out;
+    if (blockIdx.x == 0 && blockIdx.y == 0) p2p_stamp(a, 2, 2);
 }
 #endif  // DG_SHARD_TU
 
