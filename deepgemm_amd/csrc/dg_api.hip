@@ -1639,7 +1639,7 @@ int dg_moe_scatter_to_masked(const void* x_fp8, const float* x_sf, const void* t
                              void* a_out, float* sfa_out, float* row_weight_out, int32_t* slot_out, int32_t* masked_m_out, void* error_word,
                              int64_t a_stride_g, int64_t a_stride_m, int64_t sfa_stride_g, int64_t sfa_stride_k, int64_t row_weight_stride_g,
                              void* stream) {
-    DG_CHECK(tokens >= 0 && hidden > 0 && hidden % 128 == 0 && topk > 0 && num_experts > 0 && max_m > 0);
+    DG_CHECK(tokens >= 0 && hidden > 0 && hidden % 128 == 0 && topk > 0 && topk <= dg::kMoeMaxTopk && num_experts > 0 && max_m > 0);
     DG_CHECK(x_fp8 != nullptr && x_sf != nullptr && topk_idx != nullptr && topk_weights != nullptr && a_out != nullptr && sfa_out != nullptr &&
              row_weight_out != nullptr && slot_out != nullptr && masked_m_out != nullptr && error_word != nullptr);
     DG_CHECK(aligned16(x_fp8) && aligned16(a_out) && x_stride_m % 16 == 0 && a_stride_m % 16 == 0 && a_stride_g % 16 == 0);
@@ -1664,7 +1664,7 @@ int dg_moe_combine_from_masked(const void* y2_bf16, const int32_t* slot, int tok
     DG_CHECK(y2_bf16 != nullptr && slot != nullptr && y_bf16 != nullptr && aligned16(y2_bf16) && aligned16(y_bf16));
     if (tokens == 0)
         return 0;
-    hipLaunchKernelGGL(dg::dg_moe_combine_kernel, dim3(static_cast<unsigned>(tokens)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(dg::dg_moe_combine_kernel, dim3(static_cast<unsigned>(tokens), static_cast<unsigned>((hidden + 2047) / 2048)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t*>(y2_bf16), slot, tokens, topk, hidden, y2_row_stride, static_cast<uint16_t*>(y_bf16), y_stride_m);
     DG_HIP_CHECK(hipGetLastError());
     return 0;

@@ -362,6 +362,7 @@ void dg_fp8_gemm_stream_swiglu_kernel(const GemmParams p, const SwigluOut o) {
 // arrival order of the claims; no RESULT does: every row of the grouped GEMMs and of the per-token re-quantisation is computed
 // independently of its neighbours, and the combine sums a token's rows in top-k order.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kMoeMaxTopk = 32;      // top-k entries per token of the scatter kernel (their slot claims go out together, one per thread)
 struct MoeRoute {
     const uint8_t* x; const float* x_sf; const void* topk_idx; const float* topk_w;
     int tokens, hidden, topk, num_experts, max_m, idx64;
@@ -373,39 +374,42 @@ struct MoeRoute {
 #ifndef DG_SHARD_TU   // (a plain kernel: defined once, in the dg_api.hip translation unit -- see kernel_instances.inc)
 __global__ __launch_bounds__(256)
 void dg_moe_scatter_kernel(const MoeRoute r) {
-    __shared__ int s_pos;
+    // (round 6: the token's top-k entries claim their slots TOGETHER -- one atomic round trip instead of top-k in a row -- and the row is read once)
+    __shared__ int s_pos[kMoeMaxTopk], s_e[kMoeMaxTopk];
     const int t = blockIdx.x;
-    for (int j = 0; j < r.topk; ++j) {
+    if (threadIdx.x < r.topk) {
+        const int j = threadIdx.x;
         const int64_t e64 = r.idx64 ? static_cast<const int64_t*>(r.topk_idx)[static_cast<int64_t>(t) * r.topk + j]
                                     : static_cast<int64_t>(static_cast<const int32_t*>(r.topk_idx)[static_cast<int64_t>(t) * r.topk + j]);
         const bool valid = e64 >= 0 && e64 < r.num_experts;          // (-1 = no expert for this entry, as the reference's masked top-k)
-        const int e = static_cast<int>(e64);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int pos = -1;
-            if (valid) {
-                pos = atomicAdd(r.counts + e, 1);
-                if (pos >= r.max_m) {                                // more rows than the buffer was sized for: dropped, counted, visible
-                    atomicAdd(r.errors, 1u);
-                    atomicSub(r.counts + e, 1);
-                    pos = -1;
-                }
+        const int e = valid ? static_cast<int>(e64) : 0;
+        int pos = -1;
+        if (valid) {
+            pos = atomicAdd(r.counts + e, 1);
+            if (pos >= r.max_m) {                                    // more rows than the buffer was sized for: dropped, counted, visible
+                atomicAdd(r.errors, 1u);
+                atomicSub(r.counts + e, 1);
+                pos = -1;
             }
-            s_pos = pos;
-            r.slot[static_cast<int64_t>(t) * r.topk + j] = pos < 0 ? -1 : e * r.max_m + pos;
         }
-        __syncthreads();
-        const int pos = s_pos;
-        if (pos < 0)
-            continue;
-        const uint4* src = reinterpret_cast<const uint4*>(r.x + static_cast<int64_t>(t) * r.x_sm);
-        uint4* dst = reinterpret_cast<uint4*>(r.a + e * r.a_sg + static_cast<int64_t>(pos) * r.a_sm);
-        for (int c = threadIdx.x; c < r.hidden / 16; c += 256)
-            dst[c] = src[c];
-        for (int kb = threadIdx.x; kb < r.hidden / 128; kb += 256)
-            r.sfa[e * r.sfa_sg + kb * r.sfa_sk + pos] = r.x_sf[static_cast<int64_t>(t) * r.xsf_sm + kb];
-        if (threadIdx.x == 0)
+        s_pos[j] = pos; s_e[j] = e;
+        r.slot[static_cast<int64_t>(t) * r.topk + j] = pos < 0 ? -1 : e * r.max_m + pos;
+        if (pos >= 0)
             r.rw[e * r.rw_sg + pos] = r.topk_w[static_cast<int64_t>(t) * r.topk + j];
+    }
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(r.x + static_cast<int64_t>(t) * r.x_sm);
+    for (int c = threadIdx.x; c < r.hidden / 16; c += 256) {
+        const uint4 v = src[c];
+        for (int j = 0; j < r.topk; ++j)
+            if (s_pos[j] >= 0)
+                reinterpret_cast<uint4*>(r.a + s_e[j] * r.a_sg + static_cast<int64_t>(s_pos[j]) * r.a_sm)[c] = v;
+    }
+    for (int kb = threadIdx.x; kb < r.hidden / 128; kb += 256) {
+        const float sf = r.x_sf[static_cast<int64_t>(t) * r.xsf_sm + kb];
+        for (int j = 0; j < r.topk; ++j)
+            if (s_pos[j] >= 0)
+                r.sfa[s_e[j] * r.sfa_sg + kb * r.sfa_sk + s_pos[j]] = sf;
     }
 }
 #endif
@@ -415,26 +419,39 @@ void dg_moe_scatter_kernel(const MoeRoute r) {
 __global__ __launch_bounds__(256)
 void dg_moe_combine_kernel(const uint16_t* y2, const int32_t* slot, int tokens, int topk, int hidden, int64_t y2_row_stride, uint16_t* y,
                            int64_t y_sm) {
+    // grid (tokens, ceil(hidden / 2048)), round 6: a thread owns 8 columns of one token and has the rows of all its entries in flight together
+    // (one token per workgroup with one row at a time: top-k x hidden / 2048 dependent (slot, row) load pairs per thread, 10.4 us for 64 tokens)
     const int t = blockIdx.x;
-    for (int c = threadIdx.x * 8; c < hidden; c += 256 * 8) {
-        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < topk; ++j) {
-            const int s = slot[static_cast<int64_t>(t) * topk + j];
-            if (s < 0)
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 8;
+    if (c >= hidden)
+        return;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < topk; j0 += 8) {
+        int s[8];
+        uint4 v[8];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u)
+            s[u] = j0 + u < topk ? slot[static_cast<int64_t>(t) * topk + j0 + u] : -1;
+        #pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s[u] >= 0)
+                v[u] = *reinterpret_cast<const uint4*>(y2 + static_cast<int64_t>(s[u]) * y2_row_stride + c);
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s[u] < 0)
                 continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(y2 + static_cast<int64_t>(s) * y2_row_stride + c);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 sum[2 * i] += bf16_lo(w[i]);
                 sum[2 * i + 1] += bf16_hi(w[i]);
             }
         }
-        uint4 out;
-        out.x = pack_bf16(sum[0], sum[1]); out.y = pack_bf16(sum[2], sum[3]);
-        out.z = pack_bf16(sum[4], sum[5]); out.w = pack_bf16(sum[6], sum[7]);
-        *reinterpret_cast<uint4*>(y + static_cast<int64_t>(t) * y_sm + c) = out;
     }
+    uint4 out;
+    out.x = pack_bf16(sum[0], sum[1]); out.y = pack_bf16(sum[2], sum[3]);
+    out.z = pack_bf16(sum[4], sum[5]); out.w = pack_bf16(sum[6], sum[7]);
+    *reinterpret_cast<uint4*>(y + static_cast<int64_t>(t) * y_sm + c) = out;
 }
 #endif
 
