@@ -59,6 +59,11 @@ def golden_quantisers():
 
 
 @pytest.fixture(scope='session')
+def golden_gran32():
+    return Golden('gran32.npz')
+
+
+@pytest.fixture(scope='session')
 def golden_gemm():
     return Golden('gemm_cases.npz')
 

@@ -12,7 +12,7 @@ The reference's CUDA kernels cannot run here (no NVIDIA GPU, no nvcc, CUTLASS su
 kernel-output goldens; each GEMM fixture instead stores the reference-quantised operands, the reference test result and
 this repository's oracle output with its reference-calc_diff, which pins the oracle at the reference's own gate (< 1e-3).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [quantisers|gemm|layout|gran32 ...]
 """
 import importlib.util
 import os
@@ -113,6 +113,41 @@ def gemm_fixtures():
     print('gemm_cases.npz', len(out), 'arrays')
 
 
+def gran32_fixtures():
+    """Scale granularity 32 along K with UE8M0 scales (the reference's SM100 MX recipe for FP8 x FP8: csrc/apis/gemm.hpp:311-312,
+    tests/generators.py:192-194, 230: both operands through per_token_cast_to_fp8(..., gran_k=32)): the reference quantiser's bytes, its packed
+    words, and one GEMM case with the reference test expression and this repository's oracle at gran_k = 32."""
+    import oracle
+    out = {}
+    torch.manual_seed(4321)
+    for name, shape in {'tok32_5x200': (5, 200), 'tok32_130x384': (130, 384)}.items():
+        x = torch.randn(shape, dtype=torch.bfloat16) * 3
+        x[0, :7] = 0
+        out[f'{name}_x'] = bits(x)
+        q, sf = ref_math.per_token_cast_to_fp8(x, use_ue8m0=True, gran_k=32)
+        out[f'{name}_q'], out[f'{name}_sf'] = bits(q), bits(sf)
+    x = torch.randn((64, 512), dtype=torch.bfloat16)
+    out['tok32_packed_x'] = bits(x)
+    q, sf = ref_math.per_token_cast_to_fp8(x, use_ue8m0=True, gran_k=32, use_packed_ue8m0=True)
+    out['tok32_packed_q'], out['tok32_packed_sf'] = bits(q), bits(sf)
+    m, n, k = 96, 136, 640
+    torch.manual_seed(0)
+    a = torch.randn((m, k), dtype=torch.bfloat16)
+    b = torch.randn((n, k), dtype=torch.bfloat16)
+    ref_d = (a.float() @ b.float().t()).to(torch.bfloat16)                # tests/generators.py:312
+    a_q, sfa = ref_math.per_token_cast_to_fp8(a, use_ue8m0=True, gran_k=32)
+    b_q, sfb = ref_math.per_token_cast_to_fp8(b, use_ue8m0=True, gran_k=32)
+    d = torch.empty((m, n), dtype=torch.bfloat16)
+    oracle.fp8_gemm_nt(a_q, sfa, b_q, sfb, d, gran_n=1, gran_k=32)
+    diff = float(ref_numeric.calc_diff(d, ref_d))
+    assert diff < 1e-3, diff
+    out['g32_a_q'], out['g32_sfa'], out['g32_b_q'], out['g32_sfb'] = bits(a_q), bits(sfa), bits(b_q), bits(sfb)
+    out['g32_ref_d'], out['g32_oracle_d'], out['g32_ref_calc_diff'] = bits(ref_d), bits(d), np.float64(diff)
+    print('gran_k = 32: reference calc_diff(oracle, ref_d) =', diff)
+    np.savez_compressed(os.path.join(HERE, 'gran32.npz'), **out)
+    print('gran32.npz', len(out), 'arrays')
+
+
 def load_ref_function(rel_path: str, name: str, namespace: dict):
     """Compiles ONE top-level function out of a reference file that cannot be imported as a whole."""
     import ast
@@ -144,6 +179,6 @@ def layout_fixtures():
 
 
 if __name__ == '__main__':
-    quantiser_fixtures()
-    gemm_fixtures()
-    layout_fixtures()
+    makers = {'quantisers': quantiser_fixtures, 'gemm': gemm_fixtures, 'layout': layout_fixtures, 'gran32': gran32_fixtures}
+    for which in sys.argv[1:] or list(makers):               # (python tests/golden/make_golden.py [quantisers|gemm|layout|gran32 ...])
+        makers[which]()
