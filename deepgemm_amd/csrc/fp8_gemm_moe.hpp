@@ -691,6 +691,8 @@ void dg_moe_p2p_reduce_kernel(const P2pArgs a) {
         if (!p2p_wait_flag(reinterpret_cast<const uint32_t*>(self + a.lay.combined) + threadIdx.x, a.epoch, a.timeout_ticks) && blockIdx.x == 0 && blockIdx.y == 0)
             atomicAdd(a.errors + 3, 1u);
     __syncthreads();
+    // (no acquire fence: every returned row is read with system-scope loads -- sc0 sc1, coherent by themselves like the polls of the flag; a
+    //  cache invalidate in each of the (token, column block) workgroups cost the kernel 6.5 us of its 9; pair_ok is an earlier kernel's output)
     if (blockIdx.x == 0 && blockIdx.y == 0) p2p_stamp(a, 2, 1);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.swiglu_errors != nullptr)
         a.errors[1] = *a.swiglu_errors;
