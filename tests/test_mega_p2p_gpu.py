@@ -97,6 +97,31 @@ def test_p2p_protocol_with_one_rank_is_the_scatter_gather_path():
         buf.destroy(); ref_buf.destroy()
 
 
+@pytest.mark.parametrize('num_experts,top_k,hidden,inter,tokens', [(16, 9, 2304, 256, 33), (8, 2, 4096, 384, 64), (32, 8, 1024, 128, 7)])
+def test_p2p_one_rank_other_geometries(num_experts, top_k, hidden, inter, tokens):
+    """More than eight entries per token (the reduce kernel's second batch of rows in flight), a hidden size over several 2048-column blocks with a
+    partial last one, few tokens: the five-launch step against the scatter / gather path, bit for bit; both against themselves on a second step."""
+    import deepgemm_amd as dg
+    from deepgemm_amd import mega
+    max_tokens = 64
+    l1, l2 = _weights(0, num_experts, hidden, inter)
+    ref_buf = mega.SymmBuffer(None, num_experts, max_tokens, top_k, hidden, inter)
+    buf = mega.SymmBuffer(None, num_experts, max_tokens, top_k, hidden, inter, p2p=True)
+    try:
+        for step in range(2):
+            x, idx, w = _inputs(3, step, tokens, num_experts, top_k, hidden)
+            x, idx, w = (x[0].cuda(), x[1].cuda()), idx.cuda(), w.cuda()
+            want = _one_rank(ref_buf, l1, l2, x, idx, w, hidden, 10.0)
+            _fill(buf, x, idx, w)
+            y = torch.full((tokens, hidden), float('nan'), dtype=torch.bfloat16, device='cuda')
+            dg.fp8_mega_moe(y, l1, l2, buf, activation_clamp=10.0)
+            torch.cuda.synchronize()
+            assert buf.errors.tolist() == [0, 0, 0, 0], (step, buf.errors.tolist())
+            assert torch.equal(y.view(torch.int16), want.view(torch.int16)), step
+    finally:
+        buf.destroy(); ref_buf.destroy()
+
+
 def _worker(rank: int, world: int, port: int, queue, scenario: str):
     try:
         import torch.distributed as dist
