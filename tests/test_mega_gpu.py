@@ -174,7 +174,8 @@ def _unfused_moe(x, topk_idx, topk_w, w1, w2, clamp):
     return y.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize('tokens,experts,topk,hidden,inter,clamp', [(37, 8, 2, 512, 256, None), (64, 4, 3, 1024, 512, 10.0), (5, 16, 4, 256, 128, None)])
+@pytest.mark.parametrize('tokens,experts,topk,hidden,inter,clamp', [(37, 8, 2, 512, 256, None), (64, 4, 3, 1024, 512, 10.0), (5, 16, 4, 256, 128, None),
+                                                                         (21, 16, 9, 2304, 128, None)])     # (round 6: > 8 entries per token, two column blocks of the combine)
 def test_reference_shaped_mega_moe_entry(tokens, experts, topk, hidden, inter, clamp):
     """fp8_mega_moe(y, l1, l2, sym_buffer) (deep_gemm/mega/__init__.py:155-173) at world size 1: routing -> fused L1 -> L2 -> combine ==
     the unfused pipeline bit for bit; entries without an expert (-1) are skipped; the per-expert counts land in the stats tensor; the
