@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0|dense_ue8m0_g32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0|dense_ue8m0_g32|wgrad_ue8m0|kgrouped_ue8m0|kgrouped_ue8m0_g32]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -37,10 +37,10 @@ PEAK_HBM_GBS = 8000.0
 RECIPE_1_1_128_ROOF = 32.0 / 62.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
              'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
-             'contiguous_ue8m0', 'dense_ue8m0_g32']
+             'contiguous_ue8m0', 'dense_ue8m0_g32', 'wgrad_ue8m0', 'kgrouped_ue8m0', 'kgrouped_ue8m0_g32']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
              'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
-             'contiguous_ue8m0', 'dense_ue8m0_g32']
+             'contiguous_ue8m0', 'dense_ue8m0_g32', 'wgrad_ue8m0', 'kgrouped_ue8m0', 'kgrouped_ue8m0_g32']
 # HBM-bound workloads whose per-call weight stream is smaller than the 256 MiB Infinity Cache (MALL): the rotation must cover more than the
 # cache, or the "fraction of 8 TB/s" is a cache-read rate (the reference flushes 8 GB between timed iterations: deep_gemm/testing/bench.py:93,108).
 # sets x (bytes not re-used across calls) >= COLD_ROTATION_BYTES; the other HBM-bound lines stream >= 235 MB of weights per call x >= 2 sets.
@@ -318,21 +318,53 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
                             + ('under-filled launch: K split' if name == 'dgrad_ksplit' else 'K tail on the fast path' + (', packed UE8M0 scales' if packed else '')) + ')',
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
-    elif name in ('wgrad', 'wgrad_ksplit'):
-        # (wgrad_ksplit: the sweep's wgrad entry of a 576-wide layer -- 48 tiles for 256 CUs: the K pieces run as groups of one launch)
-        m, n, k = (4096, 4096, 7168) if name == 'wgrad' else (576, 4096, 7168)
+    elif name in ('wgrad', 'wgrad_ksplit', 'wgrad_ue8m0'):
+        # (wgrad_ksplit: the sweep's wgrad entry of a 576-wide layer -- 48 tiles for 256 CUs: the K pieces run as groups of one launch;
+        #  wgrad_ue8m0, round 6: the same GEMM with the reference's SM100 scale format -- packed UE8M0 words per row of both operands -- on the
+        #  hardware-scaled kernel: no FP32 promotion, so the (1, 1, 128) VALU roof does not apply)
+        m, n, k = (576, 4096, 7168) if name == 'wgrad_ksplit' else (4096, 4096, 7168)
+        packed = name == 'wgrad_ue8m0'
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float, per_token_b=True)
-            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
-            b = (case.b[0], dg.get_mn_major_tma_aligned_tensor(case.b[1]))
+            case = gen.generate_normal(m, n, k, accumulate=True, out_dtype=torch.float, per_token_b=True, use_ue8m0=packed)
+            if packed:
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b)
+            else:
+                a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+                b = (case.b[0], dg.get_mn_major_tma_aligned_tensor(case.b[1]))
+            case.a_bf16 = case.b_bf16 = None
             cases.append(case)
             calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d, c=c.d, recipe=(1, 1, 128)))
         flops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * (m + n) * (k // 128) + 8 * m * n           # FP32 D read and written
-        desc = {'workload': f'fp8_gemm_nt recipe (1, 1, 128), FP32 accumulate into D, M={m} N={n} K={k} (wgrad form, tests/generators.py:146-153)',
-                'm': m, 'n': n, 'k': k, 'recipe_roof': RECIPE_1_1_128_ROOF}
+        desc = {'workload': f'fp8_gemm_nt recipe (1, 1, 128), FP32 accumulate into D, M={m} N={n} K={k} (wgrad form, tests/generators.py:146-153)' +
+                            (', packed UE8M0 scales (hardware-scaled MFMA)' if packed else ''),
+                'm': m, 'n': n, 'k': k}
+        if not packed:
+            desc['recipe_roof'] = RECIPE_1_1_128_ROOF
         check = lambda: float('nan')                               # noqa: E731  (D keeps accumulating: parity is the tests' job)
+    elif name in ('kgrouped_ue8m0', 'kgrouped_ue8m0_g32'):
+        # the reference's SM100 form of the K-grouped GEMM (round 6): MN-major operands, UE8M0 scales of granularity 128 / 32 handed over as packed
+        # words; the call = re-majoring pass of both operands + the hardware-scaled K-grouped kernel
+        import random
+        g, m, n, ek = 8, 4096, 7168, 4096
+        gran_k = 32 if name.endswith('_g32') else 128
+        random.seed(0)
+        ks = [max(128, int(ek * random.uniform(0.7, 1.3)) // 128 * 128) for _ in range(g)]
+        for i in range(min(sets, 2)):
+            gen.reset_seed(i)
+            case = gen.generate_k_grouped_contiguous_ue8m0(g, m, n, ks, gran_k)
+            a = (case.a[0], gen.pack_k_grouped_ue8m0(case.a[1], ks, gran_k))
+            b = (case.b[0], gen.pack_k_grouped_ue8m0(case.b[1], ks, gran_k))
+            case.a_groups = case.b_groups = None
+            cases.append(case)
+            calls.append(lambda a=a, b=b, c=case: dg.k_grouped_fp8_gemm_tn_contiguous(a, b, c.d, c.ks, c.grouped_layout, c=c.d, recipe=(1, 1, gran_k)))
+        flops = 2.0 * m * n * sum(ks)
+        nbytes = (m + n) * sum(ks) * (1 + 1 / gran_k) + 8.0 * g * m * n
+        desc = {'workload': f'k_grouped_fp8_gemm_tn_contiguous G={g} M={m} N={n} sum_k={sum(ks)}, packed UE8M0 scales of granularity {gran_k} '
+                            '(the reference\'s SM100 form, tests/generators.py:190-213; re-majoring pass included)',
+                'm': m, 'n': n, 'sum_k': sum(ks), 'groups': g}
+        check = lambda: float('nan')                               # noqa: E731
     elif name == 'kgrouped':
         import random
         g, m, n, ek = 8, 4096, 7168, 4096

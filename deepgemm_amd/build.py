@@ -18,7 +18,7 @@ import tempfile
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libdeepgemm_amd.so')
 SOURCES = ['dg_api.hip', 'dg_shard.hip', 'kernel_instances.inc']
-NUM_SHARDS = 8                          # shard ids 0 .. NUM_SHARDS - 1 of kernel_instances.inc
+NUM_SHARDS = 9                          # shard ids 0 .. NUM_SHARDS - 1 of kernel_instances.inc
 MONOLITHIC = os.environ.get('DG_MONOLITHIC', '') not in ('', '0')
 HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_moe.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

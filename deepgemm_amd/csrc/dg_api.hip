@@ -2017,6 +2017,142 @@ int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const
     return 0;
 }
 
+int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, float* d,
+                                int m, int n, int total_k, const int32_t* ks_host, const int32_t* psum_layout, int num_groups,
+                                int k_alignment, int gran_k, int64_t a_stride_m, int64_t b_stride_n,
+                                int64_t sfa_stride_k, int64_t sfb_stride_k, void* stream) {
+    DG_CHECK(m >= 0 && n >= 0 && num_groups >= 0 && total_k >= 0);
+    if (m == 0 || n == 0 || num_groups == 0 || total_k == 0)
+        return 0;
+    DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr);
+    DG_CHECK(gran_k == 128 || gran_k == 32);
+    DG_CHECK(k_alignment > 0 && k_alignment % 32 == 0);
+    const bool psum = psum_layout != nullptr;
+    DG_CHECK(psum || ks_host != nullptr);
+    DG_CHECK(num_groups <= (psum ? 128 : dg::kMaxKGroups));
+    dg::GemmParams p{};
+    p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.d = d;
+    p.sfa = reinterpret_cast<const float*>(sfa_packed); p.sfb = reinterpret_cast<const float*>(sfb_packed);
+    p.layout = psum_layout;
+    p.m = m; p.n = n; p.k = total_k; p.num_groups = num_groups;
+    p.a_sm = a_stride_m; p.a_sk = 1; p.b_sn = b_stride_n; p.b_sk = 1;
+    p.sfa_sm = 1; p.sfa_sk = sfa_stride_k; p.sfb_sn = 1; p.sfb_sk = sfb_stride_k;
+    p.d_sm = n; p.d_sg = static_cast<int64_t>(m) * n;
+    p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1;
+    p.m_alignment = k_alignment; p.kg_blocks = 0; p.kg_psum = psum ? 1 : 0;
+    if (!psum) {
+        int64_t sum_k = 0;
+        for (int g = 0; g < num_groups; ++g) {
+            DG_CHECK(ks_host[g] >= 0 && ks_host[g] % 32 == 0);
+            p.kg_prefix[g] = static_cast<int>(sum_k);
+            sum_k += ks_host[g];
+            DG_CHECK(sum_k <= total_k);
+        }
+        p.kg_prefix[num_groups] = static_cast<int>(sum_k);
+    }
+    // K-major rows the LDS-DMA pieces can address (16-byte chunks, 32-bit offsets), scale rows the 16-byte loads can (see fast_eligible)
+    const bool ok = aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= total_k && b_stride_n >= total_k &&
+                    a_stride_m <= (1 << 22) && b_stride_n <= (1 << 22) && aligned16(sfa_packed) && aligned16(sfb_packed) &&
+                    sfa_stride_k % 4 == 0 && sfb_stride_k % 4 == 0 && sfa_stride_k >= m && sfb_stride_k >= n;
+    if (!ok) {
+        g_last_error = "dg_k_grouped_fp8_gemm_ue8m0 needs K-major FP8 operands with 16-byte aligned rows (pitch <= 4 MiB) and packed scale rows "
+                       "whose pitch is a multiple of four words behind a 16-byte aligned base (nothing was launched)";
+        return 3;
+    }
+    p.gemm_type = dg::kKGrouped;
+    const bool big = m > 128;
+    const int bm = big ? 256 : 128;
+    p.num_m_tiles = ceil_div(m, bm);
+    p.num_n_tiles = ceil_div(n, 256);
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    p.d_vec_ok = aligned16(p.d) && (p.d_sm * 4) % 16 == 0 && (p.d_sg * 4) % 16 == 0;
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * num_groups;
+    if (grid > 0x7fffffffL)
+        return fail(__FILE__, __LINE__, "grid too large");
+    // One workgroup per tile, group-major: the hardware hands the next tile to whichever CU frees up, so groups of different K extents balance.
+    const dim3 g3(static_cast<unsigned>(grid)), b3(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gran_k == 32) {
+        g_last_config = big ? "e8_quad_kg_g32_256x256" : "e8_quad_kg_g32_128x256";
+        if (big) hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true, true>), g3, b3, 0, s, p);
+        else hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true, true>), g3, b3, 0, s, p);
+    } else {
+        g_last_config = big ? "e8_quad_kg_256x256" : "e8_quad_kg_128x256";
+        if (big) hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, false, true>), g3, b3, 0, s, p);
+        else hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, false, true>), g3, b3, 0, s, p);
+    }
+    DG_HIP_CHECK(hipGetLastError());
+    if (env_knobs().print_configs)
+        fprintf(stderr, "[deepgemm_amd] ue8m0 k-grouped m=%d n=%d total_k=%d groups=%d gran_k=%d -> %s\n", m, n, total_k, num_groups, gran_k,
+                g_last_config.c_str());
+    return 0;
+}
+
+namespace dg {
+// FP32 power-of-two scales of a K-grouped operand -> the packed words of the K-grouped hardware-scaled kernels (see the header).  One thread per
+// (packed row, four consecutive mn): finds the packed row's group by one pass over the groups, reads up to four scale rows, keeps the exponent bytes.
+__global__ __launch_bounds__(256)
+void dg_pack_sf_k_grouped_ue8m0_kernel(const float* sf, int32_t* out, const int32_t* group_ks, int num_groups, int mn, int sf_k, int packed_sf_k,
+                                       int gran_k, int k_alignment, int use_psum) {
+    const int packed_row = blockIdx.y;
+    const int mn4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (mn4 >= mn)
+        return;
+    int sf_rows = 0, packed_rows = 0, prev_end = 0, row0 = -1, row_end = 0, first_packed = 0;
+    for (int g = 0; g < num_groups; ++g) {
+        int group_k;
+        if (use_psum) {
+            const int end = group_ks[g];
+            group_k = end - (prev_end + k_alignment - 1) / k_alignment * k_alignment;
+            prev_end = end;
+        } else {
+            group_k = group_ks[g];
+        }
+        const int rows = group_k > 0 ? (group_k + gran_k - 1) / gran_k : 0;
+        if (packed_row < packed_rows + (rows + 3) / 4) {
+            row0 = sf_rows; row_end = sf_rows + rows; first_packed = packed_rows;
+            break;
+        }
+        sf_rows += rows;
+        packed_rows += (rows + 3) / 4;
+    }
+    if (row0 < 0)
+        return;                                         // a packed row beyond the groups' last: left as it is (the reference returns as well)
+    uint32_t word[4] = {0, 0, 0, 0};
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = row0 + (packed_row - first_packed) * 4 + j;
+        if (r < row_end && r < sf_k) {
+            const uint4 v = *reinterpret_cast<const uint4*>(sf + static_cast<int64_t>(r) * mn + mn4);
+            word[0] |= ((v.x >> 23) & 0xffu) << (8 * j);
+            word[1] |= ((v.y >> 23) & 0xffu) << (8 * j);
+            word[2] |= ((v.z >> 23) & 0xffu) << (8 * j);
+            word[3] |= ((v.w >> 23) & 0xffu) << (8 * j);
+        }
+    }
+    *reinterpret_cast<uint4*>(out + static_cast<int64_t>(packed_row) * mn + mn4) = make_uint4(word[0], word[1], word[2], word[3]);
+}
+}  // namespace dg
+
+int dg_pack_sf_k_grouped_ue8m0(const float* sf, int32_t* out, const int32_t* group_ks, int num_groups, int mn, int sf_k, int packed_sf_k,
+                               int gran_k, int k_alignment, int use_psum, void* stream) {
+    DG_CHECK(num_groups >= 0 && mn >= 0 && sf_k >= 0 && packed_sf_k >= 0);
+    if (num_groups == 0 || mn == 0 || packed_sf_k == 0)
+        return 0;
+    DG_CHECK(sf != nullptr && out != nullptr && group_ks != nullptr);
+    DG_CHECK(num_groups <= 128 && mn % 4 == 0);
+    DG_CHECK(gran_k == 128 || gran_k == 32);
+    DG_CHECK(k_alignment > 0 && k_alignment % 32 == 0);
+    DG_CHECK(aligned16(sf) && aligned16(out));
+    DG_CHECK(packed_sf_k <= 65535);
+    const dim3 grid((mn / 4 + 255) / 256, packed_sf_k);
+    hipLaunchKernelGGL(dg::dg_pack_sf_k_grouped_ue8m0_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), sf, out, group_ks, num_groups, mn,
+                       sf_k, packed_sf_k, gran_k, k_alignment, use_psum);
+    DG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int dg_transpose_sf_fp32(const float* sf, float* out, int batches, int mn, int sf_k, void* stream) {
     DG_CHECK(batches >= 0 && mn >= 0 && sf_k >= 0);
     if (batches == 0 || mn == 0 || sf_k == 0)

@@ -186,9 +186,25 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // takes byte g of the row's word.  One change against the gran-128 kernel: the words of block kb + 1 are loaded at the top of block kb (older than
 // its pieces: landed by barrier Z's counted wait) and, behind the block's last MFMA, shifted down by 8 g per lane (16 VALU operations per K block)
 // so that every lane's byte sits in byte 0: op_sel stays 0.
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false>
+// KG (round 6, second half): the K-grouped GEMM with packed UE8M0 scales -- the reference's SM100 form of k_grouped_fp8_gemm_tn_contiguous
+// (csrc/apis/gemm.hpp:299-346, impls/sm100_fp8_fp4_gemm_1d1d.cuh with GemmType::KGroupedContiguous; scheduler/gemm.cuh:74-85,238-261).  Recipe
+// (1, 1, gran_k): one exponent per ROW of A and per ROW of B and gran_k K bytes -- which is the MX format the scaled MFMA takes as it is: no FP32
+// promotion at all, the whole group's K range accumulates in the matrix core.  Group g: D[g] (FP32) += A[:, K_g] B[:, K_g]^T over its K range of the
+// K-major operands ([m, sum_k] / [n, sum_k]: the host layer re-majors the reference's MN-major tensors once); tiles in group-major order, one per
+// workgroup.  Scale words as the reference packs them (impls/smxx_layout.cuh:148-246): group g owns ceil(ceil(k_g / gran_k) / 4) packed rows of
+// [packed_sf_k, mn] counted from the end of the group before it; byte j of the group's packed row r = scale block 4 r + j of the group.  Granularity 128:
+// K block kb of the group reads byte kb & 3 of row kb >> 2; granularity 32: row kb, lane group g takes byte g (G32 above).  Either way the loop is the
+// G32 loop: block kb + 1's words are loaded under block kb and shifted down so that the byte sits in byte 0 (a group's K extent is any multiple of
+// 32: whole K quads cannot be assumed, and a fifth copy of the block body does not fit -- see the K tail note below).
+// K ranges: kg_prefix (host-side extents) or, kg_psum, the device-side psum layout with K alignment m_alignment (group starts at the previous end
+// rounded up to the alignment; the k-columns between a group's end and the next start hold zeros by the layout's contract).  A partial last block:
+// the 16-byte chunks at and beyond the group's aligned end are pushed out of the descriptor's range (tail_bias, the K_TAIL mechanism) and land as zeros.
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false, bool KG = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     static_assert(!G32 || (QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0 && !TABSK), "G32: the two production four-wave forms");
+    static_assert(!KG || (QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0 && !TABSK), "KG: the two production four-wave forms");
+    constexpr bool G32L = G32 || KG;        // the loop that shifts every block's scale bytes into byte 0 (no op_sel, no K quads)
+    constexpr bool TAIL = K_TAIL || KG;     // a partial last K block, masked through the descriptor range
     static_assert(!TABSK || (BM == 128 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0), "TABSK: the 128-row production form");
     static_assert(!K_TAIL || (BM == 128 && !STAGED && QV == 0 && WAVES_N == 2), "K tail: the 128-row production form");
     static_assert(HS == 0 || (BM == 256 && BN == 256 && QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL), "HS: the 256 x 256 four-wave form");
@@ -212,8 +228,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    int num_kb = K_TAIL ? (p.k + 127) / 128 : p.k / 128, num_kq = (num_kb + 3) / 4;      // (TABSK: of the work item's K range)
-    const int k_tail = K_TAIL ? (p.k & 127) : 0;
+    int num_kb = K_TAIL ? (p.k + 127) / 128 : p.k / 128, num_kq = (num_kb + 3) / 4;      // (TABSK: of the work item's K range; KG: of the tile's group)
+    int k_tail = K_TAIL ? (p.k & 127) : 0;
     const int piece_row = lane >> 3;
     const int src_chunk = (lane & 7) ^ piece_row;
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
@@ -253,7 +269,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     constexpr int POS = N_PRE + N_POST, DEPTH = POS / 2;            // piece positions per K block; staging registers (each serves two positions)
     static_assert(POS % 2 == 0, "a staging register serves two positions per K block");
     const int lane16 = lane * 16;
-    [[maybe_unused]] const int tail_bias = (K_TAIL && k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
+    [[maybe_unused]] int tail_bias = (K_TAIL && k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;       // (KG: per tile)
     const int sfa_kq_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kq_stride = static_cast<int>(p.sfb_sk) * 4;   // bytes per K quad
 
     const long long t_entry = p.dbg != nullptr ? DG_STAMP_CLOCK() : 0;
@@ -296,7 +312,42 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
         if (!t.valid)
             break;
         const int64_t ad_group = (p.gemm_type == kMasked) ? t.group : 0;
+        const int64_t d_group = KG ? t.group : ad_group;            // (KG: every group is a full M x N output)
         const int m_base = t.m0 + wm * WM, n_base = t.n0 + wn * WN;
+        [[maybe_unused]] int kg_k0 = 0, kg_sf_row0 = 0, kg_k_mask = 0;
+        if constexpr (KG) {
+            // the group's K range [k0, k0 + extent), the extent up to which the operand bytes are the group's own or the layout's zeros (k_mask)
+            // and the first of its packed scale rows: one scalar pass over the groups in front of it (<= 128 of them, once per tile)
+            const int gran4 = G32 ? 128 : 512;                       // K bytes per packed scale row
+            int prev_end = 0, rows = 0, k0 = 0, extent = 0, mask = 0;
+            for (int g = 0; g <= t.group; ++g) {
+                int start, end, aligned_end;
+                if (p.kg_psum) {
+                    const int a = p.m_alignment;                     // (host: a multiple of 32)
+                    start = (prev_end + a - 1) / a * a;
+                    end = imin(p.layout[g], p.k);
+                    aligned_end = imin((end + a - 1) / a * a, p.k);
+                    prev_end = end;
+                } else {
+                    start = p.kg_prefix[g];
+                    end = aligned_end = p.kg_prefix[g + 1];
+                }
+                const int ext = imax(end - start, 0);
+                if (g < t.group)
+                    rows += (ext + gran4 - 1) / gran4;
+                else
+                    k0 = start, extent = ext, mask = imax(aligned_end - start, 0);
+            }
+            kg_k0 = __builtin_amdgcn_readfirstlane(k0);
+            kg_sf_row0 = __builtin_amdgcn_readfirstlane(rows);
+            kg_k_mask = __builtin_amdgcn_readfirstlane(mask);
+            extent = __builtin_amdgcn_readfirstlane(extent);
+            num_kb = (extent + 127) / 128;
+            num_kq = (num_kb + 3) / 4;
+            // chunks of the last block at and beyond the aligned end: out of range (zeros); none when the aligned end covers the block
+            k_tail = kg_k_mask >= num_kb * 128 ? 0 : kg_k_mask - (num_kb - 1) * 128;
+            tail_bias = (k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
+        }
         auto advance = [&] {
             if (t.second_pass) {
                 pass = 1;
@@ -305,6 +356,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 tile_id += num_launched;
             }
         };
+        if (KG && num_kb <= 0) {            // an empty group: D[g] stays as it is (c was folded into d by the host layer)
+            advance();
+            continue;
+        }
         if (t.m_end <= t.m0) {
             // nothing to compute (padding rows of a contiguous layout): zero rows only.  Kept apart from the main path so that
             // the accumulators there have ONE definition chain (a join with this path would be resolved by copying all of them
@@ -328,18 +383,19 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
 
         {
             // (TABSK: the piece's K range starts at K quad sk_kq0 -- operand bases, scale bases and extents move, every index below is relative)
-            const int k_ext = TABSK ? num_kb * 128 : p.k;
-            const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm + (TABSK ? sk_kq0 * 512 : 0));
-            const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn + (TABSK ? sk_kq0 * 512 : 0));
+            // (KG: the group's column range of the K-major operands; b_sg / sfb_sg are 0 -- one B for the launch)
+            const int k_ext = TABSK ? num_kb * 128 : KG ? imin(kg_k_mask, num_kb * 128) : p.k;
+            const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm + (TABSK ? sk_kq0 * 512 : 0) + (KG ? kg_k0 : 0));
+            const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn + (TABSK ? sk_kq0 * 512 : 0) + (KG ? kg_k0 : 0));
             const int a_bytes = __builtin_amdgcn_readfirstlane((imin(t.m_end - t.m0, BM) - 1) * lda + k_ext);
             const int b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - t.n0, BN) - 1) * ldb + k_ext);
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base) - (M0S ? M0_SHARE_BIAS : 0), 0, a_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base) - (M0S ? M0_SHARE_BIAS : 0), 0, b_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             // packed scale words: element (row, kq) at base[kq * stride + row] (int32); rows of the whole A (masked: of the group)
             const int num_sf = G32 ? num_kb : num_kq;       // rows of the scale tensors along K: one per K quad (G32: per K block)
-            const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg + (TABSK ? sk_kq0 * p.sfa_sk : 0)),
+            const v4i sfa_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfa + ad_group * p.sfa_sg + (TABSK ? sk_kq0 * p.sfa_sk : 0) + (KG ? kg_sf_row0 * p.sfa_sk : 0)),
                                             (num_sf - 1) * sfa_kq_stride + p.m * 4);
-            const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + (TABSK ? sk_kq0 * p.sfb_sk : 0)),
+            const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + (TABSK ? sk_kq0 * p.sfb_sk : 0) + (KG ? kg_sf_row0 * p.sfb_sk : 0)),
                                             (num_sf - 1) * sfb_kq_stride + p.n * 4);
             const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
             // B row of N-subtile ns, MFMA row slot i = lane & 15: wave_n0 + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)
@@ -353,12 +409,12 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         a_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
                 else if constexpr (M0S)
                     DG_LDS_DMA_PIECE_SUB(a_rsrc, lds + slot_off + (wave * A_ITERS + (q & ~3)) * 1024,
-                                         a_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0),
+                                         a_piece_voff[q] + (TAIL && j >= num_kb - 1 ? tail_bias : 0),
                                          (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16,
-                        a_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0), (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+                        a_piece_voff[q] + (TAIL && j >= num_kb - 1 ? tail_bias : 0), (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
             };
             auto issue_b_piece = [&](int slot_off, int j, int q) {
                 if (NO_DMA) return;
@@ -368,12 +424,12 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         b_voff, b_piece_soff[q] + (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
                 else if constexpr (M0S)
                     DG_LDS_DMA_PIECE_SUB(b_rsrc, lds + B_BASE + slot_off + (wave * B_ITERS + (q & ~3)) * 1024,
-                                         b_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0),
+                                         b_piece_voff[q] + (TAIL && j >= num_kb - 1 ? tail_bias : 0),
                                          (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
-                        b_piece_voff[q] + (K_TAIL && j >= num_kb - 1 ? tail_bias : 0), (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
+                        b_piece_voff[q] + (TAIL && j >= num_kb - 1 ? tail_bias : 0), (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, 0, 0);
             };
             // STAGED: position `pos` (0 .. POS - 1: N_PRE in rows 0 .. MS-3, N_POST in the last two rows; >= POS: the next block's) of
             // block kb is: second half of B(kb+1) | A(kb+2) | first half of B(kb+2)
@@ -399,16 +455,19 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 const int q = imin(kq, num_sf - 1);
                 issue_e8q_scale_loads<MS, NS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
             };
-            // G32: every lane's own byte of the landed words into byte 0 (lane group g: bits [8 g, 8 g + 8))
-            [[maybe_unused]] auto shift_down = [&](E8LandingQ& dst, const E8LandingQ& src) {
+            // G32: every lane's own byte of the landed words into byte 0 (lane group g: bits [8 g, 8 g + 8)); KG at granularity 128: byte kb & 3
+            // of the word, the same for every lane.  Row of the scale tensors and shift of K block kb:
+            [[maybe_unused]] auto sf_row = [&](int kb) { return G32 ? kb : kb >> 2; };
+            [[maybe_unused]] auto sf_shift = [&](int kb) { return G32 ? g32_shift : (kb & 3) * 8; };
+            [[maybe_unused]] auto shift_down = [&](E8LandingQ& dst, const E8LandingQ& src, int sh) {
                 #pragma unroll
                 for (int q = 0; q < MS / 4; ++q)
                     #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        dst.sa[q][e] = static_cast<int>(static_cast<unsigned>(src.sa[q][e]) >> g32_shift);
+                        dst.sa[q][e] = static_cast<int>(static_cast<unsigned>(src.sa[q][e]) >> sh);
                 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
-                    dst.sb[ns] = static_cast<int>(static_cast<unsigned>(src.sb[ns]) >> g32_shift);
+                    dst.sb[ns] = static_cast<int>(static_cast<unsigned>(src.sb[ns]) >> sh);
             };
 
             if constexpr (HS != 0) {
@@ -561,7 +620,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
             tie_e8q_landing<MS, NS>(cur);
             if constexpr (G32)
-                shift_down(cur, cur);
+                shift_down(cur, cur, g32_shift);        // (KG at granularity 128: block 0 is byte 0)
             raw_barrier();
             if constexpr (STAGED) {
                 #pragma unroll
@@ -584,17 +643,18 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // words (block J == 1 of a whole quad); TIE_NEXT: they are waited for at this block's barrier (J == 2).
             // G32, 256-row form: `land` receives block kb + 1's words -- one load per MFMA gap in steps 2 .. 15 (all of them older than the A pieces,
             // the only operations barrier Z's counted wait leaves in flight), tied at barrier Z, shifted IN PLACE in the gaps of the last two rows
-            // (one word per step) -- and is the next block's `w`: the loop alternates the two register sets, nothing is copied.
-            auto block = [&](auto jc, auto load_next, auto tie_next, const E8LandingQ& w, int kb, E8LandingQ& land) {
+            // (one word per step) into `w`'s own registers as they fall free: one block body, one register set in use.
+            auto block = [&](auto jc, auto load_next, auto tie_next, E8LandingQ& w, int kb, E8LandingQ& land) {
                 constexpr int J = decltype(jc)::value;
-                constexpr bool G32_SPREAD = G32 && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
+                constexpr bool G32_SPREAD = G32L && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
                 constexpr bool LOAD_NEXT = decltype(load_next)::value, TIE_NEXT = decltype(tie_next)::value;
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
                 const uint8_t* b_next_tile = lds + B_BASE + (b_cur ^ B_BYTES) + (wn * WN) * 128;
-                [[maybe_unused]] const int g32_q = imin(kb + 1, num_sf - 1);
-                if constexpr (G32 && !G32_SPREAD)
-                    issue_scales(land, kb + 1);     // block kb + 1's words: older than every piece of this block, in by barrier Z's counted wait
+                [[maybe_unused]] const int g32_q = imin(sf_row(kb + 1), num_sf - 1);
+                [[maybe_unused]] const int g32_sh = sf_shift(kb + 1);
+                if constexpr (G32L && !G32_SPREAD)
+                    issue_scales(land, sf_row(kb + 1));     // block kb + 1's words: older than every piece of this block, in by barrier Z's counted wait
                 // ---- rows 0 .. MS-3 ----
                 #pragma unroll
                 for (int step = 0; step < PRE; ++step) {
@@ -645,7 +705,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
                 }
                 if (TIE_NEXT) tie_e8q_landing<MS, NS>(nxt);         // the next K quad's words (issued one block earlier) are in
-                if (G32) tie_e8q_landing<MS, NS>(land);             // G32: the next block's words, issued in this block
+                if (G32L) tie_e8q_landing<MS, NS>(land);            // G32 / KG: the next block's words, issued in this block
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
@@ -671,18 +731,30 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     if constexpr (STAGED && POST_STRIDE >= 4)
                         if (step % POST_STRIDE == 3)
                             stage_load((N_PRE + step / POST_STRIDE) % DEPTH, N_PRE + step / POST_STRIDE + DEPTH, kb);
-                    if constexpr (G32_SPREAD) {         // one landed word per gap: its lane group's byte into byte 0
-                        if (step < 8)
-                            land.sa[step / 4][step % 4] = static_cast<int>(static_cast<unsigned>(land.sa[step / 4][step % 4]) >> g32_shift);
-                        else
-                            land.sb[step - 8] = static_cast<int>(static_cast<unsigned>(land.sb[step - 8]) >> g32_shift);
+                    if constexpr (G32_SPREAD) {
+                        // one landed word per gap: its byte into byte 0 -- and into w's OWN register, as soon as this block is done with it (the A
+                        // words of rows 0 .. 5 died with the rows above; the B word of N-subtile ns after step 2 ns + 1): the loop has ONE block
+                        // body and one register set for the words in use (see the loop below for why)
+                        if (step < 6)
+                            w.sa[step / 4][step % 4] = static_cast<int>(static_cast<unsigned>(land.sa[step / 4][step % 4]) >> g32_sh);
+                        else if (step <= 10)
+                            w.sb[step - 6] = static_cast<int>(static_cast<unsigned>(land.sb[step - 6]) >> g32_sh);
+                        else if (step == 12 || step == 14)
+                            w.sb[step / 2 - 1] = static_cast<int>(static_cast<unsigned>(land.sb[step / 2 - 1]) >> g32_sh);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (G32 && !G32_SPREAD)
-                    shift_down(land, land);
-                if constexpr (G32)
+                if constexpr (G32L) {
+                    asm volatile("s_nop 4" ::: "memory");           // the last MFMAs' scale operands -> VALU writes of the same registers
+                    if constexpr (G32_SPREAD) {                     // the three words the last two steps still used
+                        w.sb[7] = static_cast<int>(static_cast<unsigned>(land.sb[7]) >> g32_sh);
+                        w.sa[1][2] = static_cast<int>(static_cast<unsigned>(land.sa[1][2]) >> g32_sh);
+                        w.sa[1][3] = static_cast<int>(static_cast<unsigned>(land.sa[1][3]) >> g32_sh);
+                    } else {
+                        shift_down(w, land, g32_sh);
+                    }
                     asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> the next block's MFMAs
+                }
                 const int a_free = a_cur;
                 a_cur = a_nxt;
                 a_nxt = a_fill;
@@ -693,14 +765,15 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
             using Yes = std::true_type; using No = std::false_type;
             int kb = 0;
-            if constexpr (G32) {
-                // one word per row and K block, every lane's byte shifted into byte 0; the two register sets alternate
-                for (; kb + 2 <= num_kb; kb += 2) {
+            if constexpr (G32L) {
+                // one word per row and K block, every lane's byte shifted into byte 0.  ONE block body in a plain loop: `cur` holds the words in
+                // use, `nxt` receives the next block's and is shifted back into `cur` as its registers fall free.  (Until the K-grouped kernels
+                // the loop alternated the two sets over two bodies plus a third for an odd block count; with three bodies the accumulators meet at
+                // join points, hipcc resolves those with accumulator copies it places where it likes -- e.g. in front of the odd block -- and a
+                // copy taken there misses that block's MFMAs: seen as acc[2][7] of every tile with an odd K-block count losing its last block once
+                // the FP32 reduce-add epilogue changed the register pressure.  One body, one definition chain, no copies.)
+                for (; kb < num_kb; ++kb)
                     block(I0{}, No{}, No{}, cur, kb, nxt);
-                    block(I0{}, No{}, No{}, nxt, kb + 1, cur);
-                }
-                if (kb < num_kb)
-                    block(I0{}, No{}, No{}, cur, kb++, nxt);
             } else {
             for (; kb + 4 <= num_kb; kb += 4) {                 // whole K quads: byte select by op_sel, no shifts
                 block(I0{}, No{}, No{}, cur, kb, nxt);
@@ -728,7 +801,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 asm volatile("s_nop 3" ::: "memory");
                 block(I0{}, No{}, No{}, w, kb, nxt);
             }
-            }   // (!G32)
+            }   // (!G32L)
             if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA -> accumulator reads; the tail's re-read pieces
             __syncthreads();
@@ -763,7 +836,47 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     // code needs are made right behind an asm output, i.e. at this point and not at the loop exit)
                     asm volatile("" : "+a"(acc[ms][4 * g]), "+a"(acc[ms][4 * g + 1]), "+a"(acc[ms][4 * g + 2]), "+a"(acc[ms][4 * g + 3]));
                     const v4f quad4[4] = {acc[ms][4 * g], acc[ms][4 * g + 1], acc[ms][4 * g + 2], acc[ms][4 * g + 3]};
-                    store_rows_full_line<MS, true>(p, t, ad_group * p.d_sg, quad4, ms, m_base, n_base + 64 * g);
+                    store_rows_full_line<MS, true>(p, t, d_group * p.d_sg, quad4, ms, m_base, n_base + 64 * g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (p.d_dtype != 0 && p.accumulate && p.d_vec_ok && n_base + WN <= p.n && p.head_lr == 0 && t.m_end > t.m_begin && t.zero_to <= t.zero_from) {
+            // FP32 reduce-add (D += A B^T: the weight-gradient forms -- dense recipe (1, 1, gran_k) with packed scales, the K-grouped GEMM), round 6:
+            // the old values of FOUR M-subtiles x all N-subtiles (4 * NS loads of 16 bytes per lane, 4 * NS * 4 VGPRs) are in flight before the
+            // first add -- MS / 4 memory round trips per wave tile instead of 2 MS through store_tile (one per M-subtile and half: 16 trips of ~2 us
+            // were 35 us of a 117 us call at 4096 x 4096 x 7168 and half of the K-grouped call).  Loads from a row clamped into the tile's rows
+            // (always inside D), stores predicated; an accumulator leaves its AGPRs right in front of its add.
+            static_assert(MS % 4 == 0, "four M-subtiles per round trip");
+            float* dbase = reinterpret_cast<float*>(p.d) + d_group * p.d_sg;
+            const int lg = lane >> 4;
+            int coff[NS];
+            #pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                coff[ns] = n_base + (ns >> 2) * 64 + lg * 8 + ((ns & 3) >> 1) * 32 + (ns & 1) * 4;
+            #pragma unroll
+            for (int mb = 0; mb < MS; mb += 4) {
+                v4f old[4][NS];
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = m_base + (lane & 15) * MS + mb + u;
+                    const float* src = dbase + static_cast<int64_t>(imin(imax(row, t.m_begin), t.m_end - 1)) * p.d_sm;
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        old[u][ns] = *reinterpret_cast<const v4f*>(src + coff[ns]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = m_base + (lane & 15) * MS + mb + u;
+                    float* dst = dbase + static_cast<int64_t>(row) * p.d_sm;
+                    const bool live = row >= t.m_begin && row < t.m_end;
+                    #pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) {
+                        asm volatile("" : "+a"(acc[mb + u][ns]));
+                        const v4f v = acc[mb + u][ns] + old[u][ns];
+                        if (live)
+                            *reinterpret_cast<v4f*>(dst + coff[ns]) = v;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -780,7 +893,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         asm volatile("" : "+a"(acc[ms][4 * G + j]));
                         out[ms][j] = acc[ms][4 * G + j];
                     }
-                store_tile<MS, 4, true>(p, t, ad_group * p.d_sg, out, m_base, n_base + 64 * G);
+                store_tile<MS, 4, true>(p, t, d_group * p.d_sg, out, m_base, n_base + 64 * G);
             };
             store_half(std::integral_constant<int, 0>{});
             if constexpr (NS == 8)
@@ -797,10 +910,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false, bool KG = false>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK, G32>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK, G32, KG>(p);
 }
 
 // Second phase of the TABSK remainder walk: one workgroup per (remainder tile, 32-row quarter) adds the tile's partial slabs in piece order

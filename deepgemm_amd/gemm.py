@@ -313,11 +313,15 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
         if c is not None and not same_cd:
             d.copy_(c)
         if fast_args is not None:
-            # K-major operands, SFA already in the kernel's layout, no K-split workspace: every integer argument of the C call is a
+            # K-major operands, SFA already in the kernel's layout: every integer argument of the C call is a
             # function of the signature -- only the five pointers and the stream are read per call (host path of a decode-sized
             # call: 12.5 -> ~8 us; the kernel of m = 1, 4096 x 7168 takes 7.4 us)
+            stream = current_stream_ptr(fast_args[1])
+            # (round 6: shapes the library cuts along K -- fast_args[2] -- take the stream's scratch buffer on this path too: 18.4 -> 9 us of host
+            #  time per call of a 192 x 4096 x 7168 problem whose kernel takes 24)
+            ws = _split_k_workspace(d.device, stream) if fast_args[2] else None
             check(lib.dg_fp8_gemm_nt_ws(a_data.data_ptr(), a_sf.data_ptr(), b_data.data_ptr(), b_sf.data_ptr(), d.data_ptr(), *fast_args[0],
-                                        None, 0, current_stream_ptr(fast_args[1])))
+                                        ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, stream))
             return
         sfa = a_sf if sfa_ready else get_mn_major_tma_aligned_tensor(a_sf)
         a_data, b_data = _dense_operands(a_data, b_data, sfa, gran_n, m, n, k)
@@ -345,11 +349,11 @@ def fp8_gemm_nt(a: TensorPair, b: TensorPair, d: torch.Tensor, c: Optional[torch
     require_device(a_data, b_data, sfa, sfb, d)
     if sfb is b_sf and len(_VALIDATED_DENSE) < 4096:
         fast_args = None
-        if (sfa is a_sf and a_data.stride(-1) == 1 and b_data.stride(-1) == 1 and
-                not lib.dg_dense_wants_workspace(m, n, k, 0, 0, gran_n)):
+        if sfa is a_sf and a_data.stride(-1) == 1 and b_data.stride(-1) == 1:
             fast_args = ((m, n, k, a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1), sfa.stride(0), sfa.stride(1),
                           sfb.stride(0), sfb.stride(1), gran_n, d.stride(0), _dtype_code(d), int(c is not None)),
-                         d.device.index if d.device.index is not None else -1)
+                         d.device.index if d.device.index is not None else -1,
+                         bool(lib.dg_dense_wants_workspace(m, n, k, 0, 0, gran_n)))
         _VALIDATED_DENSE[key] = (m, n, k, gran_n, sfa is a_sf, fast_args)
     a_data, b_data = _dense_operands(a_data, b_data, sfa, gran_n, m, n, k)
     _call_dense(a_data, sfa, b_data, sfb, d, c, m, n, k, gran_n)
@@ -571,6 +575,63 @@ def _k_grouped_psum_launch(a_data, sfa, b_data, sfb, d, m, n, total_k, psum_layo
     return True
 
 
+def _k_grouped_packed_sf(sf: torch.Tensor, mn: int, ks, grouped_layout: torch.Tensor, num_groups: int, gran_k: int, k_alignment: int,
+                         use_psum_layout: bool) -> torch.Tensor:
+    """transform_k_grouped_sf_into_required_layout on SM100 (csrc/apis/layout.hpp:92-121): int tensors are the packed words already and are only
+    checked (check_k_grouped_packed_ue8m0_tensor, csrc/jit_kernels/impls/smxx_layout.hpp:319-355); FP32 tensors ``[sf_k, mn]`` -- power-of-two
+    values, per group ceil(k_g / gran_k) compact rows -- are packed on the device, four exponent bytes per word, every group starting a new word row
+    (get_k_grouped_mn_major_tma_aligned_packed_ue8m0_tensor, :255-317 -> dg_pack_sf_k_grouped_ue8m0)."""
+    host_assert(sf.dim() == 2, 'sf.dim() == 2')
+    host_assert(sf.is_contiguous(), 'sf.is_contiguous()')
+    host_assert(num_groups <= 128 and mn % 4 == 0, 'num_groups <= 128 and mn % 4 == 0')
+    host_assert(sf.size(1) == mn, 'sf.size(1) == mn')
+    has_ks = ks is not None and len(ks) > 0
+    host_assert(has_ks or use_psum_layout, 'use_psum_layout')
+    if sf.dtype == torch.int:
+        host_assert(sf.size(0) > 0, 'packed_sf_k > 0')
+        if has_ks and not use_psum_layout:
+            host_assert(sf.size(0) >= sum(-(-int(k) // (gran_k * 4)) for k in ks), 'packed_sf_k >= aligned_packed_sf_k')
+        return sf
+    host_assert(sf.dtype == torch.float, 'sf.scalar_type() == torch::kFloat or sf.scalar_type() == torch::kInt')
+    sf_k = int(sf.size(0))
+    if has_ks:
+        packed_sf_k = sum(-(-int(k) // (gran_k * 4)) for k in ks)
+        host_assert(use_psum_layout or sum(-(-int(k) // gran_k) for k in ks) == sf_k, 'use_psum_layout or ref_sf_k == sf_k')
+    else:
+        packed_sf_k = (sf_k + num_groups * 3) // 4
+    out = torch.empty((packed_sf_k, mn), dtype=torch.int, device=sf.device)
+    if packed_sf_k == 0:
+        return out
+    require_device(sf, grouped_layout)
+    check(lib.dg_pack_sf_k_grouped_ue8m0(sf.data_ptr(), out.data_ptr(), grouped_layout.data_ptr(), num_groups, mn, sf_k, packed_sf_k, gran_k,
+                                         k_alignment, int(use_psum_layout), current_stream_ptr()))
+    return out
+
+
+def _k_grouped_tn_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, ks, grouped_layout, m: int, n: int, sum_k: int, gran_k: int, k_alignment: int,
+                               use_psum_layout: bool) -> None:
+    """The reference's SM100 form of the K-grouped GEMM (csrc/apis/gemm.hpp:333-342 -> sm100_k_grouped_fp8_gemm_1d1d): UE8M0 scales of
+    granularity 128 or 32 along K, one exponent per column of the MN-major operands -- the MX block format of the scaled MFMA, so the whole
+    group's K range accumulates in the matrix core with no FP32 promotion (e8_quad_kg_*).  The operands are re-majored once ([sum_k, mn] ->
+    [mn, sum_k]: the four-wave kernels read K-major rows)."""
+    num_groups = int(d.size(0))
+    sfa = _k_grouped_packed_sf(a_sf, m, ks, grouped_layout, num_groups, gran_k, k_alignment, use_psum_layout)
+    sfb = _k_grouped_packed_sf(b_sf, n, ks, grouped_layout, num_groups, gran_k, k_alignment, use_psum_layout)
+    host_assert(sum_k % 16 == 0, 'sum_k % 16 == 0 (K-major rows of whole 16-byte chunks)')
+    a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))       # [m, sum_k], [n, sum_k]: K-major
+    require_device(a_km, b_km, sfa, sfb, d, grouped_layout)
+    import ctypes
+    if use_psum_layout:
+        ks_arr, ks_ptr, layout_ptr = None, None, grouped_layout.data_ptr()
+    else:
+        host_assert(num_groups <= 64, 'num_groups <= 64 (K extents handed over by value)')
+        ks_arr = (ctypes.c_int32 * num_groups)(*[int(k) for k in ks])
+        ks_ptr, layout_ptr = ctypes.cast(ks_arr, ctypes.c_void_p), None
+    check(lib.dg_k_grouped_fp8_gemm_ue8m0(a_km.data_ptr(), sfa.data_ptr(), b_km.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, sum_k,
+                                          ks_ptr, layout_ptr, num_groups, k_alignment, gran_k, a_km.stride(0), b_km.stride(0),
+                                          sfa.stride(0), sfb.stride(0), current_stream_ptr()))
+
+
 def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks_cpu, grouped_layout: torch.Tensor,
                                      c: Optional[torch.Tensor] = None, recipe: Tuple[int, int, int] = (1, 1, 128),
                                      compiled_dims: str = 'mn', use_psum_layout: bool = False) -> None:
@@ -611,20 +672,26 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     the rows in between hold zeros (tests/generators.py:480-530) and ``ks_cpu`` may be missing -- the K ranges are then read on the
     device, no host copy of the group sizes exists.  Implemented for FP32 per-channel scales with ``gran_k`` = 128 and any K alignment that
     is a multiple of 32 (round 6: 32 / 160 / 192 / 224 of the reference's SM100 sweep -- compact scale rows counted from each group's start,
-    partial last blocks); ``gran_k`` 32 needs per-32 FP32 promotion, which no kernel here has."""
+    partial last blocks).  UE8M0 scales (round 6: int tensors of packed exponent words, FP32 tensors in the ``'sm100'`` scaling-factor mode,
+    and every call with ``gran_k`` = 32 -- the reference's SM100 semantics, any K alignment that is a multiple of 32, with or without the psum
+    layout) run on the hardware-scaled K-grouped kernels: see ``_k_grouped_tn_packed_ue8m0``."""
     (a_data, a_sf), (b_data, b_sf) = a, b
     ks = ks_cpu
     recipe = tuple(recipe)
     host_assert(recipe[0] == 1 and recipe[1] == 1, 'std::get<0>(recipe) == 1 and std::get<1>(recipe) == 1')
-    host_assert(recipe[2] == 128, 'gran_k == 128 (gran_k == 32 needs the packed UE8M0 scale format)')
+    gran_k = recipe[2]
+    host_assert(gran_k == 32 or gran_k == 128, 'gran_k == 32 or gran_k == 128')
     k_alignment = runtime.get_mk_alignment_for_contiguous_layout()
     host_assert(k_alignment % 32 == 0, 'k_alignment % 32 == 0')
     host_assert(d.dim() == 3, 'd.dim() == 3')
     num_groups, m, n = (int(x) for x in d.shape)
     host_assert(a_data.dim() == 2 and b_data.dim() == 2, 'a.first.dim() == 2 and b.first.dim() == 2')
+    # UE8M0 scales -- packed int words, FP32 tensors in the 'sm100' scaling-factor mode (the reference's cast, csrc/apis/layout.hpp:112-114), and
+    # granularity 32 always (it only exists in that format): the hardware-scaled K-grouped kernels, the reference's SM100 semantics
+    packed = (a_sf.dtype == torch.int and b_sf.dtype == torch.int) or gran_k == 32 or _casts_to_ue8m0(a_sf, b_sf, False)
     # (K extents in whole scale blocks -- the reference's `k % k_alignment == 0` at 128 -- except in the psum form, whose ranges are read on the
-    #  device: any alignment that is a multiple of 32, round 6)
-    general = use_psum_layout and k_alignment != 128
+    #  device, and with UE8M0 scales: any alignment that is a multiple of 32, round 6)
+    general = (use_psum_layout and k_alignment != 128) or packed
     sum_k = _check_k_grouped_args(ks, grouped_layout, num_groups, use_psum_layout, k_alignment if general else 128, int(a_data.size(0)))
     host_assert(a_data.dtype == torch.float8_e4m3fn and b_data.dtype == torch.float8_e4m3fn,
                 'ab.scalar_type() == torch::kFloat8_e4m3fn')
@@ -637,6 +704,9 @@ def k_grouped_fp8_gemm_tn_contiguous(a: TensorPair, b: TensorPair, d: torch.Tens
     if _early_return(m, n, sum_k, d, c):
         return
     host_assert(a_sf.dim() == 2 and b_sf.dim() == 2, 'sf.dim() == 2')
+    if packed:
+        _k_grouped_tn_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, ks, grouped_layout, m, n, sum_k, gran_k, k_alignment, use_psum_layout)
+        return
     if general:
         # K alignment != 128 (the reference's SM100 sweep: 32 / 160 / 192 / 224 at gran_k = 128, tests/generators.py:192-194): groups start at
         # multiples of the alignment, their scale rows are compact and count from the group's own start (ceil(extent / 128) per non-empty group:

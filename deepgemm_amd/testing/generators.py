@@ -254,6 +254,69 @@ def generate_k_grouped_contiguous_psum(num_groups: int, m: int, n: int, real_ks:
     return KGroupedCase((a_q, sfa), (b_q, sfb), a_groups, b_groups, c, c.clone(), ref_d, [align(k, k_alignment) for k in real_ks], layout)
 
 
+def generate_k_grouped_contiguous_ue8m0(num_groups: int, m: int, n: int, real_ks: List[int], gran_k: int = 128, k_alignment: int = 128,
+                                        use_psum_layout: bool = False, device: str = 'cuda') -> KGroupedCase:
+    """The reference's SM100 K-grouped inputs (tests/generators.py:436-530 with use_ue8m0 = True): MN-major ``a [total_k, m]``, ``b [total_k, n]``;
+    every group cast on its own copy padded to whole ``gran_k`` blocks (k_grouped_per_channel_cast_to_fp8, :411-433) with power-of-two FP32 scales
+    ``[sum over groups of ceil(k_g / gran_k), mn]``, compact, in group order.  ``use_psum_layout``: ``grouped_layout`` holds the groups' ENDS, a group
+    starts at the previous end rounded up to ``k_alignment`` and the rows in between hold zeros, ``real_ks`` may be anything; otherwise
+    ``grouped_layout`` holds the extents, which must be multiples of ``k_alignment``.  ``a_groups`` / ``b_groups``: each group's K-major
+    ``([mn, k_pad] fp8, [mn, k_pad / gran_k] scales)`` for the oracle; ``ks``: the aligned extents (``ks_cpu``)."""
+    assert len(real_ks) == num_groups and k_alignment % 32 == 0 and gran_k in (32, 128)
+    from ..utils.math import per_channel_cast_to_fp8
+    if use_psum_layout:
+        ends = build_psum_layout_from_ks(real_ks, k_alignment)
+        total_k = align(ends[-1] if ends else 0, k_alignment)
+    else:
+        assert all(k % k_alignment == 0 for k in real_ks)
+        ends, total = [], 0
+        for k in real_ks:
+            total += k
+            ends.append(total)
+        total_k = total
+    a_q = torch.zeros((total_k, m), device=device, dtype=torch.float8_e4m3fn)
+    b_q = torch.zeros((total_k, n), device=device, dtype=torch.float8_e4m3fn)
+    c = torch.randn((num_groups, m, n), device=device, dtype=torch.float) * 32
+    ref_d = torch.empty_like(c)
+    a_groups, b_groups, sfa_rows, sfb_rows = [], [], [], []
+    for g, (k, end) in enumerate(zip(real_ks, ends)):
+        if k == 0:
+            ref_d[g] = c[g]
+            a_groups.append(None), b_groups.append(None)
+            continue
+        start, k_pad = end - k, align(k, gran_k)
+        a_g = torch.zeros((k_pad, m), device=device, dtype=torch.bfloat16)
+        b_g = torch.zeros((k_pad, n), device=device, dtype=torch.bfloat16)
+        a_g[:k], b_g[:k] = torch.randn((k, m), device=device, dtype=torch.bfloat16), torch.randn((k, n), device=device, dtype=torch.bfloat16)
+        ref_d[g] = c[g] + a_g.float().t() @ b_g.float()
+        qa, sa = per_channel_cast_to_fp8(a_g, use_ue8m0=True, gran_k=gran_k)
+        qb, sb = per_channel_cast_to_fp8(b_g, use_ue8m0=True, gran_k=gran_k)
+        a_q[start:end], b_q[start:end] = qa[:k], qb[:k]
+        sfa_rows.append(sa), sfb_rows.append(sb)
+        a_groups.append((qa.t().contiguous(), sa.t().contiguous()))
+        b_groups.append((qb.t().contiguous(), sb.t().contiguous()))
+    sfa = torch.cat(sfa_rows) if sfa_rows else torch.empty((0, m), device=device, dtype=torch.float)
+    sfb = torch.cat(sfb_rows) if sfb_rows else torch.empty((0, n), device=device, dtype=torch.float)
+    layout = torch.tensor(ends if use_psum_layout else list(real_ks), device=device, dtype=torch.int32)
+    return KGroupedCase((a_q, sfa), (b_q, sfb), a_groups, b_groups, c, c.clone(), ref_d, [align(k, k_alignment) for k in real_ks], layout)
+
+
+def pack_k_grouped_ue8m0(sf: torch.Tensor, group_ks: List[int], gran_k: int) -> torch.Tensor:
+    """FP32 power-of-two scales ``[sum of ceil(k_g / gran_k), mn]`` -> the packed int32 words ``[sum of ceil(k_g / (4 gran_k)), mn]`` of the
+    reference's K-grouped layout (impls/smxx_layout.cuh:148-246): every group starts a new word row, byte j of its row r = its scale block
+    4 r + j, zero beyond its last block.  Host-side statement for tests (the device path is dg_pack_sf_k_grouped_ue8m0)."""
+    rows, start = [], 0
+    for k in group_ks:
+        blocks = -(-k // gran_k)
+        exps = (sf[start:start + blocks].contiguous().view(torch.int32) >> 23) & 0xff
+        padded = torch.zeros((-(-blocks // 4) * 4, sf.size(1)), dtype=torch.int32, device=sf.device)
+        padded[:blocks] = exps
+        q = padded.view(-1, 4, sf.size(1))
+        rows.append(q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16) | (q[:, 3] << 24))
+        start += blocks
+    return torch.cat(rows).contiguous() if rows else torch.empty((0, sf.size(1)), dtype=torch.int32, device=sf.device)
+
+
 def generate_k_grouped_contiguous(num_groups: int, m: int, n: int, ks: List[int], k_major: bool,
                                   device: str = 'cuda') -> KGroupedCase:
     """tests/generators.py:436-477: ``a [sum_k, m]``, ``b [sum_k, n]`` BF16, per group ``ref_d[g] = c[g] + a_g^T @ b_g``;

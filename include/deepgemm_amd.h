@@ -330,6 +330,32 @@ int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const
                                           int64_t sfa_stride_m, int64_t sfa_stride_k, int64_t sfb_stride_n, int64_t sfb_stride_k,
                                           int k_alignment, void* stream);
 
+/* K-grouped GEMM with packed UE8M0 scale words: the reference's SM100 form of k_grouped_fp8_gemm_tn_contiguous.  Replaces
+ * sm100_k_grouped_fp8_gemm_1d1d (csrc/jit_kernels/impls/sm100_fp8_fp4_gemm_1d1d.hpp:244-318) as called from csrc/apis/gemm.hpp:299-346
+ * with int scale tensors (or FP32 ones after dg_pack_sf_k_grouped_ue8m0).  Recipe (1, 1, gran_k), gran_k = 128 or 32: one exponent per row of a /
+ * row of b and gran_k K bytes -- the MX block format of the scaled MFMA; no FP32 promotion, D[g] += A[:, K_g] B[:, K_g]^T accumulates in the
+ * matrix core over the group's whole K range.
+ *   a [m, total_k], b [n, total_k] K-major FP8 (row pitches a_stride_m / b_stride_n, 16-byte aligned; the reference's MN-major tensors after
+ *     dg_transpose_fp8); d [num_groups, m, n] FP32, accumulated in place.
+ *   K ranges: psum_layout == NULL: ks_host[g] (host, multiples of 32) one after another; psum_layout != NULL (device int32 [num_groups], ks_host
+ *     ignored): group g covers [align(end[g-1], k_alignment), end[g]) and the columns up to align(end[g], k_alignment) hold zeros (the reference's
+ *     psum layout, tests/generators.py:480-530, scheduler/gemm.cuh:74-85).  k_alignment % 32 == 0.  A group's last 128-block may be partial.
+ *   sfa_packed [packed_sf_k, m], sfb_packed [packed_sf_k, n] int32, unit stride along m / n, row pitches sf*_stride_k (words, multiples of 4,
+ *     16-byte aligned base): as the reference packs them (impls/smxx_layout.cuh:148-246) -- group g owns ceil(ceil(k_g / gran_k) / 4) rows counted
+ *     from the end of the group before it; byte j of its row r = exponent of its scale block 4 r + j (0 beyond its last block).
+ *   At most 64 groups with ks_host, 128 with psum_layout.  Returns 3 without launching when an alignment condition fails. */
+int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, float* d,
+                                int m, int n, int total_k, const int32_t* ks_host, const int32_t* psum_layout, int num_groups,
+                                int k_alignment, int gran_k, int64_t a_stride_m, int64_t b_stride_n,
+                                int64_t sfa_stride_k, int64_t sfb_stride_k, void* stream);
+/* FP32 power-of-two scales of a K-grouped operand, [sf_k, mn] row-major (per group ceil(k_g / gran_k) rows, compact, in group order), into the
+ * packed words above ([packed_sf_k, mn] int32, row pitch mn).  Replaces pack_fp32_into_ue8m0 with kNumGroups > 1
+ * (deep_gemm/include/deep_gemm/impls/smxx_layout.cuh:146-246, host side csrc/jit_kernels/impls/smxx_layout.hpp:255-317).  group_ks: device int32
+ * [num_groups] -- K extents, or (use_psum != 0) psum ends with the K alignment k_alignment.  mn % 4 == 0, num_groups <= 128; only the exponent
+ * byte of each value is kept (the reference asserts sign and mantissa are zero).  Rows of `out` beyond the groups' last are left untouched. */
+int dg_pack_sf_k_grouped_ue8m0(const float* sf, int32_t* out, const int32_t* group_ks, int num_groups, int mn, int sf_k, int packed_sf_k,
+                               int gran_k, int k_alignment, int use_psum, void* stream);
+
 /* M-grouped contiguous GEMM.  Replaces sm90_m_grouped_fp8_gemm_contiguous_1d2d (impls/sm90_fp8_gemm_1d2d.hpp:147) /
  * sm100_m_grouped_fp8_fp4_gemm_contiguous_1d1d (impls/sm100_fp8_fp4_gemm_1d1d.hpp:161) as called from
  * m_grouped_fp8_fp4_gemm_nt_contiguous (csrc/apis/gemm.hpp:166-232).

@@ -242,8 +242,17 @@ def test_newer_operators_exist_and_validate_on_the_host():
     with pytest.raises(RuntimeError, match='no CPU path'):                  # everything valid: stops at the device check
         dg.k_grouped_fp8_gemm_nt_contiguous(kg.a, kg.b, kg.d, kg.ks, kg.grouped_layout, c=kg.c)
     kt = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], False, device='cpu')
-    with pytest.raises(RuntimeError, match='gran_k == 128'):
+    with pytest.raises(RuntimeError, match='gran_k == 32 or gran_k == 128'):
+        dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, kt.ks, kt.grouped_layout, c=kt.c, recipe=(1, 1, 64))
+    # granularity 32 is the UE8M0 form (round 6): these scale tensors have one row per 128 K, not per 32 -- the layout step's own check
+    with pytest.raises(RuntimeError, match='ref_sf_k == sf_k'):
         dg.k_grouped_fp8_gemm_tn_contiguous(kt.a, kt.b, kt.d, kt.ks, kt.grouped_layout, c=kt.c, recipe=(1, 1, 32))
+    with pytest.raises(RuntimeError, match='packed_sf_k >= aligned_packed_sf_k'):       # packed words: too few rows for the groups
+        dg.k_grouped_fp8_gemm_tn_contiguous((kt.a[0], torch.zeros((1, 128), dtype=torch.int)), (kt.b[0], torch.zeros((1, 128), dtype=torch.int)),
+                                            kt.d, kt.ks, kt.grouped_layout, c=kt.c)
+    with pytest.raises(RuntimeError, match='no CPU path'):                  # packed words, everything valid: stops at the device check
+        dg.k_grouped_fp8_gemm_tn_contiguous((kt.a[0], torch.zeros((2, 128), dtype=torch.int)), (kt.b[0], torch.zeros((2, 128), dtype=torch.int)),
+                                            kt.d, kt.ks, kt.grouped_layout, c=kt.c)
     with pytest.raises(RuntimeError, match='sum_k'):
         dg.k_grouped_fp8_gemm_tn_contiguous((kt.a[0][:256], kt.a[1]), kt.b, kt.d, kt.ks, kt.grouped_layout, c=kt.c)
     # skip_head_mid: the width of d must reserve the middle columns
