@@ -459,6 +459,18 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // of the word, the same for every lane.  Row of the scale tensors and shift of K block kb:
             [[maybe_unused]] auto sf_row = [&](int kb) { return G32 ? kb : kb >> 2; };
             [[maybe_unused]] auto sf_shift = [&](int kb) { return G32 ? g32_shift : (kb & 3) * 8; };
+            // One scale word of K block `kb` shifted down, as an instruction that STAYS where it is written: left as plain C++ the shifts of the
+            // single-body loop are sunk to the top of the next block -- sixteen VALU slots in front of its first MFMA, 2.5 % of C2 (ISA checked).
+            [[maybe_unused]] auto shifted_word = [&](int src, int kb) {
+                int out;
+                if constexpr (G32) {
+                    asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(out) : "v"(g32_shift), "v"(src));
+                } else {
+                    const int sh = __builtin_amdgcn_readfirstlane((kb & 3) * 8);
+                    asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(out) : "s"(sh), "v"(src));
+                }
+                return out;
+            };
             [[maybe_unused]] auto shift_down = [&](E8LandingQ& dst, const E8LandingQ& src, int sh) {
                 #pragma unroll
                 for (int q = 0; q < MS / 4; ++q)
@@ -603,7 +615,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(0, 0, q);
             #pragma unroll
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
-            issue_scales(cur, 0);
+            // (the shifted-scale loop of the 256-row forms takes a block's words from `nxt`, see G32_DEFER in block())
+            constexpr bool SPREAD_FORM = G32L && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
+            issue_scales(SPREAD_FORM ? nxt : cur, 0);
             #pragma unroll
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
             #pragma unroll
@@ -618,9 +632,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
-            tie_e8q_landing<MS, NS>(cur);
-            if constexpr (G32)
-                shift_down(cur, cur, g32_shift);        // (KG at granularity 128: block 0 is byte 0)
+            if constexpr (SPREAD_FORM) {
+                tie_e8q_landing<MS, NS>(nxt);
+                shift_down(cur, nxt, sf_shift(0));      // (`nxt` keeps the raw words: block 0 redoes its four deferred ones from there)
+            } else {
+                tie_e8q_landing<MS, NS>(cur);
+                if constexpr (G32)
+                    shift_down(cur, cur, g32_shift);    // (KG at granularity 128: block 0 is byte 0)
+            }
             raw_barrier();
             if constexpr (STAGED) {
                 #pragma unroll
@@ -646,7 +665,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // (one word per step) into `w`'s own registers as they fall free: one block body, one register set in use.
             auto block = [&](auto jc, auto load_next, auto tie_next, E8LandingQ& w, int kb, E8LandingQ& land) {
                 constexpr int J = decltype(jc)::value;
-                constexpr bool G32_SPREAD = G32L && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
+                constexpr bool G32_SPREAD = SPREAD_FORM;
                 constexpr bool LOAD_NEXT = decltype(load_next)::value, TIE_NEXT = decltype(tie_next)::value;
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
@@ -685,6 +704,15 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         if (step % PRE_STRIDE == 3)                 // one filler per gap (both in one gap held up the next MFMA)
                             stage_load((step / PRE_STRIDE) % DEPTH, step / PRE_STRIDE + DEPTH, kb);
                     if constexpr (G32_SPREAD) {
+                        // G32_DEFER: the four words the previous block's LAST steps still read (the A words of rows 6, 7 and the B words of N-subtiles
+                        // 6, 7) are shifted into w's registers HERE, out of `land`, which still holds this block's raw words -- its reload starts in gap 2
+                        // with sa[0]; sa[1] follows in gap 3 (behind the shift there), sb[6] / sb[7] in gaps 14 / 15.  First readers: steps 6, 7 and the last two rows.  Nothing waits
+                        // between two blocks (shifted behind the previous block's last MFMA they cost an s_nop + three VALU slots of every block: 2.5 %)
+                        // (every write of a w register keeps >= 3 MFMAs behind the last MFMA that read it as its scale operand)
+                        if (step == 2) w.sa[1][2] = shifted_word(land.sa[1][2], kb);
+                        if (step == 3) w.sa[1][3] = shifted_word(land.sa[1][3], kb);
+                        if (step == 4) w.sb[6] = shifted_word(land.sb[6], kb);
+                        if (step == 5) w.sb[7] = shifted_word(land.sb[7], kb);
                         // gaps 2, 3, 4, 6, 7, 10, 11, 12, 14, 15 (pieces sit in gaps 1, 5, 9, 13, ...; fragment reads in gaps 0, 8, ...)
                         constexpr int kSlots[10] = {2, 3, 4, 6, 7, 10, 11, 12, 14, 15};
                         #pragma unroll
@@ -735,26 +763,21 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         // one landed word per gap: its byte into byte 0 -- and into w's OWN register, as soon as this block is done with it (the A
                         // words of rows 0 .. 5 died with the rows above; the B word of N-subtile ns after step 2 ns + 1): the loop has ONE block
                         // body and one register set for the words in use (see the loop below for why)
-                        if (step < 6)
-                            w.sa[step / 4][step % 4] = static_cast<int>(static_cast<unsigned>(land.sa[step / 4][step % 4]) >> g32_sh);
-                        else if (step <= 10)
-                            w.sb[step - 6] = static_cast<int>(static_cast<unsigned>(land.sb[step - 6]) >> g32_sh);
-                        else if (step == 12 || step == 14)
-                            w.sb[step / 2 - 1] = static_cast<int>(static_cast<unsigned>(land.sb[step / 2 - 1]) >> g32_sh);
+                        if (step < 4)
+                            w.sa[0][step] = shifted_word(land.sa[0][step], kb + 1);
+                        else if (step == 5 || step == 7)
+                            w.sa[1][(step - 5) / 2] = shifted_word(land.sa[1][(step - 5) / 2], kb + 1);
+                        else if (step % 2 == 0 && step <= 14)           // sb[0] @ 4, sb[1] @ 6, ... sb[5] @ 14 (last read at 2 ns + 1)
+                            w.sb[step / 2 - 2] = shifted_word(land.sb[step / 2 - 2], kb + 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (G32L) {
+                if constexpr (G32L && !G32_SPREAD) {
                     asm volatile("s_nop 4" ::: "memory");           // the last MFMAs' scale operands -> VALU writes of the same registers
-                    if constexpr (G32_SPREAD) {                     // the three words the last two steps still used
-                        w.sb[7] = static_cast<int>(static_cast<unsigned>(land.sb[7]) >> g32_sh);
-                        w.sa[1][2] = static_cast<int>(static_cast<unsigned>(land.sa[1][2]) >> g32_sh);
-                        w.sa[1][3] = static_cast<int>(static_cast<unsigned>(land.sa[1][3]) >> g32_sh);
-                    } else {
-                        shift_down(w, land, g32_sh);
-                    }
+                    shift_down(w, land, g32_sh);
                     asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> the next block's MFMAs
                 }
+                // (G32_SPREAD: the last four words are deferred into the next block's first gaps: no wait here)
                 const int a_free = a_cur;
                 a_cur = a_nxt;
                 a_nxt = a_fill;
