@@ -471,6 +471,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 }
                 return out;
             };
+            [[maybe_unused]] auto moved_word = [&](int src) {
+                int out;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(out) : "v"(src));
+                return out;
+            };
             [[maybe_unused]] auto shift_down = [&](E8LandingQ& dst, const E8LandingQ& src, int sh) {
                 #pragma unroll
                 for (int q = 0; q < MS / 4; ++q)
@@ -617,6 +622,12 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
             // (the shifted-scale loop of the 256-row forms takes a block's words from `nxt`, see G32_DEFER in block())
             constexpr bool SPREAD_FORM = G32L && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
+#ifndef DG_QUAD_SPREAD
+#define DG_QUAD_SPREAD 0            // (1: tuning builds.  Measured neutral, same box, product against variant: dense_ue8m0 80.0-80.8 us either way,
+                                    //  contiguous_ue8m0 136.2-137.7 either way -- profiles/r06_probe/quad_spread_neutral.log: the ten moves and the
+                                    //  s_nop between two K quads are not where the op_sel loop loses time)
+#endif
+            constexpr bool QUAD_SPREAD_FORM = DG_QUAD_SPREAD && !G32L && QV == 0 && !STAGED && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
             issue_scales(SPREAD_FORM ? nxt : cur, 0);
             #pragma unroll
             for (int q = 0; q < A_ITERS; ++q) issue_a_piece(A_BYTES, 1, q);
@@ -639,6 +650,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 tie_e8q_landing<MS, NS>(cur);
                 if constexpr (G32)
                     shift_down(cur, cur, g32_shift);    // (KG at granularity 128: block 0 is byte 0)
+                if constexpr (QUAD_SPREAD_FORM)
+                    nxt = cur;                          // (QUAD_SPREAD: block 0 of the first quad moves four words out of `nxt`)
             }
             raw_barrier();
             if constexpr (STAGED) {
@@ -666,6 +679,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             auto block = [&](auto jc, auto load_next, auto tie_next, E8LandingQ& w, int kb, E8LandingQ& land) {
                 constexpr int J = decltype(jc)::value;
                 constexpr bool G32_SPREAD = SPREAD_FORM;
+                // QUAD_SPREAD (round 6, the op_sel loop of the 256-row form): the next K quad's words move from `land` into w's registers inside
+                // block J == 3 as those fall free (and the last four in the first gaps of the next quad's block J == 0) instead of ten moves and an
+                // s_nop between two quads, right behind the MFMAs that read the destination registers -- the schedule of the shifted-scale loop
+                constexpr bool QUAD_SPREAD = QUAD_SPREAD_FORM;
                 constexpr bool LOAD_NEXT = decltype(load_next)::value, TIE_NEXT = decltype(tie_next)::value;
                 const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
                 const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
@@ -709,6 +726,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         // with sa[0]; sa[1] follows in gap 3 (behind the shift there), sb[6] / sb[7] in gaps 14 / 15.  First readers: steps 6, 7 and the last two rows.  Nothing waits
                         // between two blocks (shifted behind the previous block's last MFMA they cost an s_nop + three VALU slots of every block: 2.5 %)
                         // (every write of a w register keeps >= 3 MFMAs behind the last MFMA that read it as its scale operand)
+                    }
+                    if constexpr (QUAD_SPREAD && J == 0) {          // (the first quad of a tile: `land` was set to the same words by the prologue)
+                        if (step == 2) w.sa[1][2] = moved_word(land.sa[1][2]);
+                        if (step == 3) w.sa[1][3] = moved_word(land.sa[1][3]);
+                        if (step == 4) w.sb[6] = moved_word(land.sb[6]);
+                        if (step == 5) w.sb[7] = moved_word(land.sb[7]);
+                    }
+                    if constexpr (G32_SPREAD) {
                         if (step == 2) w.sa[1][2] = shifted_word(land.sa[1][2], kb);
                         if (step == 3) w.sa[1][3] = shifted_word(land.sa[1][3], kb);
                         if (step == 4) w.sb[6] = shifted_word(land.sb[6], kb);
@@ -770,6 +795,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         else if (step % 2 == 0 && step <= 14)           // sb[0] @ 4, sb[1] @ 6, ... sb[5] @ 14 (last read at 2 ns + 1)
                             w.sb[step / 2 - 2] = shifted_word(land.sb[step / 2 - 2], kb + 1);
                     }
+                    if constexpr (QUAD_SPREAD && J == 3) {
+                        if (step < 4)
+                            w.sa[0][step] = moved_word(land.sa[0][step]);
+                        else if (step == 5 || step == 7)
+                            w.sa[1][(step - 5) / 2] = moved_word(land.sa[1][(step - 5) / 2]);
+                        else if (step % 2 == 0 && step <= 14)
+                            w.sb[step / 2 - 2] = moved_word(land.sb[step / 2 - 2]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (G32L && !G32_SPREAD) {
@@ -803,8 +836,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 block(I1{}, Yes{}, No{}, cur, kb + 1, nxt);
                 block(I2{}, No{}, Yes{}, cur, kb + 2, nxt);
                 block(I3{}, No{}, No{}, cur, kb + 3, nxt);
-                cur = nxt;
-                asm volatile("s_nop 3" ::: "memory");           // VALU-written scale registers -> MFMA
+                if constexpr (!QUAD_SPREAD_FORM) {              // (QUAD_SPREAD: moved inside the blocks)
+                    cur = nxt;
+                    asm volatile("s_nop 3" ::: "memory");       // VALU-written scale registers -> MFMA
+                }
             }
             // K tail (k % 512 != 0): up to three more blocks out of the last quad's words (loaded by the last whole quad, or by
             // the prologue when there is none), the byte shifted down by VALU
