@@ -32,7 +32,7 @@ SIGNATURES = {
     'dg_moe_combine_from_masked': (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _i64, _vp]),
     'dg_k_grouped_fp8_gemm_nt_contiguous': (_i32, [_vp] * 5 + [_i32, _i32, _vp, _i32, _i32] + [_i64] * 6 + [_vp]),
     'dg_k_grouped_fp8_gemm_tn_psum': (_i32, [_vp] * 5 + [_i32, _i32, _i32, _vp, _i32, _i32] + [_i64] * 6 + [_vp]),
-    'dg_k_grouped_fp8_gemm_ue8m0': (_i32, [_vp] * 5 + [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32] + [_i64] * 4 + [_vp]),
+    'dg_k_grouped_fp8_gemm_ue8m0': (_i32, [_vp] * 5 + [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32] + [_i64] * 4 + [_vp]),
     'dg_pack_sf_k_grouped_ue8m0': (_i32, [_vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     'dg_k_grouped_fp8_gemm_tn_psum_aligned': (_i32, [_vp] * 5 + [_i32, _i32, _i32, _vp, _i32, _i32] + [_i64] * 6 + [_i32, _vp]),
     'dg_m_grouped_fp8_gemm_nt_contiguous': (_i32, [_vp] * 6 + [_i32] * 4 + [_i64] * 11 + [_i32, _i32, _vp]),

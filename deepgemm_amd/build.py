@@ -18,11 +18,18 @@ import tempfile
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libdeepgemm_amd.so')
 SOURCES = ['dg_api.hip', 'dg_shard.hip', 'kernel_instances.inc']
-NUM_SHARDS = 9                          # shard ids 0 .. NUM_SHARDS - 1 of kernel_instances.inc
+NUM_SHARDS = 10                         # shard ids 0 .. NUM_SHARDS - 1 of kernel_instances.inc
 MONOLITHIC = os.environ.get('DG_MONOLITHIC', '') not in ('', '0')
+# Per-shard compiler flags.  Shard 9 (the K-grouped quad kernels that read MN-major operands in place): their block body holds ~130 inline-asm
+# statements more than the K-major form's, which takes the fully unrolled K-block loops over LLVM's `#pragma unroll` cost limit (16 K units); past
+# it the pragma is silently ignored, the accumulator indices stay dynamic and hipcc keeps all 256 accumulators in scratch (agpr_count 16, 1 200
+# scratch operations in the loop) -- the mechanism behind every "one more copy of the block body and the accumulators go to memory" note in the
+# sources.  The other shards are compiled as they always were.
+SHARD_FLAGS = {9: ['-mllvm', '-pragma-unroll-threshold=200000']}
 HEADERS = ['fp8_gemm_kernels.hpp', 'fp8_gemm_quad.hpp', 'fp8_gemm_moe.hpp', os.path.join('..', '..', 'include', 'deepgemm_amd.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize'] + (['-DDG_MONOLITHIC'] if MONOLITHIC else [])
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize'] + \
+        (['-DDG_MONOLITHIC', '-mllvm', '-pragma-unroll-threshold=200000'] if MONOLITHIC else [])      # (one unit: shard 9's flag for all, see SHARD_FLAGS)
 # DG_EXPERIMENTS=1: also build the timing ablations / rejected kernel variants that HISTORY.md quotes (tools/cycles.py,
 # tools/sustained.py, tools/trace*.py take their names); they roughly triple the compile time and are never selected.
 # Their sources live outside the product: tools/experiments/ (no product build reads them).
@@ -59,7 +66,7 @@ def _hipcc_version() -> str:
 
 
 def _stamp() -> str:
-    return ' '.join([HIPCC, _hipcc_version(), *FLAGS])
+    return ' '.join([HIPCC, _hipcc_version(), *FLAGS, *(f'shard{n}:' + ','.join(v) for n, v in sorted(SHARD_FLAGS.items()))])
 
 
 def is_stale() -> bool:
@@ -102,7 +109,7 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
             cwd = _snapshot(root)
             units = [('dg_api.o', ['dg_api.hip'])]
             if not MONOLITHIC:
-                units += [(f'dg_shard{n}.o', [f'-DDG_SHARD={n}', 'dg_shard.hip']) for n in range(NUM_SHARDS)]
+                units += [(f'dg_shard{n}.o', [*SHARD_FLAGS.get(n, []), f'-DDG_SHARD={n}', 'dg_shard.hip']) for n in range(NUM_SHARDS)]
 
             def compile_unit(unit):
                 cmd = [HIPCC, *FLAGS, '-c', *unit[1], '-o', unit[0]]

@@ -2019,9 +2019,10 @@ int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const
 
 int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, float* d,
                                 int m, int n, int total_k, const int32_t* ks_host, const int32_t* psum_layout, int num_groups,
-                                int k_alignment, int gran_k, int64_t a_stride_m, int64_t b_stride_n,
+                                int k_alignment, int gran_k, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
                                 int64_t sfa_stride_k, int64_t sfb_stride_k, void* stream) {
     DG_CHECK(m >= 0 && n >= 0 && num_groups >= 0 && total_k >= 0);
+    DG_CHECK(ab_layout == DG_KGROUPED_COLUMNS || ab_layout == DG_KGROUPED_ROWS);
     if (m == 0 || n == 0 || num_groups == 0 || total_k == 0)
         return 0;
     DG_CHECK(a != nullptr && b != nullptr && sfa_packed != nullptr && sfb_packed != nullptr && d != nullptr);
@@ -2035,7 +2036,9 @@ int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const 
     p.sfa = reinterpret_cast<const float*>(sfa_packed); p.sfb = reinterpret_cast<const float*>(sfb_packed);
     p.layout = psum_layout;
     p.m = m; p.n = n; p.k = total_k; p.num_groups = num_groups;
-    p.a_sm = a_stride_m; p.a_sk = 1; p.b_sn = b_stride_n; p.b_sk = 1;
+    const bool mn_major = ab_layout == DG_KGROUPED_ROWS;       // a [total_k, m], b [total_k, n] as they are: a_stride_m / b_stride_n are the k-row pitches
+    if (mn_major) { p.a_sm = 1; p.a_sk = a_stride_m; p.b_sn = 1; p.b_sk = b_stride_n; }
+    else { p.a_sm = a_stride_m; p.a_sk = 1; p.b_sn = b_stride_n; p.b_sk = 1; }
     p.sfa_sm = 1; p.sfa_sk = sfa_stride_k; p.sfb_sn = 1; p.sfb_sk = sfb_stride_k;
     p.d_sm = n; p.d_sg = static_cast<int64_t>(m) * n;
     p.sfb_gran_n = 1; p.d_dtype = DG_FP32; p.accumulate = 1;
@@ -2051,12 +2054,18 @@ int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const 
         p.kg_prefix[num_groups] = static_cast<int>(sum_k);
     }
     // K-major rows the LDS-DMA pieces can address (16-byte chunks, 32-bit offsets), scale rows the 16-byte loads can (see fast_eligible)
-    const bool ok = aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= total_k && b_stride_n >= total_k &&
-                    a_stride_m <= (1 << 22) && b_stride_n <= (1 << 22) && aligned16(sfa_packed) && aligned16(sfb_packed) &&
-                    sfa_stride_k % 4 == 0 && sfb_stride_k % 4 == 0 && sfa_stride_k >= m && sfb_stride_k >= n;
+    const bool sf_ok = aligned16(sfa_packed) && aligned16(sfb_packed) && sfa_stride_k % 4 == 0 && sfb_stride_k % 4 == 0 && sfa_stride_k >= m && sfb_stride_k >= n;
+    const bool ok = mn_major
+        // in place: the 256-row form only, k-rows the LDS-DMA pieces can address with 32-bit offsets
+        ? sf_ok && m > 128 && aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= m && b_stride_n >= n &&
+          static_cast<int64_t>(total_k) * a_stride_m < (1LL << 31) && static_cast<int64_t>(total_k) * b_stride_n < (1LL << 31) && forced_config() == "auto"
+        : sf_ok && aligned16(a) && aligned16(b) && a_stride_m % 16 == 0 && b_stride_n % 16 == 0 && a_stride_m >= total_k && b_stride_n >= total_k &&
+          a_stride_m <= (1 << 22) && b_stride_n <= (1 << 22);
     if (!ok) {
-        g_last_error = "dg_k_grouped_fp8_gemm_ue8m0 needs K-major FP8 operands with 16-byte aligned rows (pitch <= 4 MiB) and packed scale rows "
-                       "whose pitch is a multiple of four words behind a 16-byte aligned base (nothing was launched)";
+        g_last_error = mn_major ? "dg_k_grouped_fp8_gemm_ue8m0(DG_KGROUPED_ROWS) needs m > 128, 16-byte aligned MN-major operands (pitch x total_k < 2 GiB) and "
+                                  "packed scale rows whose pitch is a multiple of four words (nothing was launched: re-major and use DG_KGROUPED_COLUMNS)"
+                                : "dg_k_grouped_fp8_gemm_ue8m0 needs K-major FP8 operands with 16-byte aligned rows (pitch <= 4 MiB) and packed scale rows "
+                                  "whose pitch is a multiple of four words behind a 16-byte aligned base (nothing was launched)";
         return 3;
     }
     p.gemm_type = dg::kKGrouped;
@@ -2073,7 +2082,11 @@ int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const 
     // One workgroup per tile, group-major: the hardware hands the next tile to whichever CU frees up, so groups of different K extents balance.
     const dim3 g3(static_cast<unsigned>(grid)), b3(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (gran_k == 32) {
+    if (mn_major) {
+        g_last_config = gran_k == 32 ? "e8_quad_kg_mn_g32_256x256" : "e8_quad_kg_mn_256x256";
+        if (gran_k == 32) hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true, true, true>), g3, b3, 0, s, p);
+        else hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, false, true, true>), g3, b3, 0, s, p);
+    } else if (gran_k == 32) {
         g_last_config = big ? "e8_quad_kg_g32_256x256" : "e8_quad_kg_g32_128x256";
         if (big) hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true, true>), g3, b3, 0, s, p);
         else hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true, true>), g3, b3, 0, s, p);

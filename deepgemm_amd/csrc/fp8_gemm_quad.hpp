@@ -32,6 +32,15 @@
 namespace dg {
 
 struct E8LandingQ { v4i sa[2]; int sb[8]; };
+// The same words for wave tiles whose rows keep their NATURAL order (MN-major operands read in place, MNK below): the lane's A rows are 16 apart,
+// so every word is a load of its own.
+struct E8LandingQN { int sa[8]; int sb[8]; };
+template <typename L> __device__ __forceinline__ int e8_sa(const L& l, int ms) {
+    if constexpr (std::is_same_v<L, E8LandingQN>) return l.sa[ms]; else return l.sa[ms / 4][ms % 4];
+}
+template <typename L> __device__ __forceinline__ void e8_set_sa(L& l, int ms, int v) {
+    if constexpr (std::is_same_v<L, E8LandingQN>) l.sa[ms] = v; else l.sa[ms / 4][ms % 4] = v;
+}
 
 // Packed scale words of one K quad: MS consecutive words of the lane's MS interleaved A rows (one or two dwordx4) and one
 // word per N-subtile for its B rows.  K quad in the soffset, the N-subtile in the immediate offset.  NOT valid until the wait.
@@ -119,6 +128,26 @@ __device__ __forceinline__ void issue_e8q_scale_load_one(E8LandingQ& l, int inde
 #undef DG_E8Q_SB
 }
 
+// Natural row order (E8LandingQN): word of A row m0 + 16 ms + i and of B row n0 + 16 ns + i for the lane's i = lane & 15 -- sixteen dword loads, the
+// M- / N-subtile in the immediate offset.  `index` 0 .. 7: A subtile, 8 .. 15: B subtile; a constant after unrolling.
+__device__ __forceinline__ void issue_e8n_scale_load_one(E8LandingQN& l, int index, const v4i& sfa_rsrc, int sfa_voff, int sfa_soff,
+                                                         const v4i& sfb_rsrc, int sfb_voff, int sfb_soff) {
+#define DG_E8N_SA(i, off) asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:" #off : "=&v"(l.sa[i]) : "v"(sfa_voff), "s"(sfa_rsrc), "s"(sfa_soff) : "memory")
+#define DG_E8N_SB(i, off) asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:" #off : "=&v"(l.sb[i]) : "v"(sfb_voff), "s"(sfb_rsrc), "s"(sfb_soff) : "memory")
+    switch (index) {
+    case 0: DG_E8N_SA(0, 0); break;    case 1: DG_E8N_SA(1, 64); break;   case 2: DG_E8N_SA(2, 128); break;  case 3: DG_E8N_SA(3, 192); break;
+    case 4: DG_E8N_SA(4, 256); break;  case 5: DG_E8N_SA(5, 320); break;  case 6: DG_E8N_SA(6, 384); break;  case 7: DG_E8N_SA(7, 448); break;
+    case 8: DG_E8N_SB(0, 0); break;    case 9: DG_E8N_SB(1, 64); break;   case 10: DG_E8N_SB(2, 128); break; case 11: DG_E8N_SB(3, 192); break;
+    case 12: DG_E8N_SB(4, 256); break; case 13: DG_E8N_SB(5, 320); break; case 14: DG_E8N_SB(6, 384); break; default: DG_E8N_SB(7, 448); break;
+    }
+#undef DG_E8N_SA
+#undef DG_E8N_SB
+}
+__device__ __forceinline__ void tie_e8n_landing(E8LandingQN& l) {
+    asm volatile("" : "+v"(l.sa[0]), "+v"(l.sa[1]), "+v"(l.sa[2]), "+v"(l.sa[3]), "+v"(l.sa[4]), "+v"(l.sa[5]), "+v"(l.sa[6]), "+v"(l.sa[7]),
+                      "+v"(l.sb[0]), "+v"(l.sb[1]), "+v"(l.sb[2]), "+v"(l.sb[3]), "+v"(l.sb[4]), "+v"(l.sb[5]), "+v"(l.sb[6]), "+v"(l.sb[7]) :: "memory");
+}
+
 // The scaled MFMA accumulating in place, as inline asm: with the builtin hipcc treats every accumulator update as a new
 // value, gives results and inputs different registers and rotates 256 registers back at the loop end through thousands of
 // v_accvgpr moves and scratch spills.  "+a" pins each accumulator to one AGPR quad for the whole K loop.  J = byte of the
@@ -199,8 +228,16 @@ __device__ __forceinline__ void mfma_e8_inplace(v4f& acc, const v8i& rows_operan
 // K ranges: kg_prefix (host-side extents) or, kg_psum, the device-side psum layout with K alignment m_alignment (group starts at the previous end
 // rounded up to the alignment; the k-columns between a group's end and the next start hold zeros by the layout's contract).  A partial last block:
 // the 16-byte chunks at and beyond the group's aligned end are pushed out of the descriptor's range (tail_bias, the K_TAIL mechanism) and land as zeros.
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false, bool KG = false>
+// MNK (with KG, 256 x 256): the operands are the reference's MN-major tensors as they are -- a [total_k, m], b [total_k, n], unit stride along m / n, row
+// pitches a_sk / b_sk -- no re-majoring pass (0.19 of 1.23 ms at 8 x 4096 x 7168 x ~4096).  The LDS image of an operand's K block is [128 k][256 mn
+// bytes] with the 16-byte chunks of row k stored at chunk ^ f(k) (load_fragment_tr's layout, fp8_gemm_kernels.hpp); an LDS-DMA piece is 4 k-rows x 256
+// bytes; a fragment is four ds_read_b64_tr_b8 (the hardware transpose read: the same 32 K slots per lane as a K-major fragment) instead of two
+// ds_read_b128; A and B rows keep their natural order, so a lane's scale words are sixteen separate loads (E8LandingQN) and the epilogue maps
+// accumulator (ms, ns) to rows m0 + 16 ms + i, columns n0 + 16 ns + 4 g.  A group's k-rows beyond its aligned end lie outside the descriptor (zeros).
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false, bool KG = false,
+          bool MNK = false>
 __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
+    static_assert(!MNK || (KG && BM == 256 && BN == 256 && DG_M0_SHARE), "MNK: the K-grouped 256 x 256 form");
     static_assert(!G32 || (QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0 && !TABSK), "G32: the two production four-wave forms");
     static_assert(!KG || (QV == 0 && !STAGED && WAVES_N == 2 && !K_TAIL && HS == 0 && !TABSK), "KG: the two production four-wave forms");
     constexpr bool G32L = G32 || KG;        // the loop that shifts every block's scale bytes into byte 0 (no op_sel, no K quads)
@@ -235,7 +272,32 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
     [[maybe_unused]] const int g32_shift = (lane >> 4) * 8;         // G32: lane group g supplies the scale of MX block g = byte g of the row's word
     auto read_fragment = [&](const uint8_t* tile_rows) { return load_fragment(tile_rows, frag_off); };
-    const int lda = static_cast<int>(p.a_sm), ldb = static_cast<int>(p.b_sn);
+    // MNK: the transpose read of 16-row subtile `sub` (0 .. 15 of the operand's 256 rows) out of the [128 k][256] image at `tile`
+    [[maybe_unused]] const int tr_lane_base = (16 * (lane >> 4) + ((lane & 15) >> 1)) * 256 + (lane & 1) * 8;
+    [[maybe_unused]] const int tr_swz = ((lane & 15) >> 1) | (((lane >> 4) & 1) << 3);
+    // (inline asm with hand-placed lgkmcnt waits, as in pipe_pc_kernel_body: behind the BUILTIN form of the read hipcc puts an s_waitcnt vmcnt(0) --
+    //  it cannot tell the read from the LDS-DMA pieces in flight -- and the K loop ran 4.4 us per block instead of 1.3)
+    //  The four 8-byte results are put together into the MFMA operand AT ONCE: staged in their own registers until the wait (FragTr, as pipe_pc does
+    //  with its four + two fragments) the sixteen fragments of this kernel do not fit -- 170 scratch operations in the K loop.  That is only correct
+    //  if hipcc allocates the four results INTO the operand's registers (no copy in front of the wait); it does, and tests/test_codegen.py's
+    //  landing check (no instruction touches a load's registers before its wait) holds the build to it.
+    [[maybe_unused]] auto read_tr_now = [&](const uint8_t* tile, int chunk_off) {
+        v2i_t q0, q1, q2, q3;
+        const int addr = static_cast<int>(reinterpret_cast<uintptr_t>(tile)) + tr_lane_base + chunk_off;
+        asm volatile("ds_read_b64_tr_b8 %0, %1" : "=&v"(q0) : "v"(addr) : "memory");
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:2048" : "=&v"(q1) : "v"(addr) : "memory");
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:16384" : "=&v"(q2) : "v"(addr) : "memory");
+        asm volatile("ds_read_b64_tr_b8 %0, %1 offset:18432" : "=&v"(q3) : "v"(addr) : "memory");
+        return v8i{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+    };
+    [[maybe_unused]] auto read_a_tr = [&](int slot, int ms) { return read_tr_now(lds + slot, ((wm * (BM / 32) + ms) ^ tr_swz) << 4); };
+    [[maybe_unused]] auto read_b_tr = [&](int slot, int ns) {
+        return read_tr_now(lds + (A_SLOTS * A_BYTES) + slot, ((wn * (BN / WAVES_N / 16) + ns) ^ tr_swz) << 4);
+    };
+    // K-major images: fragment ms of A / ns of B out of the ring slot at byte offset `slot` (B: relative to B_BASE)
+    auto frag_a = [&](int slot, int ms) { return load_fragment(lds + slot + (wm * (BM / 2) + ms * 16) * 128, frag_off); };
+    auto frag_b = [&](int slot, int ns) { return load_fragment(lds + (A_SLOTS * A_BYTES) + slot + (wn * (BN / WAVES_N) + ns * 16) * 128, frag_off); };
+    const int lda = static_cast<int>(MNK ? p.a_sk : p.a_sm), ldb = static_cast<int>(MNK ? p.b_sk : p.b_sn);
     // A rows interleaved inside a wave's WM rows (LDS row position ms * 16 + i holds tile row i * MS + ms): a lane's MS row
     // scales are MS consecutive words of the MN-major scale tensor.  See duo_kernel_body.
     auto a_unit_row = [](int u) { return (u / (WM / 8)) * WM + (u & 1) * 8 * MS + ((u % (WM / 8)) >> 1); };
@@ -250,6 +312,17 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
         #pragma unroll
         for (int q = 0; q < B_ITERS; ++q)
             b_piece_soff[q] = __builtin_amdgcn_readfirstlane(b_row_perm<WN>(q * (NW * 8)) * ldb);
+    } else if constexpr (MNK) {
+        // unit u = 4 k-rows x 256 bytes at LDS offset 1024 u: lane l lands at row 4 u + (l >> 4), chunk position l & 15, and so carries source chunk
+        // (l & 15) ^ f(k) of k-row k = 4 u + (l >> 4); u = wave * 8 + q (groups of four share one M0, as below)
+        #pragma unroll
+        for (int q = 0; q < A_ITERS; ++q) {
+            const int k_in = 4 * (wave * A_ITERS + q) + (lane >> 4);
+            const int f = (k_in & 7) | (((k_in >> 4) & 1) << 3);
+            const int chunk = (((lane & 15) ^ f) << 4) + M0_SHARE_BIAS - (q & 3) * 1024;
+            a_piece_voff[q] = k_in * lda + chunk;
+            b_piece_voff[q] = k_in * ldb + chunk;
+        }
     } else if constexpr (M0S) {
         // a wave owns A_ITERS (B_ITERS) CONSECUTIVE units: groups of four pieces share one M0 (DG_LDS_DMA_PIECE_SUB)
         #pragma unroll
@@ -346,7 +419,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             num_kq = (num_kb + 3) / 4;
             // chunks of the last block at and beyond the aligned end: out of range (zeros); none when the aligned end covers the block
             k_tail = kg_k_mask >= num_kb * 128 ? 0 : kg_k_mask - (num_kb - 1) * 128;
-            tail_bias = (k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;
+            tail_bias = (!MNK && k_tail != 0 && src_chunk * 16 >= k_tail) ? 0x40000000 : 0;     // (MNK: the k-rows beyond the end are out of range by themselves)
         }
         auto advance = [&] {
             if (t.second_pass) {
@@ -385,10 +458,14 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // (TABSK: the piece's K range starts at K quad sk_kq0 -- operand bases, scale bases and extents move, every index below is relative)
             // (KG: the group's column range of the K-major operands; b_sg / sfb_sg are 0 -- one B for the launch)
             const int k_ext = TABSK ? num_kb * 128 : KG ? imin(kg_k_mask, num_kb * 128) : p.k;
-            const uint8_t* a_base = uniform_ptr(p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm + (TABSK ? sk_kq0 * 512 : 0) + (KG ? kg_k0 : 0));
-            const uint8_t* b_base = uniform_ptr(p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn + (TABSK ? sk_kq0 * 512 : 0) + (KG ? kg_k0 : 0));
-            const int a_bytes = __builtin_amdgcn_readfirstlane((imin(t.m_end - t.m0, BM) - 1) * lda + k_ext);
-            const int b_bytes = __builtin_amdgcn_readfirstlane((imin(p.n - t.n0, BN) - 1) * ldb + k_ext);
+            const uint8_t* a_base = uniform_ptr(MNK ? p.a + static_cast<int64_t>(kg_k0) * lda + t.m0
+                                                    : p.a + ad_group * p.a_sg + static_cast<int64_t>(t.m0) * p.a_sm + (TABSK ? sk_kq0 * 512 : 0) + (KG ? kg_k0 : 0));
+            const uint8_t* b_base = uniform_ptr(MNK ? p.b + static_cast<int64_t>(kg_k0) * ldb + t.n0
+                                                    : p.b + static_cast<int64_t>(t.group) * p.b_sg + static_cast<int64_t>(t.n0) * p.b_sn + (TABSK ? sk_kq0 * 512 : 0) + (KG ? kg_k0 : 0));
+            // (MNK: the descriptor ends with the last k-row's valid bytes; a lane past M (N) inside an earlier row reads the next k-row's head --
+            //  bytes that only reach rows / columns which are never stored)
+            const int a_bytes = __builtin_amdgcn_readfirstlane(MNK ? (k_ext - 1) * lda + (p.m - t.m0) : (imin(t.m_end - t.m0, BM) - 1) * lda + k_ext);
+            const int b_bytes = __builtin_amdgcn_readfirstlane(MNK ? (k_ext - 1) * ldb + (p.n - t.n0) : (imin(p.n - t.n0, BN) - 1) * ldb + k_ext);
             const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a_base) - (M0S ? M0_SHARE_BIAS : 0), 0, a_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(b_base) - (M0S ? M0_SHARE_BIAS : 0), 0, b_bytes + (M0S ? M0_SHARE_BIAS : 0), 0x00020000);
             // packed scale words: element (row, kq) at base[kq * stride + row] (int32); rows of the whole A (masked: of the group)
@@ -397,9 +474,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                                             (num_sf - 1) * sfa_kq_stride + p.m * 4);
             const v4i sfb_rsrc = scale_rsrc(reinterpret_cast<uint64_t>(p.sfb + static_cast<int64_t>(t.group) * p.sfb_sg + (TABSK ? sk_kq0 * p.sfb_sk : 0) + (KG ? kg_sf_row0 * p.sfb_sk : 0)),
                                             (num_sf - 1) * sfb_kq_stride + p.n * 4);
-            const int sfa_voff = (t.m0 + wm * WM + (lane & 15) * MS) * 4;
+            const int sfa_voff = MNK ? (t.m0 + wm * WM + (lane & 15)) * 4 : (t.m0 + wm * WM + (lane & 15) * MS) * 4;
             // B row of N-subtile ns, MFMA row slot i = lane & 15: wave_n0 + (ns >> 1) * 32 + (i >> 2) * 8 + (ns & 1) * 4 + (i & 3)
-            const int sfb_voff = (t.n0 + wn * WN + ((lane & 15) >> 2) * 8 + (lane & 3)) * 4;
+            const int sfb_voff = MNK ? (t.n0 + wn * WN + (lane & 15)) * 4 : (t.n0 + wn * WN + ((lane & 15) >> 2) * 8 + (lane & 3)) * 4;
 
             auto issue_a_piece = [&](int slot_off, int j, int q) {
                 if (NO_DMA) return;
@@ -410,7 +487,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 else if constexpr (M0S)
                     DG_LDS_DMA_PIECE_SUB(a_rsrc, lds + slot_off + (wave * A_ITERS + (q & ~3)) * 1024,
                                          a_piece_voff[q] + (TAIL && j >= num_kb - 1 ? tail_bias : 0),
-                                         (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
+                                         (HOT_DMA ? 0 : imin(j, num_kb - 1)) * (MNK ? 128 * lda : 128), q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         a_rsrc, (__attribute__((address_space(3))) void*)(lds + slot_off + (wave + NW * q) * 1024), 16,
@@ -425,7 +502,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 else if constexpr (M0S)
                     DG_LDS_DMA_PIECE_SUB(b_rsrc, lds + B_BASE + slot_off + (wave * B_ITERS + (q & ~3)) * 1024,
                                          b_piece_voff[q] + (TAIL && j >= num_kb - 1 ? tail_bias : 0),
-                                         (HOT_DMA ? 0 : imin(j, num_kb - 1)) * 128, q, 0);
+                                         (HOT_DMA ? 0 : imin(j, num_kb - 1)) * (MNK ? 128 * ldb : 128), q, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(lds + B_BASE + slot_off + (wave + NW * q) * 1024), 16,
@@ -450,10 +527,21 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             auto stage_write = [&](int r, int lds_off) {
                 *reinterpret_cast<v4i*>(lds + lds_off + lane16) = stage[r];
             };
-            E8LandingQ cur, nxt;
-            auto issue_scales = [&](E8LandingQ& l, int kq) {
+            using Landing = std::conditional_t<MNK, E8LandingQN, E8LandingQ>;
+            Landing cur, nxt;
+            auto issue_scales = [&](Landing& l, int kq) {
                 const int q = imin(kq, num_sf - 1);
-                issue_e8q_scale_loads<MS, NS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
+                if constexpr (MNK) {
+                    asm volatile("s_nop 4" ::: "memory");       // SGPR operands written by VALU just before (see issue_e8q_scale_loads)
+                    #pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        issue_e8n_scale_load_one(l, i, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
+                } else {
+                    issue_e8q_scale_loads<MS, NS>(l, sfa_rsrc, sfa_voff, q * sfa_kq_stride, sfb_rsrc, sfb_voff, q * sfb_kq_stride);
+                }
+            };
+            auto tie_landing = [&](Landing& l) {
+                if constexpr (MNK) tie_e8n_landing(l); else tie_e8q_landing<MS, NS>(l);
             };
             // G32: every lane's own byte of the landed words into byte 0 (lane group g: bits [8 g, 8 g + 8)); KG at granularity 128: byte kb & 3
             // of the word, the same for every lane.  Row of the scale tensors and shift of K block kb:
@@ -476,12 +564,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 asm volatile("v_mov_b32 %0, %1" : "=v"(out) : "v"(src));
                 return out;
             };
-            [[maybe_unused]] auto shift_down = [&](E8LandingQ& dst, const E8LandingQ& src, int sh) {
+            [[maybe_unused]] auto shift_down = [&](Landing& dst, const Landing& src, int sh) {
                 #pragma unroll
-                for (int q = 0; q < MS / 4; ++q)
-                    #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        dst.sa[q][e] = static_cast<int>(static_cast<unsigned>(src.sa[q][e]) >> sh);
+                for (int ms = 0; ms < MS; ++ms)
+                    e8_set_sa(dst, ms, static_cast<int>(static_cast<unsigned>(e8_sa(src, ms)) >> sh));
                 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns)
                     dst.sb[ns] = static_cast<int>(static_cast<unsigned>(src.sb[ns]) >> sh);
@@ -644,10 +730,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS + B_ITERS / 2, 0));
             if constexpr (SPREAD_FORM) {
-                tie_e8q_landing<MS, NS>(nxt);
+                tie_landing(nxt);
                 shift_down(cur, nxt, sf_shift(0));      // (`nxt` keeps the raw words: block 0 redoes its four deferred ones from there)
             } else {
-                tie_e8q_landing<MS, NS>(cur);
+                tie_landing(cur);
                 if constexpr (G32)
                     shift_down(cur, cur, g32_shift);    // (KG at granularity 128: block 0 is byte 0)
                 if constexpr (QUAD_SPREAD_FORM)
@@ -663,11 +749,24 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // slots (byte offsets): A(kb), A(kb+1), A(kb+2) [= where A(kb+2) is filled]; B(kb), B(kb+1)
             int a_cur = 0, a_nxt = A_BYTES, a_fill = 2 * A_BYTES, b_cur = 0;
             v8i bf[NS], af[4];
+            // MNK: the transpose reads are asm (the compiler knows neither their latency nor their counter): every first use of a fragment sits
+            // behind a counted lgkmcnt wait.  The reads of a wave return in order; per block they are issued as
+            //   rows 0 .. 5: A(ms + 2) at the head of row ms | barrier Z (lgkmcnt 0) | last two rows: B'(ns) behind step 2 ns + 1, A'(0) at step 4, A'(1) at step 10
+            // (' = of the next block), four reads each.
+            if constexpr (MNK) {
+                #pragma unroll
+                for (int ns = 0; ns < NS; ++ns)
+                    bf[ns] = read_b_tr(0, ns);
+                af[0] = read_a_tr(0, 0);
+                af[1] = read_a_tr(0, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
-                bf[ns] = read_fragment(lds + B_BASE + (wn * WN + ns * 16) * 128);
-            af[0] = read_fragment(lds + (wm * WM) * 128);
-            af[1] = read_fragment(lds + (wm * WM + 16) * 128);
+                bf[ns] = frag_b(0, ns);
+            af[0] = frag_a(0, 0);
+            af[1] = frag_a(0, 1);
+            }
 
             if (p.dbg != nullptr) t_loop0 = DG_STAMP_CLOCK();
             asm volatile("s_nop 7" ::: "memory");               // zero-initialised accumulators (VALU writes) -> first MFMA
@@ -676,7 +775,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             // G32, 256-row form: `land` receives block kb + 1's words -- one load per MFMA gap in steps 2 .. 15 (all of them older than the A pieces,
             // the only operations barrier Z's counted wait leaves in flight), tied at barrier Z, shifted IN PLACE in the gaps of the last two rows
             // (one word per step) into `w`'s own registers as they fall free: one block body, one register set in use.
-            auto block = [&](auto jc, auto load_next, auto tie_next, E8LandingQ& w, int kb, E8LandingQ& land) {
+            auto block = [&](auto jc, auto load_next, auto tie_next, Landing& w, int kb, Landing& land) {
                 constexpr int J = decltype(jc)::value;
                 constexpr bool G32_SPREAD = SPREAD_FORM;
                 // QUAD_SPREAD (round 6, the op_sel loop of the 256-row form): the next K quad's words move from `land` into w's registers inside
@@ -684,9 +783,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 // s_nop between two quads, right behind the MFMAs that read the destination registers -- the schedule of the shifted-scale loop
                 constexpr bool QUAD_SPREAD = QUAD_SPREAD_FORM;
                 constexpr bool LOAD_NEXT = decltype(load_next)::value, TIE_NEXT = decltype(tie_next)::value;
-                const uint8_t* a_tile = lds + a_cur + (wm * WM) * 128;
-                const uint8_t* a_next_tile = lds + a_nxt + (wm * WM) * 128;
-                const uint8_t* b_next_tile = lds + B_BASE + (b_cur ^ B_BYTES) + (wn * WN) * 128;
+                const int b_next_slot = b_cur ^ B_BYTES;
                 [[maybe_unused]] const int g32_q = imin(sf_row(kb + 1), num_sf - 1);
                 [[maybe_unused]] const int g32_sh = sf_shift(kb + 1);
                 if constexpr (G32L && !G32_SPREAD)
@@ -698,9 +795,24 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     // on this power-limited part worth 0.4-0.5 us of 79 (same box, 3 of 4 pairs: profiles/r05_probe/quad_serpentine_order_ab.log);
                     // the accumulators are independent: same bits
                     const int ms = step / NS, ns = (ms & 1) ? NS - 1 - step % NS : step % NS;
+                    if constexpr (MNK) {
+                        if (step % NS == 0 && ms + 2 < MS)
+                            af[(ms + 2) & 3] = read_a_tr(a_cur, ms + 2);
+                        if (step == 0)          // behind A(2): the last 15 reads may still fly -- A(2), B'(7), B'(6), three of B'(5); B'(0 .. 4), A'(0), A'(1) are in
+                            asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+                        else if (step == 5)
+                            asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");        // B'(6), B'(7), A(2) behind B'(5)
+                        else if (step == 6)
+                            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                        else if (step == 7)
+                            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        else if (step % NS == 0 && ms >= 2)
+                            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");         // A(ms + 1), A(ms + 2) behind A(ms)
+                    } else {
                     if (step % NS == 0 && !NO_READS)
-                        af[(ms + 2) & 3] = read_fragment(a_tile + (ms + 2) * 2048);
-                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                        af[(ms + 2) & 3] = frag_a(a_cur, ms + 2);
+                    }
+                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], e8_sa(w, ms));
                     // pieces: one per PRE_STRIDE steps: second half of B(kb+1), then A(kb+2)
                     if (step % PRE_STRIDE == 1) {
                         const int q = step / PRE_STRIDE;
@@ -728,22 +840,33 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         // (every write of a w register keeps >= 3 MFMAs behind the last MFMA that read it as its scale operand)
                     }
                     if constexpr (QUAD_SPREAD && J == 0) {          // (the first quad of a tile: `land` was set to the same words by the prologue)
-                        if (step == 2) w.sa[1][2] = moved_word(land.sa[1][2]);
-                        if (step == 3) w.sa[1][3] = moved_word(land.sa[1][3]);
+                        if (step == 2) e8_set_sa(w, 6, moved_word(e8_sa(land, 6)));
+                        if (step == 3) e8_set_sa(w, 7, moved_word(e8_sa(land, 7)));
                         if (step == 4) w.sb[6] = moved_word(land.sb[6]);
                         if (step == 5) w.sb[7] = moved_word(land.sb[7]);
                     }
                     if constexpr (G32_SPREAD) {
-                        if (step == 2) w.sa[1][2] = shifted_word(land.sa[1][2], kb);
-                        if (step == 3) w.sa[1][3] = shifted_word(land.sa[1][3], kb);
+                        if (step == 2) e8_set_sa(w, 6, shifted_word(e8_sa(land, 6), kb));
+                        if (step == 3) e8_set_sa(w, 7, shifted_word(e8_sa(land, 7), kb));
                         if (step == 4) w.sb[6] = shifted_word(land.sb[6], kb);
                         if (step == 5) w.sb[7] = shifted_word(land.sb[7], kb);
                         // gaps 2, 3, 4, 6, 7, 10, 11, 12, 14, 15 (pieces sit in gaps 1, 5, 9, 13, ...; fragment reads in gaps 0, 8, ...)
+                        if constexpr (MNK) {
+                            // sixteen loads, two per gap, all of them in front of the first A piece (gap 17): older than what barrier Z leaves in flight
+                            constexpr int kSlotsN[8] = {6, 7, 10, 11, 12, 14, 15, 16};
+                            #pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                if (step == kSlotsN[i]) {
+                                    issue_e8n_scale_load_one(land, 2 * i, sfa_rsrc, sfa_voff, g32_q * sfa_kq_stride, sfb_rsrc, sfb_voff, g32_q * sfb_kq_stride);
+                                    issue_e8n_scale_load_one(land, 2 * i + 1, sfa_rsrc, sfa_voff, g32_q * sfa_kq_stride, sfb_rsrc, sfb_voff, g32_q * sfb_kq_stride);
+                                }
+                        } else {
                         constexpr int kSlots[10] = {2, 3, 4, 6, 7, 10, 11, 12, 14, 15};
                         #pragma unroll
                         for (int i = 0; i < 10; ++i)
                             if (step == kSlots[i])
                                 issue_e8q_scale_load_one(land, i, sfa_rsrc, sfa_voff, g32_q * sfa_kq_stride, sfb_rsrc, sfb_voff, g32_q * sfb_kq_stride);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -757,8 +880,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 } else {
                     __builtin_amdgcn_s_waitcnt(waitcnt_imm(NO_DMA ? 0 : A_ITERS, 0));
                 }
-                if (TIE_NEXT) tie_e8q_landing<MS, NS>(nxt);         // the next K quad's words (issued one block earlier) are in
-                if (G32L) tie_e8q_landing<MS, NS>(land);            // G32 / KG: the next block's words, issued in this block
+                if (TIE_NEXT) tie_landing(nxt);                     // the next K quad's words (issued one block earlier) are in
+                if (G32L) tie_landing(land);                        // G32 / KG: the next block's words, issued in this block
                 if (!NO_BARRIER) raw_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (LOAD_NEXT) issue_scales(nxt, (kb >> 2) + 1);   // older than every piece issued from here on
@@ -766,11 +889,17 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 #pragma unroll
                 for (int step = 0; step < POST; ++step) {
                     const int ns = step >> 1, ms = MS - 2 + ((step & 1) ^ (ns & 1));
-                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], w.sa[ms / 4][ms % 4]);
+                    mfma_e8_inplace<J>(acc[ms][ns], bf[ns], af[ms & 3], w.sb[ns], e8_sa(w, ms));
+                    if constexpr (MNK) {
+                        if (step & 1) bf[ns] = read_b_tr(b_next_slot, ns);
+                        if (step == POST / 4) af[0] = read_a_tr(a_nxt, 0);
+                        if (step == (POST * 5) / 8) af[1] = read_a_tr(a_nxt, 1);
+                    } else {
                     if ((step & 1) && !NO_READS)
-                        bf[ns] = read_fragment(b_next_tile + ns * 2048);
-                    if (step == POST / 4 && !NO_READS) af[0] = read_fragment(a_next_tile);
-                    if (step == (POST * 5) / 8 && !NO_READS) af[1] = read_fragment(a_next_tile + 2048);
+                        bf[ns] = frag_b(b_next_slot, ns);
+                    if (step == POST / 4 && !NO_READS) af[0] = frag_a(a_nxt, 0);
+                    if (step == (POST * 5) / 8 && !NO_READS) af[1] = frag_a(a_nxt, 1);
+                    }
                     if (step % POST_STRIDE == 1) {
                         if constexpr (STAGED) {
                             const int pos = N_PRE + step / POST_STRIDE;
@@ -789,17 +918,17 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         // words of rows 0 .. 5 died with the rows above; the B word of N-subtile ns after step 2 ns + 1): the loop has ONE block
                         // body and one register set for the words in use (see the loop below for why)
                         if (step < 4)
-                            w.sa[0][step] = shifted_word(land.sa[0][step], kb + 1);
+                            e8_set_sa(w, step, shifted_word(e8_sa(land, step), kb + 1));
                         else if (step == 5 || step == 7)
-                            w.sa[1][(step - 5) / 2] = shifted_word(land.sa[1][(step - 5) / 2], kb + 1);
+                            e8_set_sa(w, 4 + (step - 5) / 2, shifted_word(e8_sa(land, 4 + (step - 5) / 2), kb + 1));
                         else if (step % 2 == 0 && step <= 14)           // sb[0] @ 4, sb[1] @ 6, ... sb[5] @ 14 (last read at 2 ns + 1)
                             w.sb[step / 2 - 2] = shifted_word(land.sb[step / 2 - 2], kb + 1);
                     }
                     if constexpr (QUAD_SPREAD && J == 3) {
                         if (step < 4)
-                            w.sa[0][step] = moved_word(land.sa[0][step]);
+                            e8_set_sa(w, step, moved_word(e8_sa(land, step)));
                         else if (step == 5 || step == 7)
-                            w.sa[1][(step - 5) / 2] = moved_word(land.sa[1][(step - 5) / 2]);
+                            e8_set_sa(w, 4 + (step - 5) / 2, moved_word(e8_sa(land, 4 + (step - 5) / 2)));
                         else if (step % 2 == 0 && step <= 14)
                             w.sb[step / 2 - 2] = moved_word(land.sb[step / 2 - 2]);
                     }
@@ -862,6 +991,8 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             }   // (!G32L)
             if (p.dbg != nullptr) t_loop1 = DG_STAMP_CLOCK();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMA -> accumulator reads; the tail's re-read pieces
+            if constexpr (MNK)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last block's asm fragment reads: their registers are free game for the epilogue
             __syncthreads();
             }   // (default schedule)
         }
@@ -910,13 +1041,15 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             int coff[NS];
             #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
-                coff[ns] = n_base + (ns >> 2) * 64 + lg * 8 + ((ns & 3) >> 1) * 32 + (ns & 1) * 4;
+                coff[ns] = MNK ? n_base + ns * 16 + lg * 4 : n_base + (ns >> 2) * 64 + lg * 8 + ((ns & 3) >> 1) * 32 + (ns & 1) * 4;
+            // (MNK: natural order -- accumulator (ms, ns) holds rows m_base + 16 ms + i, columns n_base + 16 ns + 4 g .. + 3)
+            auto row_of = [&](int ms) { return MNK ? m_base + ms * 16 + (lane & 15) : m_base + (lane & 15) * MS + ms; };
             #pragma unroll
             for (int mb = 0; mb < MS; mb += 4) {
                 v4f old[4][NS];
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int row = m_base + (lane & 15) * MS + mb + u;
+                    const int row = row_of(mb + u);
                     const float* src = dbase + static_cast<int64_t>(imin(imax(row, t.m_begin), t.m_end - 1)) * p.d_sm;
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
@@ -925,7 +1058,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int row = m_base + (lane & 15) * MS + mb + u;
+                    const int row = row_of(mb + u);
                     float* dst = dbase + static_cast<int64_t>(row) * p.d_sm;
                     const bool live = row >= t.m_begin && row < t.m_end;
                     #pragma unroll
@@ -951,6 +1084,9 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         asm volatile("" : "+a"(acc[ms][4 * G + j]));
                         out[ms][j] = acc[ms][4 * G + j];
                     }
+                if constexpr (MNK)      // natural rows and columns: subtiles 4 G .. 4 G + 3 are the 64 columns from n_base + 64 G
+                    store_tile<MS, 4, false, false, true>(p, t, d_group * p.d_sg, out, m_base, n_base + 64 * G);
+                else
                 store_tile<MS, 4, true>(p, t, d_group * p.d_sg, out, m_base, n_base + 64 * G);
             };
             store_half(std::integral_constant<int, 0>{});
@@ -968,10 +1104,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false, bool KG = false>
+template <int BM, int BN, int QV = 0, bool STAGED = false, int WAVES_N = 2, bool K_TAIL = false, int HS = 0, bool TABSK = false, bool G32 = false, bool KG = false,
+          bool MNK = false>
 __global__ __launch_bounds__(128 * WAVES_N)
 void dg_fp8_gemm_quad_e8_kernel(const GemmParams p) {
-    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK, G32, KG>(p);
+    quad_e8_kernel_body<BM, BN, QV, STAGED, WAVES_N, K_TAIL, HS, TABSK, G32, KG, MNK>(p);
 }
 
 // Second phase of the TABSK remainder walk: one workgroup per (remainder tile, 32-row quarter) adds the tile's partial slabs in piece order

@@ -618,8 +618,7 @@ def _k_grouped_tn_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, ks, grouped_layout
     sfa = _k_grouped_packed_sf(a_sf, m, ks, grouped_layout, num_groups, gran_k, k_alignment, use_psum_layout)
     sfb = _k_grouped_packed_sf(b_sf, n, ks, grouped_layout, num_groups, gran_k, k_alignment, use_psum_layout)
     host_assert(sum_k % 16 == 0, 'sum_k % 16 == 0 (K-major rows of whole 16-byte chunks)')
-    a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))       # [m, sum_k], [n, sum_k]: K-major
-    require_device(a_km, b_km, sfa, sfb, d, grouped_layout)
+    require_device(a_data, b_data, sfa, sfb, d, grouped_layout)
     import ctypes
     if use_psum_layout:
         ks_arr, ks_ptr, layout_ptr = None, None, grouped_layout.data_ptr()
@@ -627,9 +626,18 @@ def _k_grouped_tn_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, ks, grouped_layout
         host_assert(num_groups <= 64, 'num_groups <= 64 (K extents handed over by value)')
         ks_arr = (ctypes.c_int32 * num_groups)(*[int(k) for k in ks])
         ks_ptr, layout_ptr = ctypes.cast(ks_arr, ctypes.c_void_p), None
-    check(lib.dg_k_grouped_fp8_gemm_ue8m0(a_km.data_ptr(), sfa.data_ptr(), b_km.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, sum_k,
-                                          ks_ptr, layout_ptr, num_groups, k_alignment, gran_k, a_km.stride(0), b_km.stride(0),
-                                          sfa.stride(0), sfb.stride(0), current_stream_ptr()))
+
+    def launch(a_op, b_op, layout):
+        return lib.dg_k_grouped_fp8_gemm_ue8m0(a_op.data_ptr(), sfa.data_ptr(), b_op.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, sum_k,
+                                               ks_ptr, layout_ptr, num_groups, k_alignment, gran_k, layout, a_op.stride(0), b_op.stride(0),
+                                               sfa.stride(0), sfb.stride(0), current_stream_ptr())
+    # the MN-major tensors as they are wherever the library takes them (transposing fragment reads: m > 128, aligned rows); it declines without
+    # launching otherwise and the operands are re-majored once ([sum_k, mn] -> [mn, sum_k])
+    rc = launch(a_data, b_data, _KGROUPED_ROWS)
+    if rc == _NO_NATIVE_KERNEL:
+        a_km, b_km = _remajor(a_data.transpose(0, 1)), _remajor(b_data.transpose(0, 1))
+        rc = launch(a_km, b_km, _KGROUPED_COLUMNS)
+    check(rc)
 
 
 def k_grouped_fp8_gemm_nt_contiguous(a: TensorPair, b: TensorPair, d: torch.Tensor, ks_cpu, grouped_layout: torch.Tensor,

@@ -335,8 +335,10 @@ int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const
  * with int scale tensors (or FP32 ones after dg_pack_sf_k_grouped_ue8m0).  Recipe (1, 1, gran_k), gran_k = 128 or 32: one exponent per row of a /
  * row of b and gran_k K bytes -- the MX block format of the scaled MFMA; no FP32 promotion, D[g] += A[:, K_g] B[:, K_g]^T accumulates in the
  * matrix core over the group's whole K range.
- *   a [m, total_k], b [n, total_k] K-major FP8 (row pitches a_stride_m / b_stride_n, 16-byte aligned; the reference's MN-major tensors after
- *     dg_transpose_fp8); d [num_groups, m, n] FP32, accumulated in place.
+ *   ab_layout DG_KGROUPED_ROWS: a [total_k, m], b [total_k, n] MN-major as the reference hands them over (k-row pitches a_stride_m / b_stride_n,
+ *     16-byte aligned), read in place through transposing fragment reads -- needs m > 128, returns 3 WITHOUT launching otherwise (callers
+ *     re-major with dg_transpose_fp8 and retry with DG_KGROUPED_COLUMNS); DG_KGROUPED_COLUMNS: a [m, total_k], b [n, total_k] K-major (row
+ *     pitches a_stride_m / b_stride_n, 16-byte aligned).  d [num_groups, m, n] FP32, accumulated in place.
  *   K ranges: psum_layout == NULL: ks_host[g] (host, multiples of 32) one after another; psum_layout != NULL (device int32 [num_groups], ks_host
  *     ignored): group g covers [align(end[g-1], k_alignment), end[g]) and the columns up to align(end[g], k_alignment) hold zeros (the reference's
  *     psum layout, tests/generators.py:480-530, scheduler/gemm.cuh:74-85).  k_alignment % 32 == 0.  A group's last 128-block may be partial.
@@ -346,7 +348,7 @@ int dg_k_grouped_fp8_gemm_tn_psum_aligned(const void* a, const float* sfa, const
  *   At most 64 groups with ks_host, 128 with psum_layout.  Returns 3 without launching when an alignment condition fails. */
 int dg_k_grouped_fp8_gemm_ue8m0(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, float* d,
                                 int m, int n, int total_k, const int32_t* ks_host, const int32_t* psum_layout, int num_groups,
-                                int k_alignment, int gran_k, int64_t a_stride_m, int64_t b_stride_n,
+                                int k_alignment, int gran_k, int ab_layout, int64_t a_stride_m, int64_t b_stride_n,
                                 int64_t sfa_stride_k, int64_t sfb_stride_k, void* stream);
 /* FP32 power-of-two scales of a K-grouped operand, [sf_k, mn] row-major (per group ceil(k_g / gran_k) rows, compact, in group order), into the
  * packed words above ([packed_sf_k, mn] int32, row pitch mn).  Replaces pack_fp32_into_ue8m0 with kNumGroups > 1

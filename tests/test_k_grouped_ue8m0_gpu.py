@@ -54,7 +54,9 @@ def test_k_grouped_ue8m0_host_extents(gran_k, num_groups, m, n, ks):
     packed_b = (case.b[0], gen.pack_k_grouped_ue8m0(case.b[1], ks, gran_k))
     d = case.c.clone()
     dg.k_grouped_fp8_gemm_tn_contiguous(packed_a, packed_b, d, ks, case.grouped_layout, c=d, recipe=recipe)
-    assert dg.last_config() == ('e8_quad_kg_' + ('g32_' if gran_k == 32 else '') + ('256x256' if m > 128 else '128x256')), dg.last_config()
+    # MN-major operands in place (transposing fragment reads) where the library takes them: m > 128 and 16-byte aligned k-rows; else re-majored
+    in_place = m > 128 and m % 16 == 0 and n % 16 == 0
+    assert dg.last_config() == ('e8_quad_kg_' + ('mn_' if in_place else '') + ('g32_' if gran_k == 32 else '') + ('256x256' if m > 128 else '128x256')), dg.last_config()
     _check_groups(d, case, ks, gran_k, f'k-grouped ue8m0 gran {gran_k}')
     # c in another buffer: read, never written
     d2, c_before = torch.empty_like(case.c), case.c.clone()
@@ -64,6 +66,35 @@ def test_k_grouped_ue8m0_host_extents(gran_k, num_groups, m, n, ks):
     d3 = case.c.clone()
     _with_fp32_scales(gran_k, lambda: dg.k_grouped_fp8_gemm_tn_contiguous(case.a, case.b, d3, ks, case.grouped_layout, c=d3, recipe=recipe))
     assert dg.last_config().startswith('e8_quad_kg_') and torch.equal(d3, d)
+
+
+@pytest.mark.parametrize('gran_k', [128, 32])
+@pytest.mark.parametrize('use_psum,k_alignment', [(False, 128), (True, 128), (True, 160), (True, 32), (False, 96)])
+def test_k_grouped_ue8m0_in_place_equals_re_majored(gran_k, use_psum, k_alignment):
+    """The MN-major tensors read in place (e8_quad_kg_mn_*: LDS-DMA of [k][m] rows, ds_read_b64_tr_b8 fragments, natural row order) against the
+    K-major kernel on re-majored copies: the same K-block order per accumulator -- the same bits; both against the oracle.  A row pitch that is
+    not a multiple of 16 bytes (a view with an odd offset) must fall back to the re-majored path."""
+    real_ks = [300, 0, 129, 512, 96, 1000] if use_psum else [k_alignment * q for q in (3, 0, 1, 5, 2, 7)]
+    m, n = 272, 528
+    gen.reset_seed(gran_k + k_alignment + 5)
+    dg.set_mk_alignment_for_contiguous_layout(k_alignment)
+    try:
+        case = gen.generate_k_grouped_contiguous_ue8m0(len(real_ks), m, n, real_ks, gran_k, k_alignment, use_psum_layout=use_psum)
+        a = (case.a[0], gen.pack_k_grouped_ue8m0(case.a[1], real_ks, gran_k))
+        b = (case.b[0], gen.pack_k_grouped_ue8m0(case.b[1], real_ks, gran_k))
+        d = case.c.clone()
+        dg.k_grouped_fp8_gemm_tn_contiguous(a, b, d, case.ks, case.grouped_layout, c=d, recipe=(1, 1, gran_k), use_psum_layout=use_psum)
+        assert dg.last_config() == ('e8_quad_kg_mn_g32_256x256' if gran_k == 32 else 'e8_quad_kg_mn_256x256'), dg.last_config()
+        _check_groups(d, case, real_ks, gran_k, f'in place, gran {gran_k}, alignment {k_alignment}, psum {use_psum}')
+        # the same operands behind a base that is off 16 bytes: re-majored, K-major kernel
+        a_off = torch.empty((case.a[0].numel() + 1,), dtype=torch.uint8, device='cuda')[1:].view(torch.float8_e4m3fn).view(case.a[0].shape)
+        a_off.copy_(case.a[0])
+        d2 = case.c.clone()
+        dg.k_grouped_fp8_gemm_tn_contiguous((a_off, a[1]), b, d2, case.ks, case.grouped_layout, c=d2, recipe=(1, 1, gran_k), use_psum_layout=use_psum)
+        assert dg.last_config() == ('e8_quad_kg_g32_256x256' if gran_k == 32 else 'e8_quad_kg_256x256'), dg.last_config()
+        assert torch.equal(d2, d)
+    finally:
+        dg.set_mk_alignment_for_contiguous_layout(128)
 
 
 @pytest.mark.parametrize('gran_k,k_alignment', [(32, 32), (32, 128), (32, 160), (32, 224), (128, 128), (128, 160), (128, 224), (128, 32), (128, 192)])

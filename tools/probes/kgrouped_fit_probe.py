@@ -3,7 +3,9 @@
 8192 K per group, operands pre-re-majored, C entry called directly (no host work in the timed region).   python tools/probes/kgrouped_fit_probe.py"""
 import sys, ctypes
 sys.path.insert(0, '.')
+import os
 import torch, deepgemm_amd as dg
+LAYOUT = 2 if os.environ.get('KG_MN') else 1          # KG_MN=1: the operands as [sum_k, mn] (read in place)
 from deepgemm_amd._lib import lib, check, current_stream_ptr
 from deepgemm_amd.testing import generators as gen
 from deepgemm_amd.gemm import _remajor
@@ -23,13 +25,13 @@ for k in (1024, 2048, 4096, 8192):
     ks = [k] * g
     gen.reset_seed(0)
     sum_k = sum(ks)
-    a = torch.randn((m, sum_k), device='cuda').to(torch.float8_e4m3fn); b = torch.randn((n, sum_k), device='cuda').to(torch.float8_e4m3fn)
+    a = torch.randn((sum_k, m) if LAYOUT == 2 else (m, sum_k), device='cuda').to(torch.float8_e4m3fn); b = torch.randn((sum_k, n) if LAYOUT == 2 else (n, sum_k), device='cuda').to(torch.float8_e4m3fn)
     sfa = torch.full((sum_k // 512, m), 0x7f7f7f7f, dtype=torch.int32, device='cuda'); sfb = torch.full((sum_k // 512, n), 0x7f7f7f7f, dtype=torch.int32, device='cuda')
     d = torch.zeros((g, m, n), device='cuda')
     ks_arr = (ctypes.c_int32 * g)(*ks)
     def call():
         check(lib.dg_k_grouped_fp8_gemm_ue8m0(a.data_ptr(), sfa.data_ptr(), b.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, sum_k,
-                                              ctypes.cast(ks_arr, ctypes.c_void_p), None, g, 128, 128, a.stride(0), b.stride(0), sfa.stride(0), sfb.stride(0),
+                                              ctypes.cast(ks_arr, ctypes.c_void_p), None, g, 128, 128, LAYOUT, a.stride(0), b.stride(0), sfa.stride(0), sfb.stride(0),
                                               current_stream_ptr()))
     t = time_us(call)
     rounds = g * 16 * 28 / 256
