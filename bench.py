@@ -345,7 +345,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         check = lambda: float('nan')                               # noqa: E731  (D keeps accumulating: parity is the tests' job)
     elif name in ('kgrouped_ue8m0', 'kgrouped_ue8m0_g32'):
         # the reference's SM100 form of the K-grouped GEMM (round 6): MN-major operands, UE8M0 scales of granularity 128 / 32 handed over as packed
-        # words; the call = re-majoring pass of both operands + the hardware-scaled K-grouped kernel
+        # words; one launch of the hardware-scaled K-grouped kernel, which reads the MN-major operands in place
         import random
         g, m, n, ek = 8, 4096, 7168, 4096
         gran_k = 32 if name.endswith('_g32') else 128
@@ -362,7 +362,7 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
         flops = 2.0 * m * n * sum(ks)
         nbytes = (m + n) * sum(ks) * (1 + 1 / gran_k) + 8.0 * g * m * n
         desc = {'workload': f'k_grouped_fp8_gemm_tn_contiguous G={g} M={m} N={n} sum_k={sum(ks)}, packed UE8M0 scales of granularity {gran_k} '
-                            '(the reference\'s SM100 form, tests/generators.py:190-213; re-majoring pass included)',
+                            '(the reference\'s SM100 form, tests/generators.py:190-213; MN-major operands in place)',
                 'm': m, 'n': n, 'sum_k': sum(ks), 'groups': g}
         check = lambda: float('nan')                               # noqa: E731
     elif name == 'kgrouped':

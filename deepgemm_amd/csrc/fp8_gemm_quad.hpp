@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else if (p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
+        } else if (!MNK && p.d_dtype == 0 && !p.accumulate && p.d_vec_ok && n_base + WN <= p.n) {
             // BF16 full-line stores, one M-subtile at a time: 32 accumulator registers leave the AGPRs, are packed, exchanged and
             // stored before the next 32 are touched (left alone hipcc reads all of them up front and spills half).
             #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K-grouped GEMM of the reference's sweep (8 groups, m 4096, n 7168, k ~ 4096 each) in three forms on one box: FP32 scales (pipe_pc, K-major flat /
-MN-major in place) and packed UE8M0 words at granularity 128 / 32 (e8_quad_kg: re-majoring pass + hardware-scaled kernel), with the re-majoring
+MN-major in place) and packed UE8M0 words at granularity 128 / 32 (e8_quad_kg_mn: operands in place; e8_quad_kg: re-majoring pass + hardware-scaled kernel), with the re-majoring
 pass timed alone.   python tools/probes/kgrouped_ue8m0_probe.py"""
 import sys, random
 sys.path.insert(0, '.')
@@ -41,5 +41,11 @@ for gran_k in (128, 32):
     print('gran', gran_k, 'diff', calc_diff(d, case.ref_d), dg.last_config())
     t = time_us(lambda: dg.k_grouped_fp8_gemm_tn_contiguous(a, b, d, ks, case.grouped_layout, c=d, recipe=(1, 1, gran_k)))
     tr = time_us(lambda: (_remajor(a[0].transpose(0, 1)), _remajor(b[0].transpose(0, 1))))
-    print(f'packed UE8M0 gran {gran_k}: call {t:.0f} us ({flops / t / 1e6:.0f} TFLOPS), re-majoring alone {tr:.0f} us -> kernel ~{t - tr:.0f} us ({flops / (t - tr) / 1e6:.0f} TFLOPS)')
+    print(f'packed UE8M0 gran {gran_k}, MN-major operands in place: call {t:.0f} us ({flops / t / 1e6:.0f} TFLOPS) {dg.last_config()}')
+    # the same operands behind a base that is off 16 bytes: the library declines the in-place form, the host re-majors (K-major kernel)
+    a_off = torch.empty((a[0].numel() + 1,), dtype=torch.uint8, device='cuda')[1:].view(torch.float8_e4m3fn).view(a[0].shape)
+    a_off.copy_(a[0])
+    t2 = time_us(lambda: dg.k_grouped_fp8_gemm_tn_contiguous((a_off, a[1]), b, d, ks, case.grouped_layout, c=d, recipe=(1, 1, gran_k)))
+    print(f'   re-majored (operands off alignment): call {t2:.0f} us ({flops / t2 / 1e6:.0f} TFLOPS) {dg.last_config()}; the re-majoring pass alone {tr:.0f} us')
+    del a_off
     del case, a, b, d
