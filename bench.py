@@ -542,7 +542,7 @@ def cpu_baseline(workload: str):
         if i:
             best = min(best, dt)
     return {'value': 2.0 * m * n * k / best / 1e12, 'unit': 'TFLOPS', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'full {m}x{n}x{k}, reference test expr (generators.py:312), min of 2 runs, {best:.2f} s each, cpu_count {os.cpu_count()}'}
+            'sample': f'full {m}x{n}x{k}, reference test expr (generators.py:312), min of 2 runs, {best:.2f} s each'}
 
 
 def run(rank: int, world: int, local_rank: int, args):
@@ -631,14 +631,15 @@ def run(rank: int, world: int, local_rank: int, args):
         if world == 1 and headline and not args.no_secondary:
             detail = run_secondary(args.sets)
             # The driver keeps the last 2000 characters of stdout: the full records go out FIRST, on a line of their own that is not
-            # a JSON line (prefix), the headline line carries {workload: [roofline.frac, us per call, 'mfma' | 'hbm']} and comes LAST.
+            # a JSON line (prefix), the headline line carries {workload: [roofline.frac, us per call(, 'h' = HBM-bound)(, second frac)]} and comes LAST.
             print('secondary_detail: ' + json.dumps(detail), flush=True)
-            line['secondary'] = {name: ([_sig(rec['roofline']['frac']), _sig(rec['roofline']['kernel_us']), rec['roofline']['bound'][0]] +
-                                        ([_sig(rec['roofline']['frac_useful'])] if 'frac_useful' in rec['roofline'] else []) +
-                                        ([_sig(rec['roofline']['frac_of_recipe_roof'])] if 'frac_of_recipe_roof' in rec['roofline'] else [])
+            line['secondary'] = {name: ([_sig(rec['roofline']['frac'], 3), _sig(rec['roofline']['kernel_us'])] +
+                                        (['h'] if rec['roofline']['bound'] == 'hbm' else []) +
+                                        ([_sig(rec['roofline']['frac_useful'], 3)] if 'frac_useful' in rec['roofline'] else []) +
+                                        ([_sig(rec['roofline']['frac_of_recipe_roof'], 3)] if 'frac_of_recipe_roof' in rec['roofline'] else [])
                                         if 'roofline' in rec else rec.get('error', '?')[:40])
                                  for name, rec in zip(SECONDARY, detail)}
-            line['secondary_key'] = '[frac of 5 PF (m) | 8 TB/s (h), us/call, bound, 4th: frac on data rows | of (1,1,128) roof]'
+            line['secondary_key'] = "[frac of 5 PF ('h': of 8 TB/s), us/call, trailing number: frac on data rows | of (1,1,128) roof]"
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
         if 'secondary' in line:         # keep the whole headline line inside the driver's 2000-character tail

@@ -815,18 +815,18 @@ def test_import_is_fork_safe_and_bench_runs():
     assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1 and line['cpu_baseline']['value'] > 0
     assert 'zero-copy' in line['config']['sfa_layout']
     # the driver-visible record of the other configurations (C3 per layout, C4, C5, wgrad, K-grouped, packed UE8M0, dgrad entries ...):
-    # compact {workload: [frac, us, bound(, frac on data rows)]} on the headline line, which must fit the driver's 2000-character tail;
+    # compact {workload: [frac, us(, 'h')(, frac on data rows)]} on the headline line, which must fit the driver's 2000-character tail;
     # the full records on a prefixed (non-JSON) line before it
     assert len(out.stdout.splitlines()[-1]) < 2000, len(out.stdout.splitlines()[-1])
     secondary = line['secondary']
-    assert len(secondary) == 23 and not [v for v in secondary.values() if isinstance(v, str)], secondary
-    for name, rec in secondary.items():
-        assert 0 < rec[0] < 1 and rec[1] > 0 and rec[2] in ('m', 'h'), (name, rec)
-    assert {rec[2] for rec in secondary.values()} == {'m', 'h'} and len(secondary['contiguous']) == 4
+    assert len(secondary) == 26 and not [v for v in secondary.values() if isinstance(v, str)], secondary
+    for name, rec in secondary.items():             # [frac, us(, 'h' = HBM-bound)(, frac on data rows | of the recipe's roof)]
+        assert 0 < rec[0] < 1 and rec[1] > 0 and all(v == 'h' or 0 < v < 1 for v in rec[2:]), (name, rec)
+    assert secondary['masked'][2] == 'h' and len(secondary['c3_nt']) == 2 and len(secondary['contiguous']) == 3 and len(secondary['kgrouped_ue8m0']) == 2
     detail = [ln for ln in out.stdout.splitlines() if ln.startswith('secondary_detail: ')]
     assert len(detail) == 1
     detail = json.loads(detail[0][len('secondary_detail: '):])
-    assert len(detail) == 23 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
+    assert len(detail) == 26 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
     # --gpus N without a launcher must not silently run one rank
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '2', '--warmup', '1'],
                          capture_output=True, text=True, timeout=600)
