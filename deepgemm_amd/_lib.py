@@ -21,6 +21,8 @@ SIGNATURES = {
     'dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0': (_i32, [_vp] * 6 + [_i32] * 4 + [_i64] * 11 + [_i32, _i32, _vp]),
     'dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws': (_i32, [_vp] * 6 + [_i32] * 4 + [_i64] * 11 + [_i32, _i32, _vp, _i64, _vp]),
     'dg_m_grouped_fp8_gemm_nt_masked_ue8m0': (_i32, [_vp] * 6 + [_i32] * 5 + [_i64] * 14 + [_vp]),
+    'dg_fp8_gemm_nt_ue8m0_ws': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    'dg_ue8m0_dense_wants_workspace': (_i32, [_i32] * 3),
     'dg_fp8_gemm_nt_ue8m0_g32': (_i32, [_vp] * 5 + [_i32] * 3 + [_i64] * 8 + [_i64, _i32, _i32, _vp]),
     'dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_g32': (_i32, [_vp] * 6 + [_i32] * 4 + [_i64] * 11 + [_i32, _i32, _vp, _i64, _vp]),
     'dg_m_grouped_fp8_gemm_nt_masked_ue8m0_g32': (_i32, [_vp] * 6 + [_i32] * 5 + [_i64] * 14 + [_vp]),

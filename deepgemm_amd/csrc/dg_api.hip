@@ -1091,8 +1091,76 @@ const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
     return e8_config_by_name(big ? "e8_quad_g32_256x256" : "e8_quad_g32_128x256");
 }
 
+// Under-filled dense launches of the hardware-scaled kernels (round 6: packed-scale dgrad shapes with a narrow N and a long K -- 4096 x 512 x 32768 is
+// 32 tiles of 256 x 256, one K loop of 256 blocks on an eighth of the chip -- and narrow-layer weight gradients): the K axis is cut into `pieces`
+// ranges of whole K quads that run as the groups of ONE launch of the K-grouped kernel, each writing an FP32 partial matrix into the caller's
+// workspace; dg_sum_partials_kernel adds them in piece order and performs the operator's output step (the recipe-(1, 1, 128) split's scheme,
+// launch_per_col_split).  Returns the number of pieces (0 = one ordinary launch; the model is at the end of the function).  workspace_bytes = 0:
+// "as large as needed" (the host layer's query).
+int e8_split_pieces(const dg::GemmParams& p, size_t workspace_bytes) {
+    if (p.gemm_type != dg::kNormal || p.head_lr > 0 || p.m <= 128 || p.k % 512 != 0 || forced_config() != "auto" || !fast_eligible(p))
+        return 0;
+    if (p.sfa_sm != 1 || p.sfb_sn != 1)
+        return 0;
+    const long tiles = static_cast<long>(ceil_div(p.m, 256)) * ceil_div(p.n, 256), num_kb = p.k / 128;
+    const size_t per_piece = static_cast<size_t>(p.m) * p.n * sizeof(float);
+    long pieces = std::min<long>(std::min<long>(8, num_cus() / tiles), num_kb / 8);        // (at least two K quads per piece)
+    const long fit = workspace_bytes > 0 ? (workspace_bytes > 4096 ? static_cast<long>((workspace_bytes - 4096) / per_piece) : 0) : 8;
+    pieces = std::min<long>(pieces, fit);
+    if (pieces < 2 || num_kb < 24)
+        return 0;
+    // calibrated on profiles/r06_probe/packed_dense_ksplit_ab.log: one launch = the 128-row kernel at ~0.75 us per K block while its tiles fit the chip
+    // (576 x 4096 x 7168: 54 us), 1.35 per round of 256-row tiles otherwise; the split's pieces run 256-row tiles at 1.35 us per K block and the
+    // summing kernel moves (pieces + 2) x m x n x 4 bytes at ~3.7 TB/s (4096 x 512 x 32768: 255 -> 105 us, 1024 x 1024 x 16384: 96 -> 59; at 56 K
+    // blocks the split loses 5 us and is not taken)
+    const long tiles128 = static_cast<long>(ceil_div(p.m, 128)) * ceil_div(p.n, 256);
+    const double t_one = tiles128 <= num_cus() ? 12.0 + 0.75 * num_kb : 12.0 + 1.35 * num_kb * ceil_div(static_cast<int>(tiles), num_cus());
+    const double t_split = 27.0 + 1.35 * ((num_kb + pieces - 1) / pieces) + static_cast<double>(pieces + 2) * per_piece / 3.7e6;
+    return t_split < 0.85 * t_one ? static_cast<int>(pieces) : 0;
+}
+
+int launch_e8_split(const dg::GemmParams& dense, int pieces, void* stream, int gran_k) {
+    dg::GemmParams p = dense;
+    float* parts = reinterpret_cast<float*>(static_cast<uint8_t*>(dense.sk_workspace) + 4096);
+    p.d = parts; p.d_sm = dense.n; p.d_sg = static_cast<int64_t>(dense.m) * dense.n; p.d_dtype = DG_FP32; p.accumulate = 0;
+    p.gemm_type = dg::kKGrouped; p.num_groups = pieces; p.kg_blocks = 0; p.kg_psum = 0; p.m_alignment = 128; p.layout = nullptr;
+    p.b_sg = 0; p.sfb_sg = 0; p.sfb_gran_n = 1;
+    p.sk_workspace = nullptr; p.sk_first_tile = 0; p.sk_tiles = 0; p.sk_factor = 1;
+    const int num_kq = dense.k / 512;
+    for (int i = 0; i <= pieces; ++i)
+        p.kg_prefix[i] = 512 * static_cast<int>(static_cast<long>(i) * num_kq / pieces);
+    p.num_m_tiles = ceil_div(p.m, 256);
+    p.num_n_tiles = ceil_div(p.n, 256);
+    p.group_m = p.num_m_tiles >= 8 ? 4 : (p.num_m_tiles >= 2 ? 2 : 1);
+    p.d_vec_ok = dense.n % 4 == 0;
+    p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    const long grid = static_cast<long>(p.num_m_tiles) * p.num_n_tiles * pieces;
+    g_last_config = gran_k == 32 ? "e8_quad_ks_g32_256x256" : "e8_quad_ks_256x256";
+    if (gran_k == 32)
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), p);
+    else
+        hipLaunchKernelGGL((dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, false, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), p);
+    DG_HIP_CHECK(hipGetLastError());
+    const size_t elem = dense.d_dtype == DG_BF16 ? 2 : 4;
+    const int vec_ok = dense.n % 4 == 0 && (dense.d_dtype == DG_BF16 || (aligned16(dense.d) && (dense.d_sm * elem) % 16 == 0));
+    const long quads = static_cast<long>(dense.m) * ((dense.n + 3) / 4);
+    const long blocks = std::min<long>((quads + 255) / 256, static_cast<long>(num_cus()) * 8);
+    hipLaunchKernelGGL(dg::dg_sum_partials_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       parts, pieces, static_cast<int64_t>(dense.m) * dense.n, dense.d, dense.m, dense.n, dense.d_sm, dense.d_dtype,
+                       dense.accumulate, vec_ok);
+    DG_HIP_CHECK(hipGetLastError());
+    if (env_knobs().print_configs)
+        fprintf(stderr, "[deepgemm_amd] ue8m0 dense m=%d n=%d k=%d -> %s pieces=%d grid=%ld\n", dense.m, dense.n, dense.k, g_last_config.c_str(), pieces, grid);
+    return 0;
+}
+
 int launch_e8(dg::GemmParams& p, int expected_m, void* stream, int gran_k = 128) {
     const bool k_tail = p.k % 128 != 0;
+    if (p.sk_workspace != nullptr && p.gemm_type == dg::kNormal)
+        if (const int pieces = e8_split_pieces(p, g_workspace_bytes); pieces >= 2)
+            return launch_e8_split(p, pieces, stream, gran_k);
     const bool mn_form = gran_k != 32 && e8_mn_eligible(p);           // an MN-major operand read in place
     if (gran_k == 32 && (k_tail || !fast_eligible(p))) {
         g_last_error = "packed-UE8M0 GEMMs with scale granularity 32 need K-major, 16-byte aligned FP8 operands and k % 128 == 0";
@@ -1263,7 +1331,8 @@ static int dg_fp8_gemm_nt_ue8m0_impl(const void* a, const int32_t* sfa_packed, c
                          int m, int n, int k,
                          int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
-                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream, int gran_k) {
+                         int64_t d_stride_m, int d_dtype, int accumulate, void* stream, int gran_k,
+                         void* workspace = nullptr, int64_t workspace_bytes = 0) {
     DG_CHECK(m >= 0 && n >= 0 && k > 0);
     if (m == 0 || n == 0)
         return 0;
@@ -1271,6 +1340,7 @@ static int dg_fp8_gemm_nt_ue8m0_impl(const void* a, const int32_t* sfa_packed, c
     DG_CHECK(d_dtype == DG_BF16 || d_dtype == DG_FP32);
     DG_CHECK(d_stride_m >= n);
     DG_CHECK(sfa_stride_m == 1 && sfb_stride_n == 1);       // MN-major packed scale words (the reference's TMA layout)
+    DG_CHECK(workspace == nullptr || (aligned16(workspace) && workspace_bytes >= 4096));
     dg::GemmParams p{};
     p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.d = d;
     p.sfa = reinterpret_cast<const float*>(sfa_packed); p.sfb = reinterpret_cast<const float*>(sfb_packed);
@@ -1282,6 +1352,8 @@ static int dg_fp8_gemm_nt_ue8m0_impl(const void* a, const int32_t* sfa_packed, c
     p.sfb_gran_n = 128; p.d_dtype = d_dtype; p.accumulate = accumulate ? 1 : 0;
     p.gemm_type = dg::kNormal; p.m_alignment = 0;
     p.sfb_gran_n = 128;                                      // only so that the K-major / alignment test below applies
+    p.sk_workspace = workspace;
+    g_workspace_bytes = workspace != nullptr ? static_cast<size_t>(workspace_bytes) : 0;
     if (!fast_eligible(p, p.k % 128 == 0) && !e8_mn_eligible(p)) {
         g_last_error = "dg_fp8_gemm_nt_ue8m0 needs 16-byte aligned FP8 operands: K-major (k % 128 == 0, or k % 16 == 0 and k > 128) or, with "
                        "k % 128 == 0, MN-major (m resp. n % 16 == 0)";
@@ -1296,6 +1368,29 @@ int dg_fp8_gemm_nt_ue8m0(const void* a, const int32_t* sfa_packed, const void* b
                          int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                          int64_t d_stride_m, int d_dtype, int accumulate, void* stream) {
     return dg_fp8_gemm_nt_ue8m0_impl(a, sfa_packed, b, sfb_packed, d, m, n, k, a_stride_m, a_stride_k, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq, sfb_stride_n, sfb_stride_kq, d_stride_m, d_dtype, accumulate, stream, 128);
+}
+
+int dg_fp8_gemm_nt_ue8m0_ws(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                            int m, int n, int k,
+                            int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                            int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                            int64_t d_stride_m, int d_dtype, int accumulate, int gran_k, void* workspace, int64_t workspace_bytes, void* stream) {
+    DG_CHECK(gran_k == 128 || gran_k == 32);
+    return dg_fp8_gemm_nt_ue8m0_impl(a, sfa_packed, b, sfb_packed, d, m, n, k, a_stride_m, a_stride_k, b_stride_n, b_stride_k, sfa_stride_m, sfa_stride_kq,
+                                     sfb_stride_n, sfb_stride_kq, d_stride_m, d_dtype, accumulate, stream, gran_k, workspace, workspace_bytes);
+}
+
+int dg_ue8m0_dense_wants_workspace(int m, int n, int k) {
+    // would the automatic selection cut this packed-scale dense problem (K-major, 16-byte aligned, densely packed operands) along K if the caller
+    // lent it a workspace?  The host layer asks before it creates / passes one (dg_dense_wants_workspace's twin for the hardware-scaled path).
+    if (m <= 0 || n <= 0 || k <= 0)
+        return 0;
+    dg::GemmParams p{};
+    p.a = p.b = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(1) << 20);
+    p.m = m; p.n = n; p.k = k; p.num_groups = 1;
+    p.a_sm = k; p.a_sk = 1; p.b_sn = k; p.b_sk = 1; p.sfa_sm = 1; p.sfb_sn = 1;
+    p.gemm_type = dg::kNormal;
+    return e8_split_pieces(p, 0) >= 2 ? 1 : 0;
 }
 
 int dg_fp8_gemm_nt_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,

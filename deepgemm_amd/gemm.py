@@ -203,11 +203,16 @@ def _fp8_gemm_nt_packed_ue8m0(a_data, a_sf, b_data, b_sf, d, c, recipe, recipe_a
             a_data = _as_k_major(a_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
         if plan & 2 and b_data.stride(-1) != 1:
             b_data = _as_k_major(b_data, REMAJOR_MIN_MACS if REMAJOR_MIN_MACS > 0 else 1)
-    check((lib.dg_fp8_gemm_nt_ue8m0_g32 if gran_k == 32 else lib.dg_fp8_gemm_nt_ue8m0)(
+    # (under-filled launches with a long K loop are cut along K when the stream's scratch buffer is handed over: the library owns the rule)
+    ws = None
+    if a_data.stride(-1) == 1 and b_data.stride(-1) == 1 and lib.dg_ue8m0_dense_wants_workspace(m, n, k):
+        ws = _split_k_workspace(d.device, current_stream_ptr())
+    check(lib.dg_fp8_gemm_nt_ue8m0_ws(
         a_data.data_ptr(), sfa.data_ptr(), b_data.data_ptr(), sfb.data_ptr(), d.data_ptr(), m, n, k,
         a_data.stride(0), a_data.stride(1), b_data.stride(0), b_data.stride(1),
         sfa.stride(0), sfa.stride(1), sfb.stride(0), sfb.stride(1),
-        d.stride(0), _dtype_code(d), int(c is not None), current_stream_ptr()))
+        d.stride(0), _dtype_code(d), int(c is not None), gran_k,
+        ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, current_stream_ptr()))
 
 
 _SPLIT_K_WORKSPACES = {}

@@ -103,6 +103,18 @@ int dg_m_grouped_fp8_gemm_nt_contiguous_ue8m0_ws(const void* a, const int32_t* s
                                                  int64_t sfb_stride_g, int64_t sfb_stride_n, int64_t sfb_stride_kq,
                                                  int64_t d_stride_m, int use_psum, int m_alignment,
                                                  void* workspace, int64_t workspace_bytes, void* stream);
+/* dg_fp8_gemm_nt_ue8m0 / _g32 with a caller-owned scratch buffer (dg_split_k_workspace_bytes() bytes, 16-byte aligned; NULL = none): under-filled
+ * launches with a long K loop (packed-scale dgrad shapes such as 4096 x 512 x 32768, narrow-layer weight gradients: m > 128, k % 512 == 0, at most
+ * half the CUs' worth of 256 x 256 tiles) are cut along K into pieces that run as the groups of one launch of the K-grouped hardware-scaled
+ * kernel; a second kernel on the same stream adds the FP32 partials in piece order and performs the output step.  gran_k 128 or 32.  The C ABI
+ * never allocates: without a workspace the call runs as one ordinary launch.  dg_ue8m0_dense_wants_workspace: would a K-major, aligned problem
+ * of this shape be cut (the host layer asks before it creates a buffer). */
+int dg_fp8_gemm_nt_ue8m0_ws(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
+                            int m, int n, int k,
+                            int64_t a_stride_m, int64_t a_stride_k, int64_t b_stride_n, int64_t b_stride_k,
+                            int64_t sfa_stride_m, int64_t sfa_stride_kq, int64_t sfb_stride_n, int64_t sfb_stride_kq,
+                            int64_t d_stride_m, int d_dtype, int accumulate, int gran_k, void* workspace, int64_t workspace_bytes, void* stream);
+int dg_ue8m0_dense_wants_workspace(int m, int n, int k);
 /* Scale granularity 32 along K (round 6) -- the reference's SM100 MX recipe for FP8 x FP8 operands: recipe (1, 1, 32) / recipe_a = (1, 32)
  * (csrc/apis/gemm.hpp:311-312 gran_k == 32 or gran_k == 128; csrc/apis/layout.hpp:48-58 the (INT, 1, gran_k) and the FP32 cast branches;
  * per_token_cast_to_fp8(..., gran_k = 32, use_packed_ue8m0 = True), deep_gemm/utils/math.py:26-38; sweep tests/generators.py:192-194,230).

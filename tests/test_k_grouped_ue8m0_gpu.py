@@ -166,3 +166,47 @@ def test_k_grouped_ue8m0_full_size_group():
         want = torch.empty((rows.numel(), 7168), dtype=torch.float)
         oracle.fp8_gemm_nt(a_g[rows].cpu(), sfa_g[rows].cpu(), b_g.cpu(), sfb_g.cpu(), want, c=case.c[1][rows].cpu(), gran_n=1, gran_k=gran_k)
         assert_close_fp32(d[1][rows], want, f'full-size k-grouped ue8m0 gran {gran_k}, short group')
+
+
+@pytest.mark.parametrize('gran_k', [128, 32])
+@pytest.mark.parametrize('m,n,k,accumulate,out_dtype', [(256, 512, 8192, False, torch.bfloat16), (576, 1024, 14336, True, torch.float),
+                                                       (1000, 264, 16384, False, torch.float), (512, 512, 16384, True, torch.bfloat16)])
+def test_packed_dense_k_split_runs_as_k_groups(gran_k, m, n, k, accumulate, out_dtype):
+    """Under-filled packed-scale dense problems with a long K loop (round 6): the K axis cut into pieces that run as the groups of one launch of the
+    K-grouped hardware-scaled kernel (e8_quad_ks_*), FP32 partials summed in piece order by dg_sum_partials_kernel -- against the oracle, and
+    against the same call as ONE launch (forced kernel: whole K loops; the split changes only where the FP32 partial sums are cut)."""
+    from deepgemm_amd.utils.math import pack_ue8m0_to_int, per_token_cast_to_fp8
+    gen.reset_seed(m + k + gran_k)
+    case = gen.generate_normal(m, n, k, accumulate=accumulate, out_dtype=out_dtype, per_token_b=True, use_ue8m0=True)
+    if gran_k == 32:
+        qa, qb = per_token_cast_to_fp8(case.a_bf16, True, 32), per_token_cast_to_fp8(case.b_bf16, True, 32)
+        a = (qa[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, 32)))
+        b = (qb[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, 32)))
+        fp32_a, fp32_b = qa, qb
+    else:
+        a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b)
+        fp32_a, fp32_b = case.a, case.b
+    c0 = case.d.clone() if accumulate else None
+    kw = dict(c=case.d if accumulate else None, recipe=(1, 1, gran_k))
+    dg.fp8_gemm_nt(a, b, case.d, **kw)
+    assert dg.last_config() == ('e8_quad_ks_g32_256x256' if gran_k == 32 else 'e8_quad_ks_256x256'), dg.last_config()
+    want = torch.empty((m, n), dtype=out_dtype)
+    oracle.fp8_gemm_nt(fp32_a[0].cpu(), fp32_a[1].cpu(), fp32_b[0].cpu(), fp32_b[1].cpu(), want, c=c0.cpu() if accumulate else None, gran_n=1, gran_k=gran_k)
+    if out_dtype == torch.float:
+        assert_close_fp32(case.d, want, f'packed dense K split {m}x{n}x{k} gran {gran_k}')
+    else:
+        from gpu_helpers import assert_close_to_oracle
+        assert_close_to_oracle(case.d, want, f'packed dense K split {m}x{n}x{k} gran {gran_k}', addend=c0)
+    # one launch over the whole K loop (a forced kernel takes no K split)
+    dg.set_forced_config('e8_quad_g32_128x256' if gran_k == 32 else 'e8_quad_128x256')
+    try:
+        d1 = c0.clone() if accumulate else torch.empty_like(case.d)
+        dg.fp8_gemm_nt(a, b, d1, c=d1 if accumulate else None, recipe=(1, 1, gran_k))
+        assert dg.last_config() in ('e8_quad_g32_128x256', 'e8_quad_128x256')
+    finally:
+        dg.set_forced_config('auto')
+    assert calc_diff(case.d.float(), d1.float()) < 2e-6
+    # a second call gives the same bits (piece order is fixed)
+    d2 = c0.clone() if accumulate else torch.empty_like(case.d)
+    dg.fp8_gemm_nt(a, b, d2, c=d2 if accumulate else None, recipe=(1, 1, gran_k))
+    assert torch.equal(d2, case.d)
