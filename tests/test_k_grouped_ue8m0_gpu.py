@@ -210,3 +210,49 @@ def test_packed_dense_k_split_runs_as_k_groups(gran_k, m, n, k, accumulate, out_
     d2 = c0.clone() if accumulate else torch.empty_like(case.d)
     dg.fp8_gemm_nt(a, b, d2, c=d2 if accumulate else None, recipe=(1, 1, gran_k))
     assert torch.equal(d2, case.d)
+
+
+def test_k_grouped_ue8m0_and_packed_k_split_in_a_hip_graph():
+    """Both round-6 paths inside a hipGraph: the K-grouped call with packed words (operands in place: one kernel, nothing allocated) and with FP32
+    scales in the psum form (the layout step's pack kernel + the GEMM, ranges read on the device) replay to the eager bits; the packed-scale dense K
+    split captured on a stream that owns its workspace keeps the pieces, on a fresh stream it runs as one launch (no allocation during capture)."""
+    gen.reset_seed(41)
+    real_ks = [384, 0, 512, 200]
+    case = gen.generate_k_grouped_contiguous_ue8m0(4, 272, 528, real_ks, 32, 128, use_psum_layout=True)
+    packed_a = (case.a[0], gen.pack_k_grouped_ue8m0(case.a[1], real_ks, 32))
+    packed_b = (case.b[0], gen.pack_k_grouped_ue8m0(case.b[1], real_ks, 32))
+    want = case.c.clone()
+    dg.k_grouped_fp8_gemm_tn_contiguous(packed_a, packed_b, want, None, case.grouped_layout, c=want, recipe=(1, 1, 32), use_psum_layout=True)
+    torch.cuda.synchronize()
+    for a, b in ((packed_a, packed_b), (case.a, case.b)):
+        d = case.c.clone()
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            dg.k_grouped_fp8_gemm_tn_contiguous(a, b, d, None, case.grouped_layout, c=d, recipe=(1, 1, 32), use_psum_layout=True)
+        for _ in range(2):
+            d.copy_(case.c)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(d, want)
+    # dense K split
+    m, n, k = 256, 512, 8192
+    dense = gen.generate_normal(m, n, k, per_token_b=True, use_ue8m0=True)
+    a, b = gen.packed_ue8m0_operand(*dense.a), gen.packed_ue8m0_operand(*dense.b)
+    torch.cuda.synchronize()
+    warm = torch.cuda.Stream()
+    with torch.cuda.stream(warm):
+        dg.fp8_gemm_nt(a, b, dense.d, recipe=(1, 1, 128))
+        assert dg.last_config() == 'e8_quad_ks_256x256'
+    warm.synchronize()
+    eager = dense.d.clone()
+    for stream, name in ((warm, 'e8_quad_ks_256x256'), (torch.cuda.Stream(), None)):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            dg.fp8_gemm_nt(a, b, dense.d, recipe=(1, 1, 128))
+        assert name is None or dg.last_config() == name
+        assert name is not None or not dg.last_config().startswith('e8_quad_ks_'), dg.last_config()
+        dense.d.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dense.d, eager) if name else calc_diff(dense.d.float(), eager.float()) < 2e-6
