@@ -708,6 +708,10 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
             for (int q = 0; q < B_ITERS; ++q) issue_b_piece(0, 0, q);
             // (the shifted-scale loop of the 256-row forms takes a block's words from `nxt`, see G32_DEFER in block())
             constexpr bool SPREAD_FORM = G32L && MS == 8 && NS == 8 && PRE_STRIDE == 4 && POST == 16;
+#ifndef DG_RMW_NT
+#define DG_RMW_NT 0                 // (1 / 2 / 3: non-temporal loads / stores / both in the FP32 reduce-add epilogue -- measured 1-8 % slower on the K-grouped
+                                    //  call, profiles/r06_probe/rmw_epilogue_nontemporal_negative.log)
+#endif
 #ifndef DG_QUAD_SPREAD
 #define DG_QUAD_SPREAD 0            // (1: tuning builds.  Measured neutral, same box, product against variant: dense_ue8m0 80.0-80.8 us either way,
                                     //  contiguous_ue8m0 136.2-137.7 either way -- profiles/r06_probe/quad_spread_neutral.log: the ten moves and the
@@ -1053,7 +1057,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                     const float* src = dbase + static_cast<int64_t>(imin(imax(row, t.m_begin), t.m_end - 1)) * p.d_sm;
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns)
+#if DG_RMW_NT & 1            // (tuning builds: non-temporal policy on the old values' loads (1) / the stores (2))
+                        old[u][ns] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + coff[ns]));
+#else
                         old[u][ns] = *reinterpret_cast<const v4f*>(src + coff[ns]);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 #pragma unroll
@@ -1066,7 +1074,11 @@ __device__ __forceinline__ void quad_e8_kernel_body(const GemmParams& p) {
                         asm volatile("" : "+a"(acc[mb + u][ns]));
                         const v4f v = acc[mb + u][ns] + old[u][ns];
                         if (live)
+#if DG_RMW_NT & 2
+                            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst + coff[ns]));
+#else
                             *reinterpret_cast<v4f*>(dst + coff[ns]) = v;
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
