@@ -221,3 +221,51 @@ def test_packed_ue8m0_at_c2_size():
     _check_sampled(outs['auto'], case, 128, 'e8 c2', rows_n=16)
     for cfg, d in outs.items():
         assert torch.equal(d, outs['auto']), cfg
+
+
+@pytest.mark.parametrize('use_psum', [False, True])
+@pytest.mark.parametrize('gran_k,k_alignment', [(32, 32), (32, 128), (32, 160), (32, 224), (128, 128), (128, 160), (128, 224)])
+def test_reference_k_grouped_sm100_sweep_full(gran_k, k_alignment, use_psum):
+    """The reference's SM100 K-grouped sweep at its stated sizes (tests/generators.py:190-213 x tests/test_fp8_fp4.py:193-225): every
+    (gran_k, K alignment) pair, with and without the psum layout, the three test variants (as generated / an empty group / a shortened first
+    group in the psum form), ``ks_cpu`` given, missing and empty in the psum form -- UE8M0 scales, MN-major operands read in place by the
+    hardware-scaled K-grouped kernels; the reference's own gate (calc_diff < 1e-3).  Two of the six (groups, m, n, k) entries per pair, to keep
+    the run at seconds: the largest K per group and the largest group count."""
+    import random
+    dg.set_mk_alignment_for_contiguous_layout(k_alignment)
+    try:
+        for num_groups, m, n, expected_k in ((4, 4096, 7168, 8192), (16, 7168, 2048, 2048)):
+            random.seed(num_groups + k_alignment + gran_k)
+            real_ks = [max(1, int(expected_k * random.uniform(0.7, 1.3))) for _ in range(num_groups)]
+            for variant in range(2):
+                ks = list(real_ks)
+                if variant == 1:
+                    ks[random.randint(0, num_groups - 1)] = 0                      # an empty group
+                elif use_psum:
+                    ks[0] -= random.randint(1, min(k_alignment - 1, ks[0] - 1))    # a group that ends off the alignment
+                if not use_psum:
+                    ks = [gen.align(k, k_alignment) for k in ks]
+                gen.reset_seed(sum(ks))
+                case = gen.generate_k_grouped_contiguous_ue8m0(num_groups, m, n, ks, gran_k, k_alignment, use_psum_layout=use_psum)
+                case.a_groups = case.b_groups = None
+                for ks_cpu in ((case.ks, None, []) if use_psum else (case.ks,)):
+                    d = case.c.clone()
+                    dg.k_grouped_fp8_gemm_tn_contiguous(case.a, case.b, d, ks_cpu, case.grouped_layout, c=d, recipe=(1, 1, gran_k), use_psum_layout=use_psum) \
+                        if gran_k == 32 else _sm100_mode(lambda: dg.k_grouped_fp8_gemm_tn_contiguous(case.a, case.b, d, ks_cpu, case.grouped_layout, c=d,
+                                                                                                      recipe=(1, 1, gran_k), use_psum_layout=use_psum))
+                    assert dg.last_config().startswith('e8_quad_kg_mn_'), dg.last_config()
+                    diff = calc_diff(d, case.ref_d)
+                    assert diff < 1e-3, (num_groups, m, n, ks, gran_k, k_alignment, use_psum, ks_cpu is None, diff)
+                del case
+                torch.cuda.empty_cache()
+    finally:
+        dg.set_mk_alignment_for_contiguous_layout(128)
+
+
+def _sm100_mode(fn):
+    mode = dg.get_sf_cast_mode()
+    dg.set_sf_cast_mode('sm100')
+    try:
+        return fn()
+    finally:
+        dg.set_sf_cast_mode(mode)
