@@ -26,4 +26,4 @@ find $OUT -type f ! -name "*.csv" ! -name "*.log" ! -name "*.txt" ! -name "*.jso
 python tools/trim_profiles.py $OUT > /dev/null
 find $OUT -type f -size +2M -delete
 python tools/summarize_prof.py $OUT > $OUT/SUMMARY.txt 2>&1
-tail -5 $OUT/*_stats.log | grep -v amdgpu | cut -c1-400
+tail -q -n 5 $OUT/*_stats.log | grep -v amdgpu | cut -c1-400
