@@ -3,7 +3,8 @@
 not tile multiples, both granularities, K alignments 32 .. 256, host extents or the psum layout (ks_cpu given or missing), FP32 scale tensors or
 packed words.  Checker: a float64 product of the dequantised operands of every group (torch on the GPU; the layout logic -- group starts, scale rows,
 masked tails -- is what is fuzzed; tolerance: the FP32-output bound of tests/gpu_helpers.py, rel-Frobenius 5e-5; the arithmetic is pinned to the oracle by tests/test_k_grouped_ue8m0_gpu.py).
-    python tools/fuzz_k_grouped_ue8m0.py [seeds] [first_seed]"""
+    python tools/fuzz_k_grouped_ue8m0.py [seeds] [first_seed] [aligned]        (aligned: m > 128, m and n multiples of 16 -- every case reads its
+    MN-major operands in place, e8_quad_kg_mn_*)"""
 import random
 import sys
 sys.path.insert(0, '.')
@@ -13,6 +14,7 @@ from deepgemm_amd.testing import generators as gen
 
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+aligned = len(sys.argv) > 3 and sys.argv[3] == 'aligned'
 fails = 0
 for seed in range(first, first + seeds):
     rng = random.Random(seed)
@@ -22,6 +24,8 @@ for seed in range(first, first + seeds):
     groups = rng.randint(1, 70 if use_psum and rng.random() < 0.15 else 9)
     m = 4 * rng.randint(1, 150)
     n = 4 * rng.randint(1, 180)
+    if aligned:
+        m, n = 16 * rng.randint(9, 60), 16 * rng.randint(1, 70)
     if use_psum:
         real_ks = [0 if rng.random() < 0.15 else rng.randint(1, 900) for _ in range(groups)]
     else:
@@ -56,7 +60,7 @@ for seed in range(first, first + seeds):
             want = case.c[g_].double() + ad @ bd.t()
             rel = ((d[g_].double() - want).norm() / want.norm()).item()
             worst = max(worst, rel)
-        ok = worst <= 5e-5 and cfg.startswith('e8_quad_kg_')
+        ok = worst <= 5e-5 and cfg.startswith('e8_quad_kg_mn_' if aligned else 'e8_quad_kg_')
         fails += 0 if ok else 1
         print(f'seed {seed}: gran {gran_k} align {k_alignment} psum {int(use_psum)} ks {ks_mode} packed {int(packed_words)} G {groups} m {m} n {n} '
               f'sum_k {sum(real_ks)} {cfg} worst rel {worst:.2e} {"ok" if ok else "FAIL"}')
