@@ -226,6 +226,10 @@ const E8Config kE8Configs[] = {
     // scaled MFMA takes its own byte): the two four-wave forms, selected by the *_g32 entry points only (E8Config::g32)
     {"e8_quad_g32_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true>, 256, 256, 256, false, true, false, 1, true},
     {"e8_quad_g32_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true>, 128, 256, 256, false, true, false, 1, true},
+    // ... and the decode-sized stream tiles (every stage carries its K block's words)
+    {"e8_stream_g32_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 0, false, true>, 64, 32, 256, false, true, true, 1, true},
+    {"e8_stream2_g32_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 0, 1, true, 0, false, true>, 64, 128, 256, false, true, true, 2, true},
+    {"e8_stream_nt2_g32_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2, 1, true, 0, false, true>, 64, 128, 256, false, true, true, 2, true},
 #ifdef DG_EXPERIMENTS
 #define DG_EXPERIMENT_ROWS_E8
 #include "experiment_configs.inc"
@@ -1088,6 +1092,17 @@ const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
         big = big && p.m_alignment == 128 && tiles256 >= 4L * num_cus();
     if (p.gemm_type == dg::kContiguousPsum)
         big = false;
+    // decode-sized M: the stream tiles, by the rule of the granularity-128 selection (select_e8_config)
+    if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && p.sfa_sm == 1 && p.sfb_sn == 1) {
+        const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
+        const char* wide = static_cast<double>(groups) * p.n * p.k >= 80e6 ? "e8_stream_nt2_g32_64x128" : "e8_stream2_g32_64x128";
+        if (m_hint <= 64)
+            return e8_config_by_name(tiles128 >= 96 ? wide : "e8_stream_g32_64x32");
+        if (m_hint <= 256 && tiles128 < 96)
+            return e8_config_by_name("e8_stream_g32_64x32");
+        if (m_hint <= 256 && tiles128 < 256)
+            return e8_config_by_name(wide);
+    }
     return e8_config_by_name(big ? "e8_quad_g32_256x256" : "e8_quad_g32_128x256");
 }
 

@@ -2875,9 +2875,14 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
 // others, so they are resident or done: no deadlock whatever the residency -- waits for them (bounded) and adds the partials IN PIECE
 // ORDER (((p0 + p1) + ...) + own: bit-repeatable), then stores the tile through the shared epilogue.
 // Workspace: 4 KiB header | 32 KiB of flags ([tile][8]) | slabs [tile][8][BM * BN] FP32.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false>
+// G32 (with E8, round 6): scale granularity 32 along K (the MX recipe) at decode-sized M -- one packed word per row and 128-K block (byte g = MX
+// block g of the block), every stage carries ITS block's words, and lane group g of the scaled MFMA shifts its own byte down (what
+// quad_e8_kernel_body's G32 form does; probed in profiles/r06_probe/g32_scale_byte_mapping.log).  Before it these problems ran the 128-row
+// four-wave tile: 68-70 us for m <= 256 at 4096 x 7168 against 25-38 for granularity 128, the masked C5 shape 80 against 43.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false, bool G32 = false>
 __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     static_assert(!KSPLIT || (!E8 && LW == 0 && B_AUX != 64), "KSPLIT: the FP32-scale stream tile");
+    static_assert(!G32 || E8, "G32: a form of the packed-scale stream tile");
     constexpr int NW = WAVES_M * WAVES_N, TW = NW + LW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
     constexpr int SFB_PIECES = E8 ? (BN + 63) / 64 : 1;
@@ -2967,7 +2972,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             // SFA of the tile's rows: MN-major, rows m0 .. m0+63 are 256 contiguous bytes per K block
             const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
             // (E8: the strides are per K quad and the "K block" index of a scale row is j >> 2)
-            const int num_sf_k = E8 ? (num_kb + 3) / 4 : num_kb_total;      // (KSPLIT: a piece's blocks are addressed from the operands' first block)
+            const int num_sf_k = E8 ? (G32 ? num_kb : (num_kb + 3) / 4) : num_kb_total;      // (KSPLIT: a piece's blocks are addressed from the operands' first block)
             float* sfa_tile = uniform_pointer(const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0);
             const int sfa_rows = uniform_int(imin(p.m - t.m0, BM));
             // (GSF: 16-byte requests -- the MN-major layout pads the rows to a multiple of four, so a request that starts below sfa_rows is whole)
@@ -3012,7 +3017,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 if constexpr (GSF)
                     return;
                 // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
-                const int jsf = E8 ? j >> 2 : j;
+                const int jsf = E8 && !G32 ? j >> 2 : j;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     sfa_rsrc, (__attribute__((address_space(3))) void*)(stage + SFA_OFF), 4,
                     static_cast<int>(static_cast<unsigned>(lane * 4 + jsf * sfa_kb_stride) | oob), 0, 0, 0);
@@ -3134,7 +3139,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     break;
                 const uint8_t* stage = lds + cur + u * BLOCK_BYTES;
                 if constexpr (E8) {
-                    const int shift = ((sb * KBS + u) & 3) * 8;         // this block's byte of the quad's words
+                    const int shift = G32 ? (lane >> 4) * 8 : ((sb * KBS + u) & 3) * 8;     // this block's byte of the quad's words (G32: the lane group's byte of the block's words)
                     int ea[MS], eb[NS];
                     if constexpr (MS == 4) {
                         const v4i qa = *reinterpret_cast<const v4i*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
@@ -3272,10 +3277,10 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false, bool G32 = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64)
 void dg_fp8_gemm_stream_kernel(const GemmParams p) {
-    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8, LW, KSPLIT>(p);
+    stream_kernel_body<BM, BN, WAVES_M, WAVES_N, STAGES, B_AUX, KBS, E8, LW, KSPLIT, G32>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -44,7 +44,8 @@ def test_dense_packed_gran_k_32(m, n, k):
     assert pa.shape == (m, k // 128) and pb.shape == (n, k // 128)
     d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
     dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d, recipe=(1, 1, 32))
-    assert dg.last_config().startswith('e8_quad_g32'), dg.last_config()
+    # (decode-sized M: the granularity-32 stream tiles, e8_stream*_g32_*; else the four-wave forms)
+    assert dg.last_config().startswith('e8_') and '_g32_' in dg.last_config() and (m > 256 or 'stream' in dg.last_config()), dg.last_config()
     want = torch.empty((m, n), dtype=torch.bfloat16)
     oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, gran_n=1, gran_k=32)
     assert_close_to_oracle(d, want, 'packed ue8m0, gran_k 32')
@@ -123,7 +124,7 @@ def test_gran_k_32_fp32_scales_in_sm100_mode():
     try:
         d = torch.empty_like(d_packed)
         dg.fp8_gemm_nt((a_q, sfa), (b_q, sfb_blocks), d, recipe=(1, 32, 32))
-        assert dg.last_config().startswith('e8_quad_g32')
+        assert dg.last_config().startswith('e8_') and '_g32_' in dg.last_config()
     finally:
         dg.set_sf_cast_mode('sm90')
     assert torch.equal(d.view(torch.int16), d_packed.view(torch.int16))
@@ -234,3 +235,30 @@ def test_full_size_c2_c4_c5_gran_k_32():
         want = _device_oracle32(a_q[g, :rows], sfa[g, :rows], w_q[g], sfw[g])
         assert calc_diff(d[g, :rows], want) < 2e-6, g
         assert bool(torch.isnan(d[g, rows:]).all())
+
+
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 7168), (17, 520, 1408), (64, 4096, 2048), (200, 264, 384), (96, 7168, 1536)])
+def test_decode_sized_gran_k_32_runs_on_stream_tiles(m, n, k):
+    """Decode-sized M at granularity 32 (round 6): the stream tiles with every stage carrying its K block's words (e8_stream*_g32_*) instead of the
+    128-row four-wave tile (68 -> 21 us at 4096 x 7168) -- against the oracle, and bit for bit against the four-wave form forced by name (both
+    accumulate in the matrix core in K order)."""
+    gen.reset_seed(m + n + k)
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    (a_q, sfa, pa), (b_q, sfb, pb) = _cast32(a), _cast32(b)
+    d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+    dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d, recipe=(1, 1, 32))
+    assert dg.last_config().startswith('e8_stream') and '_g32_' in dg.last_config(), dg.last_config()
+    if m * n * k <= 64 * 4096 * 2048:
+        want = torch.empty((m, n), dtype=torch.bfloat16)
+        oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, gran_n=1, gran_k=32)
+        assert_close_to_oracle(d, want, 'decode-sized gran_k 32')
+    assert calc_diff(d, (a.float() @ b.float().t()).to(torch.bfloat16)) < gen.FP8_MAX_DIFF
+    dg.set_forced_config('e8_quad_g32_128x256')
+    try:
+        d2 = torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d2, recipe=(1, 1, 32))
+        assert dg.last_config() == 'e8_quad_g32_128x256'
+    finally:
+        dg.set_forced_config('auto')
+    assert torch.equal(d.view(torch.int16), d2.view(torch.int16))
