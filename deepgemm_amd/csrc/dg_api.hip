@@ -226,6 +226,11 @@ const E8Config kE8Configs[] = {
     // scaled MFMA takes its own byte): the two four-wave forms, selected by the *_g32 entry points only (E8Config::g32)
     {"e8_quad_g32_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true>, 256, 256, 256, false, true, false, 1, true},
     {"e8_quad_g32_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true>, 128, 256, 256, false, true, false, 1, true},
+    // round 6: batch-1 .. 32 decode with packed scales: the skinny weight-stream kernel with the scaled MFMA (one workgroup per 16 columns)
+    {"e8_skinny_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true>, 16, 16, 512, false, false, false},
+    {"e8_skinny_32", dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true, true>, 32, 16, 512, false, false, false},
+    {"e8_skinny_g32_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true, true>, 16, 16, 512, false, false, false, 1, true},
+    {"e8_skinny_g32_32", dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true, true, true>, 32, 16, 512, false, false, false, 1, true},
     // ... and the decode-sized stream tiles (every stage carries its K block's words)
     {"e8_stream_g32_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 0, false, true>, 64, 32, 256, false, true, true, 1, true},
     {"e8_stream2_g32_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 0, 1, true, 0, false, true>, 64, 128, 256, false, true, true, 2, true},
@@ -970,8 +975,22 @@ const E8Config* e8_config_by_name(const char* name) {
     return nullptr;
 }
 
+// Decode batches (M <= 32), dense, packed scales: the rule of the FP32-scale skinny kernels (select_config).  nullptr = not this class.
+const char* e8_skinny_pick(const dg::GemmParams& p, bool g32) {
+    if (p.gemm_type != dg::kNormal || p.head_lr != 0 || p.n % 16 != 0 || p.k % 128 != 0 || p.sfa_sm != 1 || p.sfb_sn != 1 || !fast_eligible(p))
+        return nullptr;
+    const int num_kb = p.k / 128;
+    if (p.m <= 16 && num_kb >= 16)
+        return g32 ? "e8_skinny_g32_16" : "e8_skinny_16";
+    if (p.m > 16 && p.m <= 32 && num_kb >= 48 && num_kb <= 64 && p.n <= 4608)
+        return g32 ? "e8_skinny_g32_32" : "e8_skinny_32";
+    return nullptr;
+}
+
 const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
     const E8Config* cfg = nullptr;
+    if (const char* skinny = e8_skinny_pick(p, false))
+        return e8_config_by_name(skinny);
     {
         const int m_hint = expected_m > 0 ? expected_m : p.m;
         const long groups = p.gemm_type == dg::kMasked ? p.num_groups : 1;
@@ -1092,6 +1111,8 @@ const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
         big = big && p.m_alignment == 128 && tiles256 >= 4L * num_cus();
     if (p.gemm_type == dg::kContiguousPsum)
         big = false;
+    if (const char* skinny = e8_skinny_pick(p, true))
+        return e8_config_by_name(skinny);
     // decode-sized M: the stream tiles, by the rule of the granularity-128 selection (select_e8_config)
     if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && p.sfa_sm == 1 && p.sfb_sn == 1) {
         const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
@@ -1245,6 +1266,11 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream, int gran_k = 128)
         g_last_error = std::string("config '") + cfg->name + "' does not divide the contiguous-layout M alignment";
         return 3;
     }
+    const bool skinny = std::strncmp(cfg->name, "e8_skinny", 9) == 0;
+    if (skinny && (p.m > cfg->bm || p.gemm_type != dg::kNormal || p.head_lr != 0 || k_tail || mn_form || p.sfa_sm != 1 || p.sfb_sn != 1)) {
+        g_last_error = std::string("config '") + cfg->name + "' implements dense K-major problems with m <= its row count and whole K blocks";
+        return 3;
+    }
     g_last_config = cfg->name;
     p.num_m_tiles = ceil_div(p.m, cfg->bm);
     p.num_n_tiles = ceil_div(p.n, cfg->bn);
@@ -1253,6 +1279,14 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream, int gran_k = 128)
     p.d_vec_ok = aligned16(p.d) && (p.d_sm * elem) % 16 == 0 && (p.d_sg * elem) % 16 == 0;
     p.d_nt = output_streams_past_l2(p);
     p.dbg = g_debug_buffer.load(std::memory_order_relaxed);
+    if (skinny) {                       // one workgroup per 16 output columns (not a tile walk)
+        p.skinny_cols = 0;
+        hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(p.num_n_tiles)), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
+        DG_HIP_CHECK(hipGetLastError());
+        if (env_knobs().print_configs)
+            fprintf(stderr, "[deepgemm_amd] ue8m0 m=%d n=%d k=%d -> %s grid=%d\n", p.m, p.n, p.k, cfg->name, p.num_n_tiles);
+        return 0;
+    }
     long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
     if (p.gemm_type == dg::kMasked)
         total *= p.num_groups;

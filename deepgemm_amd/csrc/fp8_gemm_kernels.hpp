@@ -4140,10 +4140,16 @@ void dg_fp8_gemm_generic_kernel(const GemmParams p) {
 // bits as the register-direct form.
 // ACOAL: the same for the activation rows (they come from the L2, but their load instructions were as scattered: at m = 16 A is as many bytes
 // per workgroup as the weights).
-template <int MS, int CH = 4, int NSUB = 1, bool COAL = false, bool ACOAL = false>
+// E8 (round 6): packed UE8M0 scale words -- one per ROW of A and per weight ROW and four K blocks (G32: per 128-K block, byte g = MX block g) -- with
+// the hardware-scaled MFMA accumulating a wave's K range in place (no promotion): the batch-1 .. 32 decode of the packed-scale path, which ran
+// the 64 x 32 stream tile (15.5 us for 29 MB of weights against 7.6 here with FP32 scales).  A lane (r, g) holds row r of both operands'
+// fragments, so its two scale words are those of A row 16 ms + r and of weight row n0 + 16 s + r.
+template <int MS, int CH = 4, int NSUB = 1, bool COAL = false, bool ACOAL = false, bool E8 = false, bool G32 = false>
 __global__ __launch_bounds__(512)
 void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
     static_assert(!ACOAL || COAL, "ACOAL shares the staging buffers' geometry with COAL");
+    static_assert(!G32 || E8, "G32: a form of the packed-scale kernel");
+    using SfT = std::conditional_t<E8, int, float>;
     constexpr int NW = 8;                                       // CH: K blocks per software-pipeline chunk (two chunks in flight)
     static_assert(MS * NSUB <= NW, "one wave per (M-subtile, N-subtile) sums the partial tiles");
     __shared__ float red[NW][MS * NSUB][256];
@@ -4156,8 +4162,10 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
     const int kb_begin = wave * num_kb / NW, kb_end = (wave + 1) * num_kb / NW;
     const uint8_t* b_ptr[NSUB];
     [[maybe_unused]] const uint8_t* b_ptr_hi[NSUB];             // COAL: rows (l >> 3) and (l >> 3) + 8
-    const float* sfb_ptr[NSUB];
+    const SfT* sfb_ptr[NSUB];
     [[maybe_unused]] const int st_write = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);        // + 1024 for the upper eight rows
+    // fragment chunks of lane group g: g and g + 4 -- the matrix core's natural K order (registers 0-3 = K bytes 16 g .., 4-7 = 64 + 16 g ..), in
+    // which the scale byte SUPPLIED by lane group g applies to MX block g of the row (profiles/r06_probe/g32_scale_byte_mapping.log): G32 as it is
     [[maybe_unused]] const int st_read_lo = r * 128 + ((g ^ (r & 7)) << 4), st_read_hi = r * 128 + (((g + 4) ^ (r & 7)) << 4);
     #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -4169,11 +4177,14 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
         }
         // a lane's four output columns are n0 + 16 s + 4 g .. + 3 (n0 is a multiple of 4: they never straddle a 128-column scale block,
         // the 16-column subtile of the two-subtile form may)
-        sfb_ptr[s] = p.sfb + static_cast<int64_t>(imin(n0 + s * 16 + 4 * g, p.n - 1) / 128) * p.sfb_sn;
+        if constexpr (E8)
+            sfb_ptr[s] = reinterpret_cast<const SfT*>(p.sfb) + static_cast<int64_t>(imin(n0 + s * 16 + r, p.n - 1)) * p.sfb_sn;
+        else
+            sfb_ptr[s] = reinterpret_cast<const SfT*>(p.sfb) + static_cast<int64_t>(imin(n0 + s * 16 + 4 * g, p.n - 1) / 128) * p.sfb_sn;
     }
     const uint8_t* a_ptr[MS];
     [[maybe_unused]] const uint8_t* a_ptr_hi[MS];               // ACOAL: rows (l >> 3) and (l >> 3) + 8 of the subtile, chunk l & 7
-    const float* sfa_ptr[MS];
+    const SfT* sfa_ptr[MS];
     #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
         const int row = imin(ms * 16 + r, p.m - 1);             // rows past m: a valid row's bytes, the result is never stored
@@ -4183,28 +4194,29 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
         } else {
             a_ptr[ms] = p.a + static_cast<int64_t>(row) * p.a_sm + g * 16;
         }
-        sfa_ptr[ms] = p.sfa + static_cast<int64_t>(row) * p.sfa_sm;
+        sfa_ptr[ms] = reinterpret_cast<const SfT*>(p.sfa) + static_cast<int64_t>(row) * p.sfa_sm;
     }
 
-    struct Chunk { v4i b[CH][NSUB][2]; v4i a[MS][CH][2]; float sa[MS][CH]; float sb[CH][NSUB]; };
+    struct Chunk { v4i b[CH][NSUB][2]; v4i a[MS][CH][2]; SfT sa[MS][CH]; SfT sb[CH][NSUB]; };
     auto load_chunk = [&](Chunk& c, int kb0) {
         #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int kb = imin(kb0 + j, num_kb - 1);          // past the range: re-read the last block (never used)
             const int64_t off = static_cast<int64_t>(kb) * 128;
+            const int64_t ksf = E8 && !G32 ? kb >> 2 : kb;     // row of the scale tensors along K (packed words: one per K quad; G32: per K block)
             #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
                 c.b[j][s][0] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off));
                 if constexpr (COAL) c.b[j][s][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr_hi[s] + off));
                 else c.b[j][s][1] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_ptr[s] + off + 64));
-                c.sb[j][s] = sfb_ptr[s][static_cast<int64_t>(kb) * p.sfb_sk];
+                c.sb[j][s] = sfb_ptr[s][ksf * p.sfb_sk];
             }
             #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
                 c.a[ms][j][0] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off);
                 if constexpr (ACOAL) c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr_hi[ms] + off);
                 else c.a[ms][j][1] = *reinterpret_cast<const v4i*>(a_ptr[ms] + off + 64);
-                c.sa[ms][j] = sfa_ptr[ms][static_cast<int64_t>(kb) * p.sfa_sk];
+                c.sa[ms][j] = sfa_ptr[ms][ksf * p.sfa_sk];
             }
         }
     };
@@ -4250,11 +4262,19 @@ void dg_fp8_gemm_skinny_kernel(const GemmParams p) {
                     const v8i bf = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     #pragma unroll
                     for (int ms = 0; ms < MS; ++ms) {
+                        if constexpr (E8) {
+                            // this block's byte of the words (G32: the lane group's byte of the block's words) into byte 0; in-place accumulation
+                            const int shift = G32 ? g * 8 : ((kb0 + j) & 3) * 8;
+                            acc[ms][s] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                                bf, afs[ms], acc[ms][s], 0, 0, 0, static_cast<int>(static_cast<unsigned>(c.sb[j][s]) >> shift), 0,
+                                static_cast<int>(static_cast<unsigned>(c.sa[ms][j]) >> shift));
+                        } else {
                         const v4f part = mfma_fp8_k128(bf, afs[ms]);
                         const float scale = c.sa[ms][j] * c.sb[j][s];
                         #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[ms][s][e] = __builtin_fmaf(scale, part[e], acc[ms][s][e]);
+                        }
                     }
                 }
             }

@@ -37,8 +37,8 @@ PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K
     'dg_fp8_gemm_quad_e8_kernel<256,256,0,0,2,0,0,0,0,1,0>', 'dg_fp8_gemm_quad_e8_kernel<128,256,0,0,2,0,0,0,0,1,0>',       # round 6: K-grouped, packed UE8M0 (KG)
     'dg_fp8_gemm_quad_e8_kernel<256,256,0,0,2,0,0,0,1,1,0>', 'dg_fp8_gemm_quad_e8_kernel<128,256,0,0,2,0,0,0,1,1,0>',
     'dg_fp8_gemm_quad_e8_kernel<256,256,0,0,2,0,0,0,0,1,1>', 'dg_fp8_gemm_quad_e8_kernel<256,256,0,0,2,0,0,0,1,1,1>',       # ... MN-major operands in place (MNK)
-    'dg_fp8_gemm_skinny_kernel<1,4,1,0,0>', 'dg_fp8_gemm_skinny_kernel<2,4,1,0,0>', 'dg_fp8_gemm_skinny_kernel<1,4,2,0,0>',
-    'dg_fp8_gemm_skinny_kernel<1,4,1,1,0>', 'dg_fp8_gemm_skinny_kernel<2,4,1,1,0>', 'dg_fp8_gemm_skinny_kernel<1,4,2,1,0>', 'dg_fp8_gemm_skinny_kernel<1,4,1,1,1>', 'dg_fp8_gemm_skinny_kernel<2,3,1,1,1>', 'dg_fp8_gemm_stream_swiglu_kernel<6>',
+    'dg_fp8_gemm_skinny_kernel<1,4,1,0,0,0,0>', 'dg_fp8_gemm_skinny_kernel<2,4,1,0,0,0,0>', 'dg_fp8_gemm_skinny_kernel<1,4,2,0,0,0,0>',
+    'dg_fp8_gemm_skinny_kernel<1,4,1,1,0,0,0>', 'dg_fp8_gemm_skinny_kernel<2,4,1,1,0,0,0>', 'dg_fp8_gemm_skinny_kernel<1,4,2,1,0,0,0>', 'dg_fp8_gemm_skinny_kernel<1,4,1,1,1,0,0>', 'dg_fp8_gemm_skinny_kernel<2,3,1,1,1,0,0>', 'dg_fp8_gemm_skinny_kernel<1,4,1,1,1,1,0>', 'dg_fp8_gemm_skinny_kernel<2,3,1,1,1,1,0>', 'dg_fp8_gemm_skinny_kernel<1,4,1,1,1,1,1>', 'dg_fp8_gemm_skinny_kernel<2,3,1,1,1,1,1>', 'dg_fp8_gemm_stream_swiglu_kernel<6>',
 ]
 
 

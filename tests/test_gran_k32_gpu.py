@@ -237,7 +237,7 @@ def test_full_size_c2_c4_c5_gran_k_32():
         assert bool(torch.isnan(d[g, rows:]).all())
 
 
-@pytest.mark.parametrize('m,n,k', [(1, 4096, 7168), (17, 520, 1408), (64, 4096, 2048), (200, 264, 384), (96, 7168, 1536)])
+@pytest.mark.parametrize('m,n,k', [(40, 4096, 7168), (17, 520, 1408), (64, 4096, 2048), (200, 264, 384), (96, 7168, 1536)])
 def test_decode_sized_gran_k_32_runs_on_stream_tiles(m, n, k):
     """Decode-sized M at granularity 32 (round 6): the stream tiles with every stage carrying its K block's words (e8_stream*_g32_*) instead of the
     128-row four-wave tile (68 -> 21 us at 4096 x 7168) -- against the oracle, and bit for bit against the four-wave form forced by name (both
@@ -262,3 +262,42 @@ def test_decode_sized_gran_k_32_runs_on_stream_tiles(m, n, k):
     finally:
         dg.set_forced_config('auto')
     assert torch.equal(d.view(torch.int16), d2.view(torch.int16))
+
+
+@pytest.mark.parametrize('gran_k', [128, 32])
+@pytest.mark.parametrize('m,n,k,accumulate,out_dtype', [(1, 4096, 7168, False, torch.bfloat16), (16, 528, 2048, False, torch.bfloat16),
+                                                       (7, 272, 2560, True, torch.float), (32, 1024, 7168, False, torch.bfloat16),
+                                                       (20, 4608, 6144, True, torch.bfloat16)])
+def test_batch_decode_with_packed_scales_runs_the_skinny_kernel(gran_k, m, n, k, accumulate, out_dtype):
+    """Batch-1 .. 32 decode with packed UE8M0 scale words (round 6, both granularities): the skinny weight-stream kernel with the scaled MFMA
+    (e8_skinny_*: a wave accumulates its eighth of K in the matrix core, the eight partial tiles are summed in wave order) -- against the oracle
+    and against the stream tile forced by name (same products, another summation split: tolerance of the K-split paths)."""
+    gen.reset_seed(m + n + k + gran_k)
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    qa, qb = per_token_cast_to_fp8(a, use_ue8m0=True, gran_k=gran_k), per_token_cast_to_fp8(b, use_ue8m0=True, gran_k=gran_k)
+    pa = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, gran_k))
+    pb = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, gran_k))
+    c0 = (torch.randn((m, n), device='cuda', dtype=out_dtype) * 8) if accumulate else None
+    d = c0.clone() if accumulate else torch.full((m, n), float('nan'), device='cuda', dtype=out_dtype)
+    dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d, c=d if accumulate else None, recipe=(1, 1, gran_k))
+    want_name = ('e8_skinny_g32_' if gran_k == 32 else 'e8_skinny_') + ('16' if m <= 16 else '32')
+    assert dg.last_config() == want_name, dg.last_config()
+    want = torch.empty((m, n), dtype=out_dtype)
+    oracle.fp8_gemm_nt(qa[0].cpu(), qa[1].cpu(), qb[0].cpu(), qb[1].cpu(), want, c=c0.cpu() if accumulate else None, gran_n=1, gran_k=gran_k)
+    if out_dtype == torch.float:
+        assert_close_fp32(d, want, f'packed skinny gran {gran_k}')
+    else:
+        assert_close_to_oracle(d, want, f'packed skinny gran {gran_k}', addend=c0)
+    dg.set_forced_config('e8_stream_g32_64x32' if gran_k == 32 else 'e8_stream_64x32')
+    try:
+        d2 = c0.clone() if accumulate else torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d2, c=d2 if accumulate else None, recipe=(1, 1, gran_k))
+        assert 'stream' in dg.last_config()
+    finally:
+        dg.set_forced_config('auto')
+    assert calc_diff(d.float(), d2.float()) < 2e-6
+    # repeatable to the bit (the eight partial tiles are summed in wave order)
+    d3 = c0.clone() if accumulate else torch.full_like(d, float('nan'))
+    dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d3, c=d3 if accumulate else None, recipe=(1, 1, gran_k))
+    assert torch.equal(d3, d)

@@ -20,7 +20,7 @@ def packed(x, mn, k, gran):
     q = per_token_cast_to_fp8(x, True, gran)
     return q[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(q[1]), mn, k, (1, gran))
 
-for m in (1, 16, 64, 128, 256):
+for m in (1, 16, 32, 64, 128, 256):
     n, k = 4096, 7168
     sets = 12
     ops = {128: [], 32: []}
