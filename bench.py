@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: achieved FP8 TFLOPS of ``fp8_gemm_nt`` at M=4096 N=4096 K=7168 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0|dense_ue8m0_g32|wgrad_ue8m0|kgrouped_ue8m0|kgrouped_ue8m0_g32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense|contiguous|masked|c3_{nt,nn,tn,tt}|wgrad|wgrad_ksplit|kgrouped|dense_ue8m0|dense_sm100|masked_ue8m0|dgrad_ktail|dgrad_ksplit|decode_m1|decode_m1_long|expert_mlp|expert_mlp_unfused|dense_sfa_rowmajor|dgrad_ktail_ue8m0|dense_m128|c3_nn_ue8m0|contiguous_ue8m0|dense_ue8m0_g32|wgrad_ue8m0|kgrouped_ue8m0|kgrouped_ue8m0_g32|decode_m1_ue8m0]
 
 A "step" is one pass of the hot path (one operator call) over one batch of synthetic, already HBM-resident input
 (``torch.manual_seed`` BF16 randn, quantised with the reference's per-token / per-block casts).  Input sets are
@@ -37,10 +37,10 @@ PEAK_HBM_GBS = 8000.0
 RECIPE_1_1_128_ROOF = 32.0 / 62.0
 WORKLOADS = ['dense', 'contiguous', 'masked', 'c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dgrad_ktail', 'dgrad_ksplit', 'masked_ue8m0', 'wgrad_ksplit',
              'dense_sm100', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
-             'contiguous_ue8m0', 'dense_ue8m0_g32', 'wgrad_ue8m0', 'kgrouped_ue8m0', 'kgrouped_ue8m0_g32']
+             'contiguous_ue8m0', 'dense_ue8m0_g32', 'wgrad_ue8m0', 'kgrouped_ue8m0', 'kgrouped_ue8m0_g32', 'decode_m1_ue8m0']
 SECONDARY = ['c3_nt', 'c3_nn', 'c3_tn', 'c3_tt', 'contiguous', 'masked', 'wgrad', 'kgrouped', 'dense_ue8m0', 'dense_sm100', 'dgrad_ktail', 'dgrad_ksplit',
              'masked_ue8m0', 'wgrad_ksplit', 'decode_m1', 'decode_m1_long', 'expert_mlp', 'dense_sfa_rowmajor', 'dgrad_ktail_ue8m0', 'dense_m128', 'c3_nn_ue8m0',
-             'contiguous_ue8m0', 'dense_ue8m0_g32', 'wgrad_ue8m0', 'kgrouped_ue8m0', 'kgrouped_ue8m0_g32']
+             'contiguous_ue8m0', 'dense_ue8m0_g32', 'wgrad_ue8m0', 'kgrouped_ue8m0', 'kgrouped_ue8m0_g32', 'decode_m1_ue8m0']
 # HBM-bound workloads whose per-call weight stream is smaller than the 256 MiB Infinity Cache (MALL): the rotation must cover more than the
 # cache, or the "fraction of 8 TB/s" is a cache-read rate (the reference flushes 8 GB between timed iterations: deep_gemm/testing/bench.py:93,108).
 # sets x (bytes not re-used across calls) >= COLD_ROTATION_BYTES; the other HBM-bound lines stream >= 235 MB of weights per call x >= 2 sets.
@@ -51,7 +51,7 @@ def cold_sets(weight_bytes: float, at_least: int) -> int:
     return max(at_least, int(-(-COLD_ROTATION_BYTES // weight_bytes)))
 
 
-GRAPHED = {'decode_m1', 'decode_m1_long', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
+GRAPHED = {'decode_m1', 'decode_m1_long', 'decode_m1_ue8m0', 'expert_mlp', 'expert_mlp_unfused'}      # launch-bound decode calls: timed as a hipGraph replay (the eager call time is reported beside it)
 
 
 def measured_counters(kernel: str, workload: str) -> dict:
@@ -204,23 +204,29 @@ def make_workload(name: str, sets: int, world: int = 1, rank: int = 0, phase_eve
                             (', packed UE8M0 scales' if packed else ''),
                 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d, cases[0].ref_d)    # noqa: E731
-    elif name in ('decode_m1', 'decode_m1_long'):
+    elif name in ('decode_m1', 'decode_m1_long', 'decode_m1_ue8m0'):
         # batch-1 decode entries of the reference's dense sweep (tests/generators.py:119-121, m = 1): a weight stream, HBM-bound
+        # ('_ue8m0', round 6: packed UE8M0 scale words -- the skinny weight-stream kernel with the scaled MFMA)
         bound = 'hbm'
-        m, n, k = (1, 4096, 7168) if name == 'decode_m1' else (1, 7168, 16384)
+        packed = name == 'decode_m1_ue8m0'
+        m, n, k = (1, 7168, 16384) if name == 'decode_m1_long' else (1, 4096, 7168)
         sets = cold_sets(n * k, sets)           # 29 MB of weights a call: 11 sets; 117 MB: 3 (cold: see COLD_ROTATION_BYTES)
         for i in range(sets):
             gen.reset_seed(i)
-            case = gen.generate_normal(m, n, k)
+            case = gen.generate_normal(m, n, k, use_ue8m0=packed)
             if i:
                 case.a_bf16 = case.b_bf16 = None        # (only case 0 is checked against the reference expression)
-            a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
             cases.append(case)
-            calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
+            if packed:
+                a, b = gen.packed_ue8m0_operand(*case.a), gen.packed_ue8m0_operand(*case.b, mn_rows=n)
+                calls.append(lambda a=a, b=b, c=case: dg.fp8_gemm_nt(a, b, c.d))
+            else:
+                a = (case.a[0], dg.get_mn_major_tma_aligned_tensor(case.a[1]))
+                calls.append(lambda a=a, c=case: dg.fp8_gemm_nt(a, c.b, c.d))
         flops = 2.0 * m * n * k
-        nbytes = m * k + n * k + 4 * m * (k // 128) + 4 * (n // 128) * (k // 128) + 2 * m * n
+        nbytes = m * k + n * k + (4 * (m + n) * (-(-k // 512)) if packed else 4 * m * (k // 128) + 4 * (n // 128) * (k // 128)) + 2 * m * n
         desc = {'workload': f'fp8_gemm_nt M={m} N={n} K={k} (decode entry of the reference sweep; timed as a hipGraph replay of 20 calls, '
-                            'the eager per-call time -- host-bound -- beside it)', 'm': m, 'n': n, 'k': k}
+                            'the eager per-call time -- host-bound -- beside it)' + (', packed UE8M0 scales' if packed else ''), 'm': m, 'n': n, 'k': k}
         check = lambda: calc_diff(cases[0].d.float(), cases[0].ref_d.float()) if m * n >= 4096 else float('nan')    # noqa: E731
     elif name in ('expert_mlp', 'expert_mlp_unfused'):
         # decode-size expert MLP of one EP rank (the single-GPU half of the reference's Mega-MoE, deep_gemm/mega/__init__.py:155): 8 local
@@ -639,7 +645,7 @@ def run(rank: int, world: int, local_rank: int, args):
                                         ([_sig(rec['roofline']['frac_of_recipe_roof'], 3)] if 'frac_of_recipe_roof' in rec['roofline'] else [])
                                         if 'roofline' in rec else rec.get('error', '?')[:40])
                                  for name, rec in zip(SECONDARY, detail)}
-            line['secondary_key'] = "[frac of 5 PF ('h': of 8 TB/s), us/call, trailing number: frac on data rows | of (1,1,128) roof]"
+            line['secondary_key'] = "[frac of 5 PF ('h': of 8 TB/s), us/call(, frac on data rows | of (1,1,128) roof)]"
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
         if 'secondary' in line:         # keep the whole headline line inside the driver's 2000-character tail
@@ -650,7 +656,11 @@ def run(rank: int, world: int, local_rank: int, args):
             if 'cpu_baseline' in line:
                 line['cpu_baseline']['value'] = _sig(line['cpu_baseline']['value'], 4)
             line['calc_diff_vs_reference_expr'] = _sig(diff, 3)
-        print(json.dumps(line, separators=(',', ':')), flush=True)
+        text = json.dumps(line, separators=(',', ':'))
+        if len(text) > 1980 and 'secondary_key' in line:       # (the key is documented in DESIGN.md section 6 as well)
+            del line['secondary_key']
+            text = json.dumps(line, separators=(',', ':'))
+        print(text, flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
