@@ -570,7 +570,7 @@ def test_bench_workload_tables_are_consistent():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert set(bench.SECONDARY) <= set(bench.WORKLOADS) and 'dense' in bench.WORKLOADS and 'dense' not in bench.SECONDARY
-    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 26 and bench.GRAPHED <= set(bench.WORKLOADS)
+    assert len(set(bench.SECONDARY)) == len(bench.SECONDARY) == 27 and bench.GRAPHED <= set(bench.WORKLOADS)
     assert bench.PEAK_FP8_TFLOPS == 5000.0
 
 
