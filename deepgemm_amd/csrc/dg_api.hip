@@ -227,6 +227,10 @@ const E8Config kE8Configs[] = {
     {"e8_quad_g32_256x256", dg::dg_fp8_gemm_quad_e8_kernel<256, 256, 0, false, 2, false, 0, false, true>, 256, 256, 256, false, true, false, 1, true},
     {"e8_quad_g32_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true>, 128, 256, 256, false, true, false, 1, true},
     // round 6: batch-1 .. 32 decode with packed scales: the skinny weight-stream kernel with the scaled MFMA (one workgroup per 16 columns)
+    // ... the 64 x 32 stream tile with four loader waves beside its four compute waves (the packed words ride in the group ring: stream_kernel_body, GSE)
+#ifndef DG_NO_GSE
+    {"e8_stream_l8_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 4>, 64, 32, 512, false, true, true},
+#endif
     {"e8_skinny_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true>, 16, 16, 512, false, false, false},
     {"e8_skinny_32", dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true, true>, 32, 16, 512, false, false, false},
     {"e8_skinny_g32_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true, true>, 16, 16, 512, false, false, false, 1, true},
@@ -1015,6 +1019,10 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
                 pick = &kE8Configs[3];
             if (pick == &kE8Configs[3])         // two workgroups per CU on a 3-stage ring, non-temporal weights from 80 MB per launch (select_config)
                 pick = e8_config_by_name(static_cast<double>(groups) * p.n * p.k >= 80e6 ? "e8_stream_nt2_64x128" : "e8_stream2_64x128");
+            // dense: the 64 x 32 tile with loader waves (the FP32-scale rule: stream_l8_64x32)
+            if (pick == &kE8Configs[5] && p.gemm_type == dg::kNormal)
+                if (const E8Config* l8 = e8_config_by_name("e8_stream_l8_64x32"))
+                    pick = l8;
             if (pick != nullptr)
                 cfg = pick;
         }

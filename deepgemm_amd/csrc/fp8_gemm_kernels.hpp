@@ -2894,19 +2894,29 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     // lane's four rows contiguous) and one 4-byte piece the four SFB values: 35 ns per K block.  They live in a ring of four group
     // slots behind the stages and are issued in front of the data pieces of the group's first block.
     constexpr bool GSF = !E8;
-    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = GSF ? A_BYTES + B_BYTES : SFB_OFF + SFB_BYTES;
+    // GSE (end of round 6): packed words of granularity 128 likewise -- a word covers a K QUAD, and every wave used to issue the quad's two or
+    // three word pieces again with each of its four K blocks (8 of the 20 pieces a wave issues per stage of the 64 x 32 tile).  Now the words of
+    // a quad land once, in the group ring (slot: 64 A words, then BN weight-row words), in front of the data pieces of the quad's first block.
+    // (Granularity 32 has a word per K block: its words keep riding in the stages.)
+#ifdef DG_NO_GSE            // (tuning build: the words ride in every stage, as before)
+    constexpr bool GSE = false, GS = GSF;
+#else
+    constexpr bool GSE = E8 && !G32, GS = GSF || GSE;
+#endif
+    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = GS ? A_BYTES + B_BYTES : SFB_OFF + SFB_BYTES;
     constexpr int STAGE_BYTES = KBS * BLOCK_BYTES;
     constexpr int SFG_OFF = STAGES * STAGE_BYTES, SFG_SLOT = 1024 + 256, SFG_SLOTS = 4;
-    constexpr int LDS_BYTES = SFG_OFF + (GSF ? SFG_SLOTS * SFG_SLOT : 0);
+    constexpr int LDS_BYTES = SFG_OFF + (GS ? SFG_SLOTS * SFG_SLOT : 0);
+    static_assert(!GSE || SFA_BYTES + SFB_BYTES <= SFG_SLOT, "a group slot holds the quad's words of both operands");
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
     // per wave per stage; GSF: the group pieces (two per four K blocks) are NOT counted -- the counted waits then ask for up to two
     // more of the younger pieces than needed (stricter, never looser; the ring has STAGES - 2 stages of slack)
     constexpr int A_PER = KBS * (BM / 8) / TW, B_PER = KBS * (BN / 8) / TW;     // LW > 0: pieces per wave and STAGE
-    static_assert(LW == 0 || (GSF && !NO_A && (KBS * (BM / 8)) % TW == 0 && (KBS * (BN / 8)) % TW == 0),
-                  "loader waves: FP32 scales, every wave issues the same number of A and of B pieces per stage");
-    constexpr int PIECES = LW > 0 ? A_PER + B_PER : ((NO_A ? 0 : A_ITERS) + B_ITERS + (GSF ? 0 : 1 + SFB_PIECES)) * KBS;
-    static_assert(!GSF || STAGES * KBS <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
+    static_assert(LW == 0 || (GS && !NO_A && (KBS * (BM / 8)) % TW == 0 && (KBS * (BN / 8)) % TW == 0),
+                  "loader waves: scales in the group ring, every wave issues the same number of A and of B pieces per stage");
+    constexpr int PIECES = LW > 0 ? A_PER + B_PER : ((NO_A ? 0 : A_ITERS) + B_ITERS + (GS ? 0 : 1 + SFB_PIECES)) * KBS;
+    static_assert(!GS || STAGES * KBS <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
     static_assert(!E8 || MS == 4 || MS == 1, "packed-scale form: a lane reads its MS row words with one LDS read");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA piece and one SFB value per tile");
@@ -2985,19 +2995,34 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
 
             // All pieces of K block j into ring slot j % STAGES (slot_off in bytes).  Blocks past the end are issued as
             // out-of-range no-ops so that the vmcnt arithmetic stays exact.
+            // the scales of K blocks j .. j + 3, j a multiple of four (blocks past the end: out of range, zeros), into the group ring
+            auto issue_group_scales = [&](int j) {
+                const unsigned oob = j < num_kb ? 0u : OOB;
+                uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                if constexpr (GSF) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                        static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
+                        static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
+                } else {                                        // GSE: the quad's packed words (strides per K quad)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 4,
+                        static_cast<int>(static_cast<unsigned>(lane * 4 + (j >> 2) * sfa_kb_stride) | oob), 0, 0, 0);
+                    #pragma unroll
+                    for (int r = 0; r < SFB_PIECES; ++r)        // the words of the tile's BN weight rows: 64 per piece
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + SFA_BYTES + r * 256), 4,
+                            static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + (j >> 2) * sfb_kb_stride) | oob), 0, 0, 0);
+                }
+            };
             auto issue_block = [&](int slot_off, int j) {
                 const unsigned oob = j < num_kb ? 0u : OOB;
                 uint8_t* stage = lds + slot_off;
-                if constexpr (GSF) {
-                    if ((j & 3) == 0) {                         // the scales of K blocks j .. j + 3 (blocks past the end: out of range, zeros)
-                        uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
-                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
-                            static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
-                    }
+                if constexpr (GS) {
+                    if ((j & 3) == 0)
+                        issue_group_scales(j);
                 }
                 #pragma unroll
                 for (int q = 0; q < (NO_A ? 0 : A_ITERS); ++q) {
@@ -3014,7 +3039,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, (kb0 + j) * 128, 0, B_AUX & 3);
                 }
-                if constexpr (GSF)
+                if constexpr (GS)
                     return;
                 // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
                 const int jsf = E8 && !G32 ? j >> 2 : j;
@@ -3040,16 +3065,8 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     #pragma unroll
                     for (int u = 0; u < KBS; ++u) {
                         const int j = sb * KBS + u;
-                        if ((j & 3) == 0) {
-                            const unsigned oob = j < num_kb ? 0u : OOB;
-                            uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
-                                static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
-                                static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
-                        }
+                        if ((j & 3) == 0)
+                            issue_group_scales(j);
                     }
                     #pragma unroll
                     for (int q = 0; q < A_PER; ++q) {
@@ -3141,19 +3158,22 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 if constexpr (E8) {
                     const int shift = G32 ? (lane >> 4) * 8 : ((sb * KBS + u) & 3) * 8;     // this block's byte of the quad's words (G32: the lane group's byte of the block's words)
                     int ea[MS], eb[NS];
+                    // the block's words: in its stage (G32), or its quad's slot of the group ring
+                    const uint8_t* words_a = GSE ? lds + SFG_OFF + (((sb * KBS + u) >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT : stage + SFA_OFF;
+                    const uint8_t* words_b = GSE ? words_a + SFA_BYTES : stage + SFB_OFF;
                     if constexpr (MS == 4) {
-                        const v4i qa = *reinterpret_cast<const v4i*>(stage + SFA_OFF + (wm * WM + (lane & 15) * MS) * 4);
+                        const v4i qa = *reinterpret_cast<const v4i*>(words_a + (wm * WM + (lane & 15) * MS) * 4);
                         #pragma unroll
                         for (int ms = 0; ms < MS; ++ms)
                             ea[ms] = static_cast<int>(static_cast<unsigned>(qa[ms]) >> shift);
                     } else {
-                        ea[0] = static_cast<int>(*reinterpret_cast<const unsigned*>(stage + SFA_OFF + (wm * WM + (lane & 15)) * 4) >> shift);
+                        ea[0] = static_cast<int>(*reinterpret_cast<const unsigned*>(words_a + (wm * WM + (lane & 15)) * 4) >> shift);
                     }
                     #pragma unroll
                     for (int ns = 0; ns < NS; ++ns) {
                         // the weight row in MFMA row slot i = lane & 15 of N-subtile ns (see b_row_perm)
                         const int col = b_row_perm<WN>(wn * WN + ns * 16 + (lane & 15));
-                        eb[ns] = static_cast<int>(*reinterpret_cast<const unsigned*>(stage + SFB_OFF + col * 4) >> shift);
+                        eb[ns] = static_cast<int>(*reinterpret_cast<const unsigned*>(words_b + col * 4) >> shift);
                     }
                     const uint8_t* a_tile = stage + (wm * WM) * 128;
                     const uint8_t* b_tile = stage + A_BYTES + (wn * WN) * 128;

@@ -819,7 +819,7 @@ def test_import_is_fork_safe_and_bench_runs():
     # the full records on a prefixed (non-JSON) line before it
     assert len(out.stdout.splitlines()[-1]) < 2000, len(out.stdout.splitlines()[-1])
     secondary = line['secondary']
-    assert len(secondary) == 26 and not [v for v in secondary.values() if isinstance(v, str)], secondary
+    assert len(secondary) == 27 and not [v for v in secondary.values() if isinstance(v, str)], secondary
     for name, rec in secondary.items():             # [frac, us(, 'h' = HBM-bound)(, frac on data rows | of the recipe's roof)]
         assert 0 < rec[0] < 1 and rec[1] > 0 and all(v == 'h' or 0 < v < 1 for v in rec[2:]), (name, rec)
     assert secondary['masked'][2] == 'h' and len(secondary['c3_nt']) == 2 and len(secondary['contiguous']) == 3 and len(secondary['kgrouped_ue8m0']) == 2
