@@ -301,3 +301,51 @@ def test_batch_decode_with_packed_scales_runs_the_skinny_kernel(gran_k, m, n, k,
     d3 = c0.clone() if accumulate else torch.full_like(d, float('nan'))
     dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d3, c=d3 if accumulate else None, recipe=(1, 1, gran_k))
     assert torch.equal(d3, d)
+
+
+def test_randomized_decode_sized_packed_shapes_both_granularities():
+    """Randomised decode-sized problems with packed scale words (end of round 6: the skinny kernels with the scaled MFMA, the stream tiles with a K
+    quad's words in the group ring, the 64 x 32 tile with loader waves): every case against the device statement of the oracle (exactly scaled
+    32- / 128-K partial products summed in FP64, rounded once) and -- where the automatic pick is a stream tile -- bit for bit against the four-wave
+    128-row tile forced by name (both accumulate in the matrix core in K order)."""
+    import random
+    rng = random.Random(2026)
+    seen = set()
+    for case in range(28):
+        gran_k = rng.choice([128, 32])
+        m = rng.choice([1, 2, 7, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 256])
+        n = rng.choice([16, 48, 272, 528, 1040, 2112, 4096, 7168]) + rng.choice([0, 0, 16, 8])
+        k = rng.choice([512, 1024, 1536, 2048, 2560, 4096, 7168])
+        accumulate = rng.random() < 0.3
+        out_dtype = torch.float if accumulate and rng.random() < 0.5 else torch.bfloat16
+        gen.reset_seed(case)
+        a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+        b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+        qa, qb = per_token_cast_to_fp8(a, use_ue8m0=True, gran_k=gran_k), per_token_cast_to_fp8(b, use_ue8m0=True, gran_k=gran_k)
+        pa = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, gran_k))
+        pb = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, gran_k))
+        c0 = (torch.randn((m, n), device='cuda', dtype=out_dtype) * 4) if accumulate else None
+        d = c0.clone() if accumulate else torch.full((m, n), float('nan'), device='cuda', dtype=out_dtype)
+        dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d, c=d if accumulate else None, recipe=(1, 1, gran_k))
+        picked = dg.last_config()
+        seen.add(picked)
+        ad = (qa[0].float().view(m, k // gran_k, gran_k) * qa[1].unsqueeze(-1)).view(m, k).double()
+        bd = (qb[0].float().view(n, k // gran_k, gran_k) * qb[1].unsqueeze(-1)).view(n, k).double()
+        exact = ad @ bd.t()
+        label = f'case {case}: {m} x {n} x {k} gran {gran_k} {picked} acc={accumulate} {out_dtype}'
+        assert not bool(torch.isnan(d).any()), label
+        if out_dtype == torch.float:
+            want = exact + (c0.double() if accumulate else 0)
+            assert float((d.double() - want).norm() / want.norm()) < 5e-5, label      # (gpu_helpers: the matrix core does not round a block sum correctly)
+        else:           # (BF16 reduce-add: the GEMM result is rounded to BF16, then added -- gpu_helpers.assert_close_to_oracle)
+            want = (exact.to(torch.bfloat16).float() + c0.float()).to(torch.bfloat16) if accumulate else exact.to(torch.bfloat16)
+            assert_close_to_oracle(d, want, label, addend=c0)
+        if 'stream' in picked:
+            dg.set_forced_config('e8_quad_g32_128x256' if gran_k == 32 else 'e8_quad_128x256')
+            try:
+                d2 = c0.clone() if accumulate else torch.full_like(d, float('nan'))
+                dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d2, c=d2 if accumulate else None, recipe=(1, 1, gran_k))
+            finally:
+                dg.set_forced_config('auto')
+            assert torch.equal(d.view(torch.int32 if out_dtype == torch.float else torch.int16), d2.view(torch.int32 if out_dtype == torch.float else torch.int16)), label
+    assert any(s.startswith('e8_skinny') for s in seen) and any('stream' in s for s in seen), seen
