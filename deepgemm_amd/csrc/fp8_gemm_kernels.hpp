@@ -2996,25 +2996,39 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             // All pieces of K block j into ring slot j % STAGES (slot_off in bytes).  Blocks past the end are issued as
             // out-of-range no-ops so that the vmcnt arithmetic stays exact.
             // the scales of K blocks j .. j + 3, j a multiple of four (blocks past the end: out of range, zeros), into the group ring
+            // ONE wave per piece (end of round 6; every wave used to issue all of them -- identical destinations, identical data -- and they were
+            // 2 of the 8 pieces a wave of the 64 x 32 tile with loader waves issues per stage): the last wave issues the A piece, the waves in front
+            // of it the B pieces.  The issuing wave's counted wait covers its group piece (it is older than the stage's data pieces; the waits only
+            // get stricter), the stage's barrier publishes it to the others.  -DDG_GROUP_SCALES_EVERY_WAVE: the form before (tuning build).
             auto issue_group_scales = [&](int j) {
                 const unsigned oob = j < num_kb ? 0u : OOB;
                 uint8_t* slot = lds + SFG_OFF + ((j >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+#ifdef DG_GROUP_SCALES_EVERY_WAVE
+                auto mine = [&](int) { return true; };
+#else
+                static_assert(TW >= 1 + SFB_PIECES, "a wave per group piece");
+                auto mine = [&](int piece) { return wave == TW - 1 - piece; };
+#endif
                 if constexpr (GSF) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
-                        static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
-                        static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
+                    if (mine(0))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
+                    if (mine(1))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024), 4,
+                            static_cast<int>(static_cast<unsigned>(sfg_b_voff) | oob), (kb0 + j) * sfb_kb_stride, 0, 0);
                 } else {                                        // GSE: the quad's packed words (strides per K quad)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 4,
-                        static_cast<int>(static_cast<unsigned>(lane * 4 + (j >> 2) * sfa_kb_stride) | oob), 0, 0, 0);
+                    if (mine(0))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 4,
+                            static_cast<int>(static_cast<unsigned>(lane * 4 + (j >> 2) * sfa_kb_stride) | oob), 0, 0, 0);
                     #pragma unroll
                     for (int r = 0; r < SFB_PIECES; ++r)        // the words of the tile's BN weight rows: 64 per piece
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + SFA_BYTES + r * 256), 4,
-                            static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + (j >> 2) * sfb_kb_stride) | oob), 0, 0, 0);
+                        if (mine(1 + r))
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + SFA_BYTES + r * 256), 4,
+                                static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + (j >> 2) * sfb_kb_stride) | oob), 0, 0, 0);
                 }
             };
             auto issue_block = [&](int slot_off, int j) {
