@@ -228,15 +228,14 @@ const E8Config kE8Configs[] = {
     {"e8_quad_g32_128x256", dg::dg_fp8_gemm_quad_e8_kernel<128, 256, 0, false, 2, false, 0, false, true>, 128, 256, 256, false, true, false, 1, true},
     // round 6: batch-1 .. 32 decode with packed scales: the skinny weight-stream kernel with the scaled MFMA (one workgroup per 16 columns)
     // ... the 64 x 32 stream tile with four loader waves beside its four compute waves (the packed words ride in the group ring: stream_kernel_body, GSE)
-#ifndef DG_NO_GSE
     {"e8_stream_l8_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 4>, 64, 32, 512, false, true, true},
-#endif
     {"e8_skinny_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true>, 16, 16, 512, false, false, false},
     {"e8_skinny_32", dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true, true>, 32, 16, 512, false, false, false},
     {"e8_skinny_g32_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true, true>, 16, 16, 512, false, false, false, 1, true},
     {"e8_skinny_g32_32", dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true, true, true>, 32, 16, 512, false, false, false, 1, true},
     // ... and the decode-sized stream tiles (every stage carries its K block's words)
     {"e8_stream_g32_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 0, false, true>, 64, 32, 256, false, true, true, 1, true},
+    {"e8_stream_l8_g32_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 4, false, true>, 64, 32, 512, false, true, true, 1, true},
     {"e8_stream2_g32_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 0, 1, true, 0, false, true>, 64, 128, 256, false, true, true, 2, true},
     {"e8_stream_nt2_g32_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2, 1, true, 0, false, true>, 64, 128, 256, false, true, true, 2, true},
 #ifdef DG_EXPERIMENTS
@@ -1125,10 +1124,12 @@ const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
     if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && p.sfa_sm == 1 && p.sfb_sn == 1) {
         const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
         const char* wide = static_cast<double>(groups) * p.n * p.k >= 80e6 ? "e8_stream_nt2_g32_64x128" : "e8_stream2_g32_64x128";
+        // (dense: the 64 x 32 tile with four loader waves, as at granularity 128)
+        const char* narrow = p.gemm_type == dg::kNormal ? "e8_stream_l8_g32_64x32" : "e8_stream_g32_64x32";
         if (m_hint <= 64)
-            return e8_config_by_name(tiles128 >= 96 ? wide : "e8_stream_g32_64x32");
+            return e8_config_by_name(tiles128 >= 96 ? wide : narrow);
         if (m_hint <= 256 && tiles128 < 96)
-            return e8_config_by_name("e8_stream_g32_64x32");
+            return e8_config_by_name(narrow);
         if (m_hint <= 256 && tiles128 < 256)
             return e8_config_by_name(wide);
     }

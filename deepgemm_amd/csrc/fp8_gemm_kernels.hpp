@@ -2885,38 +2885,40 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
     static_assert(!G32 || E8, "G32: a form of the packed-scale stream tile");
     constexpr int NW = WAVES_M * WAVES_N, TW = NW + LW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
-    constexpr int SFB_PIECES = E8 ? (BN + 63) / 64 : 1;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = 256, SFB_BYTES = 256 * SFB_PIECES;
+    constexpr bool GSF = !E8, GSE = E8 && !G32, GSG = E8 && G32;           // FP32 scales / packed words per K quad / packed words per K block
+    constexpr int SFB_PIECES = GSG ? (BN * 16 + 1023) / 1024 : E8 ? (BN + 63) / 64 : 1;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SFA_BYTES = GSE ? 256 : 1024;
     // FP32 scales (GSF): the scales do NOT ride in the stages.  An LDS-DMA instruction costs its wave ~57 (4 bytes per lane) to ~83 ns
     // (16 bytes per lane) whatever it moves (profiles/r03_fill/NOTES.md), and the two scale pieces per K block that every wave used to
     // issue were 114 of the 612 ns a wave spends per K block of a 64 x 128 tile (363 for 64 x 32).  Now ONE 16-byte-per-lane piece
     // carries the 64 row scales of FOUR K blocks (lane l: rows 4 (l & 15) .. + 3 of block 4 g + (l >> 4): the MN-major layout makes a
     // lane's four rows contiguous) and one 4-byte piece the four SFB values: 35 ns per K block.  They live in a ring of four group
     // slots behind the stages and are issued in front of the data pieces of the group's first block.
-    constexpr bool GSF = !E8;
     // GSE (end of round 6): packed words of granularity 128 likewise -- a word covers a K QUAD, and every wave used to issue the quad's two or
     // three word pieces again with each of its four K blocks (8 of the 20 pieces a wave issues per stage of the 64 x 32 tile).  Now the words of
-    // a quad land once, in the group ring (slot: 64 A words, then BN weight-row words), in front of the data pieces of the quad's first block.
-    // (Granularity 32 has a word per K block: its words keep riding in the stages.)
-#ifdef DG_NO_GSE            // (tuning build: the words ride in every stage, as before)
-    constexpr bool GSE = false, GS = GSF;
-#else
-    constexpr bool GSE = E8 && !G32, GS = GSF || GSE;
-#endif
-    constexpr int SFA_OFF = A_BYTES + B_BYTES, SFB_OFF = SFA_OFF + SFA_BYTES, BLOCK_BYTES = GS ? A_BYTES + B_BYTES : SFB_OFF + SFB_BYTES;
+    // a quad land once, in the group ring (slot: 64 A words, then BN weight-row words), in front of the data pieces of the quad's first block
+    // (same box: dense packed m = 128, 4096 x 7168 18.0 -> 16.5 us, profiles/r06_probe/e8_stream_group_words_ab.log).
+    // GSG: granularity 32 -- a word per row and K BLOCK, laid out like the FP32 scales ([K block][row], rows contiguous): the A words of four K
+    // blocks are the FP32 form's one 16-byte-per-lane piece, the weight-row words of four K blocks ([4 blocks][BN rows] in the slot) take
+    // BN / 64 such pieces (lane l of piece r: bytes 1024 r + 16 l of that image; BN = 32: the upper half of the lanes is out of range).
+    constexpr int BLOCK_BYTES = A_BYTES + B_BYTES;
     constexpr int STAGE_BYTES = KBS * BLOCK_BYTES;
-    constexpr int SFG_OFF = STAGES * STAGE_BYTES, SFG_SLOT = 1024 + 256, SFG_SLOTS = 4;
-    constexpr int LDS_BYTES = SFG_OFF + (GS ? SFG_SLOTS * SFG_SLOT : 0);
-    static_assert(!GSE || SFA_BYTES + SFB_BYTES <= SFG_SLOT, "a group slot holds the quad's words of both operands");
+    // (a piece writes all 64 lanes' bytes -- zeros for lanes that are out of range: a slot holds WHOLE pieces, 1 KiB each at 16 bytes per lane)
+    constexpr int SFG_SLOT = GSG ? 1024 + 1024 * SFB_PIECES : 1024 + 256;
+    // (two slots where the ring holds at most four K blocks -- the two-per-CU 64 x 128 tile: 72 + 6 KiB -- four otherwise)
+    constexpr int SFG_SLOTS = (GSG && STAGES * KBS <= 4) ? 2 : 4;
+    constexpr int SFG_OFF = STAGES * STAGE_BYTES;
+    constexpr int LDS_BYTES = SFG_OFF + SFG_SLOTS * SFG_SLOT;
+    static_assert(!GSE || SFA_BYTES + 256 * SFB_PIECES <= SFG_SLOT, "a group slot holds the quad's words of both operands");
     constexpr int A_ITERS = BM / 8 / NW, B_ITERS = BN / 8 / NW;
     constexpr bool NO_A = (B_AUX == 64);                       // timing experiment: the A tile is never loaded
-    // per wave per stage; GSF: the group pieces (two per four K blocks) are NOT counted -- the counted waits then ask for up to two
+    // per wave per stage; the group pieces (two or three per four K blocks) are NOT counted -- the counted waits then ask for up to three
     // more of the younger pieces than needed (stricter, never looser; the ring has STAGES - 2 stages of slack)
     constexpr int A_PER = KBS * (BM / 8) / TW, B_PER = KBS * (BN / 8) / TW;     // LW > 0: pieces per wave and STAGE
-    static_assert(LW == 0 || (GS && !NO_A && (KBS * (BM / 8)) % TW == 0 && (KBS * (BN / 8)) % TW == 0),
-                  "loader waves: scales in the group ring, every wave issues the same number of A and of B pieces per stage");
-    constexpr int PIECES = LW > 0 ? A_PER + B_PER : ((NO_A ? 0 : A_ITERS) + B_ITERS + (GS ? 0 : 1 + SFB_PIECES)) * KBS;
-    static_assert(!GS || STAGES * KBS <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
+    static_assert(LW == 0 || (!NO_A && (KBS * (BM / 8)) % TW == 0 && (KBS * (BN / 8)) % TW == 0),
+                  "loader waves: every wave issues the same number of A and of B pieces per stage");
+    constexpr int PIECES = LW > 0 ? A_PER + B_PER : ((NO_A ? 0 : A_ITERS) + B_ITERS) * KBS;
+    static_assert(STAGES * KBS <= 4 * (SFG_SLOTS - 1), "a group slot is refilled only after its last reader");
     static_assert(!E8 || MS == 4 || MS == 1, "packed-scale form: a lane reads its MS row words with one LDS read");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(BM == 64 && (BN == 128 || BN == 64 || BN == 32), "one 256-byte SFA piece and one SFB value per tile");
@@ -2985,11 +2987,12 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             const int num_sf_k = E8 ? (G32 ? num_kb : (num_kb + 3) / 4) : num_kb_total;      // (KSPLIT: a piece's blocks are addressed from the operands' first block)
             float* sfa_tile = uniform_pointer(const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0);
             const int sfa_rows = uniform_int(imin(p.m - t.m0, BM));
-            // (GSF: 16-byte requests -- the MN-major layout pads the rows to a multiple of four, so a request that starts below sfa_rows is whole)
-            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_sf_k - 1) * sfa_kb_stride + (GSF ? (sfa_rows + 3) / 4 * 4 : sfa_rows) * 4, 0x00020000);
+            // (16-byte requests: the MN-major layouts -- FP32 and packed -- pad the rows to a multiple of four, so a request that starts below the row count is whole)
+            const auto sfa_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfa_tile, 0, (num_sf_k - 1) * sfa_kb_stride + (GSE ? sfa_rows : (sfa_rows + 3) / 4 * 4) * 4, 0x00020000);
             float* sfb_tile = uniform_pointer(const_cast<float*>(p.sfb) + static_cast<int64_t>(t.group) * p.sfb_sg +
                                               (E8 ? static_cast<int64_t>(t.n0) : static_cast<int64_t>(t.n0 / 128) * p.sfb_sn));
-            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_sf_k - 1) * sfb_kb_stride + (E8 ? uniform_int(imin(p.n - t.n0, BN)) * 4 : 4),
+            const int sfb_rows = uniform_int(imin(p.n - t.n0, BN));
+            const auto sfb_rsrc = __builtin_amdgcn_make_buffer_rsrc(sfb_tile, 0, (num_sf_k - 1) * sfb_kb_stride + (GSG ? (sfb_rows + 3) / 4 * 4 * 4 : GSE ? sfb_rows * 4 : 4),
                                                                   0x00020000);
             const int sfg_a_voff = (lane >> 4) * sfa_kb_stride + (lane & 15) * 16, sfg_b_voff = (lane & 3) * sfb_kb_stride;
 
@@ -3009,7 +3012,21 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 static_assert(TW >= 1 + SFB_PIECES, "a wave per group piece");
                 auto mine = [&](int piece) { return wave == TW - 1 - piece; };
 #endif
-                if constexpr (GSF) {
+                if constexpr (GSG) {                           // a word per row and K block: the FP32 form's A piece, [4 blocks][BN rows] of weight-row words
+                    if (mine(0))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
+                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                    #pragma unroll
+                    for (int r = 0; r < SFB_PIECES; ++r)
+                        if (mine(1 + r)) {
+                            const int off = r * 1024 + lane * 16, blk = off / (BN * 4), within = off % (BN * 4);
+                            const unsigned lane_oob = blk < 4 ? 0u : OOB;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024 + r * 1024), 16,
+                                static_cast<int>(static_cast<unsigned>(blk * sfb_kb_stride + within) | oob | lane_oob), j * sfb_kb_stride, 0, 0);
+                        }
+                } else if constexpr (GSF) {
                     if (mine(0))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
@@ -3034,10 +3051,8 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             auto issue_block = [&](int slot_off, int j) {
                 const unsigned oob = j < num_kb ? 0u : OOB;
                 uint8_t* stage = lds + slot_off;
-                if constexpr (GS) {
-                    if ((j & 3) == 0)
-                        issue_group_scales(j);
-                }
+                if ((j & 3) == 0)
+                    issue_group_scales(j);
                 #pragma unroll
                 for (int q = 0; q < (NO_A ? 0 : A_ITERS); ++q) {
                     const int unit = wave + NW * q;
@@ -3052,24 +3067,6 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                                                       (static_cast<unsigned>(b_row_perm<WN>(q * (NW * 8)) * ldb) | oob));
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         b_rsrc, (__attribute__((address_space(3))) void*)(stage + A_BYTES + unit * 1024), 16, voff, (kb0 + j) * 128, 0, B_AUX & 3);
-                }
-                if constexpr (GS)
-                    return;
-                // scales: every wave issues both (identical destinations, identical data) to keep the per-wave counts equal
-                const int jsf = E8 && !G32 ? j >> 2 : j;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    sfa_rsrc, (__attribute__((address_space(3))) void*)(stage + SFA_OFF), 4,
-                    static_cast<int>(static_cast<unsigned>(lane * 4 + jsf * sfa_kb_stride) | oob), 0, 0, 0);
-                if constexpr (E8) {
-                    #pragma unroll
-                    for (int r = 0; r < SFB_PIECES; ++r)        // the words of the tile's BN weight rows: 64 per piece
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF + r * 256), 4,
-                            static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + jsf * sfb_kb_stride) | oob), 0, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        sfb_rsrc, (__attribute__((address_space(3))) void*)(stage + SFB_OFF), 4,
-                        static_cast<int>(static_cast<unsigned>(j * sfb_kb_stride) | oob), 0, 0, 0);
                 }
             };
 
@@ -3172,9 +3169,11 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 if constexpr (E8) {
                     const int shift = G32 ? (lane >> 4) * 8 : ((sb * KBS + u) & 3) * 8;     // this block's byte of the quad's words (G32: the lane group's byte of the block's words)
                     int ea[MS], eb[NS];
-                    // the block's words: in its stage (G32), or its quad's slot of the group ring
-                    const uint8_t* words_a = GSE ? lds + SFG_OFF + (((sb * KBS + u) >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT : stage + SFA_OFF;
-                    const uint8_t* words_b = GSE ? words_a + SFA_BYTES : stage + SFB_OFF;
+                    // the block's words in its group's slot of the ring: the quad's (granularity 128) or its own of the slot's four K blocks
+                    const int jb = sb * KBS + u;
+                    const uint8_t* sfg = lds + SFG_OFF + ((jb >> 2) & (SFG_SLOTS - 1)) * SFG_SLOT;
+                    const uint8_t* words_a = sfg + (GSG ? (jb & 3) * 256 : 0);
+                    const uint8_t* words_b = sfg + SFA_BYTES + (GSG ? (jb & 3) * (BN * 4) : 0);
                     if constexpr (MS == 4) {
                         const v4i qa = *reinterpret_cast<const v4i*>(words_a + (wm * WM + (lane & 15) * MS) * 4);
                         #pragma unroll

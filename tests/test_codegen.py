@@ -26,7 +26,7 @@ PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,0,0,1,0>',         # round 6: the in-kernel K split (stream_ks_64x128: dense 129 .. 256 rows)
     # round 5: 3-stage ring, two workgroups per CU (FP32 scales / packed UE8M0; default and non-temporal weight policy)
     'dg_fp8_gemm_stream_kernel<64,128,1,4,3,0,1,0,0,0,0>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,3,2,1,0,0,0,0>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,3,0,1,1,0,0,0>',
-    'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,0,0,1>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,3,0,1,1,0,0,1>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,3,2,1,1,0,0,1>',      # round 6: granularity-32 stream tiles
+    'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,0,0,1>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,4,0,1>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,3,0,1,1,0,0,1>', 'dg_fp8_gemm_stream_kernel<64,128,1,4,3,2,1,1,0,0,1>',      # round 6: granularity-32 stream tiles
    
     'dg_fp8_gemm_stream_kernel<64,128,1,4,3,2,1,1,0,0,0>', 'dg_fp8_gemm_stream_swiglu_kernel<3>',
     'dg_fp8_gemm_pipe_kernel<128,128,2,2,2>', 'dg_fp8_gemm_pipe_kernel<64,256,1,4,1>', 'dg_fp8_gemm_pipe_kernel<256,256,2,4,2>',
