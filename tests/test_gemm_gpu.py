@@ -826,7 +826,7 @@ def test_import_is_fork_safe_and_bench_runs():
     detail = [ln for ln in out.stdout.splitlines() if ln.startswith('secondary_detail: ')]
     assert len(detail) == 1
     detail = json.loads(detail[0][len('secondary_detail: '):])
-    assert len(detail) == 26 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
+    assert len(detail) == 27 and all(0 < rec['roofline']['frac'] < 1 and rec['roofline']['kernel_us'] > 0 for rec in detail)
     # --gpus N without a launcher must not silently run one rank
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64', '--steps', '2', '--warmup', '1'],
                          capture_output=True, text=True, timeout=600)
