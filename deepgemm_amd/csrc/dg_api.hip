@@ -276,6 +276,12 @@ const EnvKnobs& env_knobs() {
     return *k;
 }
 
+// Weight bytes of one launch from which the stream tiles read them with the non-temporal policy.  Round 5 set 80 MB on rotations that fitted the
+// Infinity Cache (59 MB: 14.3 us against 14.0); with cold weights -- what a model's layer sees -- the policy wins from the smallest sweep entries
+// up (m = 1, 24576 x 1536 = 38 MB: 12.3 -> 10.8 us; 32768 x 512 = 17 MB: 6.8 -> 6.6; m = 128: 19.0 -> 18.5, 10.5 -> 10.0; 7168 x 2048 = 15 MB: equal)
+// -- profiles/r06_probe/small_m_sweep_forced.log.
+constexpr double kNonTemporalWeightBytes = 16e6;
+
 bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 // whole_k_blocks = false: a partial last K block of whole 16-byte chunks is allowed (the duo kernels' tail stage)
@@ -531,10 +537,12 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         const char* pick = nullptr;
         if (m_hint <= 64)
             pick = tiles128 >= 96 ? "stream_64x128" : "stream_64x32";
-        else if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal ? 128 : 96))
-            pick = "stream_64x32";      // (dense: up to half a round of 64 x 128 tiles -- m = 128, 7168 x 2048: 13.3 us against 14.0, round 4)
-        else if (m_hint <= 256 && tiles128 < 256)
-            pick = "stream_64x128";
+        else if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal && p.k >= 4096 ? 128 : 96))
+            pick = "stream_64x32";      // (dense: up to half a round of 64 x 128 tiles while the K loop is long; with a short one the two-per-CU
+                                        //  64 x 128 tile wins -- m = 128, 7168 x 2048, 112 tiles, cold: 12.7 us against 14.2: small_m_sweep_forced.log)
+        else if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal ? 2L * num_cus() + 1 : 256))
+            pick = "stream_64x128";     // (dense: up to ONE resident round of two tiles per CU -- end of round 6, cold weights, m = 128:
+                                        //  24576 x 1536 21.4 us on 96 tiles of 128 x 256 -> 18.5, 32768 x 512 12.7 -> 10.0)
         else if (m_hint > 256 && tiles128 <= num_cus())
             pick = "stream_64x128";     // one resident round of 64 x 128 tiles (512 x 4096 x 7168: 36.9 us against 47.3 on 128 x 256 tiles)
         // ... unless the K loop is long and the caller lent a workspace: cutting every 128 x 256 tile along K over the idle CUs
@@ -552,7 +560,7 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // (profiles/r05_probe/stream2_masked.jsonl, stream2_dense.jsonl).  Non-temporal weight stream from 80 MB of weights per launch
         // (117 MB: 25.5 us against 28.3 with the default policy; 59 MB: 14.3 against 14.0).
         if (pick != nullptr && std::strcmp(pick, "stream_64x128") == 0)
-            pick = static_cast<double>(groups) * p.n * p.k >= 80e6 ? "stream_nt2_64x128" : "stream2_64x128";
+            pick = static_cast<double>(groups) * p.n * p.k >= kNonTemporalWeightBytes ? "stream_nt2_64x128" : "stream2_64x128";
         // round 6: 129 .. 256 rows whose 64 x 128 tiles fill at most half the chip: the same tile with every tile cut along K inside the kernel
         // (stream_ks_64x128: one launch, pieces x tiles resident, FP32 partials through written-through slabs, the last piece of a tile sums
         // them in piece order).  Cold inputs, us: 160 x 4096 x 7168 27.5 -> 23.4, 192 x .. 30.4 -> 23.7, 256 x .. 30.6 -> 24.5 (was duo_sk_128x256),
@@ -1012,12 +1020,12 @@ const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
             const E8Config* pick = nullptr;
             if (m_hint <= 64)
                 pick = tiles128 >= 96 ? &kE8Configs[3] : &kE8Configs[5];
-            else if (m_hint <= 256 && tiles128 < 96)
-                pick = &kE8Configs[5];
-            else if (m_hint <= 256 && tiles128 < 256)
-                pick = &kE8Configs[3];
-            if (pick == &kE8Configs[3])         // two workgroups per CU on a 3-stage ring, non-temporal weights from 80 MB per launch (select_config)
-                pick = e8_config_by_name(static_cast<double>(groups) * p.n * p.k >= 80e6 ? "e8_stream_nt2_64x128" : "e8_stream2_64x128");
+            else if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal && p.k >= 4096 ? 128 : 96))
+                pick = &kE8Configs[5];          // (the FP32-scale rule; m = 128, 7168 x 16384, 112 tiles: 63.5 us on 64 x 128 tiles, 56.8 here)
+            else if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal ? 2L * num_cus() + 1 : 256))
+                pick = &kE8Configs[3];          // (dense: up to one resident round of two tiles per CU -- m = 128, 24576 x 1536: 23.5 -> 18.1 us, 32768 x 512: 13.1 -> 9.8)
+            if (pick == &kE8Configs[3])         // two workgroups per CU on a 3-stage ring, non-temporal weights from kNonTemporalWeightBytes per launch (select_config)
+                pick = e8_config_by_name(static_cast<double>(groups) * p.n * p.k >= kNonTemporalWeightBytes ? "e8_stream_nt2_64x128" : "e8_stream2_64x128");
             // dense: the 64 x 32 tile with loader waves (the FP32-scale rule: stream_l8_64x32)
             if (pick == &kE8Configs[5] && p.gemm_type == dg::kNormal)
                 if (const E8Config* l8 = e8_config_by_name("e8_stream_l8_64x32"))
@@ -1123,14 +1131,14 @@ const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
     // decode-sized M: the stream tiles, by the rule of the granularity-128 selection (select_e8_config)
     if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && p.sfa_sm == 1 && p.sfb_sn == 1) {
         const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
-        const char* wide = static_cast<double>(groups) * p.n * p.k >= 80e6 ? "e8_stream_nt2_g32_64x128" : "e8_stream2_g32_64x128";
+        const char* wide = static_cast<double>(groups) * p.n * p.k >= kNonTemporalWeightBytes ? "e8_stream_nt2_g32_64x128" : "e8_stream2_g32_64x128";
         // (dense: the 64 x 32 tile with four loader waves, as at granularity 128)
         const char* narrow = p.gemm_type == dg::kNormal ? "e8_stream_l8_g32_64x32" : "e8_stream_g32_64x32";
         if (m_hint <= 64)
             return e8_config_by_name(tiles128 >= 96 ? wide : narrow);
-        if (m_hint <= 256 && tiles128 < 96)
+        if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal && p.k >= 4096 ? 128 : 96))
             return e8_config_by_name(narrow);
-        if (m_hint <= 256 && tiles128 < 256)
+        if (m_hint <= 256 && tiles128 < (p.gemm_type == dg::kNormal ? 2L * num_cus() + 1 : 256))
             return e8_config_by_name(wide);
     }
     return e8_config_by_name(big ? "e8_quad_g32_256x256" : "e8_quad_g32_128x256");

@@ -494,9 +494,11 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 1, 7168, 16384) == 'skinny_16ca' and pick(dense, 16, 8192, 2048) == 'skinny_16wc' and pick(dense, 1, 4096, 16384) == 'skinny_16ca' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32'
     # decode batches: the skinny weight-stream kernel for long K loops, the stream tiles for short ones / wide N
     assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32ca' and pick(dense, 24, 4096, 4096) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_l8_64x32'
-    assert pick(dense, 1, 24576, 1536) == 'stream2_64x128' and pick(dense, 1, 32768, 512) == 'stream2_64x128'
+    # (end of round 6, cold weights: non-temporal weight stream from 16 MB per launch; dense m <= 256 on the stream tile up to one resident round of two per CU)
+    assert pick(dense, 1, 24576, 1536) == 'stream_nt2_64x128' and pick(dense, 1, 32768, 512) == 'stream_nt2_64x128'
+    assert pick(dense, 128, 32768, 512) == 'stream_nt2_64x128' and pick(dense, 128, 24576, 1536, packed=1) == 'e8_stream_nt2_64x128'
     assert pick(dense, 32, 7168, 16384) == 'stream_l8_64x32' and not pick(dense, 1, 4104, 7168).startswith('skinny_16')
-    assert pick(dense, 128, 24576, 1536) == 'duo_128x256' and pick(dense, 128, 7168, 2048) == 'stream_l8_64x32'
+    assert pick(dense, 128, 24576, 1536) == 'stream_nt2_64x128' and pick(dense, 128, 7168, 2048) == 'stream2_64x128' and pick(dense, 256, 32768, 512) == 'duo_128x256'
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256'                                            # K split beats one stream tile per CU
     # round 6: 129 .. 256 rows, 64 .. CUs / 2 tiles of 64 x 128, K >= 4096: the stream tile cut along K inside the kernel (profiles/r06_probe/stream_ks_mid_m_ab.log)
     assert pick(dense, 192, 4096, 7168) == 'stream_ks_64x128' and pick(dense, 256, 4096, 7168) == 'stream_ks_64x128' and pick(dense, 256, 2112, 7168) == 'stream_ks_64x128'
@@ -515,7 +517,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(masked, 4096, 4096, 4096, groups=32, expected_m=192) == 'duo_p_256x256'
     assert pick(masked, 4096, 6144, 7168, groups=6, expected_m=20) == 'stream_nt2_64x128'               # 288 stream tiles: one resident round at two per CU (round 5)
     assert pick(masked, 64, 7168, 2048, groups=8, expected_m=48) == 'stream_nt2_64x128'                 # the expert MLP's GEMM2: 448 tiles, 117 MB
-    assert pick(masked, 4096, 4096, 4096, groups=6, expected_m=20) == 'stream_nt2_64x128' and pick(masked, 4096, 4096, 2048, groups=6, expected_m=20) == 'stream2_64x128'
+    assert pick(masked, 4096, 4096, 4096, groups=6, expected_m=20) == 'stream_nt2_64x128' and pick(masked, 4096, 4096, 2048, groups=6, expected_m=20) == 'stream_nt2_64x128'
     assert pick(masked, 4096, 6144, 7168, groups=32, expected_m=20) == 'stream_nt2_64x128'
 
 
