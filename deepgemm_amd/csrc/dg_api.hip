@@ -155,6 +155,10 @@ const Config kConfigs[] = {
     // (m = 128, 4096 x 7168: 64 tiles x 4 pieces, 344 KB per CU instead of 688 KB on 64 x 32 tiles); needs the caller's workspace
     {"stream_ks_64x128", 64, 128, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, false, 0, true>, true, false, false,
      false, true},
+    // ... and the 64 x 32 tile (four K blocks per stage) likewise: narrow layers at small M, whose 64 x 32 tiles fill a quarter of the chip or less
+    // (m = 128, n = 576 -- the MLA down-projection of the reference's sweep: 36 tiles, one K loop of 56 blocks on 36 CUs)
+    {"stream_ks_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 0, true>, true, false, false,
+     false, true},
     {"stream2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3>, true},
     {"stream_nt2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
@@ -574,6 +578,18 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
                 if (std::strcmp(kConfigs[i].name, "stream_ks_64x128") == 0)
                     return &kConfigs[i];
         }
+        // end of round 6: dense problems whose 64 x 32 tiles fill at most half the chip, with a long K loop and the caller's workspace: the tile cut
+        // along K inside the kernel (stream_ks_64x32: min(8, CUs / tiles, K blocks / 4) pieces).  Eager calls, cold weights, us: 128 x 576 x 7168 (the
+        // MLA down-projection of the reference's sweep, 36 tiles) 15.4 -> 9.6, 64 x 2112 x 7168 16.0 -> 11.7, 256 x 576 x 7168 15.6 -> 11.3,
+        // 64 x 4096 x 7168 (128 tiles, two pieces) 16.2 -> 13.2, 128 x 576 x 16384 27.7 (duo_sk_128x256) -> 12.4 -- profiles/r06_probe/stream_ks_64x32_ab.log
+        if (pick != nullptr && p.gemm_type == dg::kNormal && std::strcmp(pick, "stream_64x32") == 0 && p.sk_workspace != nullptr && p.sfb_gran_n == 128 &&
+            p.head_lr == 0 && p.k >= 4096) {
+            const long tiles32 = static_cast<long>(ceil_div(m_for_tiling, 64)) * ceil_div(p.n, 32);
+            if (tiles32 * 2 <= num_cus() && 4096 + 32768 + static_cast<size_t>(tiles32) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes)
+                for (int i = 0; i < kNumConfigs; ++i)
+                    if (std::strcmp(kConfigs[i].name, "stream_ks_64x32") == 0)
+                        return &kConfigs[i];
+        }
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && m_hint > 64) {
             const long tiles = static_cast<long>(ceil_div(m_for_tiling, 128)) * ceil_div(p.n, 256);
             const long num_kb = p.k / 128;
@@ -811,7 +827,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         static std::atomic<unsigned> ks_epoch{0};
         const long slots = num_cus();
         long pieces = std::min<long>(std::min<long>(env_knobs().ks_max_pieces, total > 0 ? slots / total : 0), p.k / 128 / 4);
-        const size_t need = 4096 + 32768 + static_cast<size_t>(total) * 8 * 64 * 128 * sizeof(float);
+        const size_t need = 4096 + 32768 + static_cast<size_t>(total) * 8 * cfg->bm * cfg->bn * sizeof(float);
         if (p.gemm_type != dg::kNormal || p.sfb_gran_n != 128 || p.head_lr != 0 || !sfa_quads_ok(p) || total > 1024) {
             g_last_error = "the stream_ks configurations implement dense problems with per-128 SFB and MN-major SFA with 16-byte aligned K-block rows";
             return 3;

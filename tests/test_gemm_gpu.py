@@ -1467,6 +1467,75 @@ def test_mid_m_k_split_random_shapes(seed):
     assert taken == 6, taken
 
 
+@pytest.mark.parametrize('m,n,k', [(128, 576, 7168), (33, 4096, 7168), (65, 520, 4096), (1, 40, 4608), (200, 96, 5120), (256, 576, 16384)])
+def test_narrow_stream_tile_with_in_kernel_k_split(m, n, k):
+    """`stream_ks_64x32` (end of round 6): the 64 x 32 stream tile (four K blocks per stage) cut along K inside the kernel -- narrow layers at small
+    M, e.g. the MLA down-projection n = 576 of the reference's sweep: forced by name against the oracle, bit-repeatable, FP32 accumulation, ragged M
+    and N, piece boundaries inside a stage; through the plain entry the automatic selection takes it (the host layer lends the workspace) and
+    repeated calls -- the epoch advances, the workspace is reused dirty -- give the same bits."""
+    gen.reset_seed(m + n + k)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    dg.set_forced_config('stream_ks_64x32')
+    try:
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(case.a, case.b, d)
+        assert dg.last_config() == 'stream_ks_64x32'
+        again = torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt(case.a, case.b, again)
+        c32 = torch.randn((m, n), device='cuda', dtype=torch.float)
+        d32 = c32.clone()
+        dg.fp8_gemm_nt(case.a, case.b, d32, c=d32)
+    finally:
+        dg.set_forced_config('auto')
+    assert_close_to_oracle(d, want, 'narrow stream tile, in-kernel K split')
+    assert torch.equal(d.view(torch.int16), again.view(torch.int16)), 'piece order is fixed: bit-repeatable'
+    assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+    want32 = torch.empty((m, n), dtype=torch.float)
+    oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want32, c=c32.cpu())
+    assert_close_fp32(d32, want32, 'narrow stream tile, in-kernel K split, fp32 accumulate')
+    if m > 32 and -(-m // 64) * -(-n // 32) * 2 <= 256:
+        outs = []
+        for _ in range(3):
+            o = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+            dg.fp8_gemm_nt(case.a, case.b, o)
+            assert dg.last_config() == 'stream_ks_64x32', dg.last_config()
+            outs.append(o)
+        assert all(torch.equal(d.view(torch.int16), o.view(torch.int16)) for o in outs)
+
+
+def test_narrow_k_split_in_a_hip_graph():
+    """A captured `stream_ks_64x32` launch (one exchange epoch per capture): replays over changing inputs against eager calls, bit for bit."""
+    m, n, k = 128, 576, 7168
+    cases = []
+    for i in range(3):
+        gen.reset_seed(70 + i)
+        cases.append(gen.generate_normal(m, n, k))
+    eager = []
+    for c in cases:
+        d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(c.a, c.b, d)
+        assert dg.last_config() == 'stream_ks_64x32'
+        eager.append(d)
+    a = (cases[0].a[0].clone(), dg.get_mn_major_tma_aligned_tensor(cases[0].a[1]).clone())
+    b = (cases[0].b[0].clone(), cases[0].b[1].clone())
+    d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dg.fp8_gemm_nt(a, b, d)                                     # (warm: plan caches, the stream's workspace)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        dg.fp8_gemm_nt(a, b, d)
+    for which in (1, 2, 0, 2, 1):
+        c = cases[which]
+        a[0].copy_(c.a[0]); a[1].copy_(dg.get_mn_major_tma_aligned_tensor(c.a[1])); b[0].copy_(c.b[0]); b[1].copy_(c.b[1])
+        d.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d.view(torch.int16), eager[which].view(torch.int16)), which
+
+
 def test_k_grouped_argument_checks():
     gen.reset_seed(1)
     case = gen.generate_k_grouped_contiguous(2, 128, 128, [128, 256], True)

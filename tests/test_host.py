@@ -412,7 +412,7 @@ def test_split_k_workspace_is_only_requested_when_the_model_says_so():
     from deepgemm_amd import gemm
     from deepgemm_amd._lib import lib
     cpu = torch.device('cpu')
-    for m, n, k in ((4096, 4096, 7168), (2048, 7168, 2048), (64, 4096, 7168), (4096, 4096, 128), (4096, 7168, 2112)):
+    for m, n, k in ((4096, 4096, 7168), (2048, 7168, 2048), (128, 4096, 7168), (64, 4096, 2048), (4096, 4096, 128), (4096, 7168, 2112)):
         assert gemm._dense_split_k_workspace(m, n, k, 128, cpu) is None, (m, n, k)
     # recipe (1, 1, 128): only under-filled launches with long K loops (wgrad of a narrow layer)
     for m, n, k in ((4096, 4096, 7168), (2112, 4096, 7168), (576, 4096, 1024), (64, 4096, 7168)):
@@ -420,6 +420,8 @@ def test_split_k_workspace_is_only_requested_when_the_model_says_so():
     wants = lambda m, n, k, gran_n=128, a_mn=0, b_mn=0: lib.dg_dense_wants_workspace(m, n, k, a_mn, b_mn, gran_n)      # noqa: E731
     assert wants(4096, 512, 32768) == 1 and wants(4096, 512, 32768, b_mn=1) == 1          # 64 tiles of 128 x 256, 256 K blocks
     assert wants(1024, 1024, 16384) == 1 and wants(512, 4096, 7168) == 1
+    # (end of round 6: 64 x 32 stream tiles that fill at most half the chip, K >= 4096, are cut along K inside the kernel: stream_ks_64x32)
+    assert wants(128, 576, 7168) == 1 and wants(64, 4096, 7168) == 1 and wants(128, 576, 2048) == 0 and wants(128, 2112, 7168) == 0
     assert wants(576, 4096, 7168, 1) == 1 and wants(576, 4096, 7168, 1, 1, 1) == 1        # 48 tiles of 256 x 256, 56 K blocks: K pieces as groups
     assert wants(4096, 512, 32768, 1) == 1
     assert wants(576, 4096, 7168, 1, 1, 0) == 0                                            # mixed majorness: the layout-agnostic kernel, no split
@@ -493,7 +495,7 @@ def test_automatic_kernel_selection_is_pinned():
     # the reference's dense sweep: small M, K tails, few tiles with long K loops, tile-count quantisation
     assert pick(dense, 1, 7168, 16384) == 'skinny_16ca' and pick(dense, 16, 8192, 2048) == 'skinny_16wc' and pick(dense, 1, 4096, 16384) == 'skinny_16ca' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32'
     # decode batches: the skinny weight-stream kernel for long K loops, the stream tiles for short ones / wide N
-    assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32ca' and pick(dense, 24, 4096, 4096) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_l8_64x32'
+    assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32ca' and pick(dense, 24, 4096, 4096) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_ks_64x32' and pick(dense, 33, 4096, 7168, workspace=0) == 'stream_l8_64x32'
     # (end of round 6, cold weights: non-temporal weight stream from 16 MB per launch; dense m <= 256 on the stream tile up to one resident round of two per CU)
     assert pick(dense, 1, 24576, 1536) == 'stream_nt2_64x128' and pick(dense, 1, 32768, 512) == 'stream_nt2_64x128'
     assert pick(dense, 128, 32768, 512) == 'stream_nt2_64x128' and pick(dense, 128, 24576, 1536, packed=1) == 'e8_stream_nt2_64x128'
@@ -501,6 +503,7 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 128, 24576, 1536) == 'stream_nt2_64x128' and pick(dense, 128, 7168, 2048) == 'stream2_64x128' and pick(dense, 256, 32768, 512) == 'duo_128x256'
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256'                                            # K split beats one stream tile per CU
     # round 6: 129 .. 256 rows, 64 .. CUs / 2 tiles of 64 x 128, K >= 4096: the stream tile cut along K inside the kernel (profiles/r06_probe/stream_ks_mid_m_ab.log)
+    assert pick(dense, 128, 576, 7168) == 'stream_ks_64x32' and pick(dense, 128, 576, 16384) == 'stream_ks_64x32' and pick(dense, 128, 576, 7168, workspace=0) == 'stream_l8_64x32'
     assert pick(dense, 192, 4096, 7168) == 'stream_ks_64x128' and pick(dense, 256, 4096, 7168) == 'stream_ks_64x128' and pick(dense, 256, 2112, 7168) == 'stream_ks_64x128'
     assert pick(dense, 192, 4096, 7168, workspace=0) == 'stream_l8_64x32' and pick(dense, 192, 2112, 7168) == 'stream_l8_64x32' and pick(dense, 256, 4096, 2048) == 'stream2_64x128'
     assert pick(dense, 192, 7168, 2048) == 'stream2_64x128' and pick(masked, 192, 4096, 7168, groups=1, expected_m=192) != 'stream_ks_64x128'
