@@ -33,6 +33,7 @@ namespace {
 // process-wide like the reference's runtime singletons (csrc/apis/runtime.hpp:12-49) and safe to set from any thread.
 thread_local std::string g_last_error;
 thread_local std::string g_last_config = "";
+std::atomic<unsigned> g_stream_ks_epoch{0};         // exchange epochs of the stream_ks launches (FP32-scale and packed forms share the workspace's flags)
 thread_local size_t g_workspace_bytes = 0;          // size of the workspace behind GemmParams::sk_workspace for the call in flight
 std::atomic<int> g_num_cus_override{0};
 std::atomic<long long*> g_debug_buffer{nullptr};
@@ -233,6 +234,11 @@ const E8Config kE8Configs[] = {
     // round 6: batch-1 .. 32 decode with packed scales: the skinny weight-stream kernel with the scaled MFMA (one workgroup per 16 columns)
     // ... the 64 x 32 stream tile with four loader waves beside its four compute waves (the packed words ride in the group ring: stream_kernel_body, GSE)
     {"e8_stream_l8_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 4>, 64, 32, 512, false, true, true},
+    // ... and the stream tiles cut along K inside the kernel (stream_kernel_body, KSPLIT: pieces of whole K quads; the rules of stream_ks_64x128 / _64x32)
+    {"e8_stream_ks_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, true, 0, true>, 64, 128, 256, false, false, true},
+    {"e8_stream_ks_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 0, true>, 64, 32, 256, false, false, true},
+    {"e8_stream_ks_g32_64x128", dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 6, 0, 1, true, 0, true, true>, 64, 128, 256, false, false, true, 1, true},
+    {"e8_stream_ks_g32_64x32", dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, true, 0, true, true>, 64, 32, 256, false, false, true, 1, true},
     {"e8_skinny_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true>, 16, 16, 512, false, false, false},
     {"e8_skinny_32", dg::dg_fp8_gemm_skinny_kernel<2, 3, 1, true, true, true>, 32, 16, 512, false, false, false},
     {"e8_skinny_g32_16", dg::dg_fp8_gemm_skinny_kernel<1, 4, 1, true, true, true, true>, 16, 16, 512, false, false, false, 1, true},
@@ -824,7 +830,6 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
     if (stream_ks) {
         // K pieces of the stream tile (see stream_kernel_body, KSPLIT): as many as keep tiles x pieces within one resident round, at most 8 and
         // at least four K blocks each; flags and slabs live in the caller's workspace
-        static std::atomic<unsigned> ks_epoch{0};
         const long slots = num_cus();
         long pieces = std::min<long>(std::min<long>(env_knobs().ks_max_pieces, total > 0 ? slots / total : 0), p.k / 128 / 4);
         const size_t need = 4096 + 32768 + static_cast<size_t>(total) * 8 * cfg->bm * cfg->bn * sizeof(float);
@@ -835,7 +840,7 @@ int launch_gemm(dg::GemmParams& p, int expected_m, void* stream) {
         if (pieces < 2 || p.sk_workspace == nullptr || need > g_workspace_bytes)
             pieces = 1;                             // whole tiles (no workspace, too many tiles): the plain 6-stage stream tile
         p.sk_factor = static_cast<int>(pieces);
-        p.sk_exchange = 0x7fc00000u | (ks_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu) | 0x100000u;
+        p.sk_exchange = 0x7fc00000u | (g_stream_ks_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu) | 0x100000u;
         const long items = total * pieces;
         hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(std::min<long>(items, slots))), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
         DG_HIP_CHECK(hipGetLastError());
@@ -1014,10 +1019,27 @@ const char* e8_skinny_pick(const dg::GemmParams& p, bool g32) {
     return nullptr;
 }
 
+// Packed-scale dense problems the stream tile is cut along K for (the FP32-scale rules of select_config: stream_ks_64x128 for 129 .. 256 rows with
+// 64 .. CUs / 2 tiles, stream_ks_64x32 where the 64 x 32 tiles fill at most half the chip; K >= 4096, the caller's workspace).  nullptr = not this class.
+const char* e8_stream_ks_pick(const dg::GemmParams& p, bool g32) {
+    if (p.gemm_type != dg::kNormal || p.head_lr != 0 || p.sk_workspace == nullptr || p.k < 4096 || p.k % 128 != 0 || p.sfa_sm != 1 || p.sfb_sn != 1 ||
+        !fast_eligible(p) || p.m > 256)
+        return nullptr;
+    const long tiles128 = static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 128), tiles32 = static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 32);
+    const size_t fixed = 4096 + 32768;
+    if (p.m > 128 && tiles128 >= 64 && tiles128 * 2 <= num_cus() && fixed + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes)
+        return g32 ? "e8_stream_ks_g32_64x128" : "e8_stream_ks_64x128";
+    if (p.m > 32 && tiles128 < 128 && tiles32 * 2 <= num_cus() && fixed + static_cast<size_t>(tiles32) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes)
+        return g32 ? "e8_stream_ks_g32_64x32" : "e8_stream_ks_64x32";
+    return nullptr;
+}
+
 const E8Config* select_e8_config(const dg::GemmParams& p, int expected_m) {
     const E8Config* cfg = nullptr;
     if (const char* skinny = e8_skinny_pick(p, false))
         return e8_config_by_name(skinny);
+    if (const char* ks = e8_stream_ks_pick(p, false))
+        return e8_config_by_name(ks);
     {
         const int m_hint = expected_m > 0 ? expected_m : p.m;
         const long groups = p.gemm_type == dg::kMasked ? p.num_groups : 1;
@@ -1144,6 +1166,8 @@ const E8Config* select_e8_g32_config(const dg::GemmParams& p, int expected_m) {
         big = false;
     if (const char* skinny = e8_skinny_pick(p, true))
         return e8_config_by_name(skinny);
+    if (const char* ks = e8_stream_ks_pick(p, true))
+        return e8_config_by_name(ks);
     // decode-sized M: the stream tiles, by the rule of the granularity-128 selection (select_e8_config)
     if ((p.gemm_type == dg::kMasked || p.gemm_type == dg::kNormal) && p.sfa_sm == 1 && p.sfb_sn == 1) {
         const long tiles128 = groups * ceil_div(m_hint, 64) * ceil_div(p.n, 128);
@@ -1227,7 +1251,8 @@ int launch_e8_split(const dg::GemmParams& dense, int pieces, void* stream, int g
 
 int launch_e8(dg::GemmParams& p, int expected_m, void* stream, int gran_k = 128) {
     const bool k_tail = p.k % 128 != 0;
-    if (p.sk_workspace != nullptr && p.gemm_type == dg::kNormal)
+    // (m <= 256 inside the rule of the stream tiles cut along K in one launch -- e8_stream_ks_pick -- stays with them: 256 x 576 x 16384)
+    if (p.sk_workspace != nullptr && p.gemm_type == dg::kNormal && !(forced_config() == "auto" && e8_stream_ks_pick(p, gran_k == 32) != nullptr))
         if (const int pieces = e8_split_pieces(p, g_workspace_bytes); pieces >= 2)
             return launch_e8_split(p, pieces, stream, gran_k);
     const bool mn_form = gran_k != 32 && e8_mn_eligible(p);           // an MN-major operand read in place
@@ -1321,6 +1346,26 @@ int launch_e8(dg::GemmParams& p, int expected_m, void* stream, int gran_k = 128)
         return 0;
     }
     long total = static_cast<long>(p.num_m_tiles) * p.num_n_tiles;
+    if (std::strncmp(cfg->name, "e8_stream_ks_", 13) == 0) {
+        // K pieces of the stream tile (launch_gemm's stream_ks branch): as many as keep tiles x pieces within one resident round, at most 8, whole K quads
+        if (p.gemm_type != dg::kNormal || p.head_lr != 0 || k_tail || mn_form || p.sfa_sm != 1 || p.sfb_sn != 1 || total > 1024) {
+            g_last_error = std::string("config '") + cfg->name + "' implements dense K-major problems with whole K blocks and at most 1024 tiles";
+            return 3;
+        }
+        const long slots = num_cus();
+        long pieces = std::min<long>(std::min<long>(env_knobs().ks_max_pieces, total > 0 ? slots / total : 0), p.k / 128 / 4);
+        const size_t need = 4096 + 32768 + static_cast<size_t>(total) * 8 * cfg->bm * cfg->bn * sizeof(float);
+        if (pieces < 2 || p.sk_workspace == nullptr || need > g_workspace_bytes)
+            pieces = 1;                             // whole tiles (no workspace, too many tiles)
+        p.sk_factor = static_cast<int>(pieces);
+        p.sk_exchange = 0x7fc00000u | (g_stream_ks_epoch.fetch_add(1, std::memory_order_relaxed) & 0xfffffu) | 0x100000u;
+        const long items = total * pieces;
+        hipLaunchKernelGGL(cfg->fn, dim3(static_cast<unsigned>(std::min<long>(items, slots))), dim3(cfg->threads), 0, static_cast<hipStream_t>(stream), p);
+        DG_HIP_CHECK(hipGetLastError());
+        if (env_knobs().print_configs)
+            fprintf(stderr, "[deepgemm_amd] ue8m0 m=%d n=%d k=%d -> %s pieces=%ld items=%ld\n", p.m, p.n, p.k, cfg->name, pieces, items);
+        return 0;
+    }
     if (p.gemm_type == dg::kMasked)
         total *= p.num_groups;
     const long slots = static_cast<long>(num_cus()) * cfg->per_cu;
@@ -1472,7 +1517,17 @@ int dg_ue8m0_dense_wants_workspace(int m, int n, int k) {
     p.m = m; p.n = n; p.k = k; p.num_groups = 1;
     p.a_sm = k; p.a_sk = 1; p.b_sn = k; p.b_sk = 1; p.sfa_sm = 1; p.sfb_sn = 1;
     p.gemm_type = dg::kNormal;
-    return e8_split_pieces(p, 0) >= 2 ? 1 : 0;
+    if (e8_split_pieces(p, 0) >= 2)
+        return 1;
+    if (forced_config().find("_ks_") != std::string::npos)     // (a K-split form forced by name -- tuning runs, tests -- gets the buffer too)
+        return 1;
+    // the stream tiles cut along K inside the kernel (e8_stream_ks_pick: the question is asked BEFORE a workspace exists -- assume the host layer's size)
+    p.sk_workspace = reinterpret_cast<void*>(static_cast<uintptr_t>(1) << 23);
+    const size_t saved = g_workspace_bytes;
+    g_workspace_bytes = static_cast<size_t>(dg_split_k_workspace_bytes());
+    const bool ks = forced_config() == "auto" && e8_skinny_pick(p, false) == nullptr && e8_stream_ks_pick(p, false) != nullptr;
+    g_workspace_bytes = saved;
+    return ks ? 1 : 0;
 }
 
 int dg_fp8_gemm_nt_ue8m0_g32(const void* a, const int32_t* sfa_packed, const void* b, const int32_t* sfb_packed, void* d,
@@ -2559,9 +2614,12 @@ const char* dg_select_config(int gemm_type, int m, int n, int k, int num_groups,
             name = e8_mn_config_name(p);
         else {
             p.a_sm = k; p.a_sk = 1; p.b_sn = k; p.b_sk = 1;
+            const size_t saved = g_workspace_bytes;     // (has_workspace: of the size the host layer creates)
+            g_workspace_bytes = has_workspace ? static_cast<size_t>(dg_split_k_workspace_bytes()) : 0;
             name = e8_contiguous_tabled(p) ? "e8_quad_tab_256x256"
                  : fast_eligible(p)        ? select_e8_config(p, expected_m)->name
                                            : (gemm_type == dg::kNormal && fast_eligible(p, false) ? "e8_quad_kt_128x256" : "");
+            g_workspace_bytes = saved;
         }
     } else if (has_workspace && per_col_split_pieces(p, 0, true) >= 2) {
         name = per_col_eligible(p) ? (per_col_bm(p, true) == 192 ? "pipe_pc_ks_192x256" : "pipe_pc_ks_256x256") : "pipe_pc_mn_ks_256x256";     // (K pieces as the groups of one launch + the summing kernel)

@@ -2881,7 +2881,7 @@ void dg_split_k_reduce_kernel(const GemmParams p) {
 // four-wave tile: 68-70 us for m <= 256 at 4096 x 7168 against 25-38 for granularity 128, the masked C5 shape 80 against 43.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int B_AUX = 0, int KBS = 1, bool E8 = false, int LW = 0, bool KSPLIT = false, bool G32 = false>
 __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
-    static_assert(!KSPLIT || (!E8 && LW == 0 && B_AUX != 64), "KSPLIT: the FP32-scale stream tile");
+    static_assert(!KSPLIT || (LW == 0 && B_AUX != 64), "KSPLIT: the plain stream tile (FP32 scales or packed words), no loader waves");
     static_assert(!G32 || E8, "G32: a form of the packed-scale stream tile");
     constexpr int NW = WAVES_M * WAVES_N, TW = NW + LW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MS = WM / 16, NS = WN / 16;
@@ -2957,8 +2957,14 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                 break;
             tile = tile_id % tiles;
             ks_piece = tile_id / tiles;
-            kb0 = ks_piece * num_kb_total / ks_pieces;
-            num_kb = (ks_piece + 1) * num_kb_total / ks_pieces - kb0;
+            if constexpr (E8) {                     // packed words: pieces of whole K quads (a word of granularity 128 covers one; the group ring is filled per quad)
+                const int quads = (num_kb_total + 3) / 4;
+                kb0 = (ks_piece * quads / ks_pieces) * 4;
+                num_kb = imin(num_kb_total, ((ks_piece + 1) * quads / ks_pieces) * 4) - kb0;
+            } else {
+                kb0 = ks_piece * num_kb_total / ks_pieces;
+                num_kb = (ks_piece + 1) * num_kb_total / ks_pieces - kb0;
+            }
         }
         const Tile t = get_tile<BM, BN>(p, tile, walk);
         if (!t.valid)
@@ -2984,7 +2990,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
             // SFA of the tile's rows: MN-major, rows m0 .. m0+63 are 256 contiguous bytes per K block
             const int sfa_kb_stride = static_cast<int>(p.sfa_sk) * 4, sfb_kb_stride = static_cast<int>(p.sfb_sk) * 4;
             // (E8: the strides are per K quad and the "K block" index of a scale row is j >> 2)
-            const int num_sf_k = E8 ? (G32 ? num_kb : (num_kb + 3) / 4) : num_kb_total;      // (KSPLIT: a piece's blocks are addressed from the operands' first block)
+            const int num_sf_k = GSE ? (num_kb_total + 3) / 4 : num_kb_total;               // (KSPLIT: a piece's blocks are addressed from the operands' first block)
             float* sfa_tile = uniform_pointer(const_cast<float*>(p.sfa) + ad_group * p.sfa_sg + t.m0);
             const int sfa_rows = uniform_int(imin(p.m - t.m0, BM));
             // (16-byte requests: the MN-major layouts -- FP32 and packed -- pad the rows to a multiple of four, so a request that starts below the row count is whole)
@@ -3016,7 +3022,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     if (mine(0))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 16,
-                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), j * sfa_kb_stride, 0, 0);
+                            static_cast<int>(static_cast<unsigned>(sfg_a_voff) | oob), (kb0 + j) * sfa_kb_stride, 0, 0);
                     #pragma unroll
                     for (int r = 0; r < SFB_PIECES; ++r)
                         if (mine(1 + r)) {
@@ -3024,7 +3030,7 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                             const unsigned lane_oob = blk < 4 ? 0u : OOB;
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + 1024 + r * 1024), 16,
-                                static_cast<int>(static_cast<unsigned>(blk * sfb_kb_stride + within) | oob | lane_oob), j * sfb_kb_stride, 0, 0);
+                                static_cast<int>(static_cast<unsigned>(blk * sfb_kb_stride + within) | oob | lane_oob), (kb0 + j) * sfb_kb_stride, 0, 0);
                         }
                 } else if constexpr (GSF) {
                     if (mine(0))
@@ -3039,13 +3045,13 @@ __device__ __forceinline__ void stream_kernel_body(const GemmParams& p) {
                     if (mine(0))
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sfa_rsrc, (__attribute__((address_space(3))) void*)slot, 4,
-                            static_cast<int>(static_cast<unsigned>(lane * 4 + (j >> 2) * sfa_kb_stride) | oob), 0, 0, 0);
+                            static_cast<int>(static_cast<unsigned>(lane * 4 + ((kb0 + j) >> 2) * sfa_kb_stride) | oob), 0, 0, 0);
                     #pragma unroll
                     for (int r = 0; r < SFB_PIECES; ++r)        // the words of the tile's BN weight rows: 64 per piece
                         if (mine(1 + r))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 sfb_rsrc, (__attribute__((address_space(3))) void*)(slot + SFA_BYTES + r * 256), 4,
-                                static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + (j >> 2) * sfb_kb_stride) | oob), 0, 0, 0);
+                                static_cast<int>(static_cast<unsigned>((r * 64 + lane) * 4 + ((kb0 + j) >> 2) * sfb_kb_stride) | oob), 0, 0, 0);
                 }
             };
             auto issue_block = [&](int slot_off, int j) {

@@ -248,7 +248,8 @@ def test_decode_sized_gran_k_32_runs_on_stream_tiles(m, n, k):
     (a_q, sfa, pa), (b_q, sfb, pb) = _cast32(a), _cast32(b)
     d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
     dg.fp8_gemm_nt((a_q, pa), (b_q, pb), d, recipe=(1, 1, 32))
-    assert dg.last_config().startswith('e8_stream') and '_g32_' in dg.last_config(), dg.last_config()
+    picked = dg.last_config()
+    assert picked.startswith('e8_stream') and '_g32_' in picked, picked
     if m * n * k <= 64 * 4096 * 2048:
         want = torch.empty((m, n), dtype=torch.bfloat16)
         oracle.fp8_gemm_nt(a_q.cpu(), sfa.cpu(), b_q.cpu(), sfb.cpu(), want, gran_n=1, gran_k=32)
@@ -261,7 +262,10 @@ def test_decode_sized_gran_k_32_runs_on_stream_tiles(m, n, k):
         assert dg.last_config() == 'e8_quad_g32_128x256'
     finally:
         dg.set_forced_config('auto')
-    assert torch.equal(d.view(torch.int16), d2.view(torch.int16))
+    if '_ks_' in picked:        # (cut along K inside the kernel: the same products in another summation split)
+        assert calc_diff(d.float(), d2.float()) < 2e-6
+    else:
+        assert torch.equal(d.view(torch.int16), d2.view(torch.int16))
 
 
 @pytest.mark.parametrize('gran_k', [128, 32])
@@ -340,7 +344,7 @@ def test_randomized_decode_sized_packed_shapes_both_granularities():
         else:           # (BF16 reduce-add: the GEMM result is rounded to BF16, then added -- gpu_helpers.assert_close_to_oracle)
             want = (exact.to(torch.bfloat16).float() + c0.float()).to(torch.bfloat16) if accumulate else exact.to(torch.bfloat16)
             assert_close_to_oracle(d, want, label, addend=c0)
-        if 'stream' in picked:
+        if 'stream' in picked and '_ks_' not in picked:         # (the K-split forms sum the pieces' partials: test_packed_stream_tiles_cut_along_k)
             dg.set_forced_config('e8_quad_g32_128x256' if gran_k == 32 else 'e8_quad_128x256')
             try:
                 d2 = c0.clone() if accumulate else torch.full_like(d, float('nan'))
@@ -349,3 +353,101 @@ def test_randomized_decode_sized_packed_shapes_both_granularities():
                 dg.set_forced_config('auto')
             assert torch.equal(d.view(torch.int32 if out_dtype == torch.float else torch.int16), d2.view(torch.int32 if out_dtype == torch.float else torch.int16)), label
     assert any(s.startswith('e8_skinny') for s in seen) and any('stream' in s for s in seen), seen
+
+
+@pytest.mark.parametrize('gran_k', [128, 32])
+@pytest.mark.parametrize('m,n,k', [(128, 576, 7168), (33, 4096, 7168), (65, 520, 4096), (200, 96, 5120), (256, 576, 16384), (192, 4096, 7168), (256, 2112, 4608)])
+def test_packed_stream_tiles_cut_along_k(gran_k, m, n, k):
+    """`e8_stream_ks_64x32` / `_64x128` and their granularity-32 forms (end of round 6): the packed-scale stream tiles cut along K inside the kernel
+    in pieces of whole K quads (the FP32-scale rules of `stream_ks_*`) -- the automatic pick through the plain entry (the host layer lends the
+    stream's workspace) against the oracle and the FP64 statement, against the unsplit tile forced by name (same products, another summation
+    split), repeated calls on the dirty workspace bit for bit, FP32 accumulation, and each form forced by name on a shape outside its rule."""
+    gen.reset_seed(m + n + k + gran_k)
+    a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+    b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+    qa, qb = per_token_cast_to_fp8(a, use_ue8m0=True, gran_k=gran_k), per_token_cast_to_fp8(b, use_ue8m0=True, gran_k=gran_k)
+    pa = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, gran_k))
+    pb = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, gran_k))
+    g = '_g32' if gran_k == 32 else ''
+    wide = m > 128 and -(-m // 64) * -(-n // 128) >= 64
+    want_name = f'e8_stream_ks{g}_64x128' if wide else f'e8_stream_ks{g}_64x32'
+    outs = []
+    for _ in range(3):
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d, recipe=(1, 1, gran_k))
+        assert dg.last_config() == want_name, dg.last_config()
+        outs.append(d)
+    d = outs[0]
+    assert all(torch.equal(d.view(torch.int16), o.view(torch.int16)) for o in outs[1:]), 'piece order is fixed: bit-repeatable'
+    ad = (qa[0].float().view(m, k // gran_k, gran_k) * qa[1].unsqueeze(-1)).view(m, k).double()
+    bd = (qb[0].float().view(n, k // gran_k, gran_k) * qb[1].unsqueeze(-1)).view(n, k).double()
+    exact = ad @ bd.t()
+    assert_close_to_oracle(d, exact.to(torch.bfloat16), f'{want_name} {m} x {n} x {k}')
+    if m * n * k <= 128 * 576 * 7168:
+        want = torch.empty((m, n), dtype=torch.bfloat16)
+        oracle.fp8_gemm_nt(qa[0].cpu(), qa[1].cpu(), qb[0].cpu(), qb[1].cpu(), want, gran_n=1, gran_k=gran_k)
+        assert_close_to_oracle(d, want, f'{want_name} against the C oracle')
+    assert calc_diff(d, (a.float() @ b.float().t()).to(torch.bfloat16)) < gen.FP8_MAX_DIFF
+    dg.set_forced_config(f'e8_stream{g}_64x32')
+    try:
+        d2 = torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d2, recipe=(1, 1, gran_k))
+        assert dg.last_config() == f'e8_stream{g}_64x32'
+    finally:
+        dg.set_forced_config('auto')
+    assert calc_diff(d.float(), d2.float()) < 2e-6
+    # FP32 accumulation into the output (the last piece reads the addend)
+    c32 = torch.randn((m, n), device='cuda', dtype=torch.float) * 4
+    d32 = c32.clone()
+    dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d32, c=d32, recipe=(1, 1, gran_k))
+    assert dg.last_config() == want_name, dg.last_config()
+    want32 = exact + c32.double()
+    assert float((d32.double() - want32).norm() / want32.norm()) < 5e-5
+    # the other form forced by name (outside its rule: any tile count up to 1024)
+    other = f'e8_stream_ks{g}_64x32' if wide else f'e8_stream_ks{g}_64x128'
+    dg.set_forced_config(other)
+    try:
+        d3 = torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt((qa[0], pa), (qb[0], pb), d3, recipe=(1, 1, gran_k))
+        assert dg.last_config() == other
+    finally:
+        dg.set_forced_config('auto')
+    assert calc_diff(d.float(), d3.float()) < 2e-6
+
+
+@pytest.mark.parametrize('gran_k', [128, 32])
+def test_packed_k_split_in_a_hip_graph(gran_k):
+    """A captured `e8_stream_ks_*` launch carries one exchange epoch: replays over changing inputs against eager calls, bit for bit."""
+    m, n, k = 128, 576, 7168
+    g = '_g32' if gran_k == 32 else ''
+
+    def operands(seed):
+        torch.manual_seed(seed)
+        a = torch.randn((m, k), device='cuda', dtype=torch.bfloat16)
+        b = torch.randn((n, k), device='cuda', dtype=torch.bfloat16)
+        qa, qb = per_token_cast_to_fp8(a, use_ue8m0=True, gran_k=gran_k), per_token_cast_to_fp8(b, use_ue8m0=True, gran_k=gran_k)
+        return (qa[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, gran_k)),
+                qb[0], dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, gran_k)))
+    cases = [operands(80 + i) for i in range(3)]
+    eager = []
+    for c in cases:
+        d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt((c[0], c[1]), (c[2], c[3]), d, recipe=(1, 1, gran_k))
+        assert dg.last_config() == f'e8_stream_ks{g}_64x32', dg.last_config()
+        eager.append(d)
+    held = [t.clone() for t in cases[0]]
+    d = torch.empty((m, n), device='cuda', dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dg.fp8_gemm_nt((held[0], held[1]), (held[2], held[3]), d, recipe=(1, 1, gran_k))      # (warm: plan caches, the stream's workspace)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        dg.fp8_gemm_nt((held[0], held[1]), (held[2], held[3]), d, recipe=(1, 1, gran_k))
+    for which in (1, 2, 0, 2, 1):
+        for dst, src in zip(held, cases[which]):
+            dst.copy_(src)
+        d.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d.view(torch.int16), eager[which].view(torch.int16)), which

@@ -477,7 +477,11 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(masked, 64, 4096, 7168, groups=8, expected_m=48, packed=1) == 'e8_stream_nt2_64x128'
     assert pick(dense, 128, 4096, 7168, packed=1) == 'e8_stream_l8_64x32'      # (end of round 6: four loader waves, the FP32-scale rule)
     # round 6: decode batches with packed scales run the skinny weight-stream kernel with the scaled MFMA (the rule of the FP32-scale skinny kernels)
-    assert pick(dense, 1, 4096, 7168, packed=1) == 'e8_skinny_16' and pick(dense, 24, 4096, 7168, packed=1) == 'e8_skinny_32' and pick(dense, 33, 4096, 7168, packed=1) == 'e8_stream_l8_64x32'
+    assert pick(dense, 1, 4096, 7168, packed=1) == 'e8_skinny_16' and pick(dense, 24, 4096, 7168, packed=1) == 'e8_skinny_32' and pick(dense, 33, 4096, 7168, packed=1, workspace=0) == 'e8_stream_l8_64x32'
+    # (end of round 6: the stream tiles cut along K inside the kernel with packed words too -- the FP32-scale rules)
+    assert pick(dense, 33, 4096, 7168, packed=1) == 'e8_stream_ks_64x32' and pick(dense, 128, 576, 7168, packed=1) == 'e8_stream_ks_64x32' and pick(dense, 192, 4096, 7168, packed=1) == 'e8_stream_ks_64x128'
+    from deepgemm_amd._lib import lib as _l
+    assert _l.dg_ue8m0_dense_wants_workspace(128, 576, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(192, 4096, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(128, 4096, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(1, 576, 7168) == 0
     # packed scales with MN-major operands: read in place where that beats a re-majoring pass (e8_mn_pays); a K tail in the nn layout (the
     # packed-scale dgrad shapes) always stays in place (round 5)
     assert pick(dense, 2048, 7168, 2048, b_mn=1, packed=1) == 'e8_duo_bmn_256x256' and pick(dense, 4096, 4096, 7168, b_mn=1, packed=1) == 'e8_quad_256x256'
