@@ -265,6 +265,7 @@ struct EnvKnobs {
     bool e8_tab_unsplit;
     int ks_max_pieces;      // DG_STREAM_KS_PIECES: upper bound of the K pieces of the stream_ks tile (tuning; default 8)
     int swiglu_fault;       // DG_TEST_SWIGLU_FAULT (tests only): 1 = odd tiles of the fused SwiGLU kernel never publish their amax
+    bool e8_split_quad_model_only;   // (tuning: e8_split_pieces prices the unsplit call as the 128-row kernel even up to 256 rows -- the rule before the end of round 6)
     EnvKnobs()
         : print_configs(getenv("DG_PRINT_CONFIGS") != nullptr), table_kernel(getenv("DG_TABLE_KERNEL") != nullptr),
           tab_unfused(getenv("DG_TAB_UNFUSED") != nullptr), sk_exchange(getenv("DG_SK_EXCHANGE") != nullptr),
@@ -272,7 +273,8 @@ struct EnvKnobs {
           group_m(getenv("DG_GROUP_M") ? atoi(getenv("DG_GROUP_M")) : 0), ks_pieces(getenv("DG_KS_PIECES") ? atoi(getenv("DG_KS_PIECES")) : 0),
           pc_bm(getenv("DG_PC_BM") ? atoi(getenv("DG_PC_BM")) : 0), e8_tab_unsplit(getenv("DG_E8_TAB_UNSPLIT") != nullptr),
           ks_max_pieces(getenv("DG_STREAM_KS_PIECES") ? std::max(1, std::min(8, atoi(getenv("DG_STREAM_KS_PIECES")))) : 8),
-          swiglu_fault(getenv("DG_TEST_SWIGLU_FAULT") ? atoi(getenv("DG_TEST_SWIGLU_FAULT")) : 0) {}
+          swiglu_fault(getenv("DG_TEST_SWIGLU_FAULT") ? atoi(getenv("DG_TEST_SWIGLU_FAULT")) : 0),
+          e8_split_quad_model_only(getenv("DG_E8_SPLIT_QUAD_MODEL_ONLY") != nullptr) {}
 };
 std::atomic<const EnvKnobs*> g_env_knobs{nullptr};
 const EnvKnobs& env_knobs() {
@@ -530,7 +532,13 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         //  1 x 7168 x 4096 8.7 against 8.6, 1 x 6144 x 7168 13.3 against 12.8, 4 x 7168 x 16384 25.0 against 24.7)
         // (17 .. 32 rows: coalesced activation loads with three K blocks per chunk from K = 6144 -- 32 x 4096 x 7168 13.3 -> 12.1 us, 32 x 4608 x 8192
         //  23.6 -> 21.1; four K blocks per wave (K = 4096) want the four-block chunks: 7.6 against 8.3; skinny_32_coalesced_activations_ab.jsonl)
-        else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608)
+        // (end of round 6: narrow layers -- at most 48 tiles of 64 x 32 -- with K >= 7168 and the caller's workspace leave 17 .. 32 rows to the
+        //  64 x 32 stream tile cut along K, below: a skinny launch is one workgroup per 16 columns, 36 for n = 576.  hipGraph replays, cold weights,
+        //  m = 17 / 24 / 32: 576 x 7168 9.8 / 10.4 / 11.2 -> 8.9 / 9.0 / 9.0 us, 1536 x 7168 10.1 / 10.7 / 11.5 -> 9.1 / 9.2 / 9.3; from n = 2112 the
+        //  skinny kernel ties or wins -- profiles/r06_probe/m17_32_skinny_vs_ks.log)
+        else if (m_for_tiling > 16 && m_for_tiling <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608 &&
+                 !(p.sk_workspace != nullptr && num_kb >= 56 && ceil_div(p.n, 32) <= 48 &&
+                   4096 + 32768 + static_cast<size_t>(ceil_div(p.n, 32)) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes))
             pick = num_kb >= 48 ? "skinny_32ca" : "skinny_32c";
         if (pick != nullptr)
             for (int i = 0; i < kNumConfigs; ++i)
@@ -576,9 +584,11 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // them in piece order).  Cold inputs, us: 160 x 4096 x 7168 27.5 -> 23.4, 192 x .. 30.4 -> 23.7, 256 x .. 30.6 -> 24.5 (was duo_sk_128x256),
         // 256 x 2112 x 7168 27.2 -> 19.4, 192 x 4096 x 4096 20.4 -> 17.3.  NOT up to 128 rows (128 x 4096 x 7168 16.7 -> 18.0, 128 x 2112 x 7168
         // 16.3 -> 24.4: the 64 x 32 tiles with loader waves already cover the chip), not with short K loops (256 x 4096 x 2048 12.7 -> 13.4), not
-        // under 64 tiles (192 x 2112 x 7168 16.6 -> 16.8).  profiles/r06_probe/stream_ks_mid_m_ab.log
+        // under 64 tiles (192 x 2112 x 7168 16.6 -> 16.8) unless the K loop is so long that the 8-wave K split below would take the problem (33 .. 63
+        // tiles -- up to 32 the 64 x 32 tile is cut -- from K = 10240: 192 x 1536 x 16384 28.1 (duo_sk_128x256) -> 21.4, 192 x 2048 x 16384 29.2 -> 24.1:
+        // profiles/r06_probe/ks_vs_duo_sk_ab.log).  profiles/r06_probe/stream_ks_mid_m_ab.log
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && p.head_lr == 0 &&
-            m_for_tiling > 128 && m_for_tiling <= 256 && p.k >= 4096 && tiles128 >= 64 && tiles128 * 2 <= num_cus() &&
+            m_for_tiling > 128 && m_for_tiling <= 256 && p.k >= 4096 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240)) && tiles128 * 2 <= num_cus() &&
             4096 + 32768 + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes) {
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, "stream_ks_64x128") == 0)
@@ -1014,7 +1024,10 @@ const char* e8_skinny_pick(const dg::GemmParams& p, bool g32) {
     const int num_kb = p.k / 128;
     if (p.m <= 16 && num_kb >= 16)
         return g32 ? "e8_skinny_g32_16" : "e8_skinny_16";
-    if (p.m > 16 && p.m <= 32 && num_kb >= 48 && num_kb <= 64 && p.n <= 4608)
+    // (narrow layers with K >= 7168 and the caller's workspace: the 64 x 32 stream tile cut along K -- the FP32-scale rule of select_config)
+    if (p.m > 16 && p.m <= 32 && num_kb >= 48 && num_kb <= 64 && p.n <= 4608 &&
+        !(p.sk_workspace != nullptr && num_kb >= 56 && ceil_div(p.n, 32) <= 48 &&
+          4096 + 32768 + static_cast<size_t>(ceil_div(p.n, 32)) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes))
         return g32 ? "e8_skinny_g32_32" : "e8_skinny_32";
     return nullptr;
 }
@@ -1027,9 +1040,10 @@ const char* e8_stream_ks_pick(const dg::GemmParams& p, bool g32) {
         return nullptr;
     const long tiles128 = static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 128), tiles32 = static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 32);
     const size_t fixed = 4096 + 32768;
-    if (p.m > 128 && tiles128 >= 64 && tiles128 * 2 <= num_cus() && fixed + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes)
+    if (p.m > 128 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240)) && tiles128 * 2 <= num_cus() &&
+        fixed + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes)
         return g32 ? "e8_stream_ks_g32_64x128" : "e8_stream_ks_64x128";
-    if (p.m > 32 && tiles128 < 128 && tiles32 * 2 <= num_cus() && fixed + static_cast<size_t>(tiles32) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes)
+    if (p.m > 16 && tiles128 < 128 && tiles32 * 2 <= num_cus() && fixed + static_cast<size_t>(tiles32) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes)
         return g32 ? "e8_stream_ks_g32_64x32" : "e8_stream_ks_64x32";
     return nullptr;
 }
@@ -1207,7 +1221,12 @@ int e8_split_pieces(const dg::GemmParams& p, size_t workspace_bytes) {
     // summing kernel moves (pieces + 2) x m x n x 4 bytes at ~3.7 TB/s (4096 x 512 x 32768: 255 -> 105 us, 1024 x 1024 x 16384: 96 -> 59; at 56 K
     // blocks the split loses 5 us and is not taken)
     const long tiles128 = static_cast<long>(ceil_div(p.m, 128)) * ceil_div(p.n, 256);
-    const double t_one = tiles128 <= num_cus() ? 12.0 + 0.75 * num_kb : 12.0 + 1.35 * num_kb * ceil_div(static_cast<int>(tiles), num_cus());
+    double t_one = tiles128 <= num_cus() ? 12.0 + 0.75 * num_kb : 12.0 + 1.35 * num_kb * ceil_div(static_cast<int>(tiles), num_cus());
+    // up to 256 rows the unsplit call runs the stream tiles (select_e8_config), not the 128-row kernel: the model of select_config (5 us + 0.27 us per
+    // K block on 64 x 32 tiles, 0.66 on 64 x 128) -- packed 192 x 2112 x 7168 was cut for a modelled 42 us where the stream tile runs ~17
+    // (profiles/r06_probe/e8_split_small_m_ab.log)
+    if (p.m <= 256 && !env_knobs().e8_split_quad_model_only)
+        t_one = std::min(t_one, 5.0 + num_kb * (static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 128) < 128 ? 0.27 : 0.66));
     const double t_split = 27.0 + 1.35 * ((num_kb + pieces - 1) / pieces) + static_cast<double>(pieces + 2) * per_piece / 3.7e6;
     return t_split < 0.85 * t_one ? static_cast<int>(pieces) : 0;
 }

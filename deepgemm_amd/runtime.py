@@ -92,6 +92,7 @@ def set_forced_config(name: str) -> None:
     from . import gemm
     gemm._VALIDATED_DENSE.clear()
     gemm._VALIDATED_MASKED.clear()
+    gemm._VALIDATED_PACKED.clear()
 
 
 def last_forced_config() -> str:

@@ -53,7 +53,7 @@ def test_golden_fixtures(golden_gemm):
             assert calc_diff(d.cpu(), ref_d) < gen.FP8_MAX_DIFF
 
 
-@pytest.mark.parametrize('m,n,k', [(1, 4096, 7168), (7, 576, 2048), (16, 2112, 7168), (17, 4096, 4096), (32, 1024, 8192), (1, 16, 128), (3, 64, 640)])
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 7168), (7, 576, 2048), (16, 2112, 7168), (17, 4096, 4096), (32, 2048, 8192), (1, 16, 128), (3, 64, 640)])
 def test_skinny_decode_kernel(m, n, k):
     """Decode batches (M <= 32) on the skinny weight-stream kernel (16 columns per workgroup, the 8 waves split K, the partial tiles are
     summed in wave order): oracle parity for BF16, FP32 and accumulating outputs, bit-repeatable, wider D rows, row-major SFA."""
@@ -609,8 +609,9 @@ def test_dense_split_k_under_filled_launch(m, n, k, b_k_major, out_dtype, accumu
         d = c_cpu.cuda() if accumulate else torch.full_like(case.d, float('nan'))
         dg.fp8_gemm_nt(case.a, case.b, d, c=d if accumulate else None)
         outs.append(d)
-    # (an MN-major B of a problem with m <= 256 is re-majored first: the K-major kernel)
-    assert dg.last_config() == ('duo_sk_128x256' if b_k_major or m <= 256 else 'duo_sk_bmn_128x256'), dg.last_config()
+    # (an MN-major B of a problem with m <= 256 is re-majored first: the K-major kernels -- since the end of round 6 the 64 x 32 stream tile cut
+    #  along K inside the kernel where its tiles fill at most half the chip: 200 x 1024 x 16384 27.5 -> 20.7 us, profiles/r06_probe/ks_vs_duo_sk_ab.log)
+    assert dg.last_config() == ('stream_ks_64x32' if m <= 256 else 'duo_sk_128x256' if b_k_major else 'duo_sk_bmn_128x256'), dg.last_config()
     assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'the piece-order reduction must be bit-repeatable'
     if out_dtype == torch.float:
         assert_close_fp32(outs[0], want, 'dense split K')
@@ -1467,7 +1468,8 @@ def test_mid_m_k_split_random_shapes(seed):
     assert taken == 6, taken
 
 
-@pytest.mark.parametrize('m,n,k', [(128, 576, 7168), (33, 4096, 7168), (65, 520, 4096), (1, 40, 4608), (200, 96, 5120), (256, 576, 16384)])
+@pytest.mark.parametrize('m,n,k', [(128, 576, 7168), (33, 4096, 7168), (65, 520, 4096), (1, 40, 4608), (200, 96, 5120), (256, 576, 16384), (24, 576, 7168),
+                                   (17, 1536, 8192)])
 def test_narrow_stream_tile_with_in_kernel_k_split(m, n, k):
     """`stream_ks_64x32` (end of round 6): the 64 x 32 stream tile (four K blocks per stage) cut along K inside the kernel -- narrow layers at small
     M, e.g. the MLA down-projection n = 576 of the reference's sweep: forced by name against the oracle, bit-repeatable, FP32 accumulation, ragged M
@@ -1494,7 +1496,8 @@ def test_narrow_stream_tile_with_in_kernel_k_split(m, n, k):
     want32 = torch.empty((m, n), dtype=torch.float)
     oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want32, c=c32.cpu())
     assert_close_fp32(d32, want32, 'narrow stream tile, in-kernel K split, fp32 accumulate')
-    if m > 32 and -(-m // 64) * -(-n // 32) * 2 <= 256:
+    # (17 .. 32 rows: narrow layers -- at most 48 tiles -- with K >= 7168 leave the skinny kernel for this tile)
+    if (m > 32 or (m > 16 and k >= 7168 and -(-n // 32) <= 48)) and -(-m // 64) * -(-n // 32) * 2 <= 256:
         outs = []
         for _ in range(3):
             o = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)

@@ -270,7 +270,7 @@ def test_decode_sized_gran_k_32_runs_on_stream_tiles(m, n, k):
 
 @pytest.mark.parametrize('gran_k', [128, 32])
 @pytest.mark.parametrize('m,n,k,accumulate,out_dtype', [(1, 4096, 7168, False, torch.bfloat16), (16, 528, 2048, False, torch.bfloat16),
-                                                       (7, 272, 2560, True, torch.float), (32, 1024, 7168, False, torch.bfloat16),
+                                                       (7, 272, 2560, True, torch.float), (32, 2048, 7168, False, torch.bfloat16),
                                                        (20, 4608, 6144, True, torch.bfloat16)])
 def test_batch_decode_with_packed_scales_runs_the_skinny_kernel(gran_k, m, n, k, accumulate, out_dtype):
     """Batch-1 .. 32 decode with packed UE8M0 scale words (round 6, both granularities): the skinny weight-stream kernel with the scaled MFMA
@@ -356,7 +356,8 @@ def test_randomized_decode_sized_packed_shapes_both_granularities():
 
 
 @pytest.mark.parametrize('gran_k', [128, 32])
-@pytest.mark.parametrize('m,n,k', [(128, 576, 7168), (33, 4096, 7168), (65, 520, 4096), (200, 96, 5120), (256, 576, 16384), (192, 4096, 7168), (256, 2112, 4608)])
+@pytest.mark.parametrize('m,n,k', [(128, 576, 7168), (33, 4096, 7168), (65, 520, 4096), (200, 96, 5120), (256, 576, 16384), (192, 4096, 7168), (256, 2112, 4608),
+                                   (24, 1536, 7168), (17, 4096, 4096), (192, 1536, 10240)])
 def test_packed_stream_tiles_cut_along_k(gran_k, m, n, k):
     """`e8_stream_ks_64x32` / `_64x128` and their granularity-32 forms (end of round 6): the packed-scale stream tiles cut along K inside the kernel
     in pieces of whole K quads (the FP32-scale rules of `stream_ks_*`) -- the automatic pick through the plain entry (the host layer lends the
@@ -369,7 +370,8 @@ def test_packed_stream_tiles_cut_along_k(gran_k, m, n, k):
     pa = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qa[1]), m, k, (1, gran_k))
     pb = dg.transform_sf_into_required_layout(pack_ue8m0_to_int(qb[1]), n, k, (1, gran_k))
     g = '_g32' if gran_k == 32 else ''
-    wide = m > 128 and -(-m // 64) * -(-n // 128) >= 64
+    tiles128 = -(-m // 64) * -(-n // 128)
+    wide = m > 128 and (tiles128 >= 64 or (tiles128 > 32 and k >= 10240))       # (17 .. 32 rows: where the skinny kernel does not apply, or narrow layers with K >= 7168)
     want_name = f'e8_stream_ks{g}_64x128' if wide else f'e8_stream_ks{g}_64x32'
     outs = []
     for _ in range(3):

@@ -480,7 +480,13 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 1, 4096, 7168, packed=1) == 'e8_skinny_16' and pick(dense, 24, 4096, 7168, packed=1) == 'e8_skinny_32' and pick(dense, 33, 4096, 7168, packed=1, workspace=0) == 'e8_stream_l8_64x32'
     # (end of round 6: the stream tiles cut along K inside the kernel with packed words too -- the FP32-scale rules)
     assert pick(dense, 33, 4096, 7168, packed=1) == 'e8_stream_ks_64x32' and pick(dense, 128, 576, 7168, packed=1) == 'e8_stream_ks_64x32' and pick(dense, 192, 4096, 7168, packed=1) == 'e8_stream_ks_64x128'
+    # (17 .. 32 rows on narrow layers with K >= 7168 leave the skinny kernel for the K-split 64 x 32 tile; 33 .. 63 tiles of 64 x 128 from K = 10240)
+    assert pick(dense, 24, 1536, 7168, packed=1) == 'e8_stream_ks_64x32' and pick(dense, 24, 1536, 7168, packed=1, workspace=0) == 'e8_skinny_32' and pick(dense, 32, 2112, 7168, packed=1) == 'e8_skinny_32'
+    assert pick(dense, 16, 576, 7168, packed=1) == 'e8_skinny_16' and pick(dense, 192, 1536, 16384, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 192, 2112, 7168, packed=1) == 'e8_stream_l8_64x32'
+    assert pick(dense, 24, 1536, 7168) == 'stream_ks_64x32' and pick(dense, 24, 1536, 7168, workspace=0) == 'skinny_32ca' and pick(dense, 32, 2112, 7168) == 'skinny_32ca' and pick(dense, 24, 576, 4096) == 'skinny_32c'
+    assert pick(dense, 192, 1536, 16384) == 'stream_ks_64x128' and pick(dense, 192, 2048, 16384) == 'stream_ks_64x128' and pick(dense, 200, 1024, 16384) == 'stream_ks_64x32'
     from deepgemm_amd._lib import lib as _l
+    assert _l.dg_ue8m0_dense_wants_workspace(192, 2112, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(320, 512, 8192) == 1      # (the two-launch split prices the stream tiles up to 256 rows)
     assert _l.dg_ue8m0_dense_wants_workspace(128, 576, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(192, 4096, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(128, 4096, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(1, 576, 7168) == 0
     # packed scales with MN-major operands: read in place where that beats a re-majoring pass (e8_mn_pays); a K tail in the nn layout (the
     # packed-scale dgrad shapes) always stays in place (round 5)

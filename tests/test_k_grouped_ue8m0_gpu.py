@@ -169,7 +169,7 @@ def test_k_grouped_ue8m0_full_size_group():
 
 
 @pytest.mark.parametrize('gran_k', [128, 32])
-@pytest.mark.parametrize('m,n,k,accumulate,out_dtype', [(256, 512, 8192, False, torch.bfloat16), (576, 1024, 14336, True, torch.float),
+@pytest.mark.parametrize('m,n,k,accumulate,out_dtype', [(320, 512, 8192, False, torch.bfloat16), (576, 1024, 14336, True, torch.float),
                                                        (1000, 264, 16384, False, torch.float), (512, 512, 16384, True, torch.bfloat16)])
 def test_packed_dense_k_split_runs_as_k_groups(gran_k, m, n, k, accumulate, out_dtype):
     """Under-filled packed-scale dense problems with a long K loop (round 6): the K axis cut into pieces that run as the groups of one launch of the
@@ -235,8 +235,8 @@ def test_k_grouped_ue8m0_and_packed_k_split_in_a_hip_graph():
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(d, want)
-    # dense K split
-    m, n, k = 256, 512, 8192
+    # dense K split (over 256 rows: up to 256 the stream tile cut along K inside the kernel takes these shapes -- e8_stream_ks_*)
+    m, n, k = 320, 512, 8192
     dense = gen.generate_normal(m, n, k, per_token_b=True, use_ue8m0=True)
     a, b = gen.packed_ue8m0_operand(*dense.a), gen.packed_ue8m0_operand(*dense.b)
     torch.cuda.synchronize()
