@@ -587,8 +587,15 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // under 64 tiles (192 x 2112 x 7168 16.6 -> 16.8) unless the K loop is so long that the 8-wave K split below would take the problem (33 .. 63
         // tiles -- up to 32 the 64 x 32 tile is cut -- from K = 10240: 192 x 1536 x 16384 28.1 (duo_sk_128x256) -> 21.4, 192 x 2048 x 16384 29.2 -> 24.1:
         // profiles/r06_probe/ks_vs_duo_sk_ab.log).  profiles/r06_probe/stream_ks_mid_m_ab.log
+        // ... and 65 .. 128 rows on WIDE layers (last session, profiles/r06_probe/m128_long_k_ab.log): from 96 tiles (two pieces) the 64 x 32 tiles'
+        // second half-round costs more than the exchange -- 128 x 6144 x 7168 29.8 -> 23.8 us, 128 x 7168 x 8192 32.8 -> 26.8 (K up to 10240: at
+        // 128 x 7168 x 16384 the 8-wave K split runs 40.2 against 48.9) -- and 64 .. 95 tiles with K >= 10240 (128 x 4096 x 10240 26.9 -> 22.3,
+        // 128 x 4096 x 16384 32.0 -> 28.2; at K = 7168 the 64 x 32 tiles stay: 16.7 against 18.0)
+        const bool ks_rows_129_256 = m_for_tiling > 128 && m_for_tiling <= 256 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240));
+        const bool ks_rows_65_128 = m_for_tiling > 64 && m_for_tiling <= 128 &&
+                                    ((tiles128 >= 96 && p.k >= 7168 && p.k <= 10240) || (tiles128 >= 64 && tiles128 < 96 && p.k >= 10240));
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && p.head_lr == 0 &&
-            m_for_tiling > 128 && m_for_tiling <= 256 && p.k >= 4096 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240)) && tiles128 * 2 <= num_cus() &&
+            (ks_rows_129_256 || ks_rows_65_128) && p.k >= 4096 && tiles128 * 2 <= num_cus() &&
             4096 + 32768 + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes) {
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, "stream_ks_64x128") == 0)
@@ -1040,7 +1047,11 @@ const char* e8_stream_ks_pick(const dg::GemmParams& p, bool g32) {
         return nullptr;
     const long tiles128 = static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 128), tiles32 = static_cast<long>(ceil_div(p.m, 64)) * ceil_div(p.n, 32);
     const size_t fixed = 4096 + 32768;
-    if (p.m > 128 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240)) && tiles128 * 2 <= num_cus() &&
+    // (65 .. 128 rows on wide layers: from 96 tiles with K >= 7168 -- 128 x 7168 x 16384 55.1 -> 42.5 us, 128 x 7168 x 8192 31.7 -> 26.3, 128 x 6144 x 7168
+    //  28.4 -> 22.9 -- and 64 .. 95 tiles from K = 12288: 128 x 4096 x 16384 29.7 -> 27.5; profiles/r06_probe/m128_long_k_ab.log)
+    const bool rows_129_256 = p.m > 128 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240));
+    const bool rows_65_128 = p.m > 64 && p.m <= 128 && ((tiles128 >= 96 && p.k >= 7168) || (tiles128 >= 64 && tiles128 < 96 && p.k >= 12288));
+    if ((rows_129_256 || rows_65_128) && tiles128 * 2 <= num_cus() &&
         fixed + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes)
         return g32 ? "e8_stream_ks_g32_64x128" : "e8_stream_ks_64x128";
     if (p.m > 16 && tiles128 < 128 && tiles32 * 2 <= num_cus() && fixed + static_cast<size_t>(tiles32) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes)

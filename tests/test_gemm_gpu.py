@@ -1391,11 +1391,12 @@ def test_stream_tile_with_in_kernel_k_split(m, n, k):
     assert_close_fp32(d32, want32, 'stream tile, in-kernel K split, fp32 accumulate')
 
 
-@pytest.mark.parametrize('m,n,k', [(192, 4096, 7168), (256, 2112, 7168), (129, 4096, 4096)])
+@pytest.mark.parametrize('m,n,k', [(192, 4096, 7168), (256, 2112, 7168), (129, 4096, 4096), (192, 1536, 10240), (128, 6144, 7168), (100, 4096, 10240), (65, 7168, 8192)])
 def test_mid_m_dense_calls_take_the_k_split_stream_tile(m, n, k):
     """The automatic selection (round 6): 129 .. 256 rows whose 64 x 128 tiles fill at most half the chip and K >= 4096 run `stream_ks_64x128`
     through the plain entry (the host layer lends the workspace: dg_dense_wants_workspace), with the oracle's result; repeated calls (the
-    exchange epoch advances, the workspace is reused dirty) give the same bits."""
+    exchange epoch advances, the workspace is reused dirty) give the same bits.  Last session: 33 .. 63 tiles from K = 10240, and 65 .. 128 rows on
+    wide layers (from 96 tiles with K = 7168 .. 10240, 64 .. 95 tiles from K = 10240)."""
     gen.reset_seed(3 * m + n + k)
     case = gen.generate_normal(m, n, k)
     want = oracle_dense(case)

@@ -485,6 +485,11 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 16, 576, 7168, packed=1) == 'e8_skinny_16' and pick(dense, 192, 1536, 16384, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 192, 2112, 7168, packed=1) == 'e8_stream_l8_64x32'
     assert pick(dense, 24, 1536, 7168) == 'stream_ks_64x32' and pick(dense, 24, 1536, 7168, workspace=0) == 'skinny_32ca' and pick(dense, 32, 2112, 7168) == 'skinny_32ca' and pick(dense, 24, 576, 4096) == 'skinny_32c'
     assert pick(dense, 192, 1536, 16384) == 'stream_ks_64x128' and pick(dense, 192, 2048, 16384) == 'stream_ks_64x128' and pick(dense, 200, 1024, 16384) == 'stream_ks_64x32'
+    # (65 .. 128 rows on wide layers: from 96 tiles of 64 x 128 the K-split 64 x 128 tile -- FP32 scales up to K = 10240, where the 8-wave split takes over)
+    assert pick(dense, 128, 6144, 7168) == 'stream_ks_64x128' and pick(dense, 128, 7168, 8192) == 'stream_ks_64x128' and pick(dense, 128, 4096, 10240) == 'stream_ks_64x128'
+    assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32' and pick(dense, 64, 7168, 16384) == 'stream_l8_64x32'
+    assert pick(dense, 128, 7168, 16384, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 96, 6144, 7168, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 128, 4096, 16384, packed=1) == 'e8_stream_ks_64x128'
+    assert pick(dense, 128, 4096, 10240, packed=1) == 'e8_stream_l8_64x32' and pick(dense, 64, 7168, 16384, packed=1) == 'e8_stream_l8_64x32'
     from deepgemm_amd._lib import lib as _l
     assert _l.dg_ue8m0_dense_wants_workspace(192, 2112, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(320, 512, 8192) == 1      # (the two-launch split prices the stream tiles up to 256 rows)
     assert _l.dg_ue8m0_dense_wants_workspace(128, 576, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(192, 4096, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(128, 4096, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(1, 576, 7168) == 0
