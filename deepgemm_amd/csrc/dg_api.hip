@@ -160,6 +160,9 @@ const Config kConfigs[] = {
     // (m = 128, n = 576 -- the MLA down-projection of the reference's sweep: 36 tiles, one K loop of 56 blocks on 36 CUs)
     {"stream_ks_64x32", 64, 32, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 32, 4, 1, 3, 0, 4, false, 0, true>, true, false, false,
      false, true},
+    // ... and a 64 x 64 tile (two K blocks per stage, four stages): m = 128, 4096 x 7168 as 128 tiles x 2 pieces, 459 KB per CU and ONE partner per tile
+    {"stream_ks_64x64", 64, 64, 256, 1, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 64, 4, 1, 4, 0, 2, false, 0, true>, true, false, false,
+     false, true},
     {"stream2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3>, true},
     {"stream_nt2_64x128", 64, 128, 256, 2, 0.0f, true, dg::dg_fp8_gemm_stream_kernel<64, 128, 1, 4, 3, 2>, true},
     // (64 x 32: four K blocks per ring stage -- a quarter of the barriers: 4-7 % on the small-M shapes; no gain on the 64 x 128 tile)
@@ -587,19 +590,31 @@ const Config* select_config(const dg::GemmParams& p, int m_for_tiling, int expec
         // under 64 tiles (192 x 2112 x 7168 16.6 -> 16.8) unless the K loop is so long that the 8-wave K split below would take the problem (33 .. 63
         // tiles -- up to 32 the 64 x 32 tile is cut -- from K = 10240: 192 x 1536 x 16384 28.1 (duo_sk_128x256) -> 21.4, 192 x 2048 x 16384 29.2 -> 24.1:
         // profiles/r06_probe/ks_vs_duo_sk_ab.log).  profiles/r06_probe/stream_ks_mid_m_ab.log
-        // ... and 65 .. 128 rows on WIDE layers (last session, profiles/r06_probe/m128_long_k_ab.log): from 96 tiles (two pieces) the 64 x 32 tiles'
+        // ... and 65 .. 128 rows on WIDE layers (last session, profiles/r06_probe/m128_long_k_ab.log): over 64 tiles (> 256 tiles of 64 x 32: 128 x 5120 x 7168
+        // 29.1 -> 20.0 us, stream_ks_64x64_ab.log) the 64 x 32 tiles'
         // second half-round costs more than the exchange -- 128 x 6144 x 7168 29.8 -> 23.8 us, 128 x 7168 x 8192 32.8 -> 26.8 (K up to 10240: at
         // 128 x 7168 x 16384 the 8-wave K split runs 40.2 against 48.9) -- and 64 .. 95 tiles with K >= 10240 (128 x 4096 x 10240 26.9 -> 22.3,
         // 128 x 4096 x 16384 32.0 -> 28.2; at K = 7168 the 64 x 32 tiles stay: 16.7 against 18.0)
         const bool ks_rows_129_256 = m_for_tiling > 128 && m_for_tiling <= 256 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240));
         const bool ks_rows_65_128 = m_for_tiling > 64 && m_for_tiling <= 128 &&
-                                    ((tiles128 >= 96 && p.k >= 7168 && p.k <= 10240) || (tiles128 >= 64 && tiles128 < 96 && p.k >= 10240));
+                                    ((tiles128 > 64 && p.k >= 7168 && p.k <= 10240) || (tiles128 == 64 && p.k >= 10240));
         if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && p.head_lr == 0 &&
             (ks_rows_129_256 || ks_rows_65_128) && p.k >= 4096 && tiles128 * 2 <= num_cus() &&
             4096 + 32768 + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes) {
             for (int i = 0; i < kNumConfigs; ++i)
                 if (std::strcmp(kConfigs[i].name, "stream_ks_64x128") == 0)
                     return &kConfigs[i];
+        }
+        // last session: a 64 x 64 tile (two K blocks per stage, four stages) cut likewise, where its tiles get three or more pieces and the 64 x 32 tiles
+        // would get two or none -- 48 .. CUs / 3 tiles, K >= 7168, 33 .. 128 rows: 128 x 2112 x 7168 15.6 -> 13.6 us, 128 x 1536 x 7168 12.6-13.4 -> 11.8,
+        // 64 x 4096 x 7168 14.0 -> 13.1; NOT at two pieces (128 x 4096 x 7168 16.1 -> 17.3, 128 x 3072 x 7168 15.9 -> 15.7) -- profiles/r06_probe/stream_ks_64x64_ab.log
+        if (pick != nullptr && p.gemm_type == dg::kNormal && p.sk_workspace != nullptr && p.sfb_gran_n == 128 && p.head_lr == 0 && p.k >= 7168 &&
+            m_for_tiling > 32 && m_for_tiling <= 128) {
+            const long tiles64 = static_cast<long>(ceil_div(m_for_tiling, 64)) * ceil_div(p.n, 64);
+            if (tiles64 >= 48 && tiles64 * 3 <= num_cus() && 4096 + 32768 + static_cast<size_t>(tiles64) * 8 * 64 * 64 * sizeof(float) <= g_workspace_bytes)
+                for (int i = 0; i < kNumConfigs; ++i)
+                    if (std::strcmp(kConfigs[i].name, "stream_ks_64x64") == 0)
+                        return &kConfigs[i];
         }
         // end of round 6: dense problems whose 64 x 32 tiles fill at most half the chip, with a long K loop and the caller's workspace: the tile cut
         // along K inside the kernel (stream_ks_64x32: min(8, CUs / tiles, K blocks / 4) pieces).  Eager calls, cold weights, us: 128 x 576 x 7168 (the
@@ -1050,7 +1065,7 @@ const char* e8_stream_ks_pick(const dg::GemmParams& p, bool g32) {
     // (65 .. 128 rows on wide layers: from 96 tiles with K >= 7168 -- 128 x 7168 x 16384 55.1 -> 42.5 us, 128 x 7168 x 8192 31.7 -> 26.3, 128 x 6144 x 7168
     //  28.4 -> 22.9 -- and 64 .. 95 tiles from K = 12288: 128 x 4096 x 16384 29.7 -> 27.5; profiles/r06_probe/m128_long_k_ab.log)
     const bool rows_129_256 = p.m > 128 && (tiles128 >= 64 || (tiles128 > 32 && p.k >= 10240));
-    const bool rows_65_128 = p.m > 64 && p.m <= 128 && ((tiles128 >= 96 && p.k >= 7168) || (tiles128 >= 64 && tiles128 < 96 && p.k >= 12288));
+    const bool rows_65_128 = p.m > 64 && p.m <= 128 && ((tiles128 > 64 && p.k >= 7168) || (tiles128 == 64 && p.k >= 12288));
     if ((rows_129_256 || rows_65_128) && tiles128 * 2 <= num_cus() &&
         fixed + static_cast<size_t>(tiles128) * 8 * 64 * 128 * sizeof(float) <= g_workspace_bytes)
         return g32 ? "e8_stream_ks_g32_64x128" : "e8_stream_ks_64x128";

@@ -25,6 +25,7 @@ PRODUCTION = [       # <BM, BN, WAVES_M, WAVES_N, PERSIST, B_MN, SPLITK, A_MN, K
     'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,4,0,0>',          # round 6: ... with packed scale words (the words of a K quad in the group ring)
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,0,0,1,0>',         # round 6: the in-kernel K split (stream_ks_64x128: dense 129 .. 256 rows)
     'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,0,0,1,0>',          # ... of the 64 x 32 tile (stream_ks_64x32: narrow layers at small M)
+    'dg_fp8_gemm_stream_kernel<64,64,4,1,4,0,2,0,0,1,0>',          # ... of a 64 x 64 tile (stream_ks_64x64: three or more pieces at 33 .. 128 rows)
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,1,0,1,0>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,0,1,0>',      # ... with packed scale words (e8_stream_ks_*)
     'dg_fp8_gemm_stream_kernel<64,128,1,4,6,0,1,1,0,1,1>', 'dg_fp8_gemm_stream_kernel<64,32,4,1,3,0,4,1,0,1,1>',
     # round 5: 3-stage ring, two workgroups per CU (FP32 scales / packed UE8M0; default and non-temporal weight policy)

@@ -1498,12 +1498,50 @@ def test_narrow_stream_tile_with_in_kernel_k_split(m, n, k):
     oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want32, c=c32.cpu())
     assert_close_fp32(d32, want32, 'narrow stream tile, in-kernel K split, fp32 accumulate')
     # (17 .. 32 rows: narrow layers -- at most 48 tiles -- with K >= 7168 leave the skinny kernel for this tile)
-    if (m > 32 or (m > 16 and k >= 7168 and -(-n // 32) <= 48)) and -(-m // 64) * -(-n // 32) * 2 <= 256:
+    takes_64x64 = 32 < m <= 128 and k >= 7168 and 48 <= -(-m // 64) * -(-n // 64) <= 85       # (three or more pieces of a 64 x 64 tile: the test below)
+    if (m > 32 or (m > 16 and k >= 7168 and -(-n // 32) <= 48)) and -(-m // 64) * -(-n // 32) * 2 <= 256 and not takes_64x64:
         outs = []
         for _ in range(3):
             o = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
             dg.fp8_gemm_nt(case.a, case.b, o)
             assert dg.last_config() == 'stream_ks_64x32', dg.last_config()
+            outs.append(o)
+        assert all(torch.equal(d.view(torch.int16), o.view(torch.int16)) for o in outs)
+
+
+@pytest.mark.parametrize('m,n,k', [(128, 2112, 7168), (33, 4096, 7168), (100, 1544, 8192), (64, 5000, 7168), (1, 72, 4608), (200, 200, 5120)])
+def test_64x64_stream_tile_with_in_kernel_k_split(m, n, k):
+    """`stream_ks_64x64` (last session of round 6): a 64 x 64 stream tile (two K blocks per stage, four stages) cut along K inside the kernel, for
+    33 .. 128 rows where its tiles get three or more pieces (48 .. CUs / 3 tiles, K >= 7168) -- forced by name against the oracle (ragged M and N,
+    odd K block counts, FP32 accumulation), bit-repeatable; inside the rule the plain entry takes it and repeated calls on the dirty workspace
+    give the same bits."""
+    gen.reset_seed(m + n + k + 64)
+    case = gen.generate_normal(m, n, k)
+    want = oracle_dense(case)
+    dg.set_forced_config('stream_ks_64x64')
+    try:
+        d = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+        dg.fp8_gemm_nt(case.a, case.b, d)
+        assert dg.last_config() == 'stream_ks_64x64'
+        again = torch.full_like(d, float('nan'))
+        dg.fp8_gemm_nt(case.a, case.b, again)
+        c32 = torch.randn((m, n), device='cuda', dtype=torch.float)
+        d32 = c32.clone()
+        dg.fp8_gemm_nt(case.a, case.b, d32, c=d32)
+    finally:
+        dg.set_forced_config('auto')
+    assert_close_to_oracle(d, want, '64 x 64 stream tile, in-kernel K split')
+    assert torch.equal(d.view(torch.int16), again.view(torch.int16)), 'piece order is fixed: bit-repeatable'
+    assert calc_diff(d, case.ref_d) < gen.FP8_MAX_DIFF
+    want32 = torch.empty((m, n), dtype=torch.float)
+    oracle.fp8_gemm_nt(*cpu_pair(case.a), *cpu_pair(case.b), want32, c=c32.cpu())
+    assert_close_fp32(d32, want32, '64 x 64 stream tile, in-kernel K split, fp32 accumulate')
+    if 32 < m <= 128 and k >= 7168 and 48 <= -(-m // 64) * -(-n // 64) <= 85:
+        outs = []
+        for _ in range(3):
+            o = torch.full((m, n), float('nan'), device='cuda', dtype=torch.bfloat16)
+            dg.fp8_gemm_nt(case.a, case.b, o)
+            assert dg.last_config() == 'stream_ks_64x64', dg.last_config()
             outs.append(o)
         assert all(torch.equal(d.view(torch.int16), o.view(torch.int16)) for o in outs)
 

@@ -421,7 +421,7 @@ def test_split_k_workspace_is_only_requested_when_the_model_says_so():
     assert wants(4096, 512, 32768) == 1 and wants(4096, 512, 32768, b_mn=1) == 1          # 64 tiles of 128 x 256, 256 K blocks
     assert wants(1024, 1024, 16384) == 1 and wants(512, 4096, 7168) == 1
     # (end of round 6: 64 x 32 stream tiles that fill at most half the chip, K >= 4096, are cut along K inside the kernel: stream_ks_64x32)
-    assert wants(128, 576, 7168) == 1 and wants(64, 4096, 7168) == 1 and wants(128, 576, 2048) == 0 and wants(128, 2112, 7168) == 0
+    assert wants(128, 576, 7168) == 1 and wants(64, 4096, 7168) == 1 and wants(128, 576, 2048) == 0 and wants(128, 3072, 7168) == 0 and wants(128, 2112, 7168) == 1      # (last session: 128 x 2112 x 7168 runs the K-split 64 x 64 tile)
     assert wants(576, 4096, 7168, 1) == 1 and wants(576, 4096, 7168, 1, 1, 1) == 1        # 48 tiles of 256 x 256, 56 K blocks: K pieces as groups
     assert wants(4096, 512, 32768, 1) == 1
     assert wants(576, 4096, 7168, 1, 1, 0) == 0                                            # mixed majorness: the layout-agnostic kernel, no split
@@ -490,6 +490,10 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32' and pick(dense, 64, 7168, 16384) == 'stream_l8_64x32'
     assert pick(dense, 128, 7168, 16384, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 96, 6144, 7168, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 128, 4096, 16384, packed=1) == 'e8_stream_ks_64x128'
     assert pick(dense, 128, 4096, 10240, packed=1) == 'e8_stream_l8_64x32' and pick(dense, 64, 7168, 16384, packed=1) == 'e8_stream_l8_64x32'
+    # (33 .. 128 rows, K >= 7168: the K-split 64 x 64 tile where it gets three or more pieces -- 48 .. 85 tiles)
+    assert pick(dense, 128, 2112, 7168) == 'stream_ks_64x64' and pick(dense, 128, 1536, 7168) == 'stream_ks_64x64' and pick(dense, 64, 4096, 7168) == 'stream_ks_64x64'
+    assert pick(dense, 128, 3072, 7168) == 'stream_l8_64x32' and pick(dense, 128, 2112, 4096) == 'stream_l8_64x32' and pick(dense, 128, 2112, 7168, workspace=0) == 'stream_l8_64x32'
+    assert pick(dense, 128, 5120, 7168) == 'stream_ks_64x128' and pick(dense, 128, 5120, 7168, packed=1) == 'e8_stream_ks_64x128'
     from deepgemm_amd._lib import lib as _l
     assert _l.dg_ue8m0_dense_wants_workspace(192, 2112, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(320, 512, 8192) == 1      # (the two-launch split prices the stream tiles up to 256 rows)
     assert _l.dg_ue8m0_dense_wants_workspace(128, 576, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(192, 4096, 7168) == 1 and _l.dg_ue8m0_dense_wants_workspace(128, 4096, 7168) == 0 and _l.dg_ue8m0_dense_wants_workspace(1, 576, 7168) == 0
@@ -510,7 +514,7 @@ def test_automatic_kernel_selection_is_pinned():
     # the reference's dense sweep: small M, K tails, few tiles with long K loops, tile-count quantisation
     assert pick(dense, 1, 7168, 16384) == 'skinny_16ca' and pick(dense, 16, 8192, 2048) == 'skinny_16wc' and pick(dense, 1, 4096, 16384) == 'skinny_16ca' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32'
     # decode batches: the skinny weight-stream kernel for long K loops, the stream tiles for short ones / wide N
-    assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32ca' and pick(dense, 24, 4096, 4096) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_ks_64x32' and pick(dense, 33, 4096, 7168, workspace=0) == 'stream_l8_64x32'
+    assert pick(dense, 16, 4096, 7168) == 'skinny_16ca' and pick(dense, 17, 4096, 7168) == 'skinny_32ca' and pick(dense, 24, 4096, 4096) == 'skinny_32c' and pick(dense, 33, 4096, 7168) == 'stream_ks_64x64' and pick(dense, 33, 2112, 7168) == 'stream_ks_64x32' and pick(dense, 33, 4096, 7168, workspace=0) == 'stream_l8_64x32'
     # (end of round 6, cold weights: non-temporal weight stream from 16 MB per launch; dense m <= 256 on the stream tile up to one resident round of two per CU)
     assert pick(dense, 1, 24576, 1536) == 'stream_nt2_64x128' and pick(dense, 1, 32768, 512) == 'stream_nt2_64x128'
     assert pick(dense, 128, 32768, 512) == 'stream_nt2_64x128' and pick(dense, 128, 24576, 1536, packed=1) == 'e8_stream_nt2_64x128'
