@@ -1047,7 +1047,8 @@ const char* e8_skinny_pick(const dg::GemmParams& p, bool g32) {
     if (p.m <= 16 && num_kb >= 16)
         return g32 ? "e8_skinny_g32_16" : "e8_skinny_16";
     // (narrow layers with K >= 7168 and the caller's workspace: the 64 x 32 stream tile cut along K -- the FP32-scale rule of select_config)
-    if (p.m > 16 && p.m <= 32 && num_kb >= 48 && num_kb <= 64 && p.n <= 4608 &&
+    // (from 32 K blocks, as the FP32-scale rule: 17 .. 32 x 4096 x 4096 at granularity 32 8.2-9.1 us against 9.9-10.1 on the K-split tile -- m17_32_skinny_vs_ks.log)
+    if (p.m > 16 && p.m <= 32 && num_kb >= 32 && num_kb <= 64 && p.n <= 4608 &&
         !(p.sk_workspace != nullptr && num_kb >= 56 && ceil_div(p.n, 32) <= 48 &&
           4096 + 32768 + static_cast<size_t>(ceil_div(p.n, 32)) * 8 * 64 * 32 * sizeof(float) <= g_workspace_bytes))
         return g32 ? "e8_skinny_g32_32" : "e8_skinny_32";

@@ -490,6 +490,8 @@ def test_automatic_kernel_selection_is_pinned():
     assert pick(dense, 128, 7168, 16384) == 'duo_sk_128x256' and pick(dense, 128, 4096, 7168) == 'stream_l8_64x32' and pick(dense, 64, 7168, 16384) == 'stream_l8_64x32'
     assert pick(dense, 128, 7168, 16384, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 96, 6144, 7168, packed=1) == 'e8_stream_ks_64x128' and pick(dense, 128, 4096, 16384, packed=1) == 'e8_stream_ks_64x128'
     assert pick(dense, 128, 4096, 10240, packed=1) == 'e8_stream_l8_64x32' and pick(dense, 64, 7168, 16384, packed=1) == 'e8_stream_l8_64x32'
+    # (packed scales at 17 .. 32 rows: the skinny kernel from 32 K blocks, as with FP32 scales)
+    assert pick(dense, 24, 4096, 4096, packed=1) == 'e8_skinny_32' and pick(dense, 24, 4096, 3968, packed=1) != 'e8_skinny_32' and pick(dense, 33, 4096, 4096, packed=1) == 'e8_stream_ks_64x32'
     # (33 .. 128 rows, K >= 7168: the K-split 64 x 64 tile where it gets three or more pieces -- 48 .. 85 tiles)
     assert pick(dense, 128, 2112, 7168) == 'stream_ks_64x64' and pick(dense, 128, 1536, 7168) == 'stream_ks_64x64' and pick(dense, 64, 4096, 7168) == 'stream_ks_64x64'
     assert pick(dense, 128, 3072, 7168) == 'stream_l8_64x32' and pick(dense, 128, 2112, 4096) == 'stream_l8_64x32' and pick(dense, 128, 2112, 7168, workspace=0) == 'stream_l8_64x32'
